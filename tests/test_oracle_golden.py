@@ -1,0 +1,186 @@
+"""Pin the CPU oracle against the golden vectors recorded from the reference
+(``tests/golden/make_golden.py``).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lsh_ref, model_ref, synth
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _sd(z, tag):
+    pre = f"{tag}/sd/"
+    return {k[len(pre):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre)}
+
+
+def _t(z, k):
+    return torch.from_numpy(z[k])
+
+
+@pytest.fixture(scope="module")
+def pieces(golden_dir):
+    return _load(golden_dir, "pieces.npz")
+
+
+def test_positional_encoding(pieces):
+    y = model_ref.scaled_positional_encoding(_sd(pieces, "pe"), "", _t(pieces, "pe/x"))
+    torch.testing.assert_close(y, _t(pieces, "pe/y"), rtol=1e-6, atol=1e-6)
+
+
+def test_encoder_prenet(pieces):
+    y = model_ref.encoder_prenet(_sd(pieces, "encpre"), "", _t(pieces, "encpre/ids"))
+    torch.testing.assert_close(y, _t(pieces, "encpre/y"), rtol=1e-5, atol=1e-5)
+
+
+def test_decoder_prenet(pieces):
+    y = model_ref.decoder_prenet(_sd(pieces, "decpre"), "", _t(pieces, "decpre/x"))
+    torch.testing.assert_close(y, _t(pieces, "decpre/y"), rtol=1e-6, atol=1e-6)
+
+
+def test_postnet(pieces):
+    y = model_ref.post_conv_net(_sd(pieces, "postnet"), "", _t(pieces, "postnet/x"), depth=2)
+    torch.testing.assert_close(y, _t(pieces, "postnet/y"), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("chunks", [5, 1])
+def test_chunked_ffn(pieces, chunks):
+    # state_dict of Chunk(WithNorm(...)) is prefixed 'fn.'; chunking must not change values
+    y = model_ref.feed_forward(_sd(pieces, "ffn"), "fn.", _t(pieces, "ffn/x"), chunks)
+    torch.testing.assert_close(y, _t(pieces, "ffn/y"), rtol=1e-5, atol=1e-6)
+
+
+def test_cross_attention(pieces):
+    y, w = model_ref.cross_attention(_sd(pieces, "xattn"), "", _t(pieces, "xattn/x"), _t(pieces, "xattn/keys"),
+                                     _t(pieces, "xattn/kpm"), heads=2)
+    torch.testing.assert_close(y, _t(pieces, "xattn/y"), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(w, _t(pieces, "xattn/w"), rtol=1e-5, atol=1e-6)
+
+
+def _ln_lin(sd, p, x):
+    return torch.nn.functional.linear(model_ref.layer_norm(sd, p + "norm.", x), sd[p + "fn.weight"], sd[p + "fn.bias"])
+
+
+def test_reversible_block_equals_residual_net(pieces):
+    """``reversible.py:46-98``: y1 = x1 + f(x2), y2 = x2 + g(y1); the reversible backward
+    must give the gradients of the plain residual network."""
+    sd = {k: v.requires_grad_() for k, v in _sd(pieces, "revblock").items()}
+    x = _t(pieces, "revblock/x").requires_grad_()
+    a, b = x.chunk(2, dim=2)
+    for i in range(2):
+        a = a + _ln_lin(sd, f"blocks.{i}.f.net.", b)
+        b = b + _ln_lin(sd, f"blocks.{i}.g.net.", a)
+    y = torch.cat([a, b], dim=2)
+    torch.testing.assert_close(y, _t(pieces, "revblock/y"), rtol=1e-6, atol=1e-6)
+    y.backward(_t(pieces, "revblock/dy"))
+    torch.testing.assert_close(x.grad, _t(pieces, "revblock/dx"), rtol=1e-5, atol=1e-6)
+    for k, v in sd.items():
+        torch.testing.assert_close(v.grad, _t(pieces, f"revblock/grad/{k}"), rtol=1e-5, atol=2e-6)
+
+
+def test_reversible_half_residual_chain(pieces):
+    """``reversible.py:134-191``: a <- a + f(b), then swap."""
+    sd = {k: v.requires_grad_() for k, v in _sd(pieces, "revhalf").items()}
+    x = _t(pieces, "revhalf/x").requires_grad_()
+    a, b = x.chunk(2, dim=2)
+    for i in range(2):
+        a = a + _ln_lin(sd, f"blocks.{2 * i}.f.net.", b)
+        a, b = b, a
+    y = torch.cat([a, b], dim=2)
+    torch.testing.assert_close(y, _t(pieces, "revhalf/y"), rtol=1e-6, atol=1e-6)
+    y.backward(_t(pieces, "revhalf/dy"))
+    torch.testing.assert_close(x.grad, _t(pieces, "revhalf/dx"), rtol=1e-5, atol=1e-6)
+    for k, v in sd.items():
+        torch.testing.assert_close(v.grad, _t(pieces, f"revhalf/grad/{k}"), rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("kind", ["mse", "l1"])
+def test_loss(pieces, kind):
+    res = model_ref.tts_loss(_t(pieces, "loss/raw"), _t(pieces, "loss/post"), _t(pieces, "loss/stop"),
+                             _t(pieces, "loss/mel"), _t(pieces, "loss/tstop"), _t(pieces, "loss/mask"),
+                             pos_weight=5.0, weights=(1.0, 0.5, 2.0), kind=kind)
+    np.testing.assert_allclose([float(r) for r in res], pieces[f"loss/{kind}"], rtol=1e-6)
+
+
+def test_pad_and_collate(pieces):
+    x = _t(pieces, "pad/x")
+    assert torch.equal(model_ref.pad_to_multiple(x, 4), _t(pieces, "pad/y4"))
+    assert torch.equal(model_ref.pad_to_multiple(x, 5), _t(pieces, "pad/y5"))   # already a multiple
+    phs = [_t(pieces, f"collate/in{i}/phonemes") for i in range(3)]
+    mels = [_t(pieces, f"collate/in{i}/spectrogram") for i in range(3)]
+    got = model_ref.collate(phs, mels)
+    for k, v in got.items():
+        assert torch.equal(v.to(_t(pieces, f"collate/out/{k}").dtype), _t(pieces, f"collate/out/{k}")), k
+
+
+def test_whole_model_wiring(golden_dir):
+    """Reference ReformerTTS + TTSLoss (LSH class = restated one) vs the functional oracle:
+    forward outputs, the four losses and every parameter-gradient norm."""
+    z = _load(golden_dir, "model_small.npz")
+    cfg = model_ref.small_cfg()
+    shapes = {k[len("shape/"):]: tuple(z[k]) for k in z.files if k.startswith("shape/")}
+    sd = {k: v.requires_grad_(v.dtype.is_floating_point and not k.endswith("inv_freq"))
+          for k, v in synth.synth_state_dict(shapes, seed=3).items()}
+    batch = {k[len("batch/"):]: _t(z, k) for k in z.files if k.startswith("batch/")}
+    rots = [_t(z, f"rot/{i}") for i in range(model_ref.count_lsh_layers(cfg))]
+    assert [tuple(r.shape) for r in rots] == model_ref.rotation_shapes(cfg, batch["phonemes"].shape[1],
+                                                                      batch["spectrogram"].shape[1] - 1)
+    spec = batch["spectrogram"]
+    raw, post, stop = model_ref.reformer_tts_forward(sd, cfg, batch["phonemes"], spec[:, :-1],
+                                                     batch["loss_mask"].mean(-1), rots)
+    torch.testing.assert_close(raw, _t(z, "out/raw"), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(post, _t(z, "out/post"), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(stop, _t(z, "out/stop"), rtol=1e-4, atol=1e-4)
+    res = model_ref.tts_loss(raw, post, stop.view(stop.shape[0], -1), spec[:, 1:], batch["stop_tokens"], batch["loss_mask"])
+    np.testing.assert_allclose([float(r.detach()) for r in res], z["out/loss"], rtol=1e-5)
+    res[0].backward()
+    for k in z.files:
+        if k.startswith("gradnorm/"):
+            name = k[len("gradnorm/"):]
+            # conv biases in front of a BatchNorm have an exactly-zero true gradient: only rounding noise there
+            np.testing.assert_allclose(float(sd[name].grad.norm()), float(z[k]), rtol=2e-4, atol=5e-5, err_msg=name)
+        if k.startswith("grad/"):
+            name = k[len("grad/"):]
+            torch.testing.assert_close(sd[name].grad, _t(z, k), rtol=2e-3, atol=1e-5, msg=name)
+
+
+def test_lsh_vectorised_vs_bruteforce():
+    """The vectorised LSH restatement against an independent float64 loop definition,
+    causal and non-causal, with a ragged padding mask."""
+    g = torch.Generator().manual_seed(0)
+    bh, t, dh, bs, nh = 2, 64, 8, 8, 3
+    qk, v = torch.randn(bh, t, dh, generator=g), torch.randn(bh, t, dh, generator=g)
+    rot = torch.randn(1, dh, nh, t // bs // 2, generator=g)
+    mask = torch.ones(bh, t, dtype=torch.bool)
+    mask[0, 50:] = False
+    for causal in (False, True):
+        for m in (None, mask):
+            out, buckets, sticker, undo = lsh_ref.lsh_attention(qk, v, rot, bs, causal, m)
+            ref, lse_tot = lsh_ref.lsh_attention_bruteforce(qk, v, sticker, bs, nh, causal, m)
+            normal = lse_tot > -1e4          # rows that can see something besides themselves
+            torch.testing.assert_close(out.double()[normal], ref[normal], rtol=1e-4, atol=1e-5)
+            torch.testing.assert_close(out.double()[~normal], ref[~normal], rtol=2e-2, atol=2e-2)
+            assert torch.equal(sticker.gather(1, undo), torch.arange(nh * t).expand(bh, -1))
+
+
+def test_lsh_integer_stages_vs_huggingface(golden_dir):
+    """Hash + stable sort against HuggingFace's implementation of the same paper
+    (per-head rotations there; ``random_rotations_per_head`` form here)."""
+    z = _load(golden_dir, "hf_lsh_int.npz")
+    for tag in ("a", "b", "c"):
+        heads, t, dh, chunk, nh = (int(x) for x in z[f"{tag}/meta"])
+        vec = torch.from_numpy(np.random.RandomState(5).standard_normal((2, heads, t, dh)).astype(np.float32))
+        rot = _t(z, f"{tag}/rot")                                   # (heads, dh, nh, nb/2)
+        qk = vec.reshape(2 * heads, t, dh)
+        rot_bh = rot.repeat(2, 1, 1, 1)                              # per batch*head row
+        buckets = lsh_ref.hash_vectors(qk, rot_bh)
+        exp = torch.from_numpy(z[f"{tag}/buckets"].astype(np.int64)).reshape(2 * heads, nh * t)
+        mism = (buckets != exp).float().mean().item()
+        assert mism < 1e-4, (tag, mism)                              # einsum order may flip exact near-ties only
+        sticker, undo = lsh_ref.sort_buckets(exp, t)
+        assert torch.equal(sticker, torch.from_numpy(z[f"{tag}/sorted_idx"].astype(np.int64)).reshape(2 * heads, -1))
+        assert torch.equal(undo, torch.from_numpy(z[f"{tag}/undo"].astype(np.int64)).reshape(2 * heads, -1))
