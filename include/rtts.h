@@ -1,0 +1,90 @@
+/*
+ * rtts.h -- C ABI of librtts_hip.so, the MI355X (gfx950) implementation of the
+ * Reformer-TTS training hot path.
+ *
+ * The reference (kowaalczyk/reformer-tts) is pure Python: it has no FFI of its
+ * own.  The seam this library plugs into is the `implementation` switch of
+ * LSHSelfAttentionWrapper (reference reformer_tts/model/reformer.py:189-220)
+ * and the reversible-block protocol (reformer_tts/model/reversible.py:46-98,
+ * 134-203); each entry point below names the reference lines whose arithmetic
+ * it replaces.  INTEGRATION.md shows the ctypes stub a maintainer adds.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - the library never allocates, frees or synchronises: outputs and
+ *     workspaces are caller-owned, launches go to the `stream` argument
+ *     (a hipStream_t passed as void*), so calls are graph-capturable;
+ *   - `bf16` buffers hold IEEE bfloat16 (uint16_t storage);
+ *   - activations of width d = H*dh are row-major with an explicit row stride
+ *     `ld` in ELEMENTS (so qk and v may be the two halves of one (B*T, 2d) GEMM
+ *     output); head h of token (b,t) starts at element (b*T+t)*ld + h*dh;
+ *   - return value 0 = launched, <0 = rejected before any launch
+ *     (rtts_last_error() gives the reason, thread-local);
+ *   - shapes supported by this build: dh == 64, bucket_size in {64,128},
+ *     T % (2*bucket_size) == 0, T <= 8192, n_hashes <= 16.
+ */
+#ifndef RTTS_H
+#define RTTS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTTS_VERSION 1
+
+int rtts_version(void);
+const char* rtts_last_error(void);
+
+/* ---- LSH attention: integer stages -------------------------------------------------
+ * Replaces hash_vectors + sort of reformer_pytorch.LSHAttention as called from
+ * reformer_tts/model/reformer.py:217.
+ *   qk        bf16 (B,T,H*dh) with row stride ld_qk
+ *   rotations f32  (rot_rows, dh, n_hashes, n_buckets/2), rot_rows = 1 (shared) or B*H
+ *   buckets   i32  (B*H, n_hashes, T)  optional (NULL to skip): bucket id incl. round offset
+ *   st        i32  (B*H, n_hashes, T)  sorted slot -> token position ("sticker % T")
+ *   undo      i32  (B*H, n_hashes, T)  optional: token -> sorted slot within its round
+ * Projection is a k-ordered fp32 fmaf chain (bit-reproducible, see oracle/lsh_int.c). */
+int rtts_lsh_hash_sort(const void* qk, int64_t ld_qk, const float* rotations, int rot_rows,
+                       int B, int H, int T, int dh, int n_hashes, int bucket_size,
+                       int32_t* buckets, int32_t* st, int32_t* undo, void* stream);
+
+/* ---- LSH attention: chunked attention forward (Appendix B steps 4-10) ----------------
+ *   qk, v  bf16 rows as above (common stride ld)
+ *   mask   u8 (B,T) 1 = valid token, or NULL
+ *   o      bf16 (B*H, n_hashes, T, dh)  per-round output, already at UNSORTED positions
+ *   lse    f32  (B*H, n_hashes, T)      per-round logsumexp of the masked logits */
+int rtts_lsh_attn_fwd(const void* qk, const void* v, int64_t ld, const int32_t* st, const uint8_t* mask,
+                      int B, int H, int T, int dh, int n_hashes, int bucket_size, int causal,
+                      void* o, float* lse, void* stream);
+
+/* ---- combine the hash rounds (step 11) and merge heads (first half of step 12) -------
+ *   out     bf16 (B,T,H*dh) row stride ld_out
+ *   lse_tot f32  (B*H, T)  logsumexp over rounds (kept for the backward) */
+int rtts_lsh_combine_fwd(const void* o, const float* lse, int B, int H, int T, int dh, int n_hashes,
+                         void* out, int64_t ld_out, float* lse_tot, void* stream);
+
+/* ---- backward of steps 4-11 ------------------------------------------------------------
+ * The rounds form ONE softmax over the multiset of (round, key) pairs, so the
+ * backward needs only lse_tot and delta = rowsum(out * dout) per (token, head):
+ *   rtts_lsh_bwd_delta : delta f32 (B*H,T) from out, dout (bf16, strides ld_out, ld_dout)
+ *   rtts_lsh_attn_bwd  : per chunk, writes bf16 partial gradients at unsorted positions
+ *        dqk_part : (3, B*H, n_hashes, T, dh)  slot 0 = query role, slot 1 = key role in the
+ *                   token's own chunk, slot 2 = key role as the looked-back chunk
+ *        dv_part  : (2, B*H, n_hashes, T, dh)  slot 0 = own chunk, slot 1 = looked-back chunk
+ *        every (slot, head, round, token) row is written exactly once: no zero-fill needed
+ *   rtts_lsh_bwd_reduce: dqk, dv bf16 (B,T,H*dh) stride ld_d = sum over slots and rounds */
+int rtts_lsh_bwd_delta(const void* out, int64_t ld_out, const void* dout, int64_t ld_dout,
+                       int B, int H, int T, int dh, float* delta, void* stream);
+int rtts_lsh_attn_bwd(const void* qk, const void* v, int64_t ld, const int32_t* st, const uint8_t* mask,
+                      const void* dout, int64_t ld_dout, const float* lse_tot, const float* delta,
+                      int B, int H, int T, int dh, int n_hashes, int bucket_size, int causal,
+                      void* dqk_part, void* dv_part, void* stream);
+int rtts_lsh_bwd_reduce(const void* dqk_part, const void* dv_part, int B, int H, int T, int dh, int n_hashes,
+                        void* dqk, void* dv, int64_t ld_d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTTS_H */

@@ -1,0 +1,54 @@
+"""ctypes binding of librtts_hip.so (C ABI declared in include/rtts.h).
+
+The product path has no CPU fallback: if the library has not been built this
+module raises, loudly, at first use."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librtts_hip.so")
+
+_i64, _i32, _vp = C.c_int64, C.c_int, C.c_void_p
+
+# name -> argtypes, exactly the prototypes of include/rtts.h
+SIGNATURES = {
+    "rtts_lsh_hash_sort": [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
+    "rtts_lsh_attn_fwd": [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "rtts_lsh_combine_fwd": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp],
+    "rtts_lsh_bwd_delta": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp],
+    "rtts_lsh_attn_bwd": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "rtts_lsh_bwd_reduce": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp],
+}
+
+_lib = None
+
+
+class RttsError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RttsError(
+                f"{LIB_PATH} is missing: build it with `python reformer-tts_amd/build.py` "
+                "(or __graft_entry__.build()). There is no CPU fallback for the HIP path.")
+        lib = C.CDLL(LIB_PATH)
+        lib.rtts_version.restype = C.c_int
+        lib.rtts_last_error.restype = C.c_char_p
+        for name, args in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        _lib = lib
+    return _lib
+
+
+def call(name: str, *args) -> None:
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RttsError(lib.rtts_last_error().decode() or f"{name} failed with code {rc}")

@@ -1,0 +1,348 @@
+// LSH chunked attention backward: one workgroup per (batch*head, sorted chunk).
+//
+// Backward of SURVEY.md Appendix B steps 4-11 (the reference gets it from autograd over
+// reformer_pytorch's eager graph, reached from reformer_tts/model/reversible.py:69-85).
+// The n_hashes rounds form ONE softmax over the multiset of (round, key) pairs:
+//     out[q] = sum_{r,k} exp(s_rqk - LSE[q]) v[k],   LSE = logsumexp over rounds and keys,
+// so with P' = exp(s - LSE) and delta[q] = out[q].dout[q]:
+//     dV[k] += P'^T dout      dS = P' * (dout V^T - delta)   (0 where the logit was replaced
+//     by the self constant)   dQ = (dS * kscale) K     G = dS^T Q,   dK = kscale (G - k^ (k^.G))
+// where kscale[k] = dh^-1/2 / |k| is the key normalisation folded into the logits.
+//
+// Layout: KEY ON THE LANE.  Wave w owns keys [64w, 64w+64) of the chunk's 2*BS keys for all BS
+// queries: S and dP come out of the MFMA as [query rows in registers][key on lane], which IS the
+// B operand of the dV^T and G^T products (contraction over the register/row index), so dV and dK
+// of a key are complete inside one wave, in registers.  Only dS crosses LDS, once, as dS^T, for
+// dQ^T = K^T dS'^T (wave w finishes query tile w).  Nothing is accumulated across workgroups:
+// each workgroup writes its rows of three dqk slots / two dv slots at UNSORTED positions
+// (slot 0: query role, slot 1: key role own chunk, slot 2: key role looked-back chunk) and
+// rtts_lsh_bwd_reduce sums slots and rounds -- deterministic, no atomics.
+#include "rtts_common.h"
+#include <float.h>
+
+#define AB_DH 64
+#define AB_ROWB 144
+
+typedef __attribute__((ext_vector_type(8))) short short8v;
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0, const unsigned char* p1) {
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((RTTS_LDS short4v*)p0);
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((RTTS_LDS short4v*)p1);
+    const short8v both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, both);
+}
+
+template <int BS, bool CAUSAL, bool MASKED>
+__global__ __launch_bounds__(BS * 2) void lsh_attn_bwd_kernel(
+    const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v, int64_t ld, const int32_t* __restrict__ st,
+    const uint8_t* __restrict__ mask, const bf16_t* __restrict__ dout, int64_t ld_do, const float* __restrict__ lse_tot,
+    const float* __restrict__ delta, int H, int T, int n_hashes, bf16_t* __restrict__ dqk_part, bf16_t* __restrict__ dv_part,
+    size_t slot_stride) {
+    constexpr int NK = 2 * BS;
+    constexpr int NQT = BS / 32;
+    constexpr int NTHR = BS * 2;
+    constexpr int DSROW = BS * 2 + 16;   // bytes per row of the dS^T image [key][query]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Ks = smem;                                  // [NK][144]  qk rows (own chunk first)
+    unsigned char* Os = Ks + NK * AB_ROWB;                     // [BS][144]  dout rows of the queries
+    unsigned char* Ds = Os + BS * AB_ROWB;                     // [NK][DSROW] dS'^T
+    float* kscale = reinterpret_cast<float*>(Ds + NK * DSROW);
+    int* kpos = reinterpret_cast<int*>(kscale + NK);
+    int* kval = kpos + NK;
+    float* qlse = reinterpret_cast<float*>(kval + NK);
+    float* qdel = qlse + BS;
+
+    const int nb = T / BS;
+    const int C = n_hashes * nb;
+    const uint32_t wi = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = wi / C, c = wi % C;
+    const int b = bh / H, h = bh % H;
+    const int cprev = (c == 0) ? C - 1 : c - 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+
+    const int32_t* st_row = st + (size_t)bh * n_hashes * T;
+    const bf16_t* qbase = qk + (size_t)b * T * ld + (size_t)h * AB_DH;
+    const bf16_t* vbase = v + (size_t)b * T * ld + (size_t)h * AB_DH;
+    const bf16_t* dobase = dout + (size_t)b * T * ld_do + (size_t)h * AB_DH;
+
+    // ---- gather K rows (all 2*BS) and dout rows (own chunk) into LDS -----------------------
+    constexpr int ITERS = NK * 8 / NTHR;   // 8
+    int trow[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int row = (it * NTHR + tid) >> 3;
+        const int slot = (row < BS) ? c * BS + row : cprev * BS + (row - BS);
+        trow[it] = st_row[slot];
+    }
+    uint4 kreg[ITERS], oreg[ITERS / 2];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) kreg[it] = *reinterpret_cast<const uint4*>(qbase + (size_t)trow[it] * ld + (tid & 7) * 8);
+#pragma unroll
+    for (int it = 0; it < ITERS / 2; ++it)   // rows < BS are the first half of the iterations
+        oreg[it] = *reinterpret_cast<const uint4*>(dobase + (size_t)trow[it] * ld_do + (tid & 7) * 8);
+    // V fragments of this wave's 64 keys go straight to registers (no other wave needs them)
+    const int myrow[2] = {wave * 64 + r, wave * 64 + 32 + r};
+    bf16x8 vf[2][4];
+    int mypos[2];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+        const int row = myrow[k2];
+        const int slot = (row < BS) ? c * BS + row : cprev * BS + (row - BS);
+        mypos[k2] = st_row[slot];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            vf[k2][ks] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)mypos[k2] * ld + ks * 16 + 8 * hh);
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int row = (it * NTHR + tid) >> 3, piece = tid & 7;
+        *reinterpret_cast<uint4*>(Ks + row * AB_ROWB + piece * 16) = kreg[it];
+        if (it < ITERS / 2) *reinterpret_cast<uint4*>(Os + row * AB_ROWB + piece * 16) = oreg[it];
+        const uint32_t u[4] = {kreg[it].x, kreg[it].y, kreg[it].z, kreg[it].w};
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a = __uint_as_float(u[k] << 16), bq = __uint_as_float(u[k] & 0xffff0000u);
+            ss = __builtin_fmaf(a, a, ss);
+            ss = __builtin_fmaf(bq, bq, ss);
+        }
+        ss += __shfl_xor(ss, 1);
+        ss += __shfl_xor(ss, 2);
+        ss += __shfl_xor(ss, 4);
+        if (piece == 0) {
+            kscale[row] = 0.125f / fmaxf(sqrtf(ss), 1e-12f);
+            kpos[row] = trow[it];
+            kval[row] = MASKED ? (int)mask[(size_t)b * T + trow[it]] : 1;
+            if (row < BS) {
+                qlse[row] = lse_tot[(size_t)bh * T + trow[it]];
+                qdel[row] = delta[(size_t)bh * T + trow[it]];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- this wave's key-side constants -----------------------------------------------------
+    bf16x8 kf[2][4];
+    float ksc[2];
+    int kvl[2];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            kf[k2][ks] = *reinterpret_cast<const bf16x8*>(Ks + myrow[k2] * AB_ROWB + (ks * 16 + 8 * hh) * 2);
+        ksc[k2] = kscale[myrow[k2]];
+        kvl[k2] = kval[myrow[k2]];
+    }
+
+    f32x16 dvacc[2][2], gacc[2][2];   // [key tile][dh tile]: rows = dh, lane = key
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            dvacc[a][d] = (f32x16){0};
+            gacc[a][d] = (f32x16){0};
+        }
+    const int trq = (lane & 15) >> 2, trp = lane & 3, trc = (lane >> 4) & 1;
+
+#pragma unroll 1
+    for (int qt = 0; qt < NQT; ++qt) {
+        bf16x8 qf[4], dof[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks] = *reinterpret_cast<const bf16x8*>(Ks + (qt * 32 + r) * AB_ROWB + (ks * 16 + 8 * hh) * 2);
+            dof[ks] = *reinterpret_cast<const bf16x8*>(Os + (qt * 32 + r) * AB_ROWB + (ks * 16 + 8 * hh) * 2);
+        }
+        // A fragments of the transposed products: element j <-> query 16*s2 + 8*(j>>2) + 4*hh + (j&3)
+        bf16x8 qtf[2][2], dotf[2][2];   // [s2][dh tile]
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int qb = qt * 32 + 16 * s2 + 4 * hh + trq;
+                const int col = (dt * 32 + 16 * trc + 4 * trp) * 2;
+                qtf[s2][dt] = tr_frag(Ks + qb * AB_ROWB + col, Ks + (qb + 8) * AB_ROWB + col);
+                dotf[s2][dt] = tr_frag(Os + qb * AB_ROWB + col, Os + (qb + 8) * AB_ROWB + col);
+            }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            f32x16 sacc = {0}, pacc = {0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[k2][ks], sacc, 0, 0, 0);    // S[q][key]
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof[ks], vf[k2][ks], pacc, 0, 0, 0);   // dP[q][key]
+            }
+            float pp[16], ds[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int q0 = qt * 32 + 8 * g + 4 * hh;
+                const float4 l4 = *reinterpret_cast<const float4*>(qlse + q0);
+                const float4 d4 = *reinterpret_cast<const float4*>(qdel + q0);
+                const int4 p4 = *reinterpret_cast<const int4*>(kpos + q0);
+                const int4 v4 = *reinterpret_cast<const int4*>(kval + q0);
+                const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv_[4] = {d4.x, d4.y, d4.z, d4.w};
+                const int pv[4] = {p4.x, p4.y, p4.z, p4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = 4 * g + j;
+                    const bool self = pv[j] == mypos[k2];
+                    bool dead = false;
+                    if (MASKED) dead = !(vv[j] && kvl[k2]);
+                    if (CAUSAL) dead = dead || (pv[j] < mypos[k2]);
+                    float x = sacc[i] * ksc[k2];
+                    if (self) x = -5e4f;
+                    const float p = (dead && !self) ? 0.f : __expf(x - lv[j]);
+                    pp[i] = p;
+                    ds[i] = self ? 0.f : p * (pacc[i] - dv_[j]);
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 pb, db;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    pb[j] = (__bf16)pp[8 * s2 + j];
+                    db[j] = (__bf16)ds[8 * s2 + j];
+                }
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dvacc[k2][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[s2][dt], pb, dvacc[k2][dt], 0, 0, 0);
+                    gacc[k2][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[s2][dt], db, gacc[k2][dt], 0, 0, 0);
+                }
+            }
+            // dS'^T[key][q] = dS * kscale[key]  (bf16), 4 consecutive queries per 8-byte store
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 pk;
+                pk.x = pack_bf16x2(ds[4 * g] * ksc[k2], ds[4 * g + 1] * ksc[k2]);
+                pk.y = pack_bf16x2(ds[4 * g + 2] * ksc[k2], ds[4 * g + 3] * ksc[k2]);
+                *reinterpret_cast<uint2*>(Ds + myrow[k2] * DSROW + (qt * 32 + 8 * g + 4 * hh) * 2) = pk;
+            }
+        }
+    }
+
+    // ---- key-side outputs: dV and dK of this wave's 64 keys -----------------------------------
+    const int round = c / nb, round_prev = cprev / nb;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+        const bool own = myrow[k2] < BS;   // wave-uniform
+        const size_t orow = ((size_t)bh * n_hashes + (own ? round : round_prev)) * T + mypos[k2];
+        bf16_t* dvp = dv_part + (own ? 0 : slot_stride) + orow * AB_DH;
+        bf16_t* dkp = dqk_part + (own ? slot_stride : 2 * slot_stride) + orow * AB_DH;
+        // k^ . G over the 64 dh (this lane holds 32 of them, the partner half the other 32)
+        float kv_[2][16];
+        float dot = 0.f;
+        const float inv_norm = ksc[k2] * 8.f;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint2 kk = *reinterpret_cast<const uint2*>(Ks + myrow[k2] * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2);
+                kv_[dt][4 * g] = __uint_as_float(kk.x << 16) * inv_norm;
+                kv_[dt][4 * g + 1] = __uint_as_float(kk.x & 0xffff0000u) * inv_norm;
+                kv_[dt][4 * g + 2] = __uint_as_float(kk.y << 16) * inv_norm;
+                kv_[dt][4 * g + 3] = __uint_as_float(kk.y & 0xffff0000u) * inv_norm;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dot = __builtin_fmaf(kv_[dt][4 * g + j], gacc[k2][dt][4 * g + j], dot);
+            }
+        dot += __shfl_xor(dot, 32);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float dk[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dk[j] = ksc[k2] * (gacc[k2][dt][4 * g + j] - kv_[dt][4 * g + j] * dot);
+                uint2 pk;
+                pk.x = pack_bf16x2(dk[0], dk[1]);
+                pk.y = pack_bf16x2(dk[2], dk[3]);
+                *reinterpret_cast<uint2*>(dkp + dt * 32 + 8 * g + 4 * hh) = pk;
+                pk.x = pack_bf16x2(dvacc[k2][dt][4 * g], dvacc[k2][dt][4 * g + 1]);
+                pk.y = pack_bf16x2(dvacc[k2][dt][4 * g + 2], dvacc[k2][dt][4 * g + 3]);
+                *reinterpret_cast<uint2*>(dvp + dt * 32 + 8 * g + 4 * hh) = pk;
+            }
+    }
+    __syncthreads();
+
+    // ---- dQ^T[dh][q] = K^T dS'^T : wave w finishes query tile w over all 2*BS keys --------------
+    {
+        const int qt = wave;
+        f32x16 dq[2] = {{0}, {0}};
+#pragma unroll 4
+        for (int kb = 0; kb < NK; kb += 16) {
+            const int keyr = kb + 8 * hh + trq;
+            const int qcol = (qt * 32 + 16 * trc + 4 * trp) * 2;
+            const bf16x8 bfrag = tr_frag(Ds + keyr * DSROW + qcol, Ds + (keyr + 4) * DSROW + qcol);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int col = (dt * 32 + 16 * trc + 4 * trp) * 2;
+                const bf16x8 afrag = tr_frag(Ks + keyr * AB_ROWB + col, Ks + (keyr + 4) * AB_ROWB + col);
+                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, dq[dt], 0, 0, 0);
+            }
+        }
+        const int qpos = kpos[qt * 32 + r];
+        bf16_t* dqp = dqk_part + (((size_t)bh * n_hashes + round) * T + qpos) * AB_DH;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 pk;
+                pk.x = pack_bf16x2(dq[dt][4 * g], dq[dt][4 * g + 1]);
+                pk.y = pack_bf16x2(dq[dt][4 * g + 2], dq[dt][4 * g + 3]);
+                *reinterpret_cast<uint2*>(dqp + dt * 32 + 8 * g + 4 * hh) = pk;
+            }
+    }
+}
+
+static bool g_bwd_attr_set[2][4];
+
+template <int BS>
+static int launch_attn_bwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const int32_t* st, const uint8_t* mask,
+                           const bf16_t* dout, int64_t ld_do, const float* lse_tot, const float* delta, int B, int H, int T,
+                           int n_hashes, int causal, bf16_t* dqk_part, bf16_t* dv_part, hipStream_t stream) {
+    constexpr int NK = 2 * BS;
+    const size_t lds = NK * AB_ROWB + BS * AB_ROWB + NK * (BS * 2 + 16) + NK * 12 + BS * 8;
+    const dim3 grid(B * H * n_hashes * (T / BS)), block(BS * 2);
+    const size_t slot_stride = (size_t)B * H * n_hashes * T * AB_DH;
+    const int vi = (causal ? 2 : 0) + (mask ? 1 : 0);
+#define AB_GO(C_, M_)                                                                                                      \
+    do {                                                                                                                   \
+        auto kern = lsh_attn_bwd_kernel<BS, C_, M_>;                                                                       \
+        if (!g_bwd_attr_set[BS == 128][vi]) {                                                                              \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            g_bwd_attr_set[BS == 128][vi] = true;                                                                          \
+        }                                                                                                                  \
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, qk, v, ld, st, mask, dout, ld_do, lse_tot, delta, H, T, n_hashes, \
+                           dqk_part, dv_part, slot_stride);                                                                \
+    } while (0)
+    if (causal) {
+        if (mask) AB_GO(true, true); else AB_GO(true, false);
+    } else {
+        if (mask) AB_GO(false, true); else AB_GO(false, false);
+    }
+#undef AB_GO
+    RTTS_LAUNCH_CHECK("rtts_lsh_attn_bwd");
+    return 0;
+}
+
+extern "C" int rtts_lsh_attn_bwd(const void* qk, const void* v, int64_t ld, const int32_t* st, const uint8_t* mask,
+                                 const void* dout, int64_t ld_dout, const float* lse_tot, const float* delta, int B, int H,
+                                 int T, int dh, int n_hashes, int bucket_size, int causal, void* dqk_part, void* dv_part,
+                                 void* stream) {
+    RTTS_REQUIRE(qk && v && st && dout && lse_tot && delta && dqk_part && dv_part, "rtts_lsh_attn_bwd: null pointer");
+    RTTS_REQUIRE(dh == AB_DH, "rtts_lsh_attn_bwd: dh=%d unsupported (this build: 64)", dh);
+    RTTS_REQUIRE(bucket_size == 64 || bucket_size == 128, "rtts_lsh_attn_bwd: bucket_size=%d unsupported (64 or 128)", bucket_size);
+    RTTS_REQUIRE(T > 0 && T % (2 * bucket_size) == 0,
+                 "rtts_lsh_attn_bwd: Sequence length (%d) needs to be divisible by target bucket size x 2 - %d", T, 2 * bucket_size);
+    RTTS_REQUIRE(B > 0 && H > 0 && n_hashes > 0, "rtts_lsh_attn_bwd: bad B/H/n_hashes");
+    RTTS_REQUIRE(ld >= (int64_t)H * dh && ld % 8 == 0 && ld_dout >= (int64_t)H * dh && ld_dout % 8 == 0,
+                 "rtts_lsh_attn_bwd: row strides must be >= H*dh and multiples of 8");
+    RTTS_REQUIRE((((uintptr_t)qk | (uintptr_t)v | (uintptr_t)dout | (uintptr_t)dqk_part | (uintptr_t)dv_part) & 15) == 0,
+                 "rtts_lsh_attn_bwd: buffers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    if (bucket_size == 64)
+        return launch_attn_bwd<64>((const bf16_t*)qk, (const bf16_t*)v, ld, st, mask, (const bf16_t*)dout, ld_dout, lse_tot, delta,
+                                   B, H, T, n_hashes, causal, (bf16_t*)dqk_part, (bf16_t*)dv_part, s);
+    return launch_attn_bwd<128>((const bf16_t*)qk, (const bf16_t*)v, ld, st, mask, (const bf16_t*)dout, ld_dout, lse_tot, delta, B,
+                                H, T, n_hashes, causal, (bf16_t*)dqk_part, (bf16_t*)dv_part, s);
+}

@@ -1,0 +1,234 @@
+// LSH chunked attention forward: one workgroup per (batch*head, sorted chunk).
+//
+// Replaces the gather / look-one-back / dots / mask / softmax / PV / unsort block of the
+// reference's LSH layer (reformer_pytorch 0.19.1 via reformer_tts/model/reformer.py:217;
+// SURVEY.md Appendix B steps 4-10) without materialising dots, masks or sorted copies.
+//
+// Per workgroup (BS = bucket size, NK = 2*BS keys = own chunk + previous chunk):
+//   1. gather the NK qk rows and NK v rows (128 B each, coalesced 16-B pieces) by `st`
+//      straight into LDS; while a row passes through registers its L2 norm is reduced, so the
+//      key normalisation becomes a per-key scale applied to the logits (never rounded to bf16);
+//   2. wave w owns queries [32w, 32w+32): S^T = K Q^T with v_mfma_f32_32x32x16_bf16, so a lane
+//      holds one query column and the softmax row-reduction stays in registers (+1 cross-half);
+//   3. masks in the reference's order (padding, causal, self=-5e4), exact row max, exp;
+//   4. O^T = V^T P^T: the P^T accumulators are the B operand as they stand (rows of X are the
+//      contraction index), V^T fragments come from the row-major V image by ds_read_b64_tr_b16;
+//   5. rows of o and lse are written directly at their UNSORTED position (round, t).
+#include "rtts_common.h"
+#include <float.h>
+
+#define AF_DH 64
+#define AF_ROWB 144   // LDS row stride (bytes): 128 B of bf16 + 16 B pad => conflict-free ds_read_b128
+
+template <int BS, bool CAUSAL, bool MASKED>
+__global__ __launch_bounds__(BS * 2) void lsh_attn_fwd_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v,
+                                                              int64_t ld, const int32_t* __restrict__ st,
+                                                              const uint8_t* __restrict__ mask, int H, int T, int n_hashes,
+                                                              bf16_t* __restrict__ o, float* __restrict__ lse) {
+    constexpr int NK = 2 * BS;
+    constexpr int NKT = NK / 32;
+    constexpr int NTHR = BS * 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Ks = smem;
+    unsigned char* Vs = Ks + NK * AF_ROWB;
+    float* kscale = reinterpret_cast<float*>(Vs + NK * AF_ROWB);
+    int* kpos = reinterpret_cast<int*>(kscale + NK);
+    int* kval = kpos + NK;
+
+    const int nb = T / BS;
+    const int C = n_hashes * nb;
+    const uint32_t wi = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = wi / C, c = wi % C;
+    const int b = bh / H, h = bh % H;
+    const int cprev = (c == 0) ? C - 1 : c - 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    const int32_t* st_row = st + (size_t)bh * n_hashes * T;
+    const bf16_t* qbase = qk + (size_t)b * T * ld + (size_t)h * AF_DH;
+    const bf16_t* vbase = v + (size_t)b * T * ld + (size_t)h * AF_DH;
+
+    // ---- 1. gather -------------------------------------------------------------------
+    constexpr int ITERS = NK * 8 / NTHR;   // = 8
+    int trow[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int row = (it * NTHR + tid) >> 3;
+        const int slot = (row < BS) ? c * BS + row : cprev * BS + (row - BS);
+        trow[it] = st_row[slot];
+    }
+    uint4 kreg[ITERS], vreg[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int piece = tid & 7;
+        kreg[it] = *reinterpret_cast<const uint4*>(qbase + (size_t)trow[it] * ld + piece * 8);
+        vreg[it] = *reinterpret_cast<const uint4*>(vbase + (size_t)trow[it] * ld + piece * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int row = (it * NTHR + tid) >> 3, piece = tid & 7;
+        *reinterpret_cast<uint4*>(Ks + row * AF_ROWB + piece * 16) = kreg[it];
+        *reinterpret_cast<uint4*>(Vs + row * AF_ROWB + piece * 16) = vreg[it];
+        const uint32_t u[4] = {kreg[it].x, kreg[it].y, kreg[it].z, kreg[it].w};
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a = __uint_as_float(u[k] << 16), bq = __uint_as_float(u[k] & 0xffff0000u);
+            ss = __builtin_fmaf(a, a, ss);
+            ss = __builtin_fmaf(bq, bq, ss);
+        }
+        ss += __shfl_xor(ss, 1);
+        ss += __shfl_xor(ss, 2);
+        ss += __shfl_xor(ss, 4);
+        if (piece == 0) {
+            kscale[row] = 0.125f / fmaxf(sqrtf(ss), 1e-12f);   // dh^-1/2 / max(|k|, eps)
+            kpos[row] = trow[it];
+            kval[row] = MASKED ? (int)mask[(size_t)b * T + trow[it]] : 1;
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. S^T = K Q^T ----------------------------------------------------------------
+    const int r = lane & 31, hh = lane >> 5;
+    const int qrow = wave * 32 + r;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Ks + qrow * AF_ROWB + (ks * 16 + 8 * hh) * 2);
+    f32x16 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        f32x16 acc = {0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + r) * AF_ROWB + (ks * 16 + 8 * hh) * 2);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc, 0, 0, 0);
+        }
+        s[kt] = acc;
+    }
+
+    // ---- 3. masks + softmax (lane = query, registers = keys) ------------------------------
+    const int qpos = kpos[qrow];
+    const int qval = kval[qrow];
+    float m = -FLT_MAX;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int key0 = kt * 32 + 8 * g + 4 * hh;
+            const float4 sc = *reinterpret_cast<const float4*>(kscale + key0);
+            const int4 kp = *reinterpret_cast<const int4*>(kpos + key0);
+            const int4 kv = *reinterpret_cast<const int4*>(kval + key0);
+            const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
+            const int kpv[4] = {kp.x, kp.y, kp.z, kp.w};
+            const int kvv[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = s[kt][4 * g + j] * scv[j];
+                if (MASKED && !(qval && kvv[j])) x = -FLT_MAX;
+                if (CAUSAL && qpos < kpv[j]) x = -FLT_MAX;
+                if (qpos == kpv[j]) x = -5e4f;
+                s[kt][4 * g + j] = x;
+                m = fmaxf(m, x);
+            }
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float p = __expf(s[kt][i] - m);
+            s[kt][i] = p;
+            l += p;
+        }
+    }
+    l += __shfl_xor(l, 32);
+
+    // ---- 4. O^T = V^T P^T ----------------------------------------------------------------
+    f32x16 oacc[2] = {{0}, {0}};
+    const int trq = (lane & 15) >> 2, trp = lane & 3, trc = (lane >> 4) & 1;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[kt][8 * s2 + j];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int keyb = kt * 32 + 16 * s2 + 4 * hh + trq;
+                const int col = dt * 32 + 16 * trc + 4 * trp;
+                const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (RTTS_LDS short4v*)(Vs + keyb * AF_ROWB + col * 2));
+                const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (RTTS_LDS short4v*)(Vs + (keyb + 8) * AF_ROWB + col * 2));
+                typedef __attribute__((ext_vector_type(8))) short short8v;
+                const short8v both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- 5. write o, lse at the unsorted position ------------------------------------------
+    const int round = c / nb;
+    const float inv_l = 1.f / l;
+    const size_t orow = ((size_t)bh * n_hashes + round) * T + qpos;
+    bf16_t* optr = o + orow * AF_DH;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 pk;
+            pk.x = pack_bf16x2(oacc[dt][4 * g] * inv_l, oacc[dt][4 * g + 1] * inv_l);
+            pk.y = pack_bf16x2(oacc[dt][4 * g + 2] * inv_l, oacc[dt][4 * g + 3] * inv_l);
+            *reinterpret_cast<uint2*>(optr + dt * 32 + 8 * g + 4 * hh) = pk;
+        }
+    }
+    if (hh == 0) lse[orow] = m + logf(l);
+}
+
+static bool g_fwd_attr_set[2][4];
+
+template <int BS>
+static int launch_attn_fwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const int32_t* st, const uint8_t* mask, int B, int H,
+                           int T, int n_hashes, int causal, bf16_t* o, float* lse, hipStream_t stream) {
+    constexpr int NK = 2 * BS;
+    const size_t lds = 2 * NK * AF_ROWB + NK * 12;
+    const dim3 grid(B * H * n_hashes * (T / BS)), block(BS * 2);
+    const int vi = (causal ? 2 : 0) + (mask ? 1 : 0);
+#define AF_GO(C_, M_)                                                                                                      \
+    do {                                                                                                                   \
+        auto kern = lsh_attn_fwd_kernel<BS, C_, M_>;                                                                       \
+        if (!g_fwd_attr_set[BS == 128][vi]) {                                                                              \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            g_fwd_attr_set[BS == 128][vi] = true;                                                                          \
+        }                                                                                                                  \
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, qk, v, ld, st, mask, H, T, n_hashes, o, lse);                   \
+    } while (0)
+    if (causal) {
+        if (mask) AF_GO(true, true); else AF_GO(true, false);
+    } else {
+        if (mask) AF_GO(false, true); else AF_GO(false, false);
+    }
+#undef AF_GO
+    RTTS_LAUNCH_CHECK("rtts_lsh_attn_fwd");
+    return 0;
+}
+
+extern "C" int rtts_lsh_attn_fwd(const void* qk, const void* v, int64_t ld, const int32_t* st, const uint8_t* mask, int B,
+                                 int H, int T, int dh, int n_hashes, int bucket_size, int causal, void* o, float* lse,
+                                 void* stream) {
+    RTTS_REQUIRE(qk && v && st && o && lse, "rtts_lsh_attn_fwd: null pointer");
+    RTTS_REQUIRE(dh == AF_DH, "rtts_lsh_attn_fwd: dh=%d unsupported (this build: 64)", dh);
+    RTTS_REQUIRE(bucket_size == 64 || bucket_size == 128, "rtts_lsh_attn_fwd: bucket_size=%d unsupported (64 or 128)", bucket_size);
+    RTTS_REQUIRE(T > 0 && T % (2 * bucket_size) == 0,
+                 "rtts_lsh_attn_fwd: Sequence length (%d) needs to be divisible by target bucket size x 2 - %d", T, 2 * bucket_size);
+    RTTS_REQUIRE(B > 0 && H > 0 && n_hashes > 0, "rtts_lsh_attn_fwd: bad B/H/n_hashes");
+    RTTS_REQUIRE(ld >= (int64_t)H * dh && ld % 8 == 0, "rtts_lsh_attn_fwd: ld must be >= H*dh and a multiple of 8");
+    RTTS_REQUIRE((((uintptr_t)qk | (uintptr_t)v | (uintptr_t)o) & 15) == 0, "rtts_lsh_attn_fwd: qk, v, o must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    if (bucket_size == 64)
+        return launch_attn_fwd<64>((const bf16_t*)qk, (const bf16_t*)v, ld, st, mask, B, H, T, n_hashes, causal, (bf16_t*)o, lse, s);
+    return launch_attn_fwd<128>((const bf16_t*)qk, (const bf16_t*)v, ld, st, mask, B, H, T, n_hashes, causal, (bf16_t*)o, lse, s);
+}

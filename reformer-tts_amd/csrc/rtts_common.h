@@ -1,0 +1,56 @@
+// Shared helpers for the gfx950 kernels of librtts_hip.so (CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/rtts.h"
+
+typedef uint16_t bf16_t;  // storage type of a bfloat16
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;   // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short short4v;
+typedef __attribute__((ext_vector_type(16))) float f32x16;    // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define RTTS_LDS __attribute__((address_space(3)))
+
+extern "C" void rtts_set_error(const char* fmt, ...);
+
+#define RTTS_REQUIRE(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            rtts_set_error(__VA_ARGS__);   \
+            return -1;                     \
+        }                                  \
+    } while (0)
+
+#define RTTS_LAUNCH_CHECK(name)                                              \
+    do {                                                                     \
+        hipError_t e_ = hipGetLastError();                                   \
+        if (e_ != hipSuccess) {                                              \
+            rtts_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return -2;                                                       \
+        }                                                                    \
+    } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
+
+// round-to-nearest-even; the plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN
+__device__ __forceinline__ bf16_t f32_to_bf16(float x) {
+    __bf16 b = (__bf16)x;
+    return __builtin_bit_cast(bf16_t, b);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// XCD-aware bijective remap of a linear workgroup id: the hardware deals workgroups
+// round-robin over the 8 XCDs, so ids congruent mod 8 share an L2.  Give each XCD a
+// contiguous range of work items so that neighbours (which share gathered rows) hit in L2.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t id, uint32_t n) {
+    const uint32_t q = n >> 3, r = n & 7u, x = id & 7u, i = id >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}

@@ -1,0 +1,214 @@
+"""GPU parity of the LSH attention kernels (through the C ABI) against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lsh_int, lsh_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from reformer_tts_amd import ops as _ops
+    return _ops
+
+
+def _heads_first(x, b, t, h, dh):
+    """(B,T,H*dh) -> (B*H,T,dh) float32 on the CPU."""
+    return x.float().cpu().view(b, t, h, dh).transpose(1, 2).reshape(b * h, t, dh)
+
+
+def _make_qkv(b, t, h, dh, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(b, t, 2 * h * dh, generator=g) * scale).bfloat16()
+
+
+def _flat_perm(st_cpu):
+    bh, nh, t = st_cpu.shape
+    sticker = (st_cpu.long() + (torch.arange(nh) * t).view(1, nh, 1)).reshape(bh, nh * t)
+    undo = torch.empty_like(sticker)
+    undo.scatter_(1, sticker, torch.arange(nh * t).expand(bh, -1))
+    return sticker, undo
+
+
+# ------------------------------------------------------------------ integer stages: bit-exact
+@pytest.mark.parametrize("b,h,t,bs,nh,per_head", [
+    (2, 2, 128, 64, 4, False), (2, 3, 256, 64, 8, True), (2, 8, 1024, 128, 8, False),
+    (1, 2, 1024, 64, 8, False), (1, 2, 4096, 64, 8, False), (1, 1, 2048, 128, 3, True),
+])
+def test_hash_sort_bit_exact(ops, b, h, t, bs, nh, per_head):
+    dh = 64
+    qkv = _make_qkv(b, t, h, dh, seed=t + nh)
+    g = torch.Generator().manual_seed(1)
+    rot = torch.randn(b * h if per_head else 1, dh, nh, t // bs // 2, generator=g)
+    qkv_d = qkv.cuda()
+    st, buckets, undo = ops.lsh_hash_sort(qkv_d[..., :h * dh], rot.cuda(), h, bs, want_buckets=True, want_undo=True)
+    torch.cuda.synchronize()
+    qk = _heads_first(qkv[..., :h * dh], b, t, h, dh)
+    exp_b = lsh_int.hash_buckets(qk.numpy(), rot.numpy())
+    assert np.array_equal(buckets.cpu().numpy(), exp_b)
+    exp_st, exp_undo = lsh_int.sort_buckets(exp_b, t // bs)
+    assert np.array_equal(st.cpu().numpy(), exp_st)
+    assert np.array_equal(undo.cpu().numpy(), exp_undo)
+
+
+def test_hash_sort_vs_huggingface_fixture(ops, golden_dir):
+    z = np.load(os.path.join(golden_dir, "hf_lsh_int.npz"))
+    for tag in ("a", "b", "c"):
+        heads, t, dh, chunk, nh = (int(x) for x in z[f"{tag}/meta"])
+        vec = torch.from_numpy(np.random.RandomState(5).standard_normal((2, heads, t, dh)).astype(np.float32))
+        vec_bf = vec.bfloat16()
+        qk = vec_bf.transpose(1, 2).reshape(2, t, heads * dh).contiguous()
+        rot = torch.from_numpy(np.tile(z[f"{tag}/rot"], (2, 1, 1, 1)))
+        st, buckets, _ = ops.lsh_hash_sort(qk.cuda(), rot.cuda(), heads, chunk, want_buckets=True)
+        exp = z[f"{tag}/buckets"].astype(np.int32).reshape(2 * heads, nh, t)
+        # the fixture hashed fp32 vectors; bf16 rounding of the input may move near-ties only
+        assert (buckets.cpu().numpy() != exp).mean() < 2e-2, tag
+        exp_st, _ = lsh_int.sort_buckets(buckets.cpu().numpy(), t // chunk)
+        assert np.array_equal(st.cpu().numpy(), exp_st), tag
+
+
+def test_hash_sort_rejects_bad_length(ops):
+    qk = torch.zeros(1, 192, 128, dtype=torch.bfloat16, device="cuda")
+    rot = torch.zeros(1, 64, 2, 1, device="cuda")
+    with pytest.raises(AssertionError, match="divisible by target bucket size"):
+        ops.lsh_hash_sort(qk, rot, 2, 64)
+
+
+# ------------------------------------------------------------------ attention forward
+CASES = [
+    # b, h, t, bs, nh, causal, masked
+    (2, 2, 128, 64, 4, False, False),
+    (2, 2, 256, 64, 4, True, True),
+    (1, 3, 512, 128, 2, True, False),
+    (2, 2, 512, 128, 8, False, True),
+    (1, 8, 1024, 128, 8, True, True),
+]
+
+
+def _run_fwd(ops, b, h, t, bs, nh, causal, masked, seed=0):
+    dh = 64
+    qkv = _make_qkv(b, t, h, dh, seed=seed + t)
+    g = torch.Generator().manual_seed(seed + 7)
+    rot = torch.randn(1, dh, nh, t // bs // 2, generator=g)
+    mask = None
+    if masked:
+        mask = torch.ones(b, t, dtype=torch.bool)
+        mask[0, t - t // 3:] = False
+        if b > 1:
+            mask[1, t // 2:] = False
+    qkv_d = qkv.cuda()
+    qk_d, v_d = qkv_d[..., :h * dh], qkv_d[..., h * dh:]
+    st, _, _ = ops.lsh_hash_sort(qk_d, rot.cuda(), h, bs)
+    o, lse = ops.lsh_attn_fwd(qk_d, v_d, st, h, bs, causal, None if mask is None else mask.cuda())
+    out, lse_tot = ops.lsh_combine_fwd(o, lse, b, h)
+    torch.cuda.synchronize()
+    return dict(qkv=qkv, qk_d=qk_d, v_d=v_d, st=st, o=o, lse=lse, out=out, lse_tot=lse_tot, mask=mask, dh=dh)
+
+
+@pytest.mark.parametrize("b,h,t,bs,nh,causal,masked", CASES)
+def test_attention_forward_vs_oracle(ops, b, h, t, bs, nh, causal, masked):
+    """Tolerance: inputs are identical bf16 values; the kernel rounds P to bf16 (2^-9 rel) before
+    PV and o/out to bf16 on store => |err| <= ~1e-2 * max|v| on rows that see other tokens.
+    Rows that can only see themselves (lse ~ -5e4) sit on fp32's 4e-3 logsumexp grid, so the
+    round weights legitimately differ there (see oracle/lsh_ref.py)."""
+    r = _run_fwd(ops, b, h, t, bs, nh, causal, masked)
+    dh = r["dh"]
+    qk = _heads_first(r["qkv"][..., :h * dh], b, t, h, dh)
+    v = _heads_first(r["qkv"][..., h * dh:], b, t, h, dh)
+    sticker, undo = _flat_perm(r["st"].cpu())
+    m = None if r["mask"] is None else r["mask"].unsqueeze(1).expand(b, h, t).reshape(b * h, t)
+    out_ref, o_ref, lse_ref = lsh_ref.lsh_attention_sorted(qk, v, sticker, undo, bs, nh, causal, m, return_parts=True)
+    o, lse = r["o"].float().cpu(), r["lse"].cpu()
+    torch.testing.assert_close(lse, lse_ref, rtol=2e-3, atol=2e-2)
+    torch.testing.assert_close(o, o_ref, rtol=2e-2, atol=2e-2)
+    out = _heads_first(r["out"], b, t, h, dh)
+    lse_tot_ref = torch.logsumexp(lse_ref, dim=1)
+    normal = lse_tot_ref > -1e4
+    torch.testing.assert_close(out[normal], out_ref[normal], rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(out[~normal], out_ref[~normal], rtol=1e-1, atol=1e-1)
+    torch.testing.assert_close(r["lse_tot"].cpu(), lse_tot_ref, rtol=2e-3, atol=2e-2)
+    # mean error is far below the worst case
+    assert (out[normal] - out_ref[normal]).abs().mean() < 3e-3
+
+
+# ------------------------------------------------------------------ attention backward
+@pytest.mark.parametrize("b,h,t,bs,nh,causal,masked", CASES)
+def test_attention_backward_vs_oracle_autograd(ops, b, h, t, bs, nh, causal, masked):
+    """Gradients of sum(out * dout) w.r.t. qk and v against autograd through the oracle on the same
+    permutation.  bf16 partials (16 per token) and bf16 P/dS operands bound the error at ~2%
+    of the gradient scale."""
+    r = _run_fwd(ops, b, h, t, bs, nh, causal, masked, seed=3)
+    dh = r["dh"]
+    g = torch.Generator().manual_seed(11)
+    dout = torch.randn(b, t, h * dh, generator=g).bfloat16()
+    dqk, dv = ops.lsh_attn_bwd(r["qk_d"], r["v_d"], r["st"], r["out"], dout.cuda(), r["lse_tot"], h, bs, causal,
+                               None if r["mask"] is None else r["mask"].cuda())
+    torch.cuda.synchronize()
+    qk = _heads_first(r["qkv"][..., :h * dh], b, t, h, dh).requires_grad_()
+    v = _heads_first(r["qkv"][..., h * dh:], b, t, h, dh).requires_grad_()
+    sticker, undo = _flat_perm(r["st"].cpu())
+    m = None if r["mask"] is None else r["mask"].unsqueeze(1).expand(b, h, t).reshape(b * h, t)
+    out_ref = lsh_ref.lsh_attention_sorted(qk, v, sticker, undo, bs, nh, causal, m)
+    out_ref.backward(_heads_first(dout, b, t, h, dh))
+    dqk_h, dv_h = _heads_first(dqk, b, t, h, dh), _heads_first(dv, b, t, h, dh)
+    for got, ref, name in ((dv_h, v.grad, "dv"), (dqk_h, qk.grad, "dqk")):
+        scale = ref.abs().max().item()
+        err = (got - ref).abs()
+        assert err.max().item() < 4e-2 * scale + 1e-3, (name, err.max().item(), scale)
+        assert err.mean().item() < 4e-3 * scale + 1e-4, (name, err.mean().item(), scale)
+
+
+def test_strided_qkv_views(ops):
+    """qk and v as the two halves of one (B,T,2d) buffer (row stride 2d) give the same result as
+    separate contiguous tensors."""
+    b, h, t, bs, nh, dh = 1, 2, 256, 64, 4, 64
+    qkv = _make_qkv(b, t, h, dh, seed=5).cuda()
+    rot = torch.randn(1, dh, nh, t // bs // 2, generator=torch.Generator().manual_seed(2)).cuda()
+    qk_v, v_v = qkv[..., :h * dh], qkv[..., h * dh:]
+    qk_c, v_c = qk_v.contiguous(), v_v.contiguous()
+    st1, _, _ = ops.lsh_hash_sort(qk_v, rot, h, bs)
+    st2, _, _ = ops.lsh_hash_sort(qk_c, rot, h, bs)
+    assert torch.equal(st1, st2)
+    o1, l1 = ops.lsh_attn_fwd(qk_v, v_v, st1, h, bs, True)
+    o2, l2 = ops.lsh_attn_fwd(qk_c, v_c, st1, h, bs, True)
+    assert torch.equal(o1, o2) and torch.equal(l1, l2)
+
+
+# ------------------------------------------------------------------ full-size properties
+def test_full_size_properties(ops):
+    """BASELINE config #2 decoder shape (B=12, H=8, T=1024, bucket 128, 8 rounds): size-independent
+    properties -- st is a permutation of 0..T-1 per round, sorted by bucket; the attention of a
+    constant V field returns the constant (softmax weights sum to one over rounds and keys);
+    the backward of that field gives dqk == 0; linearity in v."""
+    b, h, t, bs, nh, dh = 12, 8, 1024, 128, 8, 64
+    qkv = _make_qkv(b, t, h, dh, seed=42).cuda()
+    rot = torch.randn(1, dh, nh, t // bs // 2, generator=torch.Generator().manual_seed(9)).cuda()
+    qk = qkv[..., :h * dh].contiguous()
+    st, buckets, _ = ops.lsh_hash_sort(qk, rot, h, bs, want_buckets=True)
+    assert torch.equal(st.sort(dim=-1).values, torch.arange(t, device="cuda", dtype=torch.int32).expand_as(st))
+    sorted_b = buckets.gather(2, st.long())
+    assert bool((sorted_b[..., 1:] >= sorted_b[..., :-1]).all())
+    same = sorted_b[..., 1:] == sorted_b[..., :-1]
+    assert bool((st[..., 1:][same] > st[..., :-1][same]).all())            # stable
+    vconst = torch.full_like(qk, 0.75)
+    o, lse = ops.lsh_attn_fwd(qk, vconst, st, h, bs, True)
+    out, lse_tot = ops.lsh_combine_fwd(o, lse, b, h)
+    assert bool(torch.isfinite(out.float()).all())
+    torch.testing.assert_close(out.float(), torch.full_like(out, 0.75).float(), rtol=0, atol=8e-3)
+    assert bool((lse_tot.unsqueeze(1) >= lse - 1e-3).all())
+    v1, v2 = qkv[..., h * dh:].contiguous(), torch.flip(qkv[..., h * dh:], dims=[1]).contiguous()
+    outs = []
+    for vv in (v1, v2, (v1.float() + v2.float()).bfloat16()):
+        o_, l_ = ops.lsh_attn_fwd(qk, vv, st, h, bs, True)
+        outs.append(ops.lsh_combine_fwd(o_, l_, b, h)[0].float())
+    torch.testing.assert_close(outs[2], outs[0] + outs[1], rtol=0, atol=6e-2)
+    dout = torch.randn_like(out)
+    dqk, dv = ops.lsh_attn_bwd(qk, vconst, st, out, dout, lse_tot, h, bs, True)
+    assert dqk.float().abs().max().item() < 5e-2      # d(out)/d(qk) = 0 when V is constant
+    torch.cuda.synchronize()
