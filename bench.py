@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""Headline benchmark: mel-frames/sec of one Reformer-TTS training step (forward + loss + reversible
+backward + gradient all-reduce + clip + AdamW) on synthetic LJSpeech-shaped batches,
+``config/baseline.yml`` (BASELINE.json configs[1]): B=12 per GPU, text 200 -> 256, mel 1024 x 80.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement): whole-job mel-frames/s, plus
+  roofline      the dominant kernel (LSH chunk-attention backward, MFMA-bound): algorithmic FLOP per
+                launch / its average duration measured with HIP events on the launch stream
+  cpu_baseline  the CPU oracle (eager fp32 PyTorch restatement of the reference's step) timed on
+                this host's cores on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=12, help="per-GPU batch (baseline.yml: 12)")
+    ap.add_argument("--mel-len", type=int, default=1024)
+    ap.add_argument("--text-len", type=int, default=200)
+    ap.add_argument("--config", default="baseline", choices=["baseline", "long"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=25.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(model_cfg, mel_len, text_len, budget_s):
+    """Oracle forward + loss + backward on the host cores, bounded sample: B=1 at the bench's
+    sequence lengths (frames/s is size-normalised), 1 warm-up-free pass repeated while time remains."""
+    from oracle import model_ref, synth
+    from reformer_tts_amd.model.config import as_kwargs
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = as_kwargs(model_cfg)
+    from reformer_tts_amd.training import build_model
+    shapes = {k: tuple(v.shape) for k, v in build_model(model_cfg).state_dict().items()}
+    sd = {k: v.requires_grad_(v.dtype.is_floating_point and not k.endswith("inv_freq"))
+          for k, v in synth.synth_state_dict(shapes, seed=0).items()}
+    batch = model_ref.synthetic_batch(1, text_len, mel_len, seed=42)
+    g = torch.Generator().manual_seed(1)
+    rots = [torch.randn(s, generator=g) for s in model_ref.rotation_shapes(cfg, text_len, mel_len)]
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while True:
+        t0 = time.perf_counter()
+        loss = model_ref.training_forward(sd, cfg, batch, rots)[0]
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+        for v in sd.values():
+            v.grad = None
+        if time.perf_counter() + times[-1] > t_end or len(times) >= 3:
+            break
+    best = min(times)
+    return dict(value=round(mel_len / best, 2), unit="mel-frames/s", cores=cores, kind="port",
+                sample=f"B=1, text {text_len}, mel {mel_len}: forward+loss+backward of oracle/model_ref.py "
+                       f"(fp32 eager, {len(times)} pass(es), best {best:.2f} s; no optimizer step)")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from reformer_tts_amd import ops
+    from reformer_tts_amd.model.config import (baseline_model_config, baseline_training_config,
+                                               long_sequence_model_config)
+    from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
+
+    model_cfg = baseline_model_config() if args.config == "baseline" else long_sequence_model_config()
+    tcfg = baseline_training_config()
+    tcfg.batch_size = args.batch
+    model = build_model(model_cfg, dev, seed=42)          # identical init on every rank
+    trainer = Trainer(model, tcfg, dev)
+    batch = synthetic_batch(args.batch, args.text_len, args.mel_len, seed=42 + rank, device=dev)
+
+    for _ in range(args.warmup):
+        trainer.train_step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.TIMING.enable("rtts_lsh_attn_bwd/bs128")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.train_step(batch)[0]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    avg_ms, launches, flops_per_launch = ops.TIMING.summary("rtts_lsh_attn_bwd/bs128")
+    ops.TIMING.disable()
+
+    if rank == 0:
+        frames = world * args.batch * args.mel_len * args.steps
+        out = {
+            "metric": "mel-frames/sec training step, LJSpeech-shape batch",
+            "value": round(frames / elapsed, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"config/baseline.yml full Reformer-TTS training step (enc 3 / dec 3 layers, d=512, "
+                                   f"LSH 8 rounds, buckets 64/128), per-GPU batch {args.batch}, text {args.text_len}->256, "
+                                   f"mel {args.mel_len}x80" if args.config == "baseline" else
+                                   f"config/bucket-size-64-18-06.yml, per-GPU batch {args.batch}, mel {args.mel_len}",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(float(loss), 4)},
+        }
+        if launches:
+            ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "lsh_attn_bwd_kernel", "bound": "mfma", "achieved": round(ach, 2),
+                               "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
+                               "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model_cfg, args.mel_len, args.text_len, args.cpu_budget_s)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

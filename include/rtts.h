@@ -84,6 +84,21 @@ int rtts_lsh_attn_bwd(const void* qk, const void* v, int64_t ld, const int32_t* 
 int rtts_lsh_bwd_reduce(const void* dqk_part, const void* dv_part, int B, int H, int T, int dh, int n_hashes,
                         void* dqk, void* dv, int64_t ld_d, void* stream);
 
+/* ---- optimizer step over the flat parameter buffer --------------------------------------
+ * Replaces clip_grad_norm_ (pytorch-lightning gradient_clip_val, reference
+ * reformer_tts/training/train.py:77-89) and transformers.optimization.AdamW.step as configured
+ * at reformer_tts/training/wrappers.py:240-256,284-297 (beta 0.9/0.999, eps 1e-6, bias-corrected,
+ * decoupled decay applied after the update to parameters whose decay_mask byte is 1).
+ *   rtts_grad_clip_scale: scale_out[0] = grad_mult * min(1, max_norm / (grad_mult*|g| + 1e-6)),
+ *        scale_out[1] = grad_mult*|g|;  partial_ws: >= 2048 floats.  grad_mult = 1/world_size
+ *        after a sum all-reduce.  max_norm <= 0 disables clipping.
+ *   rtts_adamw_step: grads are multiplied by scale[0] on the fly (scale may be NULL = 1). */
+int rtts_grad_clip_scale(const float* grads, int64_t n, float grad_mult, float max_norm, float* partial_ws,
+                         float* scale_out, void* stream);
+int rtts_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* decay_mask,
+                    int64_t n, const float* scale, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

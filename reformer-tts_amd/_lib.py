@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librtts_hip.so")
 
-_i64, _i32, _vp = C.c_int64, C.c_int, C.c_void_p
+_i64, _i32, _vp, _f32 = C.c_int64, C.c_int, C.c_void_p, C.c_float
 
 # name -> argtypes, exactly the prototypes of include/rtts.h
 SIGNATURES = {
@@ -20,6 +20,8 @@ SIGNATURES = {
     "rtts_lsh_bwd_delta": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp],
     "rtts_lsh_attn_bwd": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     "rtts_lsh_bwd_reduce": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp],
+    "rtts_grad_clip_scale": [_vp, _i64, _f32, _f32, _vp, _vp, _vp],
+    "rtts_adamw_step": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _i32, _vp],
 }
 
 _lib = None

@@ -1,0 +1,112 @@
+"""``implementation="hip"`` of the LSH self-attention layer the reference builds at
+``/root/reference/reformer_tts/model/reformer.py:198-200`` (``reformer_pytorch.LSHSelfAttention``):
+same constructor surface, same parameter names (``toqk``, ``tov``, ``to_out``), the arithmetic of
+SURVEY.md Appendix B steps 2-11 in librtts_hip.so.
+
+MI355X-first differences from the reference's mechanism (results are the same function):
+  * the two projections run as ONE (M, d) x (d, 2d) GEMM whose halves are consumed in place
+    (row stride 2d) by the kernels -- no head split / merge copies;
+  * the forward keeps the sort permutation ``st`` (3 MB per decoder layer) instead of replaying
+    the RNG: the reversible recompute re-uses the buckets that the forward used, bit for bit;
+  * rotations come from a per-layer generator, so no global RNG state is captured.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+class _LSHAttnFn(torch.autograd.Function):
+    """qkv (B,T,2d) bf16 [qk | v], st (B*H,R,T) -> out (B,T,d) bf16 (heads merged)."""
+
+    @staticmethod
+    def forward(ctx, qkv, st, mask, heads, bucket_size, causal):
+        d = qkv.shape[-1] // 2
+        qk, v = qkv[..., :d], qkv[..., d:]
+        o, lse = ops.lsh_attn_fwd(qk, v, st, heads, bucket_size, causal, mask)
+        out, lse_tot = ops.lsh_combine_fwd(o, lse, qkv.shape[0], heads)
+        ctx.save_for_backward(qkv, st, out, lse_tot, mask)
+        ctx.cfg = (heads, bucket_size, causal)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, st, out, lse_tot, mask = ctx.saved_tensors
+        heads, bucket_size, causal = ctx.cfg
+        d = qkv.shape[-1] // 2
+        dqkv = torch.empty_like(qkv)
+        if dout.dtype != torch.bfloat16 or dout.stride(2) != 1:
+            dout = dout.to(torch.bfloat16).contiguous()
+        ops.lsh_attn_bwd(qkv[..., :d], qkv[..., d:], st, out, dout, lse_tot, heads, bucket_size, causal, mask,
+                         dqkv=(dqkv[..., :d], dqkv[..., d:]))
+        return dqkv, None, None, None, None, None
+
+
+class LSHSelfAttention(nn.Module):
+    def __init__(self, dim, heads=8, bucket_size=64, n_hashes=8, causal=False, add_local_attn_hash=False,
+                 attn_chunks=1, random_rotations_per_head=False, attend_across_buckets=True,
+                 allow_duplicate_attention=True, num_mem_kv=0, one_value_head=False, use_full_attn=False,
+                 full_attn_thres=None, return_attn=False, post_attn_dropout=0.0, dropout=0.0, seed=0):
+        super().__init__()
+        if dim % heads != 0:
+            raise AssertionError("dimensions must be divisible by number of heads")
+        unsupported = dict(add_local_attn_hash=add_local_attn_hash, attend_across_buckets=not attend_across_buckets,
+                           allow_duplicate_attention=not allow_duplicate_attention, num_mem_kv=num_mem_kv,
+                           one_value_head=one_value_head, use_full_attn=use_full_attn, return_attn=return_attn,
+                           dropout=dropout)
+        bad = [k for k, v in unsupported.items() if v]
+        if bad:
+            raise NotImplementedError(f"implementation='hip' supports the default value of {bad} only")
+        if dim // heads != 64:
+            raise NotImplementedError(f"implementation='hip' is built for dim/heads == 64 (got {dim // heads})")
+        self.dim, self.heads, self.bucket_size, self.n_hashes, self.causal = dim, heads, bucket_size, n_hashes, causal
+        self.random_rotations_per_head = random_rotations_per_head
+        self.full_attn_thres = bucket_size if full_attn_thres is None else full_attn_thres
+        self.attn_chunks = attn_chunks  # memory-only knob in the reference; no numeric effect
+        self.toqk = nn.Linear(dim, dim, bias=False)
+        self.tov = nn.Linear(dim, dim, bias=False)
+        self.to_out = nn.Linear(dim, dim)
+        self.post_attn_dropout = nn.Dropout(post_attn_dropout)
+        self.seed = seed
+        self._gen: Optional[torch.Generator] = None
+        self._saved_st: Optional[torch.Tensor] = None   # forward's permutation, re-used by the recompute
+        self.forced_rotations: Optional[torch.Tensor] = None  # tests: use these instead of sampling
+        self.last_st: Optional[torch.Tensor] = None
+
+    def _rotations(self, x, n_buckets):
+        if self.forced_rotations is not None:
+            return self.forced_rotations.to(device=x.device, dtype=torch.float32).contiguous()
+        if self._gen is None or self._gen.device != x.device:
+            self._gen = torch.Generator(device=x.device)
+            self._gen.manual_seed(0x5EED + self.seed)
+        rows = x.shape[0] * self.heads if self.random_rotations_per_head else 1
+        return torch.randn(rows, self.dim // self.heads, self.n_hashes, n_buckets // 2, device=x.device,
+                           dtype=torch.float32, generator=self._gen)
+
+    def forward(self, x, input_mask=None, recompute: bool = False, **_):
+        b, t, e = x.shape
+        if t <= self.full_attn_thres:
+            raise NotImplementedError("full-attention shortcut (T <= full_attn_thres) is outside the HIP path")
+        if t % (self.bucket_size * 2) != 0:
+            raise AssertionError(f"Sequence length ({t}) needs to be divisible by target bucket size  x 2 - {self.bucket_size * 2}")
+        w = torch.cat([self.toqk.weight, self.tov.weight], dim=0).to(torch.bfloat16)
+        qkv = F.linear(x.to(torch.bfloat16), w)                              # (B,T,2d) = [qk | v]
+        if recompute and self._saved_st is not None:
+            st = self._saved_st
+            self._saved_st = None
+        else:
+            with torch.no_grad():
+                rot = self._rotations(x, t // self.bucket_size)
+                st, _, _ = ops.lsh_hash_sort(qkv[..., :e], rot, self.heads, self.bucket_size)
+            if self.training and not torch.is_grad_enabled():
+                self._saved_st = st          # reversible forward: keep for the recompute
+        self.last_st = st
+        mask = None if input_mask is None else input_mask.to(torch.uint8)
+        out = _LSHAttnFn.apply(qkv, st, mask, self.heads, self.bucket_size, self.causal)
+        y = F.linear(out, self.to_out.weight.to(torch.bfloat16), self.to_out.bias.to(torch.bfloat16))
+        return self.post_attn_dropout(y.float())

@@ -1,0 +1,112 @@
+"""Prenets, postnet, positional encoding and position-wise FFN with the reference's module and
+parameter names (``/root/reference/reformer_tts/model/modules.py``).  Convolutions / BatchNorm /
+small linears still run on ATen (MIOpen, hipBLASLt) in this round; see DESIGN.md for which rows
+of SURVEY.md section 8a are hand-written HIP."""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+
+def _bf16_linear(x, lin: nn.Linear):
+    b = None if lin.bias is None else lin.bias.to(torch.bfloat16)
+    return F.linear(x.to(torch.bfloat16), lin.weight.to(torch.bfloat16), b)
+
+
+class EncoderPreNet(nn.Module):
+    """``modules.py:8-61``: embedding -> 3 x [dropout, conv k5, BatchNorm, ReLU] -> dropout -> linear."""
+
+    def __init__(self, num_embeddings: int, embedding_dim: int = 512, dropout: float = 0.5):
+        super().__init__()
+        self.embedding_dim = embedding_dim
+        self.embed = nn.Embedding(num_embeddings, embedding_dim, padding_idx=0)
+        self.projection = nn.Linear(embedding_dim, embedding_dim)
+        layers = [("dropout0", nn.Dropout(dropout))]
+        for i in (1, 2, 3):
+            layers += [(f"conv{i}", nn.Conv1d(embedding_dim, embedding_dim, kernel_size=5, padding=2)),
+                       (f"bn{i}", nn.BatchNorm1d(embedding_dim)), (f"relu{i}", nn.ReLU()),
+                       (f"dropout{i}", nn.Dropout(dropout))]
+        self.convolutions = nn.Sequential(OrderedDict(layers))
+
+    def forward(self, input_):
+        x = self.embed(input_).transpose(1, 2)
+        with torch.autocast(device_type=x.device.type, dtype=torch.bfloat16, enabled=x.is_cuda):
+            x = self.convolutions(x)
+            x = self.projection(x.transpose(1, 2))
+        return x.float()
+
+
+class DecoderPreNet(nn.Module):
+    """``modules.py:64-100``: fc1-ReLU-drop-fc2-ReLU-drop-projection."""
+
+    def __init__(self, input_size: int, output_size: int, hidden_size: int = 256, dropout: float = 0.5):
+        super().__init__()
+        self.input_size, self.output_size, self.hidden_size = input_size, output_size, hidden_size
+        self.layer = nn.Sequential(OrderedDict([
+            ("fc1", nn.Linear(input_size, hidden_size)), ("relu1", nn.ReLU()), ("dropout1", nn.Dropout(dropout)),
+            ("fc2", nn.Linear(hidden_size, output_size)), ("relu2", nn.ReLU()), ("dropout2", nn.Dropout(dropout)),
+            ("projection", nn.Linear(output_size, output_size))]))
+
+    def forward(self, input_):
+        with torch.autocast(device_type=input_.device.type, dtype=torch.bfloat16, enabled=input_.is_cuda):
+            out = self.layer(input_)
+        return out.float()
+
+
+class PostConvNet(nn.Module):
+    """``modules.py:103-169``: [conv k5, BatchNorm, tanh, dropout] x depth + conv k5 (the mel postnet)."""
+
+    def __init__(self, mel_size: int, num_hidden: int, dropout: float, depth: int):
+        super().__init__()
+        self.mel_size = mel_size
+        layers = []
+        for i in range(depth):
+            layers += [(f"conv{i}", nn.Conv1d(mel_size if i == 0 else num_hidden, num_hidden, kernel_size=5, padding=2)),
+                       (f"bn{i}", nn.BatchNorm1d(num_hidden)), (f"tanh{i}", nn.Tanh()), (f"dropout{i}", nn.Dropout(dropout))]
+        layers += [("convend", nn.Conv1d(num_hidden, mel_size, kernel_size=5, padding=2))]
+        self.layers = nn.Sequential(OrderedDict(layers))
+
+    def forward(self, input_):
+        x = input_.transpose(1, 2)
+        with torch.autocast(device_type=x.device.type, dtype=torch.bfloat16, enabled=x.is_cuda):
+            x = self.layers(x)
+        return x.transpose(1, 2).float()
+
+
+class ScaledPositionalEncoding(nn.Module):
+    """``modules.py:172-192``: x + alpha * dropout(table); the table interleaves [sin, cos] and the
+    dropout mask is drawn once for the (T, d) table, i.e. shared over the batch."""
+
+    def __init__(self, d_model, dropout):
+        super().__init__()
+        inv_freq = 1.0 / (10000 ** (torch.arange(0, d_model, 2).float() / d_model))
+        self.register_buffer("inv_freq", inv_freq)
+        self.alpha = nn.Parameter(torch.empty(1).normal_(0, 1))
+        self.dropout = nn.Dropout(dropout)
+        self._table = None
+
+    def table(self, length: int, device):
+        if self._table is None or self._table.shape[0] < length or self._table.device != device:
+            pos = torch.arange(length, device=device, dtype=self.inv_freq.dtype)
+            ang = pos[:, None] * self.inv_freq.to(device)[None, :]
+            self._table = torch.stack([ang.sin(), ang.cos()], dim=-1).reshape(length, -1)
+        return self._table[:length]
+
+    def forward(self, input_):
+        return input_ + self.alpha * self.dropout(self.table(input_.shape[1], input_.device))
+
+
+class FeedForward(nn.Module):
+    """``modules.py:195-207``: Linear-ReLU-Dropout-Linear (bf16 operands, fp32 accumulate)."""
+
+    def __init__(self, dim=512, hidden=2048, dropout=0.0):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(dim, hidden), nn.ReLU(), nn.Dropout(dropout), nn.Linear(hidden, dim))
+
+    def forward(self, x):
+        h = F.relu(_bf16_linear(x, self.net[0]))
+        h = self.net[2](h)
+        return _bf16_linear(h, self.net[3]).float()

@@ -1,0 +1,75 @@
+"""Top-level module (``/root/reference/reformer_tts/model/reformer_tts.py``)."""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from .modules import DecoderPreNet, EncoderPreNet, PostConvNet, ScaledPositionalEncoding
+from .reformer import ReformerDec, ReformerEnc
+
+
+class Encoder(nn.Module):
+    def __init__(self, dict_size: int, embedding_dim: int, scp_encoding_dropout: float, reformer_kwargs: Dict, prenet_kwargs: Dict):
+        super().__init__()
+        self.prenet = EncoderPreNet(num_embeddings=dict_size + 1, embedding_dim=embedding_dim, **prenet_kwargs)
+        self.positional_encoding = ScaledPositionalEncoding(embedding_dim, scp_encoding_dropout)
+        self.reformer = ReformerEnc(embedding_dim, **reformer_kwargs)
+
+    def forward(self, input_, input_mask=None):
+        return self.reformer(self.positional_encoding(self.prenet(input_)), input_mask=input_mask)
+
+
+class Decoder(nn.Module):
+    def __init__(self, num_mel_coeffs: int, embedding_dim: int, scp_encoding_dropout: float, prenet_kwargs: Dict, reformer_kwargs: Dict):
+        super().__init__()
+        self.prenet = DecoderPreNet(input_size=num_mel_coeffs, output_size=embedding_dim, **prenet_kwargs)
+        self.positional_encoding = ScaledPositionalEncoding(embedding_dim, scp_encoding_dropout)
+        self.reformer = ReformerDec(embedding_dim, **reformer_kwargs)
+        self.mel_linear = nn.Linear(embedding_dim, num_mel_coeffs)
+        self.stop_linear = nn.Linear(embedding_dim, 1)
+
+    def forward(self, input_, keys, key_padding_mask=None, input_mask=None):
+        x = self.positional_encoding(self.prenet(input_))
+        x, attention_matrices = self.reformer(x, keys=keys, key_padding_mask=key_padding_mask, input_mask=input_mask)
+        return self.mel_linear(x), self.stop_linear(x), attention_matrices
+
+
+def pad_to_multiple(tensor, pad_base):
+    """Right zero-pad (batch, seq_len, channels) to a multiple of ``pad_base`` on the tensor's own
+    device (``reformer_tts.py:224-232`` relies on a process-wide default CUDA tensor type)."""
+    new_len = ((tensor.shape[1] - 1) // pad_base + 1) * pad_base
+    return F.pad(tensor, (0, 0, 0, new_len - tensor.shape[1]))
+
+
+class ReformerTTS(nn.Module):
+    def __init__(self, num_mel_coeffs: int, dict_size: int, pad_base: int, embedding_dim: int, scp_encoding_dropout: float,
+                 enc_reformer_kwargs: Dict, enc_prenet_kwargs: Dict, dec_prenet_kwargs: Dict, dec_reformer_kwargs: Dict,
+                 postnet_kwargs: Dict):
+        super().__init__()
+        self.num_mel_coeffs = num_mel_coeffs
+        self.enc = Encoder(dict_size=dict_size, embedding_dim=embedding_dim, scp_encoding_dropout=scp_encoding_dropout,
+                           reformer_kwargs=enc_reformer_kwargs, prenet_kwargs=enc_prenet_kwargs)
+        self.dec = Decoder(num_mel_coeffs=num_mel_coeffs, embedding_dim=embedding_dim, scp_encoding_dropout=scp_encoding_dropout,
+                           prenet_kwargs=dec_prenet_kwargs, reformer_kwargs=dec_reformer_kwargs)
+        self.pad_base = pad_base
+        self.postnet = PostConvNet(mel_size=num_mel_coeffs, num_hidden=embedding_dim, **postnet_kwargs)
+
+    def forward(self, phonemes: torch.LongTensor, spectrogram: torch.Tensor,
+                spectrogram_mask: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, list]:
+        """``reformer_tts.py:103-143``: returns (mel, mel_postnet, stop, attention_matrices), all cropped
+        to the input spectrogram length."""
+        dev = spectrogram.device
+        pad_phonemes = pad_to_multiple(phonemes.unsqueeze(-1), self.pad_base).squeeze(-1).to(dev)
+        phoneme_mask = pad_phonemes != 0
+        if spectrogram_mask is None:
+            spectrogram_mask = torch.ones(spectrogram.shape[:2], device=dev)
+        spectrogram_mask = pad_to_multiple(spectrogram_mask.unsqueeze(-1).to(dev), self.pad_base).squeeze(-1).to(torch.bool)
+        pad_spec = pad_to_multiple(spectrogram, self.pad_base)
+        keys = self.enc(pad_phonemes, input_mask=phoneme_mask)
+        mel, stop, attention_matrices = self.dec(pad_spec, keys=keys, key_padding_mask=~phoneme_mask, input_mask=spectrogram_mask)
+        mel_postnet = mel + self.postnet(mel)
+        cutoff = spectrogram.shape[1]
+        return mel[:, :cutoff], mel_postnet[:, :cutoff], stop[:, :cutoff], attention_matrices

@@ -1,0 +1,182 @@
+"""Reversible residual stacks: forward without stored activations, backward with recompute.
+
+Protocol of ``/root/reference/reformer_tts/model/reversible.py`` (``forward(x, **kw)`` under
+no_grad, ``backward_pass(y, dy, **kw) -> (x, dx)``, parameter gradients accumulated as a side
+effect), with these MI355X-first changes:
+  * the two streams travel as two tensors -- no ``cat`` / ``chunk`` copy per block (the
+    reference moves 50 MB per block and direction at decoder shape); the concatenated form is
+    only assembled at the protocol boundary for callers that ask for it;
+  * no global-RNG replay: a net that needs randomness to repeat (dropout) gets its CUDA RNG state
+    captured per call, LSH layers re-use their saved sort permutation instead;
+  * after every block's ``backward_pass`` an optional hook fires, which the data-parallel trainer
+    uses to launch that block's gradient all-reduce while the next block recomputes.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional
+
+import torch
+from torch import nn
+
+
+def _has_dropout(m: nn.Module) -> bool:
+    return any(isinstance(s, nn.Dropout) and s.p > 0 for s in m.modules())
+
+
+class Deterministic(nn.Module):
+    """Holds ``net`` (name kept for the state_dict).  ``record`` captures the device RNG state when
+    the net contains active dropout; ``replay`` re-runs the net under that state."""
+
+    def __init__(self, net: nn.Module):
+        super().__init__()
+        self.net = net
+        self._rng = None
+
+    def forward(self, *args, record_rng: bool = False, set_rng: bool = False, **kwargs):
+        needs = self.training and _has_dropout(self.net)
+        if set_rng:
+            kwargs = dict(kwargs, recompute=True) if getattr(self.net, "accepts_recompute", False) else kwargs
+            if needs and self._rng is not None:
+                dev = args[0].device
+                with torch.random.fork_rng(devices=[dev] if dev.type == "cuda" else []):
+                    if dev.type == "cuda":
+                        torch.cuda.set_rng_state(self._rng, dev)
+                    else:
+                        torch.set_rng_state(self._rng)
+                    return self.net(*args, **kwargs)
+            return self.net(*args, **kwargs)
+        if record_rng and needs:
+            dev = args[0].device
+            self._rng = torch.cuda.get_rng_state(dev) if dev.type == "cuda" else torch.get_rng_state()
+        return self.net(*args, **kwargs)
+
+
+class ReversibleBlock(nn.Module):
+    """y1 = x1 + f(x2); y2 = x2 + g(y1)   (``reversible.py:46-98``)."""
+
+    def __init__(self, f, g):
+        super().__init__()
+        self.f = Deterministic(f)
+        self.g = Deterministic(g)
+
+    def forward_halves(self, x1, x2, f_args={}, g_args={}):
+        with torch.no_grad():
+            y1 = x1 + self.f(x2, record_rng=self.training, **f_args)
+            y2 = x2 + self.g(y1, record_rng=self.training, **g_args)
+        return y1, y2
+
+    def backward_halves(self, y1, y2, dy1, dy2, f_args={}, g_args={}):
+        with torch.enable_grad():
+            y1 = y1.detach().requires_grad_()
+            gy1 = self.g(y1, set_rng=True, **g_args)
+            torch.autograd.backward(gy1, dy2)
+        with torch.no_grad():
+            x2 = y2 - gy1
+            del gy1, y2
+            dx1 = dy1 + y1.grad
+            y1.grad = None
+        with torch.enable_grad():
+            x2 = x2.detach().requires_grad_()
+            fx2 = self.f(x2, set_rng=True, **f_args)
+            torch.autograd.backward(fx2, dx1)
+        with torch.no_grad():
+            x1 = y1.detach() - fx2
+            dx2 = dy2 + x2.grad
+            x2.grad = None
+        return x1, x2.detach(), dx1, dx2
+
+    def forward(self, x, f_args={}, g_args={}):
+        return torch.cat(self.forward_halves(*torch.chunk(x, 2, dim=2), f_args, g_args), dim=2)
+
+    def backward_pass(self, y, dy, f_args={}, g_args={}):
+        x1, x2, dx1, dx2 = self.backward_halves(*torch.chunk(y, 2, dim=2), *torch.chunk(dy, 2, dim=2), f_args, g_args)
+        return torch.cat([x1, x2], dim=2), torch.cat([dx1, dx2], dim=2)
+
+
+class ReversibleHalfResidual(nn.Module):
+    """y1 = x1 + f(x2); x2 passes through   (``reversible.py:134-170``)."""
+
+    def __init__(self, f):
+        super().__init__()
+        self.f = Deterministic(f)
+
+    def forward_halves(self, x1, x2, **f_args):
+        with torch.no_grad():
+            y1 = x1 + self.f(x2, record_rng=self.training, **f_args)
+        return y1, x2
+
+    def backward_halves(self, y1, x2, dy1, dx2, **f_args):
+        with torch.enable_grad():
+            x2 = x2.detach().requires_grad_()
+            fx2 = self.f(x2, set_rng=True, **f_args)
+            torch.autograd.backward(fx2, dy1)
+        with torch.no_grad():
+            x1 = y1 - fx2
+            dx2 = dx2 + x2.grad
+            x2.grad = None
+        return x1, x2.detach(), dy1, dx2
+
+    def forward(self, x, **f_args):
+        return torch.cat(self.forward_halves(*torch.chunk(x, 2, dim=2), **f_args), dim=2)
+
+    def backward_pass(self, y, dy, **f_args):
+        x1, x2, dx1, dx2 = self.backward_halves(*torch.chunk(y, 2, dim=2), *torch.chunk(dy, 2, dim=2), **f_args)
+        return torch.cat([x1, x2], dim=2), torch.cat([dx1, dx2], dim=2)
+
+
+class ReversibleSwap(nn.Module):
+    """Exchange the two streams (``reversible.py:173-191``); free here: only the references swap."""
+
+    def forward_halves(self, x1, x2, **_):
+        return x2, x1
+
+    def backward_halves(self, y1, y2, dy1, dy2, **_):
+        return y2, y1, dy2, dy1
+
+    def forward(self, x, **kwargs):
+        x1, x2 = torch.chunk(x, 2, dim=2)
+        return torch.cat([x2, x1], dim=2)
+
+    def backward_pass(self, y, dy):
+        x2, x1 = torch.chunk(y, 2, dim=2)
+        dx2, dx1 = torch.chunk(dy, 2, dim=2)
+        return torch.cat([x1, x2], dim=2), torch.cat([dx1, dx2], dim=2)
+
+
+class _ReversibleFunction(torch.autograd.Function):
+    """Keeps only the final pair of streams (``reversible.py:114-129``)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, seq, kwargs_list):
+        for block, kwargs in zip(seq.blocks, kwargs_list):
+            x1, x2 = block.forward_halves(x1, x2, **kwargs)
+        ctx.y = (x1.detach(), x2.detach())
+        ctx.seq, ctx.kwargs_list = seq, kwargs_list
+        return x1, x2
+
+    @staticmethod
+    def backward(ctx, dy1, dy2):
+        y1, y2 = ctx.y
+        ctx.y = None
+        seq = ctx.seq
+        n = len(seq.blocks)
+        for i in range(n - 1, -1, -1):
+            y1, y2, dy1, dy2 = seq.blocks[i].backward_halves(y1, y2, dy1, dy2, **ctx.kwargs_list[i])
+            if seq.block_done_hook is not None:
+                seq.block_done_hook(seq, i)
+        return dy1, dy2, None, None
+
+
+class ReversibleSequence(nn.Module):
+    def __init__(self, blocks):
+        super().__init__()
+        self.blocks = blocks
+        self.block_done_hook: Optional[Callable] = None   # (sequence, block index) after its backward_pass
+
+    def forward_halves(self, x1, x2, kwargs_list=None):
+        kwargs_list = kwargs_list if kwargs_list is not None else [{}] * len(self.blocks)
+        return _ReversibleFunction.apply(x1, x2, self, kwargs_list)
+
+    def forward(self, x, kwargs_list=None, **kwargs):
+        x1, x2 = torch.chunk(x, 2, dim=2)
+        return torch.cat(self.forward_halves(x1, x2, kwargs_list), dim=2)

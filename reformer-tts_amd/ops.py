@@ -10,6 +10,46 @@ import torch
 from . import _lib
 
 
+class _Timing:
+    """Optional HIP-event timing of one named launch on the stream it is launched on (bench.py's
+    roofline leg).  Off by default; events are resolved in ``summary`` after a device sync."""
+
+    def __init__(self):
+        self.tag = None
+        self.records = []
+
+    def enable(self, tag: str):
+        self.tag, self.records = tag, []
+
+    def disable(self):
+        self.tag = None
+
+    def start(self, tag: str):
+        if self.tag != tag:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def stop(self, ev, flops: float):
+        if ev is None:
+            return
+        end = torch.cuda.Event(enable_timing=True)
+        end.record(torch.cuda.current_stream())
+        self.records.append((ev, end, flops))
+
+    def summary(self, tag: str):
+        """-> (average launch ms, launches, algorithmic FLOP per launch)."""
+        if not self.records:
+            return 0.0, 0, 0.0
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b, _ in self.records]
+        return sum(ms) / len(ms), len(ms), sum(f for _, _, f in self.records) / len(ms)
+
+
+TIMING = _Timing()
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -102,9 +142,12 @@ def lsh_attn_bwd(qk, v, st, out, dout, lse_tot, heads: int, bucket_size: int, ca
     _lib.call("rtts_lsh_bwd_delta", out.data_ptr(), ld_out, dout.data_ptr(), ld_do, b, heads, t, dh, delta.data_ptr(), _stream())
     dqk_part = torch.empty(3, b * heads, n_hashes, t, dh, dtype=torch.bfloat16, device=dev)
     dv_part = torch.empty(2, b * heads, n_hashes, t, dh, dtype=torch.bfloat16, device=dev)
+    ev = TIMING.start(f"rtts_lsh_attn_bwd/bs{bucket_size}")
     _lib.call("rtts_lsh_attn_bwd", qk.data_ptr(), v.data_ptr(), ld, st.data_ptr(), _ptr(mask), dout.data_ptr(), ld_do,
               lse_tot.data_ptr(), delta.data_ptr(), b, heads, t, dh, n_hashes, bucket_size, int(causal), dqk_part.data_ptr(),
               dv_part.data_ptr(), _stream())
+    # five MFMA products of 2*bs*(2bs)*dh FLOP per chunk, n_hashes*T/bs chunks per head
+    TIMING.stop(ev, 5.0 * 2.0 * bucket_size * (2 * bucket_size) * dh * (n_hashes * t // bucket_size) * b * heads)
     if dqkv is None:
         dqk = torch.empty(b, t, d, dtype=torch.bfloat16, device=dev)
         dv = torch.empty(b, t, d, dtype=torch.bfloat16, device=dev)

@@ -1,0 +1,174 @@
+"""Training step of the reference's ``LitReformerTTS`` (``/root/reference/reformer_tts/training/
+wrappers.py:53-105,234-297``; ``train.py:77-89``) without Lightning: teacher-forced forward + loss,
+reversible backward, data-parallel gradient all-reduce, global-norm clip, warm-up, AdamW.
+
+MI355X-first mechanics:
+  * all parameters (and their gradients, Adam moments) live in ONE flat fp32 buffer each, the
+    modules hold views: zero_grad is one memset, clip + AdamW are two kernel launches
+    (``csrc/optim.hip``), and a data-parallel bucket is a slice -- no flatten/unflatten copies;
+  * data parallel = one process per GPU over RCCL (``torch.distributed`` backend "nccl"); the
+    gradient all-reduce of reversible block k is issued from the block-done hook while block k-1
+    recomputes; leftovers (prenets, heads, postnet) go last.  ``DistributedDataParallel`` is not
+    used: the reversible backward produces parameter gradients as a side effect of nested
+    backward calls, outside DDP's hook model (hard parts).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .. import _lib
+from ..model import ReformerTTS, TTSLoss
+from ..model.config import ReformerTTSConfig, TTSTrainingConfig, as_kwargs
+
+NO_DECAY = ("bias", "norm.weight")  # wrappers.py:240
+
+
+def build_model(cfg: ReformerTTSConfig, device=None, seed: int = 42) -> ReformerTTS:
+    torch.manual_seed(seed)  # train.py:16 seed_everything(42)
+    model = ReformerTTS(**as_kwargs(cfg))
+    return model.to(device) if device is not None else model
+
+
+def synthetic_batch(batch: int, text_len: int, mel_len: int, n_mels: int = 80, dict_size: int = 76, seed: int = 42,
+                    device=None) -> Dict[str, torch.Tensor]:
+    """LJSpeech-shaped synthetic batch in the collate layout of ``dataset/utils.py:5-42``
+    (SURVEY.md section 8d): phonemes uniform in [1, dict_size]; log-mels clamp(N(-5, 2^2), log 1e-5, 2)
+    behind a zero start frame; stop one-hot at the last frame; loss mask of ones."""
+    g = torch.Generator().manual_seed(seed)
+    ph = torch.randint(1, dict_size + 1, (batch, text_len), generator=g)
+    mel = (torch.randn(batch, mel_len, n_mels, generator=g) * 2.0 - 5.0).clamp(math.log(1e-5), 2.0)
+    spec = torch.cat([torch.zeros(batch, 1, n_mels), mel], dim=1)
+    stop = torch.zeros(batch, mel_len)
+    stop[:, -1] = 1.0
+    out = dict(phonemes=ph, spectrogram=spec, stop_tokens=stop, loss_mask=torch.ones(batch, mel_len, n_mels))
+    return {k: v.to(device) for k, v in out.items()} if device is not None else out
+
+
+class Trainer:
+    def __init__(self, model: ReformerTTS, cfg: TTSTrainingConfig, device, process_group=None):
+        self.model, self.cfg, self.device = model, cfg, torch.device(device)
+        self.loss = TTSLoss(torch.tensor(cfg.positive_stop_weight, device=self.device), cfg.raw_pred_loss_weight,
+                            cfg.post_pred_loss_weight, cfg.stop_loss_weight, cfg.spectrogram_loss)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.global_step = 0
+        self._flatten()
+        self._make_buckets()
+        self._pending: List = []
+
+    # ------------------------------------------------------------------ flat storage
+    def _flatten(self):
+        named = [(n, p) for n, p in self.model.named_parameters() if p.requires_grad]
+        total = sum(p.numel() for _, p in named)
+        pad = (-total) % 4
+        dev = self.device
+        self.flat_p = torch.zeros(total + pad, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.flat_v = torch.zeros_like(self.flat_p)
+        self.decay_mask = torch.zeros(total + pad, dtype=torch.uint8, device=dev)
+        self.n_params = total
+        self.offsets: Dict[str, tuple] = {}
+        off = 0
+        for n, p in named:
+            k = p.numel()
+            self.flat_p[off:off + k].copy_(p.detach().reshape(-1))
+            p.data = self.flat_p[off:off + k].view_as(p)
+            p.grad = self.flat_g[off:off + k].view_as(p)
+            if not any(nd in n for nd in NO_DECAY):
+                self.decay_mask[off:off + k] = 1
+            self.offsets[n] = (off, off + k)
+            off += k
+        if dev.type == "cuda":
+            self.ws_partial = torch.zeros(2048, dtype=torch.float32, device=dev)
+            self.ws_scale = torch.zeros(2, dtype=torch.float32, device=dev)
+
+    def _make_buckets(self):
+        """One bucket per reversible block (parameters of a block are contiguous in module order),
+        keyed by (stack, block index); everything else falls into the final 'rest' all-reduce."""
+        self.block_bucket: Dict[tuple, tuple] = {}
+        covered = []
+        for stack_name, seq in (("enc", self.model.enc.reformer.layers), ("dec", self.model.dec.reformer.layers)):
+            prefix = f"{stack_name}.reformer.layers.blocks."
+            for i in range(len(seq.blocks)):
+                rng = [self.offsets[n] for n in self.offsets if n.startswith(f"{prefix}{i}.")]
+                if rng:
+                    s, e = min(r[0] for r in rng), max(r[1] for r in rng)
+                    self.block_bucket[(stack_name, i)] = (s, e)
+                    covered.append((s, e))
+            seq.block_done_hook = self._make_hook(stack_name)
+        covered.sort()
+        self.rest: List[tuple] = []
+        cur = 0
+        for s, e in covered:
+            if s > cur:
+                self.rest.append((cur, s))
+            cur = max(cur, e)
+        if cur < self.n_params:
+            self.rest.append((cur, self.n_params))
+
+    def _make_hook(self, stack_name):
+        def hook(seq, i):
+            if self.world > 1 and (stack_name, i) in self.block_bucket:
+                s, e = self.block_bucket[(stack_name, i)]
+                self._pending.append(dist.all_reduce(self.flat_g[s:e], group=self.pg, async_op=True))
+        return hook
+
+    # ------------------------------------------------------------------ step pieces
+    def forward_loss(self, batch):
+        """``wrappers.py:53-72``: input frames [0, L-1), targets [1, L), mask = loss_mask.mean(-1)."""
+        spec = batch["spectrogram"]
+        raw, post, stop, _ = self.model(batch["phonemes"], spec[:, :-1], spectrogram_mask=batch["loss_mask"].mean(dim=-1))
+        return self.loss(raw, post, stop.view(stop.shape[0], -1), spec[:, 1:], batch["stop_tokens"], batch["loss_mask"])
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+
+    def backward(self, loss):
+        loss.backward()
+        if self.world > 1:
+            for s, e in self.rest:
+                self._pending.append(dist.all_reduce(self.flat_g[s:e], group=self.pg, async_op=True))
+            for w in self._pending:
+                w.wait()
+            self._pending.clear()
+
+    def lr_now(self) -> float:
+        """Linear warm-up ``lr * min(1, (step+1)/warmup)`` (``wrappers.py:284-294``)."""
+        lr = self.cfg.learning_rate
+        if self.cfg.warmup_steps is not None and self.global_step < self.cfg.warmup_steps:
+            lr *= min(1.0, float(self.global_step + 1) / self.cfg.warmup_steps)
+        return lr
+
+    def optimizer_step(self):
+        """Clip by global norm (after the all-reduce, on averaged gradients) + HF-AdamW."""
+        self.global_step += 1
+        lr = self.lr_now_for(self.global_step - 1)
+        n = self.flat_p.numel()
+        if self.device.type != "cuda":
+            raise _lib.RttsError("optimizer_step runs on the GPU only (no CPU fallback for the HIP path)")
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.call("rtts_grad_clip_scale", self.flat_g.data_ptr(), n, 1.0 / self.world, float(self.cfg.gradient_clip_val),
+                  self.ws_partial.data_ptr(), self.ws_scale.data_ptr(), stream)
+        _lib.call("rtts_adamw_step", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
+                  self.flat_v.data_ptr(), self.decay_mask.data_ptr(), n, self.ws_scale.data_ptr(), lr, 0.9, 0.999, 1e-6,
+                  float(self.cfg.weight_decay), self.global_step, stream)
+
+    def lr_now_for(self, step: int) -> float:
+        lr = self.cfg.learning_rate
+        if self.cfg.warmup_steps is not None and step < self.cfg.warmup_steps:
+            lr *= min(1.0, float(step + 1) / self.cfg.warmup_steps)
+        return lr
+
+    def train_step(self, batch):
+        """One micro-batch: forward + loss + backward (+ all-reduce) + optimizer step."""
+        self.model.train()
+        self.zero_grad()
+        total, raw_l, post_l, stop_l = self.forward_loss(batch)
+        self.backward(total)
+        self.optimizer_step()
+        return total.detach(), raw_l.detach(), post_l.detach(), stop_l.detach()
