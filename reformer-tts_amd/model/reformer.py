@@ -156,5 +156,5 @@ class ReformerDec(nn.Module):
         for kwargs in kwargs_list[::6]:
             kwargs["input_mask"] = input_mask
         self.attention_matrices_.clear()
-        y1, y2 = self.layers.forward_halves(x, x, kwargs_list)
+        y1, y2 = self.layers.forward_halves(x, x, kwargs_list, context=keys)
         return y1 + y2, self.attention_matrices_

@@ -144,13 +144,20 @@ class ReversibleSwap(nn.Module):
 
 
 class _ReversibleFunction(torch.autograd.Function):
-    """Keeps only the final pair of streams (``reversible.py:114-129``)."""
+    """Keeps only the final pair of streams (``reversible.py:114-129``).
+
+    ``context`` (the encoder output a decoder stack cross-attends to) is a differentiable input of
+    its own: during the backward the blocks see a detached leaf, whose gradient is accumulated over
+    all cross-attention blocks and handed back ONCE.  (In the reference every decoder layer's
+    nested ``autograd.backward`` walks into the encoder graph, i.e. one full encoder reversible
+    backward per decoder layer; the sum of those partial backward passes equals this single one.)"""
 
     @staticmethod
-    def forward(ctx, x1, x2, seq, kwargs_list):
+    def forward(ctx, x1, x2, context, seq, kwargs_list):
         for block, kwargs in zip(seq.blocks, kwargs_list):
             x1, x2 = block.forward_halves(x1, x2, **kwargs)
         ctx.y = (x1.detach(), x2.detach())
+        ctx.context = None if context is None else context.detach()
         ctx.seq, ctx.kwargs_list = seq, kwargs_list
         return x1, x2
 
@@ -159,12 +166,15 @@ class _ReversibleFunction(torch.autograd.Function):
         y1, y2 = ctx.y
         ctx.y = None
         seq = ctx.seq
-        n = len(seq.blocks)
-        for i in range(n - 1, -1, -1):
-            y1, y2, dy1, dy2 = seq.blocks[i].backward_halves(y1, y2, dy1, dy2, **ctx.kwargs_list[i])
+        leaf = None if ctx.context is None else ctx.context.requires_grad_()
+        for i in range(len(seq.blocks) - 1, -1, -1):
+            kwargs = ctx.kwargs_list[i]
+            if leaf is not None and "key" in kwargs:
+                kwargs = dict(kwargs, key=leaf, value=leaf)
+            y1, y2, dy1, dy2 = seq.blocks[i].backward_halves(y1, y2, dy1, dy2, **kwargs)
             if seq.block_done_hook is not None:
                 seq.block_done_hook(seq, i)
-        return dy1, dy2, None, None
+        return dy1, dy2, (None if leaf is None else leaf.grad), None, None
 
 
 class ReversibleSequence(nn.Module):
@@ -173,9 +183,9 @@ class ReversibleSequence(nn.Module):
         self.blocks = blocks
         self.block_done_hook: Optional[Callable] = None   # (sequence, block index) after its backward_pass
 
-    def forward_halves(self, x1, x2, kwargs_list=None):
+    def forward_halves(self, x1, x2, kwargs_list=None, context=None):
         kwargs_list = kwargs_list if kwargs_list is not None else [{}] * len(self.blocks)
-        return _ReversibleFunction.apply(x1, x2, self, kwargs_list)
+        return _ReversibleFunction.apply(x1, x2, context, self, kwargs_list)
 
     def forward(self, x, kwargs_list=None, **kwargs):
         x1, x2 = torch.chunk(x, 2, dim=2)
