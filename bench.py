@@ -50,7 +50,7 @@ def cpu_baseline(model_cfg, mel_len, text_len, budget_s):
     sequence lengths (frames/s is size-normalised), 1 warm-up-free pass repeated while time remains."""
     from oracle import model_ref, synth
     from reformer_tts_amd.model.config import as_kwargs
-    cores = os.cpu_count() or 1
+    cores = min(len(os.sched_getaffinity(0)), 16)      # the GPU box grants 16 host cores per GPU
     torch.set_num_threads(cores)
     cfg = as_kwargs(model_cfg)
     from reformer_tts_amd.training import build_model
@@ -100,9 +100,15 @@ def main():
     trainer = Trainer(model, tcfg, dev)
     batch = synthetic_batch(args.batch, args.text_len, args.mel_len, seed=42 + rank, device=dev)
 
-    for _ in range(args.warmup):
+    def note(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    note(f"model built ({trainer.n_params} parameters), warming up")
+    for i in range(args.warmup):
         trainer.train_step(batch)
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        note(f"warm-up step {i} done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -119,6 +125,7 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    note(f"timed region done: {1e3 * elapsed / args.steps:.2f} ms/step")
     avg_ms, launches, flops_per_launch = ops.TIMING.summary("rtts_lsh_attn_bwd/bs128")
     ops.TIMING.disable()
 

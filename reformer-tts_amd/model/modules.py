@@ -1,6 +1,6 @@
 """Prenets, postnet, positional encoding and position-wise FFN with the reference's module and
 parameter names (``/root/reference/reformer_tts/model/modules.py``).  Convolutions / BatchNorm /
-small linears still run on ATen (MIOpen, hipBLASLt) in this round; see DESIGN.md for which rows
+small linears still run on ATen GEMMs (hipBLASLt) in this round; see DESIGN.md for which rows
 of SURVEY.md section 8a are hand-written HIP."""
 from __future__ import annotations
 
@@ -9,6 +9,33 @@ from collections import OrderedDict
 import torch
 from torch import nn
 import torch.nn.functional as F
+
+
+def conv1d_k5_rows(x, conv: nn.Conv1d):
+    """Conv1d(kernel 5, padding 2) on channels-last rows: x (B, L, Cin) -> (B, L, Cout) as ONE GEMM over
+    the (B*L, 5*Cin) window matrix (bf16 operands, fp32 accumulate).  Same arithmetic as
+    ``nn.Conv1d`` on the transposed tensor; no MIOpen find/compile step, no (B,C,L) transposes."""
+    b, l, cin = x.shape
+    xp = F.pad(x.to(torch.bfloat16), (0, 0, 2, 2))
+    cols = xp.unfold(1, 5, 1).reshape(b * l, cin * 5)                 # (ci, k) order == weight.view(Cout, Cin*5)
+    w = conv.weight.to(torch.bfloat16).reshape(conv.out_channels, cin * 5)
+    return F.linear(cols, w, conv.bias.to(torch.bfloat16)).view(b, l, conv.out_channels)
+
+
+def batch_norm_rows(x, bn: nn.BatchNorm1d):
+    """BatchNorm1d on channels-last rows (B, L, C): train mode uses the biased batch statistics over
+    (B, L) and updates the running buffers (momentum 0.1, unbiased variance) like nn.BatchNorm1d."""
+    xf = x.float()
+    if bn.training:
+        var, mean = torch.var_mean(xf, dim=(0, 1), unbiased=False)
+        with torch.no_grad():
+            n = xf.shape[0] * xf.shape[1]
+            bn.running_mean.mul_(1 - bn.momentum).add_(mean, alpha=bn.momentum)
+            bn.running_var.mul_(1 - bn.momentum).add_(var * (n / max(n - 1, 1)), alpha=bn.momentum)
+            bn.num_batches_tracked += 1
+    else:
+        mean, var = bn.running_mean, bn.running_var
+    return (xf - mean) * torch.rsqrt(var + bn.eps) * bn.weight + bn.bias
 
 
 def _bf16_linear(x, lin: nn.Linear):
@@ -32,11 +59,11 @@ class EncoderPreNet(nn.Module):
         self.convolutions = nn.Sequential(OrderedDict(layers))
 
     def forward(self, input_):
-        x = self.embed(input_).transpose(1, 2)
-        with torch.autocast(device_type=x.device.type, dtype=torch.bfloat16, enabled=x.is_cuda):
-            x = self.convolutions(x)
-            x = self.projection(x.transpose(1, 2))
-        return x.float()
+        c = self.convolutions
+        x = c.dropout0(self.embed(input_))                      # (B, L, C) channels-last throughout
+        for conv, bn, drop in ((c.conv1, c.bn1, c.dropout1), (c.conv2, c.bn2, c.dropout2), (c.conv3, c.bn3, c.dropout3)):
+            x = drop(F.relu(batch_norm_rows(conv1d_k5_rows(x, conv), bn)))
+        return _bf16_linear(x, self.projection).float()
 
 
 class DecoderPreNet(nn.Module):
@@ -51,9 +78,10 @@ class DecoderPreNet(nn.Module):
             ("projection", nn.Linear(output_size, output_size))]))
 
     def forward(self, input_):
-        with torch.autocast(device_type=input_.device.type, dtype=torch.bfloat16, enabled=input_.is_cuda):
-            out = self.layer(input_)
-        return out.float()
+        l = self.layer
+        x = l.dropout1(F.relu(_bf16_linear(input_, l.fc1)))
+        x = l.dropout2(F.relu(_bf16_linear(x, l.fc2)))
+        return _bf16_linear(x, l.projection).float()
 
 
 class PostConvNet(nn.Module):
@@ -70,10 +98,12 @@ class PostConvNet(nn.Module):
         self.layers = nn.Sequential(OrderedDict(layers))
 
     def forward(self, input_):
-        x = input_.transpose(1, 2)
-        with torch.autocast(device_type=x.device.type, dtype=torch.bfloat16, enabled=x.is_cuda):
-            x = self.layers(x)
-        return x.transpose(1, 2).float()
+        x = input_                                              # (B, L, mel) channels-last throughout
+        depth = (len(self.layers) - 1) // 4
+        for i in range(depth):
+            conv, bn, drop = getattr(self.layers, f"conv{i}"), getattr(self.layers, f"bn{i}"), getattr(self.layers, f"dropout{i}")
+            x = drop(torch.tanh(batch_norm_rows(conv1d_k5_rows(x, conv), bn)))
+        return conv1d_k5_rows(x, self.layers.convend).float()
 
 
 class ScaledPositionalEncoding(nn.Module):

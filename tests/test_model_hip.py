@@ -212,9 +212,15 @@ def test_two_layer_stack_gradients_vs_oracle(gpu):
     o_res[0].backward()
     np.testing.assert_allclose(float(res[0].detach()), float(o_res[0].detach()), rtol=1e-2)
     params = dict(model.named_parameters())
+    rels = {}
     for name, ref in sdo.items():
         if ref.grad is None or float(ref.grad.norm()) < 1e-3:
             continue
         got = params[name].grad.float().cpu()
-        rel = ((got - ref.grad).norm() / ref.grad.norm()).item()
-        assert rel < 6e-2, (name, rel)
+        rels[name] = ((got - ref.grad).norm() / ref.grad.norm()).item()
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/grad_rel_err.txt", "w") as fh:
+        for k, v in sorted(rels.items(), key=lambda kv: -kv[1]):
+            fh.write(f"{v:.4f} {k}\n")
+    worst = max(rels, key=rels.get)
+    assert rels[worst] < 6e-2, (worst, rels[worst])
