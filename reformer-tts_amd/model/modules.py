@@ -19,7 +19,11 @@ def conv1d_k5_rows(x, conv: nn.Conv1d):
     xp = F.pad(x.to(torch.bfloat16), (0, 0, 2, 2))
     cols = xp.unfold(1, 5, 1).reshape(b * l, cin * 5)                 # (ci, k) order == weight.view(Cout, Cin*5)
     w = conv.weight.to(torch.bfloat16).reshape(conv.out_channels, cin * 5)
-    return F.linear(cols, w, conv.bias.to(torch.bfloat16)).view(b, l, conv.out_channels)
+    if cols.is_cuda:   # fp32 result: the BatchNorm that follows removes the channel mean, which would
+        y = torch.mm(cols, w.t(), out_dtype=torch.float32) + conv.bias   # otherwise leave bf16 rounding of the MEAN behind
+    else:
+        y = cols.float() @ w.float().t() + conv.bias
+    return y.view(b, l, conv.out_channels)
 
 
 def batch_norm_rows(x, bn: nn.BatchNorm1d):
