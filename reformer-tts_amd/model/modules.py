@@ -11,6 +11,22 @@ from torch import nn
 import torch.nn.functional as F
 
 
+class _GemmF32Out(torch.autograd.Function):
+    """y(M,N) fp32 = a(M,K) bf16 @ w(N,K)^T bf16 with an fp32 result (hipBLASLt accumulates in fp32
+    anyway; this keeps the result unrounded).  Backward: two bf16 GEMMs."""
+
+    @staticmethod
+    def forward(ctx, a, w):
+        ctx.save_for_backward(a, w)
+        return torch.mm(a, w.t(), out_dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, w = ctx.saved_tensors
+        dyb = dy.to(torch.bfloat16)
+        return dyb @ w, dyb.t() @ a
+
+
 def conv1d_k5_rows(x, conv: nn.Conv1d):
     """Conv1d(kernel 5, padding 2) on channels-last rows: x (B, L, Cin) -> (B, L, Cout) as ONE GEMM over
     the (B*L, 5*Cin) window matrix (bf16 operands, fp32 accumulate).  Same arithmetic as
@@ -20,7 +36,7 @@ def conv1d_k5_rows(x, conv: nn.Conv1d):
     cols = xp.unfold(1, 5, 1).reshape(b * l, cin * 5)                 # (ci, k) order == weight.view(Cout, Cin*5)
     w = conv.weight.to(torch.bfloat16).reshape(conv.out_channels, cin * 5)
     if cols.is_cuda:   # fp32 result: the BatchNorm that follows removes the channel mean, which would
-        y = torch.mm(cols, w.t(), out_dtype=torch.float32) + conv.bias   # otherwise leave bf16 rounding of the MEAN behind
+        y = _GemmF32Out.apply(cols, w) + conv.bias                       # otherwise leave bf16 rounding of the MEAN behind
     else:
         y = cols.float() @ w.float().t() + conv.bias
     return y.view(b, l, conv.out_channels)
