@@ -99,6 +99,46 @@ int rtts_adamw_step(float* params, const float* grads, float* exp_avg, float* ex
                     int64_t n, const float* scale, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int step, void* stream);
 
+/* ---- row-wise fused kernels around the GEMMs of a reversible block --------------------------
+ * Replace the ATen chains of WithNorm / FeedForward / residual adds (reference
+ * reformer_tts/model/reformer.py:25-45, modules.py:195-207, reversible.py:56-98) and their
+ * autograd backward.  Rows are contiguous (stride d); d in {128,256,384,512,768,1024,2048}.
+ * Column sums (bias / LayerNorm-affine gradients) are ACCUMULATED into their outputs through
+ * `partial_ws` (>= 2*256*d floats), deterministically.
+ *   rtts_ln_fwd            xn(bf16) = LayerNorm(x; eps 1e-5) * gamma + beta; keeps mean, rstd (M)
+ *   rtts_ln_bwd            dx_io += dLN(dxn); dgamma += ..., dbeta += ...
+ *   rtts_cast_colsum       dyb(bf16) = dy(fp32); dbias += colsum(dy)   (dbias may be NULL)
+ *   rtts_colsum_bf16       dbias += colsum(dh); relu_gate: dh *= (h > 0) in place first
+ *   rtts_residual_epilogue y = x + sign * (g(bf16) + bias)    (bias may be NULL)
+ *   rtts_bias_act          h(bf16) = [relu](h + bias) in place
+ *   rtts_cast_f32_bf16     flat cast (n % 4 == 0): the per-step bf16 mirror of all parameters */
+int rtts_ln_fwd(const float* x, const float* gamma, const float* beta, void* xn, float* mean, float* rstd,
+                int M, int d, void* stream);
+int rtts_ln_bwd(const void* dxn, const float* x, const float* mean, const float* rstd, const float* gamma,
+                float* dx_io, float* dgamma, float* dbeta, float* partial_ws, int M, int d, void* stream);
+int rtts_cast_colsum(const float* dy, void* dyb, float* dbias, float* partial_ws, int M, int d, void* stream);
+int rtts_colsum_bf16(void* dh, const void* h, int64_t ld, float* dbias, float* partial_ws, int M, int d,
+                     int relu_gate, void* stream);
+int rtts_residual_epilogue(const float* x, const void* g, const float* bias, float sign, float* y,
+                           int64_t M, int d, void* stream);
+int rtts_bias_act(void* h, const float* bias, int64_t M, int d, int relu, void* stream);
+int rtts_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
+
+/* ---- dense encoder-decoder attention (T_k = 128 or 256 keys on chip) ------------------------
+ * Replaces the attention core of nn.MultiheadAttention inside MultiheadAttentionWrapper
+ * (reference reformer_tts/model/reformer.py:161-186); projections stay GEMMs outside.
+ *   q   bf16 (B,Tq,H*dh) stride ld_q;  kv bf16 (B,Tk,2*H*dh) = [k | v] stride ld_kv
+ *   kvalid u8 (B,Tk) 1 = attend (i.e. NOT key_padding_mask), or NULL
+ *   o   bf16 (B,Tq,H*dh) stride ld_o;  lse f32 (B*H,Tq)
+ *   backward: delta f32 (B*H,Tq) = rowsum(o*do) (rtts_lsh_bwd_delta), dq bf16 like q,
+ *   dkv_part bf16 (Tq/128, B, Tk, 2*H*dh) partial slabs -> rtts_sum_slabs -> dkv (B,Tk,2*H*dh) */
+int rtts_xattn_fwd(const void* q, int64_t ld_q, const void* kv, int64_t ld_kv, const uint8_t* kvalid,
+                   int B, int H, int Tq, int Tk, int dh, void* o, int64_t ld_o, float* lse, void* stream);
+int rtts_xattn_bwd(const void* q, int64_t ld_q, const void* kv, int64_t ld_kv, const uint8_t* kvalid,
+                   const void* dout, int64_t ld_dout, const float* lse, const float* delta,
+                   int B, int H, int Tq, int Tk, int dh, void* dq, int64_t ld_dq, void* dkv_part, void* stream);
+int rtts_sum_slabs(const void* part, int nslabs, int64_t n, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,16 @@ SIGNATURES = {
     "rtts_lsh_attn_bwd": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     "rtts_lsh_bwd_reduce": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp],
     "rtts_grad_clip_scale": [_vp, _i64, _f32, _f32, _vp, _vp, _vp],
+    "rtts_ln_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp],
+    "rtts_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp],
+    "rtts_cast_colsum": [_vp, _vp, _vp, _vp, _i32, _i32, _vp],
+    "rtts_colsum_bf16": [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp],
+    "rtts_residual_epilogue": [_vp, _vp, _vp, _f32, _vp, _i64, _i32, _vp],
+    "rtts_bias_act": [_vp, _vp, _i64, _i32, _i32, _vp],
+    "rtts_cast_f32_bf16": [_vp, _vp, _i64, _vp],
+    "rtts_xattn_fwd": [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp],
+    "rtts_xattn_bwd": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp],
+    "rtts_sum_slabs": [_vp, _i32, _i64, _vp, _vp],
     "rtts_adamw_step": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _i32, _vp],
 }
 

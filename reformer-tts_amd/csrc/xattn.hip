@@ -1,0 +1,419 @@
+// Dense encoder-decoder ("cross") attention, forward and backward, for short key sequences
+// (T_k = 128 or 256 keys held entirely on chip; the text side of Reformer-TTS is padded to 256).
+//
+// Replaces nn.MultiheadAttention as wrapped by MultiheadAttentionWrapper
+// (/root/reference/reformer_tts/model/reformer.py:161-186): scores = (q W_q)(k W_k)^T / sqrt(dh),
+// key_padding_mask -> -inf, softmax, P V, per head; the four projections stay GEMMs outside.
+//
+// Same MFMA dataflow as the LSH chunk kernels (lsh_attn_fwd.hip / lsh_attn_bwd.hip):
+//   forward : lane = query, S^T = K Q^T, in-register softmax over all keys, O^T = V^T P^T
+//   backward: lane = key, wave w owns keys [64w, 64w+64): dV, dK complete in registers for the
+//             workgroup's 128 queries; dS^T crosses LDS once for dQ^T = K^T dS^T.  dK/dV of the
+//             T_q/128 query blocks are written as partial slabs and summed by rtts_sum_slabs
+//             (deterministic, no atomics).
+#include "rtts_common.h"
+#include <float.h>
+
+#define XA_DH 64
+#define XA_ROWB 144
+#define XA_QB 128     // queries per workgroup
+
+typedef __attribute__((ext_vector_type(8))) short xa_short8;
+
+__device__ __forceinline__ bf16x8 xa_tr_frag(const unsigned char* p0, const unsigned char* p1) {
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((RTTS_LDS short4v*)p0);
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((RTTS_LDS short4v*)p1);
+    const xa_short8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, both);
+}
+
+// ------------------------------------------------------------------------------ forward
+template <int TK>
+__global__ __launch_bounds__(256) void xattn_fwd_kernel(const bf16_t* __restrict__ q, int64_t ld_q, const bf16_t* __restrict__ kv,
+                                                        int64_t ld_kv, const uint8_t* __restrict__ kvalid, int H, int Tq,
+                                                        bf16_t* __restrict__ o, int64_t ld_o, float* __restrict__ lse) {
+    constexpr int NKT = TK / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Ks = smem;
+    unsigned char* Vs = Ks + TK * XA_ROWB;
+    int* kval = reinterpret_cast<int*>(Vs + TK * XA_ROWB);
+
+    const int nqb = Tq / XA_QB;
+    const uint32_t wi = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = wi / nqb, qb = wi % nqb;
+    const int b = bh / H, h = bh % H;
+    const int d = H * XA_DH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+
+    const bf16_t* kbase = kv + (size_t)b * TK * ld_kv + (size_t)h * XA_DH;
+    const bf16_t* vbase = kbase + d;
+    constexpr int ITERS = TK * 8 / 256;
+    uint4 kreg[ITERS], vreg[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int row = (it * 256 + tid) >> 3, piece = tid & 7;
+        kreg[it] = *reinterpret_cast<const uint4*>(kbase + (size_t)row * ld_kv + piece * 8);
+        vreg[it] = *reinterpret_cast<const uint4*>(vbase + (size_t)row * ld_kv + piece * 8);
+    }
+    // Q fragments straight from global: lane (r, hh) holds Q[q0 + r][16 ks + 8 hh .. +8]
+    const int qrow = qb * XA_QB + wave * 32 + r;
+    const bf16_t* qptr = q + ((size_t)b * Tq + qrow) * ld_q + (size_t)h * XA_DH;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qptr + ks * 16 + 8 * hh);
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int row = (it * 256 + tid) >> 3, piece = tid & 7;
+        *reinterpret_cast<uint4*>(Ks + row * XA_ROWB + piece * 16) = kreg[it];
+        *reinterpret_cast<uint4*>(Vs + row * XA_ROWB + piece * 16) = vreg[it];
+    }
+    for (int j = tid; j < TK; j += 256) kval[j] = kvalid ? (int)kvalid[(size_t)b * TK + j] : 1;
+    __syncthreads();
+
+    f32x16 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        f32x16 acc = {0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + r) * XA_ROWB + (ks * 16 + 8 * hh) * 2);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc, 0, 0, 0);
+        }
+        s[kt] = acc;
+    }
+    float m = -FLT_MAX;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int4 kvv = *reinterpret_cast<const int4*>(kval + kt * 32 + 8 * g + 4 * hh);
+            const int vv[4] = {kvv.x, kvv.y, kvv.z, kvv.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x = vv[j] ? s[kt][4 * g + j] * 0.125f : -FLT_MAX;
+                s[kt][4 * g + j] = x;
+                m = fmaxf(m, x);
+            }
+        }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float p = s[kt][i] == -FLT_MAX ? 0.f : __expf(s[kt][i] - m);
+            s[kt][i] = p;
+            l += p;
+        }
+    l += __shfl_xor(l, 32);
+
+    f32x16 oacc[2] = {{0}, {0}};
+    const int trq = (lane & 15) >> 2, trp = lane & 3, trc = (lane >> 4) & 1;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[kt][8 * s2 + j];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int keyb = kt * 32 + 16 * s2 + 4 * hh + trq;
+                const int col = (dt * 32 + 16 * trc + 4 * trp) * 2;
+                const bf16x8 vf = xa_tr_frag(Vs + keyb * XA_ROWB + col, Vs + (keyb + 8) * XA_ROWB + col);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
+            }
+        }
+    const float inv_l = 1.f / l;
+    bf16_t* optr = o + ((size_t)b * Tq + qrow) * ld_o + (size_t)h * XA_DH;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 pk;
+            pk.x = pack_bf16x2(oacc[dt][4 * g] * inv_l, oacc[dt][4 * g + 1] * inv_l);
+            pk.y = pack_bf16x2(oacc[dt][4 * g + 2] * inv_l, oacc[dt][4 * g + 3] * inv_l);
+            *reinterpret_cast<uint2*>(optr + dt * 32 + 8 * g + 4 * hh) = pk;
+        }
+    if (hh == 0) lse[(size_t)bh * Tq + qrow] = m + logf(l);
+}
+
+// ------------------------------------------------------------------------------ backward
+template <int TK>
+__global__ __launch_bounds__(TK) void xattn_bwd_kernel(const bf16_t* __restrict__ q, int64_t ld_q, const bf16_t* __restrict__ kv,
+                                                       int64_t ld_kv, const uint8_t* __restrict__ kvalid,
+                                                       const bf16_t* __restrict__ dout, int64_t ld_do, const float* __restrict__ lse,
+                                                       const float* __restrict__ delta, int H, int Tq, bf16_t* __restrict__ dq,
+                                                       int64_t ld_dq, bf16_t* __restrict__ dkv_part, int B) {
+    constexpr int NTHR = TK;                 // one wave per 64 keys
+    constexpr int DSROW = XA_QB * 2 + 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Ks = smem;                        // [TK][144]
+    unsigned char* Qs = Ks + TK * XA_ROWB;           // [128][144]
+    unsigned char* Os = Qs + XA_QB * XA_ROWB;        // [128][144]
+    unsigned char* Ds = Os + XA_QB * XA_ROWB;        // [TK][DSROW]  dS^T (already * scale)
+    float* qlse = reinterpret_cast<float*>(Ds + TK * DSROW);
+    float* qdel = qlse + XA_QB;
+
+    const int nqb = Tq / XA_QB;
+    const uint32_t wi = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = wi / nqb, qb = wi % nqb;
+    const int b = bh / H, h = bh % H;
+    const int d = H * XA_DH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+
+    const bf16_t* kbase = kv + (size_t)b * TK * ld_kv + (size_t)h * XA_DH;
+    const bf16_t* vbase = kbase + d;
+    const bf16_t* qbase = q + ((size_t)b * Tq + (size_t)qb * XA_QB) * ld_q + (size_t)h * XA_DH;
+    const bf16_t* dobase = dout + ((size_t)b * Tq + (size_t)qb * XA_QB) * ld_do + (size_t)h * XA_DH;
+
+    for (int idx = tid; idx < TK * 8; idx += NTHR) {
+        const int row = idx >> 3, piece = idx & 7;
+        *reinterpret_cast<uint4*>(Ks + row * XA_ROWB + piece * 16) =
+            *reinterpret_cast<const uint4*>(kbase + (size_t)row * ld_kv + piece * 8);
+    }
+    for (int idx = tid; idx < XA_QB * 8; idx += NTHR) {
+        const int row = idx >> 3, piece = idx & 7;
+        *reinterpret_cast<uint4*>(Qs + row * XA_ROWB + piece * 16) =
+            *reinterpret_cast<const uint4*>(qbase + (size_t)row * ld_q + piece * 8);
+        *reinterpret_cast<uint4*>(Os + row * XA_ROWB + piece * 16) =
+            *reinterpret_cast<const uint4*>(dobase + (size_t)row * ld_do + piece * 8);
+    }
+    for (int j = tid; j < XA_QB; j += NTHR) {
+        qlse[j] = lse[(size_t)bh * Tq + qb * XA_QB + j];
+        qdel[j] = delta[(size_t)bh * Tq + qb * XA_QB + j];
+    }
+    const int myrow[2] = {wave * 64 + r, wave * 64 + 32 + r};
+    bf16x8 vf[2][4], kf[2][4];
+    int kvl[2];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            vf[k2][ks] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)myrow[k2] * ld_kv + ks * 16 + 8 * hh);
+            kf[k2][ks] = *reinterpret_cast<const bf16x8*>(kbase + (size_t)myrow[k2] * ld_kv + ks * 16 + 8 * hh);
+        }
+        kvl[k2] = kvalid ? (int)kvalid[(size_t)b * TK + myrow[k2]] : 1;
+    }
+    __syncthreads();
+
+    f32x16 dvacc[2][2], gacc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            dvacc[a][c2] = (f32x16){0};
+            gacc[a][c2] = (f32x16){0};
+        }
+    const int trq = (lane & 15) >> 2, trp = lane & 3, trc = (lane >> 4) & 1;
+
+#pragma unroll 1
+    for (int qt = 0; qt < XA_QB / 32; ++qt) {
+        bf16x8 qf[4], dof[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks] = *reinterpret_cast<const bf16x8*>(Qs + (qt * 32 + r) * XA_ROWB + (ks * 16 + 8 * hh) * 2);
+            dof[ks] = *reinterpret_cast<const bf16x8*>(Os + (qt * 32 + r) * XA_ROWB + (ks * 16 + 8 * hh) * 2);
+        }
+        bf16x8 qtf[2][2], dotf[2][2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int qrow = qt * 32 + 16 * s2 + 4 * hh + trq;
+                const int col = (dt * 32 + 16 * trc + 4 * trp) * 2;
+                qtf[s2][dt] = xa_tr_frag(Qs + qrow * XA_ROWB + col, Qs + (qrow + 8) * XA_ROWB + col);
+                dotf[s2][dt] = xa_tr_frag(Os + qrow * XA_ROWB + col, Os + (qrow + 8) * XA_ROWB + col);
+            }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            f32x16 sacc = {0}, pacc = {0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[k2][ks], sacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof[ks], vf[k2][ks], pacc, 0, 0, 0);
+            }
+            float pp[16], ds[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int q0 = qt * 32 + 8 * g + 4 * hh;
+                const float4 l4 = *reinterpret_cast<const float4*>(qlse + q0);
+                const float4 d4 = *reinterpret_cast<const float4*>(qdel + q0);
+                const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = 4 * g + j;
+                    const float p = kvl[k2] ? __expf(sacc[i] * 0.125f - lv[j]) : 0.f;
+                    pp[i] = p;
+                    ds[i] = p * (pacc[i] - dl[j]) * 0.125f;
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 pb, db;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    pb[j] = (__bf16)pp[8 * s2 + j];
+                    db[j] = (__bf16)ds[8 * s2 + j];
+                }
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dvacc[k2][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[s2][dt], pb, dvacc[k2][dt], 0, 0, 0);
+                    gacc[k2][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[s2][dt], db, gacc[k2][dt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 pk;
+                pk.x = pack_bf16x2(ds[4 * g], ds[4 * g + 1]);
+                pk.y = pack_bf16x2(ds[4 * g + 2], ds[4 * g + 3]);
+                *reinterpret_cast<uint2*>(Ds + myrow[k2] * DSROW + (qt * 32 + 8 * g + 4 * hh) * 2) = pk;
+            }
+        }
+    }
+
+    // dK | dV partial slab of this query block: layout (nqb, B, TK, 2d)
+    bf16_t* slab = dkv_part + (((size_t)qb * B + b) * TK) * (size_t)(2 * d) + (size_t)h * XA_DH;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+        bf16_t* dkp = slab + (size_t)myrow[k2] * (2 * d);
+        bf16_t* dvp = dkp + d;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 pk;
+                pk.x = pack_bf16x2(gacc[k2][dt][4 * g], gacc[k2][dt][4 * g + 1]);
+                pk.y = pack_bf16x2(gacc[k2][dt][4 * g + 2], gacc[k2][dt][4 * g + 3]);
+                *reinterpret_cast<uint2*>(dkp + dt * 32 + 8 * g + 4 * hh) = pk;
+                pk.x = pack_bf16x2(dvacc[k2][dt][4 * g], dvacc[k2][dt][4 * g + 1]);
+                pk.y = pack_bf16x2(dvacc[k2][dt][4 * g + 2], dvacc[k2][dt][4 * g + 3]);
+                *reinterpret_cast<uint2*>(dvp + dt * 32 + 8 * g + 4 * hh) = pk;
+            }
+    }
+    __syncthreads();
+
+    // dQ^T[dh][q] = K^T dS^T: the TK/64 waves split the 4 query tiles
+    for (int qt = wave; qt < XA_QB / 32; qt += TK / 64) {
+        f32x16 dqa[2] = {{0}, {0}};
+#pragma unroll 4
+        for (int kb = 0; kb < TK; kb += 16) {
+            const int keyr = kb + 8 * hh + trq;
+            const int qcol = (qt * 32 + 16 * trc + 4 * trp) * 2;
+            const bf16x8 bfrag = xa_tr_frag(Ds + keyr * DSROW + qcol, Ds + (keyr + 4) * DSROW + qcol);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int col = (dt * 32 + 16 * trc + 4 * trp) * 2;
+                const bf16x8 afrag = xa_tr_frag(Ks + keyr * XA_ROWB + col, Ks + (keyr + 4) * XA_ROWB + col);
+                dqa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, dqa[dt], 0, 0, 0);
+            }
+        }
+        bf16_t* dqp = dq + ((size_t)b * Tq + (size_t)qb * XA_QB + qt * 32 + r) * ld_dq + (size_t)h * XA_DH;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 pk;
+                pk.x = pack_bf16x2(dqa[dt][4 * g], dqa[dt][4 * g + 1]);
+                pk.y = pack_bf16x2(dqa[dt][4 * g + 2], dqa[dt][4 * g + 3]);
+                *reinterpret_cast<uint2*>(dqp + dt * 32 + 8 * g + 4 * hh) = pk;
+            }
+    }
+}
+
+// out = sum over slabs (bf16 in, fp32 accumulate, bf16 out), 8 elements per thread
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const bf16_t* __restrict__ part, int nslabs, size_t n8,
+                                                        bf16_t* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int s = 0; s < nslabs; ++s) {
+            const uint4 t = reinterpret_cast<const uint4*>(part)[(size_t)s * n8 + i];
+            const uint32_t u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[2 * j] += __uint_as_float(u[j] << 16);
+                acc[2 * j + 1] += __uint_as_float(u[j] & 0xffff0000u);
+            }
+        }
+        uint4 o;
+        o.x = pack_bf16x2(acc[0], acc[1]);
+        o.y = pack_bf16x2(acc[2], acc[3]);
+        o.z = pack_bf16x2(acc[4], acc[5]);
+        o.w = pack_bf16x2(acc[6], acc[7]);
+        reinterpret_cast<uint4*>(out)[i] = o;
+    }
+}
+
+static bool g_xa_attr[2][2];
+
+static int xa_check(const char* fn, int B, int H, int Tq, int Tk, int dh, int64_t ld_q, int64_t ld_kv) {
+    RTTS_REQUIRE(dh == XA_DH, "%s: dh=%d unsupported (this build: 64)", fn, dh);
+    RTTS_REQUIRE(Tk == 128 || Tk == 256, "%s: T_k=%d unsupported (128 or 256 keys on chip)", fn, Tk);
+    RTTS_REQUIRE(Tq > 0 && Tq % XA_QB == 0, "%s: T_q=%d must be a multiple of 128", fn, Tq);
+    RTTS_REQUIRE(B > 0 && H > 0, "%s: bad B/H", fn);
+    RTTS_REQUIRE(ld_q >= (int64_t)H * dh && ld_q % 8 == 0 && ld_kv >= (int64_t)2 * H * dh && ld_kv % 8 == 0, "%s: bad row strides", fn);
+    return 0;
+}
+
+extern "C" int rtts_xattn_fwd(const void* q, int64_t ld_q, const void* kv, int64_t ld_kv, const uint8_t* kvalid, int B, int H, int Tq,
+                              int Tk, int dh, void* o, int64_t ld_o, float* lse, void* stream) {
+    RTTS_REQUIRE(q && kv && o && lse, "rtts_xattn_fwd: null pointer");
+    if (xa_check("rtts_xattn_fwd", B, H, Tq, Tk, dh, ld_q, ld_kv)) return -1;
+    RTTS_REQUIRE(ld_o >= (int64_t)H * dh && ld_o % 8 == 0, "rtts_xattn_fwd: bad ld_o");
+    RTTS_REQUIRE((((uintptr_t)q | (uintptr_t)kv | (uintptr_t)o) & 15) == 0, "rtts_xattn_fwd: buffers must be 16-byte aligned");
+    const dim3 grid(B * H * (Tq / XA_QB));
+    const size_t lds = 2 * (size_t)Tk * XA_ROWB + (size_t)Tk * 4;
+#define GO(TK_)                                                                                                           \
+    do {                                                                                                                  \
+        auto kern = xattn_fwd_kernel<TK_>;                                                                                \
+        if (!g_xa_attr[0][TK_ == 256]) {                                                                                  \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            g_xa_attr[0][TK_ == 256] = true;                                                                              \
+        }                                                                                                                 \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q, ld_q, (const bf16_t*)kv, ld_kv, \
+                           kvalid, H, Tq, (bf16_t*)o, ld_o, lse);                                                         \
+    } while (0)
+    if (Tk == 256) GO(256); else GO(128);
+#undef GO
+    RTTS_LAUNCH_CHECK("rtts_xattn_fwd");
+    return 0;
+}
+
+extern "C" int rtts_xattn_bwd(const void* q, int64_t ld_q, const void* kv, int64_t ld_kv, const uint8_t* kvalid, const void* dout,
+                              int64_t ld_dout, const float* lse, const float* delta, int B, int H, int Tq, int Tk, int dh, void* dq,
+                              int64_t ld_dq, void* dkv_part, void* stream) {
+    RTTS_REQUIRE(q && kv && dout && lse && delta && dq && dkv_part, "rtts_xattn_bwd: null pointer");
+    if (xa_check("rtts_xattn_bwd", B, H, Tq, Tk, dh, ld_q, ld_kv)) return -1;
+    RTTS_REQUIRE(ld_dout >= (int64_t)H * dh && ld_dout % 8 == 0 && ld_dq >= (int64_t)H * dh && ld_dq % 8 == 0,
+                 "rtts_xattn_bwd: bad strides");
+    RTTS_REQUIRE((((uintptr_t)q | (uintptr_t)kv | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dkv_part) & 15) == 0,
+                 "rtts_xattn_bwd: buffers must be 16-byte aligned");
+    const dim3 grid(B * H * (Tq / XA_QB));
+    const size_t lds = (size_t)Tk * XA_ROWB + 2 * (size_t)XA_QB * XA_ROWB + (size_t)Tk * (XA_QB * 2 + 16) + XA_QB * 8;
+#define GO(TK_)                                                                                                           \
+    do {                                                                                                                  \
+        auto kern = xattn_bwd_kernel<TK_>;                                                                                \
+        if (!g_xa_attr[1][TK_ == 256]) {                                                                                  \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            g_xa_attr[1][TK_ == 256] = true;                                                                              \
+        }                                                                                                                 \
+        hipLaunchKernelGGL(kern, grid, dim3(TK_), lds, (hipStream_t)stream, (const bf16_t*)q, ld_q, (const bf16_t*)kv, ld_kv, \
+                           kvalid, (const bf16_t*)dout, ld_dout, lse, delta, H, Tq, (bf16_t*)dq, ld_dq, (bf16_t*)dkv_part, B); \
+    } while (0)
+    if (Tk == 256) GO(256); else GO(128);
+#undef GO
+    RTTS_LAUNCH_CHECK("rtts_xattn_bwd");
+    return 0;
+}
+
+extern "C" int rtts_sum_slabs(const void* part, int nslabs, int64_t n, void* out, void* stream) {
+    RTTS_REQUIRE(part && out && nslabs > 0 && n > 0 && n % 8 == 0, "rtts_sum_slabs: n must be a positive multiple of 8");
+    size_t blocks = ((size_t)n / 8 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)part, nslabs,
+                       (size_t)n / 8, (bf16_t*)out);
+    RTTS_LAUNCH_CHECK("rtts_sum_slabs");
+    return 0;
+}

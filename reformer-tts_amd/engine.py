@@ -1,0 +1,372 @@
+"""Explicit (autograd-free) executor of a reversible stack on the GPU.
+
+The reference runs every block under nested ``torch.autograd.backward`` calls
+(``/root/reference/reformer_tts/model/reversible.py:62-98,148-170``) over eager ATen graphs; here
+each block is a short, fixed sequence of launches -- library GEMMs (hipBLASLt through
+``torch.mm``) and the hand-written kernels of librtts_hip.so -- for the forward, for the
+reconstruction ``x = y - f(.)`` and for the backward, with parameter gradients accumulated
+straight into the flat gradient buffer.  The two residual streams and their gradients are four
+fp32 buffers updated IN PLACE; a swap exchanges two Python references.
+
+Every block is the primitive   acc += fn(inp)   with
+    forward :  acc += fn(inp)
+    backward:  acc -= fn(inp)  (reconstruct), d_inp += J_fn(inp)^T d_acc, parameter grads += ...
+The encoder's ReversibleBlock is two such steps (f then g), the decoder's layer three with swaps.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import _lib, ops
+from .model.lsh_attention import LSHSelfAttention
+
+
+def _s() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _bf16(p: torch.Tensor) -> torch.Tensor:
+    """bf16 copy of a parameter: the trainer's per-step flat mirror when present."""
+    m = getattr(p, "_bf16_mirror", None)
+    return m if m is not None else p.detach().to(torch.bfloat16)
+
+
+def _grad(p: torch.Tensor) -> torch.Tensor:
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+class _WS:
+    """Per-device scratch for the deterministic column sums."""
+    _cache = {}
+
+    @classmethod
+    def partial(cls, device, d: int) -> torch.Tensor:
+        key = (device, d)
+        if key not in cls._cache:
+            cls._cache[key] = torch.empty(2 * 256 * d, dtype=torch.float32, device=device)
+        return cls._cache[key]
+
+
+def ln_fwd(x, norm):
+    m, d = x.shape
+    xn = torch.empty(m, d, dtype=torch.bfloat16, device=x.device)
+    mean = torch.empty(m, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(m, dtype=torch.float32, device=x.device)
+    _lib.call("rtts_ln_fwd", x.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr(), xn.data_ptr(), mean.data_ptr(),
+              rstd.data_ptr(), m, d, _s())
+    return xn, mean, rstd
+
+
+def ln_bwd(dxn, x, mean, rstd, norm, dx_io):
+    m, d = x.shape
+    _lib.call("rtts_ln_bwd", dxn.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), norm.weight.data_ptr(),
+              dx_io.data_ptr(), _grad(norm.weight).data_ptr(), _grad(norm.bias).data_ptr(), _WS.partial(x.device, d).data_ptr(),
+              m, d, _s())
+
+
+def cast_colsum(dy, dbias: Optional[torch.Tensor]):
+    m, d = dy.shape
+    dyb = torch.empty(m, d, dtype=torch.bfloat16, device=dy.device)
+    _lib.call("rtts_cast_colsum", dy.data_ptr(), dyb.data_ptr(), None if dbias is None else dbias.data_ptr(),
+              _WS.partial(dy.device, d).data_ptr(), m, d, _s())
+    return dyb
+
+
+def colsum_bf16(dh, dbias, h=None):
+    m, d = dh.shape
+    _lib.call("rtts_colsum_bf16", dh.data_ptr(), None if h is None else h.data_ptr(), dh.stride(0), dbias.data_ptr(),
+              _WS.partial(dh.device, d).data_ptr(), m, d, int(h is not None), _s())
+
+
+def residual(acc, g, bias, sign: float):
+    """acc = acc + sign * (g + bias), in place."""
+    m, d = acc.shape
+    _lib.call("rtts_residual_epilogue", acc.data_ptr(), g.data_ptr(), None if bias is None else bias.data_ptr(), float(sign),
+              acc.data_ptr(), m, d, _s())
+
+
+def wgrad(grad_view: torch.Tensor, dy: torch.Tensor, x: torch.Tensor):
+    """grad_view (N,K) fp32 += dy(M,N)^T @ x(M,K)   (bf16 operands, fp32 result)."""
+    grad_view.add_(torch.mm(dy.t(), x, out_dtype=torch.float32))
+
+
+# ------------------------------------------------------------------------------------------ blocks
+class LSHExec:
+    """WithNorm(LayerNorm, LSHSelfAttentionWrapper): acc += to_out(LSH(LN(inp)))."""
+
+    def __init__(self, withnorm):
+        self.norm = withnorm.norm
+        self.layer: LSHSelfAttention = withnorm.fn.layer
+        self.st = None
+
+    @staticmethod
+    def supported(withnorm) -> bool:
+        return withnorm.fn.layer.post_attn_dropout.p == 0.0
+
+    def _wqkv(self):
+        lyr = self.layer
+        a, b = _bf16(lyr.toqk.weight), _bf16(lyr.tov.weight)
+        if a.data_ptr() + a.numel() * 2 == b.data_ptr():          # adjacent in the flat mirror: zero-copy (2d, d) view
+            return torch.as_strided(a, (2 * a.shape[0], a.shape[1]), (a.shape[1], 1))
+        return torch.cat([a, b], dim=0)
+
+    def _wqkv_grad(self):
+        lyr = self.layer
+        ga, gb = _grad(lyr.toqk.weight), _grad(lyr.tov.weight)
+        if ga.data_ptr() + ga.numel() * 4 == gb.data_ptr():
+            return torch.as_strided(ga, (2 * ga.shape[0], ga.shape[1]), (ga.shape[1], 1)), None
+        return None, (ga, gb)
+
+    def _internals(self, inp, b, t, mask, st):
+        lyr = self.layer
+        e = lyr.dim
+        if t <= lyr.full_attn_thres:
+            raise NotImplementedError("full-attention shortcut (T <= full_attn_thres) is outside the HIP path")
+        xn, mean, rstd = ln_fwd(inp, self.norm)
+        wqkv = self._wqkv()
+        qkv = torch.mm(xn, wqkv.t()).view(b, t, 2 * e)
+        if st is None:
+            rot = lyr._rotations(qkv, t // lyr.bucket_size)
+            st, _, _ = ops.lsh_hash_sort(qkv[..., :e], rot, lyr.heads, lyr.bucket_size)
+        lyr.last_st = st
+        o, lse = ops.lsh_attn_fwd(qkv[..., :e], qkv[..., e:], st, lyr.heads, lyr.bucket_size, lyr.causal, mask)
+        out, lse_tot = ops.lsh_combine_fwd(o, lse, b, lyr.heads)
+        g = torch.mm(out.view(b * t, e), _bf16(lyr.to_out.weight).t())
+        return xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g
+
+    def forward(self, acc, inp, b, t, mask=None, **_):
+        *_, st, _, _, g = self._internals(inp, b, t, mask, None)
+        self.st = st
+        residual(acc, g, self.layer.to_out.bias, 1.0)
+
+    def backward(self, acc, inp, d_acc, d_inp, b, t, mask=None, **_):
+        lyr = self.layer
+        e = lyr.dim
+        xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g = self._internals(inp, b, t, mask, self.st)
+        self.st = None
+        residual(acc, g, lyr.to_out.bias, -1.0)                               # reconstruct the stream
+        dyb = cast_colsum(d_acc, _grad(lyr.to_out.bias))
+        out2 = out.view(b * t, e)
+        wgrad(_grad(lyr.to_out.weight), dyb, out2)
+        dout = torch.mm(dyb, _bf16(lyr.to_out.weight)).view(b, t, e)
+        dqkv = torch.empty_like(qkv)
+        ops.lsh_attn_bwd(qkv[..., :e], qkv[..., e:], st, out, dout, lse_tot, lyr.heads, lyr.bucket_size, lyr.causal, mask,
+                         dqkv=(dqkv[..., :e], dqkv[..., e:]))
+        dqkv2 = dqkv.view(b * t, 2 * e)
+        gview, pair = self._wqkv_grad()
+        if gview is not None:
+            wgrad(gview, dqkv2, xn)
+        else:
+            full = torch.mm(dqkv2.t(), xn, out_dtype=torch.float32)
+            pair[0].add_(full[:e])
+            pair[1].add_(full[e:])
+        dxn = torch.mm(dqkv2, wqkv)
+        ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp)
+
+
+class FFNExec:
+    """[Chunk(] WithNorm(LayerNorm, FeedForward) [)]: acc += W2 relu(W1 LN(inp) + b1) + b2."""
+
+    def __init__(self, mod):
+        wn = mod.fn if hasattr(mod, "chunks") else mod
+        self.norm = wn.norm
+        self.l1, self.l2 = wn.fn.net[0], wn.fn.net[3]
+
+    @staticmethod
+    def supported(mod) -> bool:
+        wn = mod.fn if hasattr(mod, "chunks") else mod
+        return wn.fn.net[2].p == 0.0
+
+    def _internals(self, inp):
+        xn, mean, rstd = ln_fwd(inp, self.norm)
+        h = torch.mm(xn, _bf16(self.l1.weight).t())
+        _lib.call("rtts_bias_act", h.data_ptr(), self.l1.bias.data_ptr(), h.shape[0], h.shape[1], 1, _s())
+        g = torch.mm(h, _bf16(self.l2.weight).t())
+        return xn, mean, rstd, h, g
+
+    def forward(self, acc, inp, b, t, **_):
+        *_, g = self._internals(inp)
+        residual(acc, g, self.l2.bias, 1.0)
+
+    def backward(self, acc, inp, d_acc, d_inp, b, t, **_):
+        xn, mean, rstd, h, g = self._internals(inp)
+        residual(acc, g, self.l2.bias, -1.0)
+        dyb = cast_colsum(d_acc, _grad(self.l2.bias))
+        wgrad(_grad(self.l2.weight), dyb, h)
+        dh = torch.mm(dyb, _bf16(self.l2.weight))
+        colsum_bf16(dh, _grad(self.l1.bias), h)                                # relu gate in place + db1
+        wgrad(_grad(self.l1.weight), dh, xn)
+        dxn = torch.mm(dh, _bf16(self.l1.weight))
+        ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp)
+
+
+class XAttnExec:
+    """WithNorm(LayerNorm, MultiheadAttentionWrapper): acc += out_proj(MHA(q=LN(inp), k=v=keys))."""
+
+    def __init__(self, withnorm):
+        self.norm = withnorm.norm
+        self.mha = withnorm.fn.layer
+
+    @staticmethod
+    def supported(withnorm) -> bool:
+        m = withnorm.fn.layer
+        return m.dropout == 0.0 and m.bias_k is None and not m.add_zero_attn and m._qkv_same_embed_dim
+
+    def _internals(self, inp, b, t, keys_bf16, kvalid):
+        m = self.mha
+        e, h = m.embed_dim, m.num_heads
+        tk = keys_bf16.shape[0] // b
+        w, bias = _bf16(m.in_proj_weight), _bf16(m.in_proj_bias)
+        xn, mean, rstd = ln_fwd(inp, self.norm)
+        q = torch.addmm(bias[:e], xn, w[:e].t())
+        kv = torch.addmm(bias[e:], keys_bf16, w[e:].t())
+        o = torch.empty(b * t, e, dtype=torch.bfloat16, device=inp.device)
+        lse = torch.empty(b * h, t, dtype=torch.float32, device=inp.device)
+        _lib.call("rtts_xattn_fwd", q.data_ptr(), e, kv.data_ptr(), 2 * e, None if kvalid is None else kvalid.data_ptr(), b, h, t,
+                  tk, e // h, o.data_ptr(), e, lse.data_ptr(), _s())
+        g = torch.mm(o, _bf16(m.out_proj.weight).t())
+        return xn, mean, rstd, w, q, kv, o, lse, g, tk
+
+    def forward(self, acc, inp, b, t, keys_bf16=None, kvalid=None, **_):
+        *_, g, _ = self._internals(inp, b, t, keys_bf16, kvalid)
+        residual(acc, g, self.mha.out_proj.bias, 1.0)
+
+    def backward(self, acc, inp, d_acc, d_inp, b, t, keys_bf16=None, kvalid=None, dkeys=None, **_):
+        m = self.mha
+        e, h = m.embed_dim, m.num_heads
+        xn, mean, rstd, w, q, kv, o, lse, g, tk = self._internals(inp, b, t, keys_bf16, kvalid)
+        residual(acc, g, m.out_proj.bias, -1.0)
+        dyb = cast_colsum(d_acc, _grad(m.out_proj.bias))
+        wgrad(_grad(m.out_proj.weight), dyb, o)
+        do = torch.mm(dyb, _bf16(m.out_proj.weight))
+        dev = inp.device
+        delta = torch.empty(b * h, t, dtype=torch.float32, device=dev)
+        _lib.call("rtts_lsh_bwd_delta", o.data_ptr(), e, do.data_ptr(), e, b, h, t, e // h, delta.data_ptr(), _s())
+        dq = torch.empty(b * t, e, dtype=torch.bfloat16, device=dev)
+        nqb = t // 128
+        part = torch.empty(nqb, b * tk, 2 * e, dtype=torch.bfloat16, device=dev)
+        _lib.call("rtts_xattn_bwd", q.data_ptr(), e, kv.data_ptr(), 2 * e, None if kvalid is None else kvalid.data_ptr(),
+                  do.data_ptr(), e, lse.data_ptr(), delta.data_ptr(), b, h, t, tk, e // h, dq.data_ptr(), e, part.data_ptr(), _s())
+        dkv = torch.empty(b * tk, 2 * e, dtype=torch.bfloat16, device=dev)
+        _lib.call("rtts_sum_slabs", part.data_ptr(), nqb, dkv.numel(), dkv.data_ptr(), _s())
+        gb, gw = _grad(m.in_proj_bias), _grad(m.in_proj_weight)
+        colsum_bf16(dq, gb[:e])
+        colsum_bf16(dkv, gb[e:])
+        wgrad(gw[:e], dq, xn)
+        wgrad(gw[e:], dkv, keys_bf16)
+        dxn = torch.mm(dq, w[:e])
+        ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp)
+        residual(dkeys, torch.mm(dkv, w[e:]), None, 1.0)                      # dkeys (fp32) += dkv W_kv
+
+
+# ------------------------------------------------------------------------------------------ stacks
+def build_program(seq) -> Optional[List[tuple]]:
+    """Translate a ReversibleSequence into a list of ("f"|"g"|"half"|"swap", executor) steps; None if
+    some block needs the general (autograd) path (active dropout inside a block, exotic options)."""
+    from .model.reformer import Chunk, LSHSelfAttentionWrapper, MultiheadAttentionWrapper, WithNorm
+    from .model.reversible import ReversibleBlock, ReversibleHalfResidual, ReversibleSwap
+
+    def make(net):
+        inner = net.fn if isinstance(net, Chunk) else net
+        if not isinstance(inner, WithNorm):
+            return None
+        if isinstance(inner.fn, LSHSelfAttentionWrapper):
+            return LSHExec(inner) if LSHExec.supported(inner) else None
+        if isinstance(inner.fn, MultiheadAttentionWrapper):
+            return XAttnExec(inner) if XAttnExec.supported(inner) else None
+        if hasattr(inner.fn, "net"):
+            return FFNExec(net) if FFNExec.supported(net) else None
+        return None
+
+    prog = []
+    for blk in seq.blocks:
+        if isinstance(blk, ReversibleBlock):
+            f, g = make(blk.f.net), make(blk.g.net)
+            if f is None or g is None:
+                return None
+            prog.append(("block", f, g))
+        elif isinstance(blk, ReversibleHalfResidual):
+            f = make(blk.f.net)
+            if f is None:
+                return None
+            prog.append(("half", f, None))
+        elif isinstance(blk, ReversibleSwap):
+            prog.append(("swap", None, None))
+        else:
+            return None
+    return prog
+
+
+def _step_kwargs(kind, kwargs, extra):
+    """Reference kwargs routing (reformer.py:89-90,147-153) -> executor keyword arguments."""
+    if kind == "block":
+        m = kwargs.get("f_args", {}).get("input_mask")
+        return dict(mask=None if m is None else m.to(torch.uint8).contiguous()), {}
+    out = {}
+    if "input_mask" in kwargs and kwargs["input_mask"] is not None:
+        out["mask"] = kwargs["input_mask"].to(torch.uint8).contiguous()
+    if "key" in kwargs:
+        out.update(extra)
+    return out, None
+
+
+class FusedStackFn(torch.autograd.Function):
+    """out = sum of the two streams after the stack; keeps only the final streams."""
+
+    @staticmethod
+    def forward(ctx, x, context, seq, kwargs_list):
+        b, t, d = x.shape
+        prog = seq._program
+        with torch.no_grad():
+            s1 = x.detach().reshape(b * t, d).clone()
+            s2 = s1.clone()
+            extra = {}
+            if context is not None:
+                kpm = next((k.get("key_padding_mask") for k in kwargs_list if "key" in k), None)
+                extra = dict(keys_bf16=context.detach().reshape(-1, d).to(torch.bfloat16),
+                             kvalid=None if kpm is None else (~kpm).to(torch.uint8).contiguous())
+            steps = []
+            for (kind, f, g), kwargs in zip(prog, kwargs_list):
+                kw, kwg = _step_kwargs(kind, kwargs, extra)
+                steps.append((kind, f, g, kw))
+                if kind == "swap":
+                    s1, s2 = s2, s1
+                elif kind == "half":
+                    f.forward(s1, s2, b, t, **kw)
+                else:
+                    f.forward(s1, s2, b, t, **kw)
+                    g.forward(s2, s1, b, t)
+            out = (s1 + s2).view(b, t, d)
+        ctx.state = (s1, s2, steps, extra, b, t, d, context is not None, seq)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        s1, s2, steps, extra, b, t, d, has_ctx, seq = ctx.state
+        ctx.state = None
+        with torch.no_grad():
+            g1 = dout.detach().reshape(b * t, d).to(torch.float32).clone()
+            g2 = g1.clone()
+            dkeys = None
+            if has_ctx:
+                dkeys = torch.zeros(extra["keys_bf16"].shape, dtype=torch.float32, device=dout.device)
+                extra = dict(extra, dkeys=dkeys)
+            for i in range(len(steps) - 1, -1, -1):
+                kind, f, g, kw = steps[i]
+                if kind == "swap":
+                    s1, s2, g1, g2 = s2, s1, g2, g1
+                elif kind == "half":
+                    if "keys_bf16" in kw:
+                        kw = dict(kw, dkeys=dkeys)
+                    f.backward(s1, s2, g1, g2, b, t, **kw)
+                else:
+                    g.backward(s2, s1, g2, g1, b, t)
+                    f.backward(s1, s2, g1, g2, b, t, **kw)
+                if seq.block_done_hook is not None:
+                    seq.block_done_hook(seq, i)
+            dx = (g1 + g2).view(b, t, d)
+        return dx, (None if dkeys is None else dkeys.view(b, -1, d)), None, None

@@ -120,8 +120,7 @@ class ReformerEnc(nn.Module):
             kwargs_list = [dict() for _ in range(self.depth)]
         for kwargs in kwargs_list:
             kwargs["f_args"] = {"input_mask": input_mask}
-        y1, y2 = self.layers.forward_halves(x, x, kwargs_list)     # cat([x, x]) without the copy
-        return y1 + y2                                              # sum of the halves (not the mean)
+        return self.layers.forward_sum(x, kwargs_list)             # cat([x, x]) ... sum of the halves (not the mean)
 
 
 class ReformerDec(nn.Module):
@@ -156,5 +155,4 @@ class ReformerDec(nn.Module):
         for kwargs in kwargs_list[::6]:
             kwargs["input_mask"] = input_mask
         self.attention_matrices_.clear()
-        y1, y2 = self.layers.forward_halves(x, x, kwargs_list, context=keys)
-        return y1 + y2, self.attention_matrices_
+        return self.layers.forward_sum(x, kwargs_list, context=keys), self.attention_matrices_

@@ -182,6 +182,22 @@ class ReversibleSequence(nn.Module):
         super().__init__()
         self.blocks = blocks
         self.block_done_hook: Optional[Callable] = None   # (sequence, block index) after its backward_pass
+        self.use_fused = True      # training on the GPU: explicit executor (engine.py) when every block supports it
+        self._program = None
+        self._program_built = False
+
+    def forward_sum(self, x, kwargs_list=None, context=None):
+        """Both streams start as ``x``; returns their sum after the stack (``reformer.py:81-93,139-158``)."""
+        kwargs_list = kwargs_list if kwargs_list is not None else [{}] * len(self.blocks)
+        if self.use_fused and self.training and x.is_cuda:
+            if not self._program_built:
+                from ..engine import build_program
+                self._program, self._program_built = build_program(self), True
+            if self._program is not None:
+                from ..engine import FusedStackFn
+                return FusedStackFn.apply(x, context, self, kwargs_list)
+        y1, y2 = self.forward_halves(x, x, kwargs_list, context)
+        return y1 + y2
 
     def forward_halves(self, x1, x2, kwargs_list=None, context=None):
         kwargs_list = kwargs_list if kwargs_list is not None else [{}] * len(self.blocks)

@@ -86,6 +86,16 @@ class Trainer:
         if dev.type == "cuda":
             self.ws_partial = torch.zeros(2048, dtype=torch.float32, device=dev)
             self.ws_scale = torch.zeros(2, dtype=torch.float32, device=dev)
+            # bf16 mirror of every parameter, refreshed by ONE cast launch per optimizer step; modules see views
+            self.flat_pb = torch.zeros(total + pad, dtype=torch.bfloat16, device=dev)
+            for n, p in named:
+                s, e = self.offsets[n]
+                p._bf16_mirror = self.flat_pb[s:e].view_as(p)
+            self.refresh_mirror()
+
+    def refresh_mirror(self):
+        _lib.call("rtts_cast_f32_bf16", self.flat_p.data_ptr(), self.flat_pb.data_ptr(), self.flat_p.numel(),
+                  torch.cuda.current_stream().cuda_stream)
 
     def _make_buckets(self):
         """One bucket per reversible block (parameters of a block are contiguous in module order),
@@ -157,6 +167,7 @@ class Trainer:
         _lib.call("rtts_adamw_step", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
                   self.flat_v.data_ptr(), self.decay_mask.data_ptr(), n, self.ws_scale.data_ptr(), lr, 0.9, 0.999, 1e-6,
                   float(self.cfg.weight_decay), self.global_step, stream)
+        self.refresh_mirror()
 
     def lr_now_for(self, step: int) -> float:
         lr = self.cfg.learning_rate

@@ -224,3 +224,43 @@ def test_two_layer_stack_gradients_vs_oracle(gpu):
             fh.write(f"{v:.4f} {k}\n")
     worst = max(rels, key=rels.get)
     assert rels[worst] < 6e-2, (worst, rels[worst])
+
+
+def test_fused_engine_matches_general_path(gpu):
+    """The explicit executor (engine.py) and the nested-autograd path run the same kernels for the
+    attention cores; everything around them differs in fusion only => outputs and every gradient
+    agree to bf16 rounding (rel-L2 <= 2e-2)."""
+    from reformer_tts_amd.model import TTSLoss
+    from reformer_tts_amd.model.config import model_config_from_dict
+    from reformer_tts_amd.training import build_model
+    cfg = model_ref.small_cfg()
+    cfg["enc_reformer_kwargs"]["depth"] = 2
+    cfg["dec_reformer_kwargs"]["depth"] = 2
+    cfg["enc_reformer_kwargs"]["attn_kwargs"]["implementation"] = "hip"
+    cfg["dec_reformer_kwargs"]["self_attn_kwargs"]["implementation"] = "hip"
+    batch = {k: v.to(gpu) for k, v in model_ref.synthetic_batch(2, 60, 200, ragged=True, seed=2).items()}
+    results = []
+    for fused in (True, False):
+        model = build_model(model_config_from_dict(cfg), gpu)
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        model.load_state_dict(synth.synth_state_dict(shapes, seed=5), strict=False)
+        model.train()
+        model.enc.reformer.layers.use_fused = fused
+        model.dec.reformer.layers.use_fused = fused
+        spec = batch["spectrogram"]
+        raw, post, stop, _ = model(batch["phonemes"], spec[:, :-1], spectrogram_mask=batch["loss_mask"].mean(-1))
+        res = TTSLoss(torch.tensor(5.0))(raw, post, stop.view(stop.shape[0], -1), spec[:, 1:], batch["stop_tokens"], batch["loss_mask"])
+        res[0].backward()
+        torch.cuda.synchronize()
+        assert (model.enc.reformer.layers._program is not None) == fused
+        results.append((raw.detach().float(), {n: p.grad.detach().float().clone() for n, p in model.named_parameters()}))
+    (raw_f, g_f), (raw_g, g_g) = results
+    assert ((raw_f - raw_g).norm() / raw_g.norm()).item() < 2e-2
+    worst = ("", 0.0)
+    for n in g_g:
+        if g_g[n].norm().item() < 1e-3:
+            continue
+        rel = ((g_f[n] - g_g[n]).norm() / g_g[n].norm()).item()
+        if rel > worst[1]:
+            worst = (n, rel)
+    assert worst[1] < 3e-2, worst
