@@ -33,6 +33,12 @@ def _bf16(p: torch.Tensor) -> torch.Tensor:
     return m if m is not None else p.detach().to(torch.bfloat16)
 
 
+def _adjacent(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """b starts where a ends, inside one storage (true for neighbours in the trainer's flat buffers)."""
+    return (a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and a.is_contiguous() and b.is_contiguous()
+            and a.data_ptr() + a.numel() * a.element_size() == b.data_ptr())
+
+
 def _grad(p: torch.Tensor) -> torch.Tensor:
     if p.grad is None:
         p.grad = torch.zeros_like(p)
@@ -110,14 +116,14 @@ class LSHExec:
     def _wqkv(self):
         lyr = self.layer
         a, b = _bf16(lyr.toqk.weight), _bf16(lyr.tov.weight)
-        if a.data_ptr() + a.numel() * 2 == b.data_ptr():          # adjacent in the flat mirror: zero-copy (2d, d) view
+        if _adjacent(a, b):                                        # neighbours in the flat mirror: zero-copy (2d, d) view
             return torch.as_strided(a, (2 * a.shape[0], a.shape[1]), (a.shape[1], 1))
         return torch.cat([a, b], dim=0)
 
     def _wqkv_grad(self):
         lyr = self.layer
         ga, gb = _grad(lyr.toqk.weight), _grad(lyr.tov.weight)
-        if ga.data_ptr() + ga.numel() * 4 == gb.data_ptr():
+        if _adjacent(ga, gb):
             return torch.as_strided(ga, (2 * ga.shape[0], ga.shape[1]), (ga.shape[1], 1)), None
         return None, (ga, gb)
 
