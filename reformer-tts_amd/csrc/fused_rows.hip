@@ -242,14 +242,21 @@ __global__ __launch_bounds__(FR_THREADS) void colsum_bf16_kernel(bf16_t* __restr
     (void)AV;
 }
 
-// out[c] += sum over the partial rows (fixed order)
+// out[c] += sum over the partial rows, in a fixed order: a block owns 64 columns, its 4 waves each
+// sum every 4th partial row (coalesced 256-B reads), then the 4 wave sums are added in wave order
 __global__ __launch_bounds__(FR_THREADS) void colsum_final_kernel(const float* __restrict__ partial, int nrows, int n,
                                                                   float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
+    __shared__ float red[FR_WAVES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int r = 0; r < nrows; ++r) s += partial[(size_t)r * n + c];
-    out[c] += s;
+    if (c < n) {
+#pragma unroll 8
+        for (int r = wave; r < nrows; r += FR_WAVES) s += partial[(size_t)r * n + c];
+    }
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < n) out[c] += (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // ---------------------------------------------------------------- elementwise epilogues
@@ -348,7 +355,7 @@ extern "C" int rtts_ln_bwd(const void* dxn, const float* x, const float* mean, c
 #define CALL(EPL, VEC) hipLaunchKernelGGL((ln_bwd_kernel<EPL, VEC>), dim3(blocks), dim3(FR_THREADS), lds, (hipStream_t)stream, (const bf16_t*)dxn, x, mean, rstd, gamma, dx_io, pg, pb, M)
     FR_DISPATCH_D(d, CALL)
 #undef CALL
-    const dim3 g2((d + FR_THREADS - 1) / FR_THREADS);
+    const dim3 g2((d + 63) / 64);
     hipLaunchKernelGGL(colsum_final_kernel, g2, dim3(FR_THREADS), 0, (hipStream_t)stream, pg, blocks, d, dgamma);
     hipLaunchKernelGGL(colsum_final_kernel, g2, dim3(FR_THREADS), 0, (hipStream_t)stream, pb, blocks, d, dbeta);
     RTTS_LAUNCH_CHECK("rtts_ln_bwd");
@@ -364,7 +371,7 @@ extern "C" int rtts_cast_colsum(const float* dy, void* dyb, float* dbias, float*
     FR_DISPATCH_D(d, CALL)
 #undef CALL
     if (dbias)
-        hipLaunchKernelGGL(colsum_final_kernel, dim3((d + FR_THREADS - 1) / FR_THREADS), dim3(FR_THREADS), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 63) / 64), dim3(FR_THREADS), 0, (hipStream_t)stream,
                            partial_ws, blocks, d, dbias);
     RTTS_LAUNCH_CHECK("rtts_cast_colsum");
     return 0;
@@ -386,7 +393,7 @@ extern "C" int rtts_colsum_bf16(void* dh, const void* h, int64_t ld, float* dbia
                            (bf16_t*)dh, (const bf16_t*)h, ld, partial_ws, M)
     FR_DISPATCH_D(d, CALL)
 #undef CALL
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((d + FR_THREADS - 1) / FR_THREADS), dim3(FR_THREADS), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 63) / 64), dim3(FR_THREADS), 0, (hipStream_t)stream,
                        partial_ws, blocks, d, dbias);
     RTTS_LAUNCH_CHECK("rtts_colsum_bf16");
     return 0;

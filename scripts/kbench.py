@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark of the LSH attention path at the baseline shapes (GPU box only).
+    python scripts/kbench.py [--iters 50] [--only fwd,bwd,...]
+Prints average launch time (HIP events on the launch stream) and algorithmic TFLOP/s or GB/s."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from reformer_tts_amd import _lib, ops  # noqa: E402
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3   # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    only = set(args.only.split(",")) if args.only else None
+    dev = torch.device("cuda:0")
+    for name, (b, h, t, bs, nh, causal) in dict(dec=(12, 8, 1024, 128, 8, True), enc=(12, 8, 256, 64, 8, False),
+                                                 long=(4, 8, 4096, 64, 8, True)).items():
+        dh = 64
+        g = torch.Generator().manual_seed(0)
+        qkv = torch.randn(b, t, 2 * h * dh, generator=g).bfloat16().to(dev)
+        qk, v = qkv[..., :h * dh], qkv[..., h * dh:]
+        rot = torch.randn(1, dh, nh, t // bs // 2, generator=g).to(dev)
+        mask = torch.ones(b, t, dtype=torch.uint8, device=dev)
+        mask[0, t - t // 4:] = 0
+        st, _, _ = ops.lsh_hash_sort(qk, rot, h, bs)
+        o, lse = ops.lsh_attn_fwd(qk, v, st, h, bs, causal, mask)
+        out, lse_tot = ops.lsh_combine_fwd(o, lse, b, h)
+        dout = torch.randn(b, t, h * dh, generator=g).bfloat16().to(dev)
+        chunks = b * h * nh * (t // bs)
+        pair_flops = 2.0 * bs * 2 * bs * dh * chunks
+        tok = b * h * t
+        res = {}
+        if not only or "hash" in only:
+            us = timeit(lambda: ops.lsh_hash_sort(qk, rot, h, bs), args.iters)
+            res["hash_sort"] = (us, f"{tok * (128 + nh * 4) / us / 1e3:8.1f} GB/s alg")
+        if not only or "fwd" in only:
+            us = timeit(lambda: ops.lsh_attn_fwd(qk, v, st, h, bs, causal, mask), args.iters)
+            res["attn_fwd"] = (us, f"{2 * pair_flops / us / 1e6:8.1f} TFLOP/s")
+        if not only or "combine" in only:
+            us = timeit(lambda: ops.lsh_combine_fwd(o, lse, b, h), args.iters)
+            res["combine"] = (us, f"{tok * (nh * 132 + 132) / us / 1e3:8.1f} GB/s alg")
+        if not only or "bwd" in only:
+            delta = torch.empty(b * h, t, device=dev)
+            dqk_part = torch.empty(3, b * h, nh, t, dh, dtype=torch.bfloat16, device=dev)
+            dv_part = torch.empty(2, b * h, nh, t, dh, dtype=torch.bfloat16, device=dev)
+            s = torch.cuda.current_stream().cuda_stream
+            ld = qkv.stride(1)
+
+            def bwd():
+                _lib.call("rtts_lsh_attn_bwd", qk.data_ptr(), v.data_ptr(), ld, st.data_ptr(), mask.data_ptr(), dout.data_ptr(),
+                          dout.stride(1), lse_tot.data_ptr(), delta.data_ptr(), b, h, t, dh, nh, bs, int(causal),
+                          dqk_part.data_ptr(), dv_part.data_ptr(), s)
+            _lib.call("rtts_lsh_bwd_delta", out.data_ptr(), out.stride(1), dout.data_ptr(), dout.stride(1), b, h, t, dh,
+                      delta.data_ptr(), s)
+            us = timeit(bwd, args.iters)
+            res["attn_bwd"] = (us, f"{5 * pair_flops / us / 1e6:8.1f} TFLOP/s")
+            dqk, dv = torch.empty_like(qk.contiguous()), torch.empty_like(qk.contiguous())
+
+            def red():
+                _lib.call("rtts_lsh_bwd_reduce", dqk_part.data_ptr(), dv_part.data_ptr(), b, h, t, dh, nh, dqk.data_ptr(),
+                          dv.data_ptr(), dqk.stride(1), s)
+            us = timeit(red, args.iters)
+            res["bwd_reduce"] = (us, f"{tok * (5 * nh * 128 + 256) / us / 1e3:8.1f} GB/s alg")
+        for k, (us, extra) in res.items():
+            print(f"{name:5s} {k:11s} {us:9.1f} us  {extra}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
