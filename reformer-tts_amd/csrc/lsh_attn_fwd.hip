@@ -8,32 +8,41 @@
 //   1. gather the NK qk rows and NK v rows (128 B each, coalesced 16-B pieces) by `st`
 //      straight into LDS; while a row passes through registers its L2 norm is reduced, so the
 //      key normalisation becomes a per-key scale applied to the logits (never rounded to bf16);
-//   2. wave w owns queries [32w, 32w+32): S^T = K Q^T with v_mfma_f32_32x32x16_bf16, so a lane
-//      holds one query column and the softmax row-reduction stays in registers (+1 cross-half);
-//   3. masks in the reference's order (padding, causal, self=-5e4), exact row max, exp;
-//   4. O^T = V^T P^T: the P^T accumulators are the B operand as they stand (rows of X are the
+//   2. wave w owns queries [32w, 32w+32) and walks the keys in tiles of 32 with an online softmax
+//      (base-2 domain): S^T tile = K Q^T with v_mfma_f32_32x32x16_bf16 -- a lane holds one query
+//      column, so the row reduction stays in registers (+1 cross-half shuffle per tile);
+//   3. masks in the reference's order (padding, causal, self = -5e4) folded into two compares:
+//      `dead` = key's effective position > query's effective position, `self` = positions equal;
+//   4. O^T += V^T P^T: the P^T accumulators are the B operand as they stand (rows of X are the
 //      contraction index), V^T fragments come from the row-major V image by ds_read_b64_tr_b16;
 //   5. rows of o and lse are written directly at their UNSORTED position (round, t).
+// The kernel is VALU-bound (about 10 vector ops per logit against 1/64 MFMA), so it is built for
+// occupancy: ~120 VGPRs, tile loop not unrolled, 2 workgroups (8 waves) per CU.
 #include "rtts_common.h"
 #include <float.h>
 
 #define AF_DH 64
 #define AF_ROWB 144   // LDS row stride (bytes): 128 B of bf16 + 16 B pad => conflict-free ds_read_b128
+#define AF_LOG2E 1.4426950408889634f
+#define AF_NEG (-1.0e30f)
+#define AF_BIGPOS 0x40000000
+
+typedef __attribute__((ext_vector_type(8))) short af_short8;
 
 template <int BS, bool CAUSAL, bool MASKED>
-__global__ __launch_bounds__(BS * 2) void lsh_attn_fwd_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v,
-                                                              int64_t ld, const int32_t* __restrict__ st,
-                                                              const uint8_t* __restrict__ mask, int H, int T, int n_hashes,
-                                                              bf16_t* __restrict__ o, float* __restrict__ lse) {
+__global__ __launch_bounds__(BS * 2, 2) void lsh_attn_fwd_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v,
+                                                                 int64_t ld, const int32_t* __restrict__ st,
+                                                                 const uint8_t* __restrict__ mask, int H, int T, int n_hashes,
+                                                                 bf16_t* __restrict__ o, float* __restrict__ lse) {
     constexpr int NK = 2 * BS;
     constexpr int NKT = NK / 32;
     constexpr int NTHR = BS * 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Ks = smem;
     unsigned char* Vs = Ks + NK * AF_ROWB;
-    float* kscale = reinterpret_cast<float*>(Vs + NK * AF_ROWB);
-    int* kpos = reinterpret_cast<int*>(kscale + NK);
-    int* kval = kpos + NK;
+    float* ksc = reinterpret_cast<float*>(Vs + NK * AF_ROWB);   // dh^-1/2 / |k| * log2(e)
+    int* kpos = reinterpret_cast<int*>(ksc + NK);                // original position (self test)
+    int* kpe = kpos + NK;                                        // effective position for the `dead` compare
 
     const int nb = T / BS;
     const int C = n_hashes * nb;
@@ -49,52 +58,62 @@ __global__ __launch_bounds__(BS * 2) void lsh_attn_fwd_kernel(const bf16_t* __re
 
     // ---- 1. gather -------------------------------------------------------------------
     constexpr int ITERS = NK * 8 / NTHR;   // = 8
-    int trow[ITERS];
+    {
+        int trow[ITERS];
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        const int row = (it * NTHR + tid) >> 3;
-        const int slot = (row < BS) ? c * BS + row : cprev * BS + (row - BS);
-        trow[it] = st_row[slot];
-    }
-    uint4 kreg[ITERS], vreg[ITERS];
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        const int piece = tid & 7;
-        kreg[it] = *reinterpret_cast<const uint4*>(qbase + (size_t)trow[it] * ld + piece * 8);
-        vreg[it] = *reinterpret_cast<const uint4*>(vbase + (size_t)trow[it] * ld + piece * 8);
-    }
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        const int row = (it * NTHR + tid) >> 3, piece = tid & 7;
-        *reinterpret_cast<uint4*>(Ks + row * AF_ROWB + piece * 16) = kreg[it];
-        *reinterpret_cast<uint4*>(Vs + row * AF_ROWB + piece * 16) = vreg[it];
-        const uint32_t u[4] = {kreg[it].x, kreg[it].y, kreg[it].z, kreg[it].w};
-        float ss = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float a = __uint_as_float(u[k] << 16), bq = __uint_as_float(u[k] & 0xffff0000u);
-            ss = __builtin_fmaf(a, a, ss);
-            ss = __builtin_fmaf(bq, bq, ss);
+        for (int it = 0; it < ITERS; ++it) {
+            const int row = (it * NTHR + tid) >> 3;
+            const int slot = (row < BS) ? c * BS + row : cprev * BS + (row - BS);
+            trow[it] = st_row[slot];
         }
-        ss += __shfl_xor(ss, 1);
-        ss += __shfl_xor(ss, 2);
-        ss += __shfl_xor(ss, 4);
-        if (piece == 0) {
-            kscale[row] = 0.125f / fmaxf(sqrtf(ss), 1e-12f);   // dh^-1/2 / max(|k|, eps)
-            kpos[row] = trow[it];
-            kval[row] = MASKED ? (int)mask[(size_t)b * T + trow[it]] : 1;
+        uint4 kreg[ITERS], vreg[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int piece = tid & 7;
+            kreg[it] = *reinterpret_cast<const uint4*>(qbase + (size_t)trow[it] * ld + piece * 8);
+            vreg[it] = *reinterpret_cast<const uint4*>(vbase + (size_t)trow[it] * ld + piece * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int row = (it * NTHR + tid) >> 3, piece = tid & 7;
+            *reinterpret_cast<uint4*>(Ks + row * AF_ROWB + piece * 16) = kreg[it];
+            *reinterpret_cast<uint4*>(Vs + row * AF_ROWB + piece * 16) = vreg[it];
+            const uint32_t u[4] = {kreg[it].x, kreg[it].y, kreg[it].z, kreg[it].w};
+            float ss = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float a = __uint_as_float(u[k] << 16), bq = __uint_as_float(u[k] & 0xffff0000u);
+                ss = __builtin_fmaf(a, a, ss);
+                ss = __builtin_fmaf(bq, bq, ss);
+            }
+            ss += __shfl_xor(ss, 1);
+            ss += __shfl_xor(ss, 2);
+            ss += __shfl_xor(ss, 4);
+            if (piece == 0) {
+                const int valid = MASKED ? (int)mask[(size_t)b * T + trow[it]] : 1;
+                ksc[row] = (0.125f * AF_LOG2E) * __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));   // 1 / max(|k|, 1e-12)
+                kpos[row] = trow[it];
+                // dead <=> kpe > qpe.  causal: positions; otherwise 0.  An invalid key is beyond every query.
+                kpe[row] = valid ? (CAUSAL ? trow[it] : 0) : AF_BIGPOS;
+            }
         }
     }
     __syncthreads();
 
-    // ---- 2. S^T = K Q^T ----------------------------------------------------------------
+    // ---- 2. per-wave online softmax over key tiles ---------------------------------------
     const int r = lane & 31, hh = lane >> 5;
     const int qrow = wave * 32 + r;
     bf16x8 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Ks + qrow * AF_ROWB + (ks * 16 + 8 * hh) * 2);
-    f32x16 s[NKT];
-#pragma unroll
+    const int qpos = kpos[qrow];
+    // an invalid query sees nothing but itself: effective position below every key's
+    const int qpe = (kpe[qrow] == AF_BIGPOS) ? -1 : (CAUSAL ? qpos : 0);
+    const int trq = (lane & 15) >> 2, trp = lane & 3, trc = (lane >> 4) & 1;
+
+    float m = AF_NEG, l = 0.f;
+    f32x16 oacc[2] = {{0}, {0}};
+#pragma unroll 1
     for (int kt = 0; kt < NKT; ++kt) {
         f32x16 acc = {0};
 #pragma unroll
@@ -102,73 +121,60 @@ __global__ __launch_bounds__(BS * 2) void lsh_attn_fwd_kernel(const bf16_t* __re
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + r) * AF_ROWB + (ks * 16 + 8 * hh) * 2);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc, 0, 0, 0);
         }
-        s[kt] = acc;
-    }
-
-    // ---- 3. masks + softmax (lane = query, registers = keys) ------------------------------
-    const int qpos = kpos[qrow];
-    const int qval = kval[qrow];
-    float m = -FLT_MAX;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
+        float tmax = AF_NEG;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int key0 = kt * 32 + 8 * g + 4 * hh;
-            const float4 sc = *reinterpret_cast<const float4*>(kscale + key0);
+            const float4 sc = *reinterpret_cast<const float4*>(ksc + key0);
             const int4 kp = *reinterpret_cast<const int4*>(kpos + key0);
-            const int4 kv = *reinterpret_cast<const int4*>(kval + key0);
+            const int4 ke = *reinterpret_cast<const int4*>(kpe + key0);
             const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
             const int kpv[4] = {kp.x, kp.y, kp.z, kp.w};
-            const int kvv[4] = {kv.x, kv.y, kv.z, kv.w};
+            const int kev[4] = {ke.x, ke.y, ke.z, ke.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float x = s[kt][4 * g + j] * scv[j];
-                if (MASKED && !(qval && kvv[j])) x = -FLT_MAX;
-                if (CAUSAL && qpos < kpv[j]) x = -FLT_MAX;
-                if (qpos == kpv[j]) x = -5e4f;
-                s[kt][4 * g + j] = x;
-                m = fmaxf(m, x);
+                float x = acc[4 * g + j] * scv[j];
+                x = (kev[j] > qpe) ? AF_NEG : x;
+                x = (kpv[j] == qpos) ? (-5e4f * AF_LOG2E) : x;
+                acc[4 * g + j] = x;
+                tmax = fmaxf(tmax, x);
             }
         }
-    }
-    m = fmaxf(m, __shfl_xor(m, 32));
-    float l = 0.f;
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float mnew = fmaxf(m, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+        m = mnew;
+        if (__any(alpha != 1.f)) {
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
+            for (int i = 0; i < 16; ++i) {
+                oacc[0][i] *= alpha;
+                oacc[1][i] *= alpha;
+            }
+        }
+        l *= alpha;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float p = __expf(s[kt][i] - m);
-            s[kt][i] = p;
+            const float p = __builtin_amdgcn_exp2f(acc[i] - mnew);
+            acc[i] = p;
             l += p;
         }
-    }
-    l += __shfl_xor(l, 32);
-
-    // ---- 4. O^T = V^T P^T ----------------------------------------------------------------
-    f32x16 oacc[2] = {{0}, {0}};
-    const int trq = (lane & 15) >> 2, trp = lane & 3, trc = (lane >> 4) & 1;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             bf16x8 pf;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[kt][8 * s2 + j];
+            for (int j = 0; j < 8; ++j) pf[j] = (__bf16)acc[8 * s2 + j];
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
                 const int keyb = kt * 32 + 16 * s2 + 4 * hh + trq;
                 const int col = dt * 32 + 16 * trc + 4 * trp;
-                const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (RTTS_LDS short4v*)(Vs + keyb * AF_ROWB + col * 2));
-                const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (RTTS_LDS short4v*)(Vs + (keyb + 8) * AF_ROWB + col * 2));
-                typedef __attribute__((ext_vector_type(8))) short short8v;
-                const short8v both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
-                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
+                const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((RTTS_LDS short4v*)(Vs + keyb * AF_ROWB + col * 2));
+                const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((RTTS_LDS short4v*)(Vs + (keyb + 8) * AF_ROWB + col * 2));
+                const af_short8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, both), pf, oacc[dt], 0, 0, 0);
             }
         }
     }
+    l += __shfl_xor(l, 32);
 
     // ---- 5. write o, lse at the unsorted position ------------------------------------------
     const int round = c / nb;
@@ -185,7 +191,7 @@ __global__ __launch_bounds__(BS * 2) void lsh_attn_fwd_kernel(const bf16_t* __re
             *reinterpret_cast<uint2*>(optr + dt * 32 + 8 * g + 4 * hh) = pk;
         }
     }
-    if (hh == 0) lse[orow] = m + logf(l);
+    if (hh == 0) lse[orow] = (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;   // v_log_f32 is log2
 }
 
 static bool g_fwd_attr_set[2][4];
