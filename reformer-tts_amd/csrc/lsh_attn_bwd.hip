@@ -9,11 +9,11 @@
 //     by the self constant)   dQ = (dS * kscale) K     G = dS^T Q,   dK = kscale (G - k^ (k^.G))
 // where kscale[k] = dh^-1/2 / |k| is the key normalisation folded into the logits.
 //
-// Layout: KEY ON THE LANE.  Wave w owns keys [64w, 64w+64) of the chunk's 2*BS keys for all BS
+// Layout: KEY ON THE LANE.  Wave w owns keys [32w, 32w+32) of the chunk's 2*BS keys for all BS
 // queries: S and dP come out of the MFMA as [query rows in registers][key on lane], which IS the
 // B operand of the dV^T and G^T products (contraction over the register/row index), so dV and dK
 // of a key are complete inside one wave, in registers.  Only dS crosses LDS, once, as dS^T, for
-// dQ^T = K^T dS'^T (wave w finishes query tile w).  Nothing is accumulated across workgroups:
+// dQ^T = K^T dS'^T (wave w finishes (query tile w/2, dh half w%2)).  Nothing is accumulated across workgroups:
 // each workgroup writes its rows of three dqk slots / two dv slots at UNSORTED positions
 // (slot 0: query role, slot 1: key role own chunk, slot 2: key role looked-back chunk) and
 // rtts_lsh_bwd_reduce sums slots and rounds -- deterministic, no atomics.
@@ -33,14 +33,15 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0, const unsigne
 }
 
 template <int BS, bool CAUSAL, bool MASKED>
-__global__ __launch_bounds__(BS * 2) void lsh_attn_bwd_kernel(
+__global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
     const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v, int64_t ld, const int32_t* __restrict__ st,
     const uint8_t* __restrict__ mask, const bf16_t* __restrict__ dout, int64_t ld_do, const float* __restrict__ lse_tot,
     const float* __restrict__ delta, int H, int T, int n_hashes, bf16_t* __restrict__ dqk_part, bf16_t* __restrict__ dv_part,
     size_t slot_stride) {
     constexpr int NK = 2 * BS;
     constexpr int NQT = BS / 32;
-    constexpr int NTHR = BS * 2;
+    constexpr int NTHR = BS * 4;
+    constexpr int KT2 = 1;                // 32-key tiles owned by one wave
     constexpr int DSROW = BS * 2 + 16;   // bytes per row of the dS^T image [key][query]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Ks = smem;                                  // [NK][144]  qk rows (own chunk first)
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(BS * 2) void lsh_attn_bwd_kernel(
     const bf16_t* dobase = dout + (size_t)b * T * ld_do + (size_t)h * AB_DH;
 
     // ---- gather K rows (all 2*BS) and dout rows (own chunk) into LDS -----------------------
-    constexpr int ITERS = NK * 8 / NTHR;   // 8
+    constexpr int ITERS = NK * 8 / NTHR;   // 4
     int trow[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
@@ -81,12 +82,13 @@ __global__ __launch_bounds__(BS * 2) void lsh_attn_bwd_kernel(
 #pragma unroll
     for (int it = 0; it < ITERS / 2; ++it)   // rows < BS are the first half of the iterations
         oreg[it] = *reinterpret_cast<const uint4*>(dobase + (size_t)trow[it] * ld_do + (tid & 7) * 8);
-    // V fragments of this wave's 64 keys go straight to registers (no other wave needs them)
-    const int myrow[2] = {wave * 64 + r, wave * 64 + 32 + r};
-    bf16x8 vf[2][4];
-    int mypos[2];
+    // V fragments of this wave's keys go straight to registers (no other wave needs them)
+    int myrow[KT2];
+    bf16x8 vf[KT2][4];
+    int mypos[KT2];
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) {
+    for (int k2 = 0; k2 < KT2; ++k2) {
+        myrow[k2] = wave * (32 * KT2) + 32 * k2 + r;
         const int row = myrow[k2];
         const int slot = (row < BS) ? c * BS + row : cprev * BS + (row - BS);
         mypos[k2] = st_row[slot];
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(BS * 2) void lsh_attn_bwd_kernel(
         ss += __shfl_xor(ss, 2);
         ss += __shfl_xor(ss, 4);
         if (piece == 0) {
-            kscale[row] = 0.125f / fmaxf(sqrtf(ss), 1e-12f);
+            kscale[row] = 0.125f * __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));   // dh^-1/2 / max(|k|, 1e-12)
             kpos[row] = trow[it];
             kval[row] = MASKED ? (int)mask[(size_t)b * T + trow[it]] : 1;
             if (row < BS) {
@@ -123,11 +125,11 @@ __global__ __launch_bounds__(BS * 2) void lsh_attn_bwd_kernel(
     __syncthreads();
 
     // ---- this wave's key-side constants -----------------------------------------------------
-    bf16x8 kf[2][4];
-    float ksc[2];
-    int kvl[2];
+    bf16x8 kf[KT2][4];
+    float ksc[KT2];
+    int kvl[KT2];
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) {
+    for (int k2 = 0; k2 < KT2; ++k2) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
             kf[k2][ks] = *reinterpret_cast<const bf16x8*>(Ks + myrow[k2] * AB_ROWB + (ks * 16 + 8 * hh) * 2);
@@ -135,9 +137,9 @@ __global__ __launch_bounds__(BS * 2) void lsh_attn_bwd_kernel(
         kvl[k2] = kval[myrow[k2]];
     }
 
-    f32x16 dvacc[2][2], gacc[2][2];   // [key tile][dh tile]: rows = dh, lane = key
+    f32x16 dvacc[KT2][2], gacc[KT2][2];   // [key tile][dh tile]: rows = dh, lane = key
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < KT2; ++a)
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
             dvacc[a][d] = (f32x16){0};
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(BS * 2) void lsh_attn_bwd_kernel(
                 dotf[s2][dt] = tr_frag(Os + qb * AB_ROWB + col, Os + (qb + 8) * AB_ROWB + col);
             }
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
+        for (int k2 = 0; k2 < KT2; ++k2) {
             f32x16 sacc = {0}, pacc = {0};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(BS * 2) void lsh_attn_bwd_kernel(
     // ---- key-side outputs: dV and dK of this wave's 64 keys -----------------------------------
     const int round = c / nb, round_prev = cprev / nb;
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) {
+    for (int k2 = 0; k2 < KT2; ++k2) {
         const bool own = myrow[k2] < BS;   // wave-uniform
         const size_t orow = ((size_t)bh * n_hashes + (own ? round : round_prev)) * T + mypos[k2];
         bf16_t* dvp = dv_part + (own ? 0 : slot_stride) + orow * AB_DH;
@@ -264,33 +266,28 @@ __global__ __launch_bounds__(BS * 2) void lsh_attn_bwd_kernel(
     }
     __syncthreads();
 
-    // ---- dQ^T[dh][q] = K^T dS'^T : wave w finishes query tile w over all 2*BS keys --------------
+    // ---- dQ^T[dh][q] = K^T dS'^T over all 2*BS keys: wave w finishes (query tile w/2, dh half w%2) ----
     {
-        const int qt = wave;
-        f32x16 dq[2] = {{0}, {0}};
+        const int qt = wave >> 1, dt = wave & 1;
+        f32x16 dq = {0};
+        const int col = (dt * 32 + 16 * trc + 4 * trp) * 2;
+        const int qcol = (qt * 32 + 16 * trc + 4 * trp) * 2;
 #pragma unroll 4
         for (int kb = 0; kb < NK; kb += 16) {
             const int keyr = kb + 8 * hh + trq;
-            const int qcol = (qt * 32 + 16 * trc + 4 * trp) * 2;
             const bf16x8 bfrag = tr_frag(Ds + keyr * DSROW + qcol, Ds + (keyr + 4) * DSROW + qcol);
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const int col = (dt * 32 + 16 * trc + 4 * trp) * 2;
-                const bf16x8 afrag = tr_frag(Ks + keyr * AB_ROWB + col, Ks + (keyr + 4) * AB_ROWB + col);
-                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, dq[dt], 0, 0, 0);
-            }
+            const bf16x8 afrag = tr_frag(Ks + keyr * AB_ROWB + col, Ks + (keyr + 4) * AB_ROWB + col);
+            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, dq, 0, 0, 0);
         }
         const int qpos = kpos[qt * 32 + r];
         bf16_t* dqp = dqk_part + (((size_t)bh * n_hashes + round) * T + qpos) * AB_DH;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 pk;
-                pk.x = pack_bf16x2(dq[dt][4 * g], dq[dt][4 * g + 1]);
-                pk.y = pack_bf16x2(dq[dt][4 * g + 2], dq[dt][4 * g + 3]);
-                *reinterpret_cast<uint2*>(dqp + dt * 32 + 8 * g + 4 * hh) = pk;
-            }
+        for (int g = 0; g < 4; ++g) {
+            uint2 pk;
+            pk.x = pack_bf16x2(dq[4 * g], dq[4 * g + 1]);
+            pk.y = pack_bf16x2(dq[4 * g + 2], dq[4 * g + 3]);
+            *reinterpret_cast<uint2*>(dqp + dt * 32 + 8 * g + 4 * hh) = pk;
+        }
     }
 }
 
@@ -302,7 +299,7 @@ static int launch_attn_bwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const 
                            int n_hashes, int causal, bf16_t* dqk_part, bf16_t* dv_part, hipStream_t stream) {
     constexpr int NK = 2 * BS;
     const size_t lds = NK * AB_ROWB + BS * AB_ROWB + NK * (BS * 2 + 16) + NK * 12 + BS * 8;
-    const dim3 grid(B * H * n_hashes * (T / BS)), block(BS * 2);
+    const dim3 grid(B * H * n_hashes * (T / BS)), block(BS * 4);
     const size_t slot_stride = (size_t)B * H * n_hashes * T * AB_DH;
     const int vi = (causal ? 2 : 0) + (mask ? 1 : 0);
 #define AB_GO(C_, M_)                                                                                                      \
