@@ -8,7 +8,8 @@
 //   1. gather the NK qk rows and NK v rows (128 B each, coalesced 16-B pieces) by `st`
 //      straight into LDS; while a row passes through registers its L2 norm is reduced, so the
 //      key normalisation becomes a per-key scale applied to the logits (never rounded to bf16);
-//   2. wave w owns queries [32w, 32w+32) and walks the keys in tiles of 32 with an online softmax
+//   2. two waves share queries [32t, 32t+32), one per half of the keys (own chunk / previous chunk), and
+//      merge (m, l, O) through LDS at the end; each walks its keys in tiles of 32 with an online softmax
 //      (base-2 domain): S^T tile = K Q^T with v_mfma_f32_32x32x16_bf16 -- a lane holds one query
 //      column, so the row reduction stays in registers (+1 cross-half shuffle per tile);
 //   3. masks in the reference's order (padding, causal, self = -5e4) folded into two compares:
@@ -17,7 +18,7 @@
 //      contraction index), V^T fragments come from the row-major V image by ds_read_b64_tr_b16;
 //   5. rows of o and lse are written directly at their UNSORTED position (round, t).
 // The kernel is VALU-bound (about 10 vector ops per logit against 1/64 MFMA), so it is built for
-// occupancy: ~120 VGPRs, tile loop not unrolled, 2 workgroups (8 waves) per CU.
+// occupancy: ~120 VGPRs, tile loop not unrolled, 2 workgroups (16 waves) per CU.
 #include "rtts_common.h"
 #include <float.h>
 
@@ -30,13 +31,14 @@
 typedef __attribute__((ext_vector_type(8))) short af_short8;
 
 template <int BS, bool CAUSAL, bool MASKED>
-__global__ __launch_bounds__(BS * 2, 2) void lsh_attn_fwd_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v,
+__global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v,
                                                                  int64_t ld, const int32_t* __restrict__ st,
                                                                  const uint8_t* __restrict__ mask, int H, int T, int n_hashes,
                                                                  bf16_t* __restrict__ o, float* __restrict__ lse) {
     constexpr int NK = 2 * BS;
     constexpr int NKT = NK / 32;
-    constexpr int NTHR = BS * 2;
+    constexpr int NTHR = BS * 4;          // two waves per 32-query tile: each walks one half of the keys
+    constexpr int NQT = BS / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Ks = smem;
     unsigned char* Vs = Ks + NK * AF_ROWB;
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(BS * 2, 2) void lsh_attn_fwd_kernel(const bf16_t* _
     const bf16_t* vbase = v + (size_t)b * T * ld + (size_t)h * AF_DH;
 
     // ---- 1. gather -------------------------------------------------------------------
-    constexpr int ITERS = NK * 8 / NTHR;   // = 8
+    constexpr int ITERS = NK * 8 / NTHR;   // = 4
     {
         int trow[ITERS];
 #pragma unroll
@@ -102,7 +104,8 @@ __global__ __launch_bounds__(BS * 2, 2) void lsh_attn_fwd_kernel(const bf16_t* _
 
     // ---- 2. per-wave online softmax over key tiles ---------------------------------------
     const int r = lane & 31, hh = lane >> 5;
-    const int qrow = wave * 32 + r;
+    const int qt = wave % NQT, kh = wave / NQT;
+    const int qrow = qt * 32 + r;
     bf16x8 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Ks + qrow * AF_ROWB + (ks * 16 + 8 * hh) * 2);
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(BS * 2, 2) void lsh_attn_fwd_kernel(const bf16_t* _
     float m = AF_NEG, l = 0.f;
     f32x16 oacc[2] = {{0}, {0}};
 #pragma unroll 1
-    for (int kt = 0; kt < NKT; ++kt) {
+    for (int kt = kh * (NKT / 2); kt < (kh + 1) * (NKT / 2); ++kt) {
         f32x16 acc = {0};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -176,6 +179,33 @@ __global__ __launch_bounds__(BS * 2, 2) void lsh_attn_fwd_kernel(const bf16_t* _
     }
     l += __shfl_xor(l, 32);
 
+    // ---- merge the two key halves of a query tile through LDS (aliases the K image) ----------
+    float* part = reinterpret_cast<float*>(Ks) + (size_t)qt * 34 * 64;   // [34][64]: 32 x O, m, l per lane
+    __syncthreads();                       // every wave is done reading K
+    if (kh == 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            part[i * 64 + lane] = oacc[0][i];
+            part[(16 + i) * 64 + lane] = oacc[1][i];
+        }
+        part[32 * 64 + lane] = m;
+        part[33 * 64 + lane] = l;
+    }
+    __syncthreads();
+    if (kh == 1) return;
+    {
+        const float m2 = part[32 * 64 + lane], l2 = part[33 * 64 + lane];
+        const float mm = fmaxf(m, m2);
+        const float a1 = __builtin_amdgcn_exp2f(m - mm), a2 = __builtin_amdgcn_exp2f(m2 - mm);
+        l = l * a1 + l2 * a2;
+        m = mm;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            oacc[0][i] = oacc[0][i] * a1 + part[i * 64 + lane] * a2;
+            oacc[1][i] = oacc[1][i] * a1 + part[(16 + i) * 64 + lane] * a2;
+        }
+    }
+
     // ---- 5. write o, lse at the unsorted position ------------------------------------------
     const int round = c / nb;
     const float inv_l = 1.f / l;
@@ -201,7 +231,7 @@ static int launch_attn_fwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const 
                            int T, int n_hashes, int causal, bf16_t* o, float* lse, hipStream_t stream) {
     constexpr int NK = 2 * BS;
     const size_t lds = 2 * NK * AF_ROWB + NK * 12;
-    const dim3 grid(B * H * n_hashes * (T / BS)), block(BS * 2);
+    const dim3 grid(B * H * n_hashes * (T / BS)), block(BS * 4);
     const int vi = (causal ? 2 : 0) + (mask ? 1 : 0);
 #define AF_GO(C_, M_)                                                                                                      \
     do {                                                                                                                   \
