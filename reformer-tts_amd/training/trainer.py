@@ -138,14 +138,18 @@ class Trainer:
     def zero_grad(self):
         self.flat_g.zero_()
 
-    def backward(self, loss):
-        loss.backward()
+    def finish_allreduce(self):
+        """Reduce what no block bucket covers (prenets, heads, postnet, ...) and wait for everything."""
         if self.world > 1:
             for s, e in self.rest:
                 self._pending.append(dist.all_reduce(self.flat_g[s:e], group=self.pg, async_op=True))
             for w in self._pending:
                 w.wait()
             self._pending.clear()
+
+    def backward(self, loss):
+        loss.backward()
+        self.finish_allreduce()
 
     def lr_now(self) -> float:
         """Linear warm-up ``lr * min(1, (step+1)/warmup)`` (``wrappers.py:284-294``)."""
