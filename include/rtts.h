@@ -139,6 +139,14 @@ int rtts_xattn_bwd(const void* q, int64_t ld_q, const void* kv, int64_t ld_kv, c
                    int B, int H, int Tq, int Tk, int dh, void* dq, int64_t ld_dq, void* dkv_part, void* stream);
 int rtts_sum_slabs(const void* part, int nslabs, int64_t n, void* out, void* stream);
 
+/* ---- weight-gradient GEMM, split over the token dimension ------------------------------------
+ * c[N][K] (fp32, stride ldc) (+)= sum_m a[m][N] * b[m][K]   (a, b bf16 with strides lda, ldb)
+ * = dW of a Linear layer y = x W^T (reference modules.py:195-207, reformer.py:161-217 via autograd).
+ * N % 128 == 0, K % 128 == 0, M % 64 == 0.  slab_ws (>= N*K*16 floats for full split) holds the
+ * per-split partial tiles; they are summed in a fixed order (deterministic).  accumulate=1: += . */
+int rtts_gemm_tn(const void* a, int64_t lda, const void* b, int64_t ldb, int M, int N, int K, float* c, int64_t ldc,
+                 int accumulate, float* slab_ws, int64_t slab_ws_floats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

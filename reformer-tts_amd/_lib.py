@@ -31,6 +31,7 @@ SIGNATURES = {
     "rtts_xattn_fwd": [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp],
     "rtts_xattn_bwd": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp],
     "rtts_sum_slabs": [_vp, _i32, _i64, _vp, _vp],
+    "rtts_gemm_tn": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _i32, _vp, _i64, _vp],
     "rtts_adamw_step": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _i32, _vp],
 }
 

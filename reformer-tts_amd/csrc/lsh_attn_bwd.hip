@@ -19,6 +19,7 @@
 // rtts_lsh_bwd_reduce sums slots and rounds -- deterministic, no atomics.
 #include "rtts_common.h"
 #include <float.h>
+#include <stdlib.h>
 
 #define AB_DH 64
 #define AB_ROWB 144
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
     const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v, int64_t ld, const int32_t* __restrict__ st,
     const uint8_t* __restrict__ mask, const bf16_t* __restrict__ dout, int64_t ld_do, const float* __restrict__ lse_tot,
     const float* __restrict__ delta, int H, int T, int n_hashes, bf16_t* __restrict__ dqk_part, bf16_t* __restrict__ dv_part,
-    size_t slot_stride) {
+    size_t slot_stride, int dbg_stop) {
     constexpr int NK = 2 * BS;
     constexpr int NQT = BS / 32;
     constexpr int NTHR = BS * 4;
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
         }
     }
     __syncthreads();
+    if (dbg_stop == 1) { if (kscale[tid & 63] == 12345.f) dqk_part[0] = 1; return; }
 
     // ---- this wave's key-side constants -----------------------------------------------------
     bf16x8 kf[KT2][4];
@@ -223,6 +225,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
         }
     }
 
+    if (dbg_stop == 2) { if (dvacc[0][0][0] + gacc[0][1][3] == 12345.f) dqk_part[0] = 1; return; }
     // ---- key-side outputs: dV and dK of this wave's 64 keys -----------------------------------
     const int round = c / nb, round_prev = cprev / nb;
 #pragma unroll
@@ -266,6 +269,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
     }
     __syncthreads();
 
+    if (dbg_stop == 3) return;
     // ---- dQ^T[dh][q] = K^T dS'^T over all 2*BS keys: wave w finishes (query tile w/2, dh half w%2) ----
     {
         const int qt = wave >> 1, dt = wave & 1;
@@ -302,6 +306,7 @@ static int launch_attn_bwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const 
     const dim3 grid(B * H * n_hashes * (T / BS)), block(BS * 4);
     const size_t slot_stride = (size_t)B * H * n_hashes * T * AB_DH;
     const int vi = (causal ? 2 : 0) + (mask ? 1 : 0);
+    static const int dbg_stop = getenv("RTTS_BWD_STOP") ? atoi(getenv("RTTS_BWD_STOP")) : 0;   // diagnostics only
 #define AB_GO(C_, M_)                                                                                                      \
     do {                                                                                                                   \
         auto kern = lsh_attn_bwd_kernel<BS, C_, M_>;                                                                       \
@@ -310,7 +315,7 @@ static int launch_attn_bwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const 
             g_bwd_attr_set[BS == 128][vi] = true;                                                                          \
         }                                                                                                                  \
         hipLaunchKernelGGL(kern, grid, block, lds, stream, qk, v, ld, st, mask, dout, ld_do, lse_tot, delta, H, T, n_hashes, \
-                           dqk_part, dv_part, slot_stride);                                                                \
+                           dqk_part, dv_part, slot_stride, dbg_stop);                                                      \
     } while (0)
     if (causal) {
         if (mask) AB_GO(true, true); else AB_GO(true, false);

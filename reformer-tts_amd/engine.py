@@ -95,9 +95,23 @@ def residual(acc, g, bias, sign: float):
               acc.data_ptr(), m, d, _s())
 
 
+_SLAB_FLOATS = 16 * 1024 * 1024   # 64 MB: 16 splits of a 2048 x 512 gradient
+
+
 def wgrad(grad_view: torch.Tensor, dy: torch.Tensor, x: torch.Tensor):
-    """grad_view (N,K) fp32 += dy(M,N)^T @ x(M,K)   (bf16 operands, fp32 result)."""
-    grad_view.add_(torch.mm(dy.t(), x, out_dtype=torch.float32))
+    """grad_view (N,K) fp32 += dy(M,N)^T @ x(M,K)   (bf16 operands, fp32 accumulation).
+    Split-K kernel of csrc/gemm_tn.hip when the shape tiles (128 | N, 128 | K, 64 | M), else hipBLASLt."""
+    m, n = dy.shape
+    k = x.shape[1]
+    if n % 128 == 0 and k % 128 == 0 and m % 64 == 0 and dy.stride(1) == 1 and x.stride(1) == 1 and grad_view.stride(1) == 1:
+        key = ("slab", dy.device)
+        if key not in _WS._cache:
+            _WS._cache[key] = torch.empty(_SLAB_FLOATS, dtype=torch.float32, device=dy.device)
+        ws = _WS._cache[key]
+        _lib.call("rtts_gemm_tn", dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), m, n, k, grad_view.data_ptr(),
+                  grad_view.stride(0), 1, ws.data_ptr(), ws.numel(), _s())
+    else:
+        grad_view.add_(torch.mm(dy.t(), x, out_dtype=torch.float32))
 
 
 # ------------------------------------------------------------------------------------------ blocks
