@@ -51,24 +51,32 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const bf16_t* __
 
     // staging map: 64 rows x 16 pieces of 16 B per operand; thread -> (row = it*16 + tid/16, piece = tid%16)
     const int srow = tid >> 4, spiece = tid & 15;
-    uint4 ra[4], rb[4];
-    auto load_stage = [&](int stage) {
-        const size_t m = (size_t)m_begin + (size_t)stage * GT_BM;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const size_t row = m + it * 16 + srow;
-            ra[it] = *reinterpret_cast<const uint4*>(a + row * lda + n0 + spiece * 8);
-            rb[it] = *reinterpret_cast<const uint4*>(b + row * ldb + k0 + spiece * 8);
-        }
-    };
-    auto store_stage = [&](int buf) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int row = it * 16 + srow;
-            *reinterpret_cast<uint4*>(As + (buf * GT_BM + row) * GT_ROWB + spiece * 16) = ra[it];
-            *reinterpret_cast<uint4*>(Bs + (buf * GT_BM + row) * GT_ROWB + spiece * 16) = rb[it];
-        }
-    };
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define GT_LOAD_STAGE(stage)                                                                       \
+    do {                                                                                           \
+        const size_t m_ = (size_t)m_begin + (size_t)(stage) * GT_BM + srow;                        \
+        ra0 = *reinterpret_cast<const uint4*>(a + (m_ + 0) * lda + n0 + spiece * 8);               \
+        ra1 = *reinterpret_cast<const uint4*>(a + (m_ + 16) * lda + n0 + spiece * 8);              \
+        ra2 = *reinterpret_cast<const uint4*>(a + (m_ + 32) * lda + n0 + spiece * 8);              \
+        ra3 = *reinterpret_cast<const uint4*>(a + (m_ + 48) * lda + n0 + spiece * 8);              \
+        rb0 = *reinterpret_cast<const uint4*>(b + (m_ + 0) * ldb + k0 + spiece * 8);               \
+        rb1 = *reinterpret_cast<const uint4*>(b + (m_ + 16) * ldb + k0 + spiece * 8);              \
+        rb2 = *reinterpret_cast<const uint4*>(b + (m_ + 32) * ldb + k0 + spiece * 8);              \
+        rb3 = *reinterpret_cast<const uint4*>(b + (m_ + 48) * ldb + k0 + spiece * 8);              \
+    } while (0)
+#define GT_STORE_STAGE(buf)                                                                        \
+    do {                                                                                           \
+        unsigned char* pa_ = As + ((buf) * GT_BM + srow) * GT_ROWB + spiece * 16;                  \
+        unsigned char* pb_ = Bs + ((buf) * GT_BM + srow) * GT_ROWB + spiece * 16;                  \
+        *reinterpret_cast<uint4*>(pa_) = ra0;                                                      \
+        *reinterpret_cast<uint4*>(pa_ + 16 * GT_ROWB) = ra1;                                       \
+        *reinterpret_cast<uint4*>(pa_ + 32 * GT_ROWB) = ra2;                                       \
+        *reinterpret_cast<uint4*>(pa_ + 48 * GT_ROWB) = ra3;                                       \
+        *reinterpret_cast<uint4*>(pb_) = rb0;                                                      \
+        *reinterpret_cast<uint4*>(pb_ + 16 * GT_ROWB) = rb1;                                       \
+        *reinterpret_cast<uint4*>(pb_ + 32 * GT_ROWB) = rb2;                                       \
+        *reinterpret_cast<uint4*>(pb_ + 48 * GT_ROWB) = rb3;                                       \
+    } while (0)
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -76,12 +84,12 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const bf16_t* __
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
 
-    load_stage(0);
-    store_stage(0);
+    GT_LOAD_STAGE(0);
+    GT_STORE_STAGE(0);
     __syncthreads();
     for (int s = 0; s < nstage; ++s) {
         const int buf = s & 1;
-        if (s + 1 < nstage) load_stage(s + 1);         // in flight during the MFMAs below
+        if (s + 1 < nstage) GT_LOAD_STAGE(s + 1);      // in flight during the MFMAs below
         const unsigned char* Ab = As + buf * GT_BM * GT_ROWB;
         const unsigned char* Bb = Bs + buf * GT_BM * GT_ROWB;
 #pragma unroll
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const bf16_t* __
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        if (s + 1 < nstage) store_stage(buf ^ 1);      // other buffer: last read two barriers ago
+        if (s + 1 < nstage) GT_STORE_STAGE(buf ^ 1);   // other buffer: its readers passed the previous barrier
         __syncthreads();
     }
 

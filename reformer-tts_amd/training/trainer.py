@@ -63,18 +63,22 @@ class Trainer:
     # ------------------------------------------------------------------ flat storage
     def _flatten(self):
         named = [(n, p) for n, p in self.model.named_parameters() if p.requires_grad]
-        total = sum(p.numel() for _, p in named)
-        pad = (-total) % 4
+        align = 8                                   # elements: 16-byte rows in the bf16 mirror, 32 B in fp32
+        starts, off = [], 0
+        for _, p in named:
+            starts.append(off)
+            off += -(-p.numel() // align) * align   # padding stays zero in every buffer
+        total = off
+        pad = 0
         dev = self.device
-        self.flat_p = torch.zeros(total + pad, dtype=torch.float32, device=dev)
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros_like(self.flat_p)
         self.flat_m = torch.zeros_like(self.flat_p)
         self.flat_v = torch.zeros_like(self.flat_p)
-        self.decay_mask = torch.zeros(total + pad, dtype=torch.uint8, device=dev)
-        self.n_params = total
+        self.decay_mask = torch.zeros(total, dtype=torch.uint8, device=dev)
+        self.n_params = total                       # padded length of the flat buffers
         self.offsets: Dict[str, tuple] = {}
-        off = 0
-        for n, p in named:
+        for (n, p), off in zip(named, starts):
             k = p.numel()
             self.flat_p[off:off + k].copy_(p.detach().reshape(-1))
             p.data = self.flat_p[off:off + k].view_as(p)
@@ -82,7 +86,6 @@ class Trainer:
             if not any(nd in n for nd in NO_DECAY):
                 self.decay_mask[off:off + k] = 1
             self.offsets[n] = (off, off + k)
-            off += k
         if dev.type == "cuda":
             self.ws_partial = torch.zeros(2048, dtype=torch.float32, device=dev)
             self.ws_scale = torch.zeros(2, dtype=torch.float32, device=dev)
