@@ -81,12 +81,14 @@ class LSHSelfAttention(nn.Module):
     def _rotations(self, x, n_buckets):
         if self.forced_rotations is not None:
             return self.forced_rotations.to(device=x.device, dtype=torch.float32).contiguous()
+        rows = x.shape[0] * self.heads if self.random_rotations_per_head else 1
+        shape = (rows, self.dim // self.heads, self.n_hashes, n_buckets // 2)
+        if getattr(self, "use_default_generator", False):     # hipGraph capture: the default generator is graph-safe
+            return torch.randn(shape, device=x.device, dtype=torch.float32)
         if self._gen is None or self._gen.device != x.device:
             self._gen = torch.Generator(device=x.device)
             self._gen.manual_seed(0x5EED + self.seed)
-        rows = x.shape[0] * self.heads if self.random_rotations_per_head else 1
-        return torch.randn(rows, self.dim // self.heads, self.n_hashes, n_buckets // 2, device=x.device,
-                           dtype=torch.float32, generator=self._gen)
+        return torch.randn(shape, device=x.device, dtype=torch.float32, generator=self._gen)
 
     def forward(self, x, input_mask=None, recompute: bool = False, **_):
         b, t, e = x.shape
