@@ -139,6 +139,35 @@ int rtts_xattn_bwd(const void* q, int64_t ld_q, const void* kv, int64_t ld_kv, c
                    int B, int H, int Tq, int Tk, int dh, void* dq, int64_t ld_dq, void* dkv_part, void* stream);
 int rtts_sum_slabs(const void* part, int nslabs, int64_t n, void* out, void* stream);
 
+/* ---- convolutional edges (prenet / postnet) and the loss ------------------------------------------
+ * Conv1d(k=5, pad=2) on channels-last rows = rtts_im2col_k5 + a library GEMM over (B*L, 5*CP); the
+ * kernels below are everything else (reference reformer_tts/model/modules.py:8-61,103-169; loss.py:28-53).
+ *   rtts_im2col_k5      cols[(b,l)][k*CP + c] = x[b][l+k-2][c] (zero padded; bf16; C, CP multiples of 8)
+ *   rtts_col2im_k5      adjoint: dx[b][l][c] = sum_k dcols[(b,l-k+2)][k*CP + c]   (bf16 or fp32 out)
+ *   rtts_conv_w_perm    wp[co][k][ci] (bf16, ci < CP zero padded) = w[co][ci][k] (fp32 master layout of nn.Conv1d)
+ *   rtts_conv_dw_unperm dw[co][ci][k] += dwp[co][k][ci]
+ *   rtts_bn_stats       per-channel batch mean / rstd (eps 1e-5) of y (M,C) fp32; optional running-stat update
+ *   rtts_bn_act_fwd     z(bf16) = dropout_p(act(gamma*(y-mean)*rstd + beta)); act 1 = ReLU, 2 = tanh;
+ *                       the dropout mask is a hash of (seed, element index), reproduced by the backward
+ *   rtts_bn_act_bwd     dy(bf16) = BatchNorm(train) backward through act and dropout; dgamma, dbeta accumulate
+ *   rtts_tts_loss       losses[4] = {total, raw, post, stop} and d_raw, d_post (rows,NM), d_stop (rows):
+ *                       masked MSE (kind 0) / L1 (kind 1) means over ALL elements + BCE-with-logits(pos_weight)
+ * partial_ws: >= (2*256 + 2)*C floats (bn) / 1536 floats (loss). */
+int rtts_im2col_k5(const void* x, int64_t ldx, int B, int L, int C, int CP, void* cols, void* stream);
+int rtts_col2im_k5(const void* dcols, int B, int L, int C, int CP, void* dx, int64_t lddx, int out_f32, void* stream);
+int rtts_conv_w_perm(const float* w, int Co, int Ci, int CP, void* wp, void* stream);
+int rtts_conv_dw_unperm(const float* dwp, int Co, int Ci, int CP, float* dw, void* stream);
+int rtts_bn_stats(const float* y, int M, int C, float* mean, float* rstd, float* run_mean, float* run_var,
+                  float* partial_ws, void* stream);
+int rtts_bn_act_fwd(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                    float drop_p, uint32_t seed, int M, int C, void* z, void* stream);
+int rtts_bn_act_bwd(const float* y, const void* dz, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                    int act, float drop_p, uint32_t seed, int M, int C, void* dy, float* dgamma, float* dbeta,
+                    float* partial_ws, void* stream);
+int rtts_tts_loss(const float* raw, const float* post, int64_t ld_mel, const float* tgt, const float* mask, const float* stop,
+                  int64_t ld_stop, const float* tstop, int rows, int NM, int kind, float pos_weight, float w_raw, float w_post,
+                  float w_stop, float* d_raw, float* d_post, float* d_stop, float* losses, float* partial_ws, void* stream);
+
 /* ---- weight-gradient GEMM, split over the token dimension ------------------------------------
  * c[N][K] (fp32, stride ldc) (+)= sum_m a[m][N] * b[m][K]   (a, b bf16 with strides lda, ldb)
  * = dW of a Linear layer y = x W^T (reference modules.py:195-207, reformer.py:161-217 via autograd).

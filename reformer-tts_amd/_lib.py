@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librtts_hip.so")
 
-_i64, _i32, _vp, _f32 = C.c_int64, C.c_int, C.c_void_p, C.c_float
+_i64, _i32, _vp, _f32, _u32 = C.c_int64, C.c_int, C.c_void_p, C.c_float, C.c_uint32
 
 # name -> argtypes, exactly the prototypes of include/rtts.h
 SIGNATURES = {
@@ -31,6 +31,14 @@ SIGNATURES = {
     "rtts_xattn_fwd": [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp],
     "rtts_xattn_bwd": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp],
     "rtts_sum_slabs": [_vp, _i32, _i64, _vp, _vp],
+    "rtts_im2col_k5": [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp],
+    "rtts_col2im_k5": [_vp, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _vp],
+    "rtts_conv_w_perm": [_vp, _i32, _i32, _i32, _vp, _vp],
+    "rtts_conv_dw_unperm": [_vp, _i32, _i32, _i32, _vp, _vp],
+    "rtts_bn_stats": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "rtts_bn_act_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _u32, _i32, _i32, _vp, _vp],
+    "rtts_bn_act_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _u32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    "rtts_tts_loss": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp],
     "rtts_gemm_tn": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _i32, _vp, _i64, _vp],
     "rtts_adamw_step": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _i32, _vp],
 }

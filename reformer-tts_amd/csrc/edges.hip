@@ -1,0 +1,417 @@
+// Kernels of the convolutional "edges" of the model: encoder prenet convolutions and the mel postnet
+// (/root/reference/reformer_tts/model/modules.py:8-61,103-169) and the loss (model/loss.py:28-53).
+//
+// A Conv1d(k=5, pad=2) on channels-last rows is im2col (here) + ONE library GEMM over the
+// (B*L, 5*C) window matrix; everything around the GEMM is fused here:
+//   im2col_k5 / col2im_k5          window matrix and its adjoint (bf16, 16-byte pieces, coalesced)
+//   conv weight permute + cast     (Cout,Cin,5) fp32 master -> (Cout,5,Cin_pad) bf16, and the adjoint for dW
+//   col_stats                      per-channel batch mean / rstd (+ running-stat update), two-stage, deterministic
+//   bn_act_fwd                     z = dropout(act(gamma * (y-mean)*rstd + beta))  -> bf16
+//   bn_act_bwd (stats + apply)     full BatchNorm(train) backward through act and dropout
+//   tts_loss_fwd_bwd               masked MSE/L1 on raw + postnet mel, BCE-with-logits(pos_weight) on stop:
+//                                  the three means AND their gradients in one pass
+// Dropout masks come from a counter-based hash of (seed, element index): reproducible in the backward
+// without storing a mask.  All HBM-streaming; column sums via per-workgroup partial rows (no atomics).
+#include "rtts_common.h"
+
+#define ED_THREADS 256
+#define ED_PBLOCKS 256
+
+__device__ __forceinline__ uint32_t ed_hash(uint32_t seed, uint32_t idx) {
+    uint32_t x = idx * 0x9E3779B1u + seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+// keep-scale of element idx: 0 (dropped) or 1/(1-p)
+__device__ __forceinline__ float ed_drop(uint32_t seed, uint32_t idx, uint32_t thresh, float scale) {
+    return ed_hash(seed, idx) >= thresh ? scale : 0.f;
+}
+
+// ------------------------------------------------------------------ im2col / col2im (k=5, pad=2)
+// cols[(b*L + l)][k*CP + c] = x[b][l + k - 2][c] (zero outside [0,L) and for c >= C); 8 channels per thread
+__global__ __launch_bounds__(ED_THREADS) void im2col_k5_kernel(const bf16_t* __restrict__ x, int64_t ldx, int B, int L, int C, int CP,
+                                                               bf16_t* __restrict__ cols) {
+    const int pieces = CP / 8;
+    const size_t total = (size_t)B * L * 5 * pieces;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int pc = (int)(i % pieces);
+        const int k = (int)((i / pieces) % 5);
+        const size_t row = i / ((size_t)pieces * 5);
+        const int l = (int)(row % L);
+        const int ls = l + k - 2;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (ls >= 0 && ls < L && pc * 8 < C) v = *reinterpret_cast<const uint4*>(x + (row + k - 2) * ldx + pc * 8);
+        *reinterpret_cast<uint4*>(cols + row * (size_t)(5 * CP) + (size_t)k * CP + pc * 8) = v;
+    }
+}
+
+// dx[b][l][c] = sum_k dcols[(b, l - k + 2)][k*CP + c]
+template <bool OUT_F32>
+__global__ __launch_bounds__(ED_THREADS) void col2im_k5_kernel(const bf16_t* __restrict__ dcols, int B, int L, int C, int CP,
+                                                               void* __restrict__ dx, int64_t lddx) {
+    const int pieces = C / 8;
+    const size_t total = (size_t)B * L * pieces;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int pc = (int)(i % pieces);
+        const size_t row = i / pieces;
+        const int l = (int)(row % L);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int ls = l - k + 2;
+            if (ls < 0 || ls >= L) continue;
+            const uint4 t = *reinterpret_cast<const uint4*>(dcols + (row - k + 2) * (size_t)(5 * CP) + (size_t)k * CP + pc * 8);
+            const uint32_t u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[2 * j] += __uint_as_float(u[j] << 16);
+                acc[2 * j + 1] += __uint_as_float(u[j] & 0xffff0000u);
+            }
+        }
+        if (OUT_F32) {
+            float* p = reinterpret_cast<float*>(dx) + row * lddx + pc * 8;
+            *reinterpret_cast<float4*>(p) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *reinterpret_cast<float4*>(p + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        } else {
+            uint4 o;
+            o.x = pack_bf16x2(acc[0], acc[1]); o.y = pack_bf16x2(acc[2], acc[3]);
+            o.z = pack_bf16x2(acc[4], acc[5]); o.w = pack_bf16x2(acc[6], acc[7]);
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(dx) + row * lddx + pc * 8) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ conv weight layouts
+// wp[co][k][ci] (bf16, Cin padded to CP with zeros) = w[co][ci][k] (fp32)
+__global__ __launch_bounds__(ED_THREADS) void conv_w_perm_kernel(const float* __restrict__ w, int Co, int Ci, int CP, bf16_t* __restrict__ wp) {
+    const size_t total = (size_t)Co * 5 * CP;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % CP), k = (int)((i / CP) % 5), co = (int)(i / ((size_t)CP * 5));
+        wp[i] = ci < Ci ? f32_to_bf16(w[((size_t)co * Ci + ci) * 5 + k]) : (bf16_t)0;
+    }
+}
+// dw[co][ci][k] += dwp[co][k][ci]
+__global__ __launch_bounds__(ED_THREADS) void conv_dw_unperm_kernel(const float* __restrict__ dwp, int Co, int Ci, int CP, float* __restrict__ dw) {
+    const size_t total = (size_t)Co * Ci * 5;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % 5), ci = (int)((i / 5) % Ci), co = (int)(i / ((size_t)Ci * 5));
+        dw[i] += dwp[((size_t)co * 5 + k) * CP + ci];
+    }
+}
+
+// ------------------------------------------------------------------ per-channel partial sums over rows
+// partial[blk][0..C) = sum_rows a(row,c); partial[blk][C..2C) = sum_rows b(row,c); thread owns 4 channels
+template <int MODE>   // 0: (y, y*y)   1: (g, g*yhat) with g = dz * act'(.) * dropmask
+__global__ __launch_bounds__(ED_THREADS) void col_partial_kernel(const float* __restrict__ y, const bf16_t* __restrict__ dz,
+                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                                 uint32_t seed, uint32_t thresh, float dscale, int M, int C,
+                                                                 float* __restrict__ partial) {
+    // block = 64 channel-quads x 4 row-lanes; grid.x = row slabs, grid.y = channel groups of 256
+    const int cq = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.y * 256 + cq * 4;
+    __shared__ float red[2][4][256];
+    float sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+    if (c < C) {
+        float mu[4] = {0, 0, 0, 0}, rs[4] = {1, 1, 1, 1}, ga[4] = {1, 1, 1, 1}, be[4] = {0, 0, 0, 0};
+        if (MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { mu[j] = mean[c + j]; rs[j] = rstd[c + j]; ga[j] = gamma[c + j]; be[j] = beta[c + j]; }
+        }
+        for (int row = blockIdx.x * 4 + rl; row < M; row += gridDim.x * 4) {
+            const float4 yv = *reinterpret_cast<const float4*>(y + (size_t)row * C + c);
+            const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+            if (MODE == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { sa[j] += yy[j]; sb[j] = __builtin_fmaf(yy[j], yy[j], sb[j]); }
+            } else {
+                const uint2 dv = *reinterpret_cast<const uint2*>(dz + (size_t)row * C + c);
+                const float dd[4] = {__uint_as_float(dv.x << 16), __uint_as_float(dv.x & 0xffff0000u), __uint_as_float(dv.y << 16),
+                                     __uint_as_float(dv.y & 0xffff0000u)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float yh = (yy[j] - mu[j]) * rs[j];
+                    const float pre = __builtin_fmaf(yh, ga[j], be[j]);
+                    float da;
+                    if (act == 1) da = pre > 0.f ? 1.f : 0.f;
+                    else { const float th = tanhf(pre); da = 1.f - th * th; }
+                    const float g = dd[j] * da * (thresh ? ed_drop(seed, (uint32_t)((size_t)row * C + c + j), thresh, dscale) : 1.f);
+                    sa[j] += g;
+                    sb[j] = __builtin_fmaf(g, yh, sb[j]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[0][rl][cq * 4 + j] = sa[j]; red[1][rl][cq * 4 + j] = sb[j]; }
+    __syncthreads();
+    const int t = threadIdx.x;   // 256 channels of this group
+    if (blockIdx.y * 256 + t < C) {
+        float* prow = partial + (size_t)blockIdx.x * 2 * C;
+        prow[blockIdx.y * 256 + t] = (red[0][0][t] + red[0][1][t]) + (red[0][2][t] + red[0][3][t]);
+        prow[C + blockIdx.y * 256 + t] = (red[1][0][t] + red[1][1][t]) + (red[1][2][t] + red[1][3][t]);
+    }
+}
+
+// mean/rstd from the partials (+ running statistics, momentum 0.1, unbiased variance)
+__global__ __launch_bounds__(ED_THREADS) void bn_finalize_stats_kernel(const float* __restrict__ partial, int nrows, int M, int C,
+                                                                       float* __restrict__ mean, float* __restrict__ rstd,
+                                                                       float* __restrict__ run_mean, float* __restrict__ run_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f, q = 0.f;
+    for (int r = 0; r < nrows; ++r) { s += partial[(size_t)r * 2 * C + c]; q += partial[(size_t)r * 2 * C + C + c]; }
+    const float mu = s / M;
+    const float var = fmaxf(q / M - mu * mu, 0.f);
+    mean[c] = mu;
+    rstd[c] = rsqrtf(var + 1e-5f);
+    if (run_mean) {
+        run_mean[c] = 0.9f * run_mean[c] + 0.1f * mu;
+        run_var[c] = 0.9f * run_var[c] + 0.1f * var * ((float)M / (float)(M > 1 ? M - 1 : 1));
+    }
+}
+
+// sums of the backward partials: out_a[c] (+)= sum partial a ; out_b[c] (+)= sum partial b ; also raw sums to sums[2C]
+__global__ __launch_bounds__(ED_THREADS) void bn_finalize_bwd_kernel(const float* __restrict__ partial, int nrows, int C,
+                                                                     float* __restrict__ sums, float* __restrict__ dgamma,
+                                                                     float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f, q = 0.f;
+    for (int r = 0; r < nrows; ++r) { s += partial[(size_t)r * 2 * C + c]; q += partial[(size_t)r * 2 * C + C + c]; }
+    sums[c] = s;
+    sums[C + c] = q;
+    dbeta[c] += s;
+    dgamma[c] += q;
+}
+
+// z = dropout(act(gamma*(y-mean)*rstd + beta)) as bf16; 4 channels per thread
+__global__ __launch_bounds__(ED_THREADS) void bn_act_fwd_kernel(const float* __restrict__ y, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, int act, uint32_t seed, uint32_t thresh,
+                                                                float dscale, size_t n4, int C, bf16_t* __restrict__ z) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * 4;
+        const int c = (int)(e % C);
+        const float4 yv = reinterpret_cast<const float4*>(y)[i];
+        const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float pre = __builtin_fmaf((yy[j] - mean[c + j]) * rstd[c + j], gamma[c + j], beta[c + j]);
+            float a = act == 1 ? fmaxf(pre, 0.f) : tanhf(pre);
+            if (thresh) a *= ed_drop(seed, (uint32_t)(e + j), thresh, dscale);
+            o[j] = a;
+        }
+        uint2 pk;
+        pk.x = pack_bf16x2(o[0], o[1]);
+        pk.y = pack_bf16x2(o[2], o[3]);
+        reinterpret_cast<uint2*>(z)[i] = pk;
+    }
+}
+
+// dy = gamma*rstd * (g - mean(g) - yhat*mean(g*yhat))  as bf16
+__global__ __launch_bounds__(ED_THREADS) void bn_act_bwd_apply_kernel(const float* __restrict__ y, const bf16_t* __restrict__ dz,
+                                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                      const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                                      uint32_t seed, uint32_t thresh, float dscale,
+                                                                      const float* __restrict__ sums, float inv_m, size_t n4, int C,
+                                                                      bf16_t* __restrict__ dy) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * 4;
+        const int c = (int)(e % C);
+        const float4 yv = reinterpret_cast<const float4*>(y)[i];
+        const uint2 dv = reinterpret_cast<const uint2*>(dz)[i];
+        const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+        const float dd[4] = {__uint_as_float(dv.x << 16), __uint_as_float(dv.x & 0xffff0000u), __uint_as_float(dv.y << 16),
+                             __uint_as_float(dv.y & 0xffff0000u)};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float rs = rstd[c + j], ga = gamma[c + j];
+            const float yh = (yy[j] - mean[c + j]) * rs;
+            const float pre = __builtin_fmaf(yh, ga, beta[c + j]);
+            float da;
+            if (act == 1) da = pre > 0.f ? 1.f : 0.f;
+            else { const float th = tanhf(pre); da = 1.f - th * th; }
+            const float g = dd[j] * da * (thresh ? ed_drop(seed, (uint32_t)(e + j), thresh, dscale) : 1.f);
+            o[j] = ga * rs * (g - sums[c + j] * inv_m - yh * sums[C + c + j] * inv_m);
+        }
+        uint2 pk;
+        pk.x = pack_bf16x2(o[0], o[1]);
+        pk.y = pack_bf16x2(o[2], o[3]);
+        reinterpret_cast<uint2*>(dy)[i] = pk;
+    }
+}
+
+// ------------------------------------------------------------------ TTS loss: values and gradients in one pass
+// raw, post (B,L,NM) f32 strided; tgt, mask (B,L,NM) f32 contiguous; stop logits (B,L) stride; tstop (B,L)
+// kind 0: MSE, 1: L1.  out[0..2] partial sums per block -> finalize.  Gradients of
+//   w_raw*mean(loss(raw*mask, tgt)) + w_post*mean(loss(post*mask, tgt)) + w_stop*mean(BCE(stop, tstop; pos_weight))
+__global__ __launch_bounds__(ED_THREADS) void tts_loss_kernel(const float* __restrict__ raw, const float* __restrict__ post, int64_t ld_mel,
+                                                              const float* __restrict__ tgt, const float* __restrict__ mask,
+                                                              const float* __restrict__ stop, int64_t ld_stop, const float* __restrict__ tstop,
+                                                              int rows, int NM, int kind, float pos_weight, float w_raw, float w_post,
+                                                              float w_stop, float* __restrict__ d_raw, float* __restrict__ d_post,
+                                                              float* __restrict__ d_stop, float* __restrict__ partial) {
+    float s_raw = 0.f, s_post = 0.f, s_stop = 0.f;
+    const size_t nel = (size_t)rows * NM;
+    const float inv_el = 1.f / (float)nel, inv_rows = 1.f / (float)rows;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nel; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / NM;
+        const int c = (int)(i % NM);
+        const float mk = mask[i], tg = tgt[i];
+        const float r = raw[row * ld_mel + c] * mk - tg, p = post[row * ld_mel + c] * mk - tg;
+        if (kind == 0) {
+            s_raw = __builtin_fmaf(r, r, s_raw);
+            s_post = __builtin_fmaf(p, p, s_post);
+            d_raw[i] = w_raw * 2.f * r * mk * inv_el;
+            d_post[i] = w_post * 2.f * p * mk * inv_el;
+        } else {
+            s_raw += fabsf(r);
+            s_post += fabsf(p);
+            d_raw[i] = w_raw * (r > 0.f ? 1.f : (r < 0.f ? -1.f : 0.f)) * mk * inv_el;
+            d_post[i] = w_post * (p > 0.f ? 1.f : (p < 0.f ? -1.f : 0.f)) * mk * inv_el;
+        }
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)rows; i += (size_t)gridDim.x * blockDim.x) {
+        const float x = stop[i * ld_stop], t = tstop[i];
+        // BCE with logits, pos_weight pw:  (1-t) x + (1 + (pw-1) t) * softplus(-x)
+        const float lw = 1.f + (pos_weight - 1.f) * t;
+        const float sp = fmaxf(-x, 0.f) + log1pf(expf(-fabsf(x)));      // softplus(-x)
+        s_stop += (1.f - t) * x + lw * sp;
+        const float sig = 1.f / (1.f + expf(-x));
+        d_stop[i] = w_stop * ((1.f - t) - lw * (1.f - sig)) * inv_rows;
+    }
+    __shared__ float red[3][ED_THREADS / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s_raw += __shfl_xor(s_raw, o);
+        s_post += __shfl_xor(s_post, o);
+        s_stop += __shfl_xor(s_stop, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s_raw;
+        red[1][threadIdx.x >> 6] = s_post;
+        red[2][threadIdx.x >> 6] = s_stop;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) partial[blockIdx.x * 3 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+
+// losses[0..3] = total, raw, post, stop
+__global__ void tts_loss_finalize_kernel(const float* __restrict__ partial, int nblocks, float inv_el, float inv_rows, float w_raw,
+                                         float w_post, float w_stop, float* __restrict__ losses) {
+    if (threadIdx.x != 0) return;
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int i = 0; i < nblocks; ++i) { a += partial[i * 3]; b += partial[i * 3 + 1]; c += partial[i * 3 + 2]; }
+    a *= inv_el; b *= inv_el; c *= inv_rows;
+    losses[0] = w_raw * a + w_post * b + w_stop * c;
+    losses[1] = a; losses[2] = b; losses[3] = c;
+}
+
+// ------------------------------------------------------------------ host side
+static inline unsigned ed_grid(size_t items) {
+    size_t b = (items + ED_THREADS - 1) / ED_THREADS;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+static inline uint32_t ed_thresh(float p) { return p <= 0.f ? 0u : (uint32_t)((double)p * 4294967296.0); }
+
+extern "C" int rtts_im2col_k5(const void* x, int64_t ldx, int B, int L, int C, int CP, void* cols, void* stream) {
+    RTTS_REQUIRE(x && cols && B > 0 && L > 0 && C > 0 && C % 8 == 0 && CP % 8 == 0 && CP >= C && ldx % 8 == 0, "rtts_im2col_k5: bad arguments");
+    hipLaunchKernelGGL(im2col_k5_kernel, dim3(ed_grid((size_t)B * L * 5 * (CP / 8))), dim3(ED_THREADS), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, ldx, B, L, C, CP, (bf16_t*)cols);
+    RTTS_LAUNCH_CHECK("rtts_im2col_k5");
+    return 0;
+}
+
+extern "C" int rtts_col2im_k5(const void* dcols, int B, int L, int C, int CP, void* dx, int64_t lddx, int out_f32, void* stream) {
+    RTTS_REQUIRE(dcols && dx && B > 0 && L > 0 && C > 0 && C % 8 == 0 && CP % 8 == 0 && CP >= C, "rtts_col2im_k5: bad arguments");
+    const dim3 grid(ed_grid((size_t)B * L * (C / 8)));
+    if (out_f32)
+        hipLaunchKernelGGL(col2im_k5_kernel<true>, grid, dim3(ED_THREADS), 0, (hipStream_t)stream, (const bf16_t*)dcols, B, L, C, CP, dx, lddx);
+    else
+        hipLaunchKernelGGL(col2im_k5_kernel<false>, grid, dim3(ED_THREADS), 0, (hipStream_t)stream, (const bf16_t*)dcols, B, L, C, CP, dx, lddx);
+    RTTS_LAUNCH_CHECK("rtts_col2im_k5");
+    return 0;
+}
+
+extern "C" int rtts_conv_w_perm(const float* w, int Co, int Ci, int CP, void* wp, void* stream) {
+    RTTS_REQUIRE(w && wp && Co > 0 && Ci > 0 && CP >= Ci, "rtts_conv_w_perm: bad arguments");
+    hipLaunchKernelGGL(conv_w_perm_kernel, dim3(ed_grid((size_t)Co * 5 * CP)), dim3(ED_THREADS), 0, (hipStream_t)stream, w, Co, Ci, CP, (bf16_t*)wp);
+    RTTS_LAUNCH_CHECK("rtts_conv_w_perm");
+    return 0;
+}
+
+extern "C" int rtts_conv_dw_unperm(const float* dwp, int Co, int Ci, int CP, float* dw, void* stream) {
+    RTTS_REQUIRE(dwp && dw && Co > 0 && Ci > 0 && CP >= Ci, "rtts_conv_dw_unperm: bad arguments");
+    hipLaunchKernelGGL(conv_dw_unperm_kernel, dim3(ed_grid((size_t)Co * Ci * 5)), dim3(ED_THREADS), 0, (hipStream_t)stream, dwp, Co, Ci, CP, dw);
+    RTTS_LAUNCH_CHECK("rtts_conv_dw_unperm");
+    return 0;
+}
+
+static inline dim3 ed_col_grid(int M, int C) {
+    int slabs = (M + 3) / 4;
+    if (slabs > ED_PBLOCKS) slabs = ED_PBLOCKS;
+    return dim3(slabs, (C + 255) / 256);
+}
+
+extern "C" int rtts_bn_stats(const float* y, int M, int C, float* mean, float* rstd, float* run_mean, float* run_var, float* partial_ws,
+                             void* stream) {
+    RTTS_REQUIRE(y && mean && rstd && partial_ws && M > 0 && C > 0 && C % 4 == 0, "rtts_bn_stats: bad arguments");
+    const dim3 grid = ed_col_grid(M, C);
+    hipLaunchKernelGGL((col_partial_kernel<0>), grid, dim3(ED_THREADS), 0, (hipStream_t)stream, y, (const bf16_t*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0u, 0u, 1.f, M, C, partial_ws);
+    hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((C + ED_THREADS - 1) / ED_THREADS), dim3(ED_THREADS), 0, (hipStream_t)stream, partial_ws,
+                       (int)grid.x, M, C, mean, rstd, run_mean, run_var);
+    RTTS_LAUNCH_CHECK("rtts_bn_stats");
+    return 0;
+}
+
+extern "C" int rtts_bn_act_fwd(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                               float drop_p, uint32_t seed, int M, int C, void* z, void* stream) {
+    RTTS_REQUIRE(y && mean && rstd && gamma && beta && z && M > 0 && C % 4 == 0 && (act == 1 || act == 2) && drop_p >= 0.f && drop_p < 1.f,
+                 "rtts_bn_act_fwd: bad arguments");
+    const size_t n4 = (size_t)M * C / 4;
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ed_grid(n4)), dim3(ED_THREADS), 0, (hipStream_t)stream, y, mean, rstd, gamma, beta, act, seed,
+                       ed_thresh(drop_p), 1.f / (1.f - drop_p), n4, C, (bf16_t*)z);
+    RTTS_LAUNCH_CHECK("rtts_bn_act_fwd");
+    return 0;
+}
+
+extern "C" int rtts_bn_act_bwd(const float* y, const void* dz, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                               int act, float drop_p, uint32_t seed, int M, int C, void* dy, float* dgamma, float* dbeta, float* partial_ws,
+                               void* stream) {
+    RTTS_REQUIRE(y && dz && mean && rstd && gamma && beta && dy && dgamma && dbeta && partial_ws && M > 0 && C % 4 == 0 && (act == 1 || act == 2),
+                 "rtts_bn_act_bwd: bad arguments");
+    const dim3 grid = ed_col_grid(M, C);
+    const uint32_t th = ed_thresh(drop_p);
+    const float ds = 1.f / (1.f - drop_p);
+    float* sums = partial_ws + (size_t)ED_PBLOCKS * 2 * C;
+    hipLaunchKernelGGL((col_partial_kernel<1>), grid, dim3(ED_THREADS), 0, (hipStream_t)stream, y, (const bf16_t*)dz, mean, rstd, gamma, beta, act,
+                       seed, th, ds, M, C, partial_ws);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + ED_THREADS - 1) / ED_THREADS), dim3(ED_THREADS), 0, (hipStream_t)stream, partial_ws,
+                       (int)grid.x, C, sums, dgamma, dbeta);
+    const size_t n4 = (size_t)M * C / 4;
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ed_grid(n4)), dim3(ED_THREADS), 0, (hipStream_t)stream, y, (const bf16_t*)dz, mean, rstd,
+                       gamma, beta, act, seed, th, ds, sums, 1.f / (float)M, n4, C, (bf16_t*)dy);
+    RTTS_LAUNCH_CHECK("rtts_bn_act_bwd");
+    return 0;
+}
+
+extern "C" int rtts_tts_loss(const float* raw, const float* post, int64_t ld_mel, const float* tgt, const float* mask, const float* stop,
+                             int64_t ld_stop, const float* tstop, int rows, int NM, int kind, float pos_weight, float w_raw, float w_post,
+                             float w_stop, float* d_raw, float* d_post, float* d_stop, float* losses, float* partial_ws, void* stream) {
+    RTTS_REQUIRE(raw && post && tgt && mask && stop && tstop && d_raw && d_post && d_stop && losses && partial_ws && rows > 0 && NM > 0,
+                 "rtts_tts_loss: bad arguments");
+    RTTS_REQUIRE(kind == 0 || kind == 1, "rtts_tts_loss: Unsupported loss type: %d", kind);
+    const int blocks = 512;
+    hipLaunchKernelGGL(tts_loss_kernel, dim3(blocks), dim3(ED_THREADS), 0, (hipStream_t)stream, raw, post, ld_mel, tgt, mask, stop, ld_stop,
+                       tstop, rows, NM, kind, pos_weight, w_raw, w_post, w_stop, d_raw, d_post, d_stop, partial_ws);
+    hipLaunchKernelGGL(tts_loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_ws, blocks, 1.f / ((float)rows * NM),
+                       1.f / (float)rows, w_raw, w_post, w_stop, losses);
+    RTTS_LAUNCH_CHECK("rtts_tts_loss");
+    return 0;
+}

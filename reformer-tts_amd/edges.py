@@ -1,0 +1,263 @@
+"""Explicit executors for the convolutional edges of the model and the loss.
+
+``ConvStackFn``     chain of [Conv1d(k5) -> BatchNorm1d(train) -> act -> Dropout] on channels-last rows
+                    (encoder prenet convolutions, ``/root/reference/reformer_tts/model/modules.py:33-48``)
+``PostnetLossFn``   decoder output -> [mel | stop] heads (``model/reformer_tts.py:65-66``) -> PostConvNet
+                    residual (``modules.py:146-169``, ``reformer_tts.py:139-143``) -> TTSLoss
+                    (``model/loss.py:28-53``), forward values and the gradient w.r.t. the decoder output
+
+A convolution is im2col + one library GEMM (hipBLASLt via ``torch.mm``); im2col/col2im, BatchNorm
+statistics / normalisation / backward, activations, dropout masks, weight re-layouts, weight gradients
+(split-K ``rtts_gemm_tn``) and the loss are kernels of ``csrc/edges.hip`` / ``gemm_tn.hip``.
+The conv bias in front of a BatchNorm only shifts the batch mean: it is folded into the running mean
+and its (exactly zero) gradient is not computed.
+"""
+from __future__ import annotations
+
+import itertools
+from typing import List
+
+import torch
+
+from . import _lib
+from .engine import WEIGHT_EPOCH, _WS, _bf16, _grad, cast_colsum, wgrad
+
+_seed_counter = itertools.count(1)
+
+
+def _s() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ws(device, c: int) -> torch.Tensor:
+    key = ("edge", device, c)
+    if key not in _WS._cache:
+        _WS._cache[key] = torch.empty((2 * 256 + 2) * c, dtype=torch.float32, device=device)
+    return _WS._cache[key]
+
+
+def _pad128(c: int) -> int:
+    return -(-c // 128) * 128
+
+
+class ConvK5:
+    """One Conv1d(kernel 5, padding 2) as im2col + GEMM; keeps what its backward needs."""
+
+    def __init__(self, conv: torch.nn.Conv1d):
+        self.conv = conv
+        self.co, self.ci = conv.out_channels, conv.in_channels
+        self.cp = _pad128(self.ci)          # input channels padded (zero weights) so that K = 5*cp tiles
+        self.cop = _pad128(self.co)         # output channels padded likewise (zero rows)
+        self._wp = None
+        self._wp_version = None
+
+    def weight_perm(self) -> torch.Tensor:
+        """(Cout_pad, 5*Cin_pad) bf16 with wp[co][k][ci] = w[co][ci][k]; rebuilt when the master changed."""
+        w = self.conv.weight
+        ver = (w._version, WEIGHT_EPOCH[0], w.data_ptr())
+        if self._wp is None or self._wp_version != ver or self._wp.device != w.device:
+            if self._wp is None or self._wp.device != w.device:
+                self._wp = torch.zeros(self.cop, 5 * self.cp, dtype=torch.bfloat16, device=w.device)
+            _lib.call("rtts_conv_w_perm", w.data_ptr(), self.co, self.ci, self.cp, self._wp.data_ptr(), _s())
+            self._wp_version = ver
+        return self._wp
+
+    def im2col(self, x: torch.Tensor, b: int, l: int) -> torch.Tensor:
+        """x bf16 (B*L, C_stride) with C = ci valid channels -> (B*L, 5*cp)."""
+        cols = torch.empty(b * l, 5 * self.cp, dtype=torch.bfloat16, device=x.device)
+        cin = -(-self.ci // 8) * 8
+        _lib.call("rtts_im2col_k5", x.data_ptr(), x.stride(0), b, l, cin, self.cp, cols.data_ptr(), _s())
+        return cols
+
+    def forward(self, x, b, l):
+        cols = self.im2col(x, b, l)
+        y = torch.mm(cols, self.weight_perm().t(), out_dtype=torch.float32)      # (M, cop) fp32, bias not added
+        return cols, y
+
+    def backward(self, dy: torch.Tensor, cols: torch.Tensor, b: int, l: int, need_dx: bool = True, dx_f32: bool = False):
+        """dy bf16 (M, cop) -> accumulates dW, returns dx (M, ci rounded up to 8) bf16/fp32."""
+        dwp = torch.zeros(self.cop, 5 * self.cp, dtype=torch.float32, device=dy.device)
+        wgrad(dwp, dy, cols)
+        _lib.call("rtts_conv_dw_unperm", dwp.data_ptr(), self.co, self.ci, self.cp, _grad(self.conv.weight).data_ptr(), _s())
+        if not need_dx:
+            return None
+        dcols = torch.mm(dy, self.weight_perm())
+        cin = -(-self.ci // 8) * 8
+        dx = torch.empty(b * l, cin, dtype=torch.float32 if dx_f32 else torch.bfloat16, device=dy.device)
+        _lib.call("rtts_col2im_k5", dcols.data_ptr(), b, l, cin, self.cp, dx.data_ptr(), dx.stride(0), int(dx_f32), _s())
+        return dx
+
+
+class ConvBNAct:
+    """Conv1d(k5) -> BatchNorm1d (batch statistics) -> act (1 relu / 2 tanh) -> Dropout(p)."""
+
+    def __init__(self, conv, bn, act: int, p: float):
+        self.c = ConvK5(conv)
+        self.bn, self.act, self.p = bn, act, float(p)
+
+    def forward(self, x, b, l):
+        cols, y = self.c.forward(x, b, l)
+        m, c = y.shape
+        dev = y.device
+        mean = torch.empty(c, dtype=torch.float32, device=dev)
+        rstd = torch.empty(c, dtype=torch.float32, device=dev)
+        bn = self.bn
+        with torch.no_grad():
+            rm = torch.empty_like(bn.running_mean)
+            _lib.call("rtts_bn_stats", y.data_ptr(), m, c, mean.data_ptr(), rstd.data_ptr(), rm.data_ptr(), bn.running_var.data_ptr(),
+                      _ws(dev, c).data_ptr(), _s())
+            # running_mean tracks the mean of (y + bias); rtts_bn_stats blended against garbage in rm, redo it exactly
+            bn.running_mean.mul_(1 - bn.momentum).add_(mean + self.c.conv.bias, alpha=bn.momentum)
+            bn.num_batches_tracked += 1
+        seed = next(_seed_counter) * 2654435761 % (1 << 32)
+        z = torch.empty(m, c, dtype=torch.bfloat16, device=dev)
+        _lib.call("rtts_bn_act_fwd", y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), self.act,
+                  self.p, seed, m, c, z.data_ptr(), _s())
+        return z, (cols, y, mean, rstd, seed)
+
+    def backward(self, dz, saved, b, l, need_dx=True, dx_f32=False):
+        cols, y, mean, rstd, seed = saved
+        m, c = y.shape
+        bn = self.bn
+        dy = torch.empty(m, c, dtype=torch.bfloat16, device=y.device)
+        _lib.call("rtts_bn_act_bwd", y.data_ptr(), dz.data_ptr(), mean.data_ptr(), rstd.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
+                  self.act, self.p, seed, m, c, dy.data_ptr(), _grad(bn.weight).data_ptr(), _grad(bn.bias).data_ptr(),
+                  _ws(y.device, c).data_ptr(), _s())
+        _grad(self.c.conv.bias)       # exists (stays zero: the true gradient of a bias in front of BatchNorm is zero)
+        return self.c.backward(dy, cols, b, l, need_dx, dx_f32)
+
+
+class ConvStackFn(torch.autograd.Function):
+    """x (B, L, C) bf16 -> z (B, L, C) bf16 through a list of ConvBNAct."""
+
+    @staticmethod
+    def forward(ctx, x, stack: List[ConvBNAct], training: bool):
+        b, l, c = x.shape
+        cur = x.reshape(b * l, c)
+        saved = []
+        for layer in stack:
+            cur, s = layer.forward(cur, b, l)
+            saved.append(s)
+        ctx.stack, ctx.saved_state, ctx.shape = stack, saved, (b, l, c)
+        return cur.view(b, l, -1)
+
+    @staticmethod
+    def backward(ctx, dz):
+        b, l, c = ctx.shape
+        cur = dz.reshape(b * l, -1).to(torch.bfloat16).contiguous()
+        for layer, s in zip(reversed(ctx.stack), reversed(ctx.saved_state)):
+            cur = layer.backward(cur, s, b, l)
+        ctx.saved_state = None
+        return cur.view(b, l, c), None, None
+
+
+def encoder_prenet_stack(prenet) -> List[ConvBNAct]:
+    c = prenet.convolutions
+    return [ConvBNAct(c.conv1, c.bn1, 1, c.dropout1.p), ConvBNAct(c.conv2, c.bn2, 1, c.dropout2.p),
+            ConvBNAct(c.conv3, c.bn3, 1, c.dropout3.p)]
+
+
+class PostnetLoss:
+    """Heads + postnet + loss for the training step (forward values, then the gradient w.r.t. the decoder output)."""
+
+    def __init__(self, model, loss_mod):
+        self.model, self.loss_mod = model, loss_mod
+        pn = model.postnet.layers
+        depth = (len(pn) - 1) // 4
+        self.layers = [ConvBNAct(getattr(pn, f"conv{i}"), getattr(pn, f"bn{i}"), 2, getattr(pn, f"dropout{i}").p) for i in range(depth)]
+        self.convend = ConvK5(pn.convend)
+        self.nm = model.num_mel_coeffs
+        self._wh = None
+
+    def _heads_weight(self):
+        mel, stop = self.model.dec.mel_linear, self.model.dec.stop_linear
+        d = mel.weight.shape[1]
+        if self._wh is None or self._wh.device != mel.weight.device:
+            self._wh = torch.zeros(128, d, dtype=torch.bfloat16, device=mel.weight.device)
+            self._bh = torch.zeros(128, dtype=torch.float32, device=mel.weight.device)
+        self._wh[:self.nm].copy_(_bf16(mel.weight))
+        self._wh[self.nm:self.nm + 1].copy_(_bf16(stop.weight))
+        self._bh[:self.nm].copy_(mel.bias.detach())
+        self._bh[self.nm:self.nm + 1].copy_(stop.bias.detach())
+        return self._wh, self._bh
+
+    def apply(self, y_dec, true_mel, true_stop, true_mask):
+        return _PostnetLossFn.apply(y_dec, true_mel, true_stop, true_mask, self)
+
+
+class _PostnetLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y_dec, true_mel, true_stop, true_mask, ex: PostnetLoss):
+        b, lp, d = y_dec.shape                      # lp = padded decoder length
+        l = true_mel.shape[1]                       # loss length (cutoff)
+        nm, dev = ex.nm, y_dec.device
+        m = b * lp
+        yb = y_dec.detach().reshape(m, d).to(torch.bfloat16)
+        wh, bh = ex._heads_weight()
+        heads = torch.mm(yb, wh.t(), out_dtype=torch.float32) + bh          # (M,128): [mel(80) | stop | 0...]
+        x0 = torch.zeros(m, 128, dtype=torch.bfloat16, device=dev)
+        x0[:, :nm] = heads[:, :nm]
+        saved, cur = [], x0
+        for layer in ex.layers:
+            cur, s = layer.forward(cur, b, lp)
+            saved.append(s)
+        cols_end = ex.convend.im2col(cur, b, lp)
+        res = torch.mm(cols_end, ex.convend.weight_perm().t(), out_dtype=torch.float32) + _pad_bias(ex.convend, dev)
+        post = heads[:, :128] + res                                           # cols >= nm are junk and never read
+        lm = ex.loss_mod
+        losses = torch.empty(4, dtype=torch.float32, device=dev)
+        d_raw = torch.zeros(m, 128, dtype=torch.float32, device=dev)
+        d_post = torch.zeros(m, 128, dtype=torch.float32, device=dev)
+        if l != lp:
+            raise NotImplementedError("fused postnet+loss needs the mel length to be a multiple of pad_base (synthetic batches are)")
+        g_raw = torch.empty(m, nm, dtype=torch.float32, device=dev)
+        g_post = torch.empty(m, nm, dtype=torch.float32, device=dev)
+        g_stop = torch.empty(m, dtype=torch.float32, device=dev)
+        kind = 0 if isinstance(lm.spectrogram_loss, torch.nn.MSELoss) else 1
+        pw = torch.empty(512 * 3, dtype=torch.float32, device=dev)
+        _lib.call("rtts_tts_loss", heads.data_ptr(), post.data_ptr(), 128, true_mel.contiguous().data_ptr(), true_mask.contiguous().data_ptr(),
+                  heads[:, nm:].data_ptr(), 128, true_stop.contiguous().data_ptr(), m, nm, kind, float(lm.pos_weight),
+                  float(lm.raw_pred_loss_weight), float(lm.post_pred_loss_weight), float(lm.stop_loss_weight), g_raw.data_ptr(),
+                  g_post.data_ptr(), g_stop.data_ptr(), losses.data_ptr(), pw.data_ptr(), _s())
+        d_raw[:, :nm] = g_raw
+        d_post[:, :nm] = g_post
+        ctx.ex, ctx.state = ex, (yb, wh, saved, cur, cols_end, d_raw, d_post, g_stop, b, lp, d)
+        return losses
+
+    @staticmethod
+    def backward(ctx, dlosses):
+        ex = ctx.ex
+        yb, wh, saved, z_last, cols_end, d_raw, d_post, g_stop, b, lp, d = ctx.state
+        ctx.state = None
+        nm, dev = ex.nm, yb.device
+        m = b * lp
+        # the stored gradients are those of losses[0]; scale them by its upstream weight (1 in the trainer)
+        scale = dlosses[0]
+        d_raw, d_post, g_stop = d_raw * scale, d_post * scale, g_stop * scale
+        # convend: res = conv(z_last) + bias;  d_res = d_post
+        dresb = cast_colsum(d_post, None)
+        _grad(ex.convend.conv.bias).add_(d_post[:, :nm].sum(0))
+        dz = ex.convend.backward(dresb, cols_end, b, lp)
+        for layer, s in zip(reversed(ex.layers[1:]), reversed(saved[1:])):
+            dz = layer.backward(dz, s, b, lp)
+        dx0 = ex.layers[0].backward(dz, saved[0], b, lp, need_dx=True, dx_f32=True)        # (M, 80) fp32
+        dheads = d_raw + d_post
+        dheads[:, :nm] += dx0[:, :nm]
+        dheads[:, nm] = g_stop
+        dhb = cast_colsum(dheads, None)
+        mel, stop = ex.model.dec.mel_linear, ex.model.dec.stop_linear
+        bsum = dheads.sum(0)
+        _grad(mel.bias).add_(bsum[:nm])
+        _grad(stop.bias).add_(bsum[nm:nm + 1])
+        dwh = torch.zeros(128, d, dtype=torch.float32, device=dev)
+        wgrad(dwh, dhb, yb)
+        _grad(mel.weight).add_(dwh[:nm])
+        _grad(stop.weight).add_(dwh[nm:nm + 1])
+        dy = torch.mm(dhb, wh).float().view(b, lp, d)
+        return dy, None, None, None, None
+
+
+def _pad_bias(c: ConvK5, dev):
+    bias = torch.zeros(c.cop, dtype=torch.float32, device=dev)
+    bias[:c.co] = c.conv.bias.detach()
+    return bias

@@ -23,6 +23,9 @@ from . import _lib, ops
 from .model.lsh_attention import LSHSelfAttention
 
 
+WEIGHT_EPOCH = [0]   # bumped by the trainer after every optimizer step (its kernels write parameters through raw pointers)
+
+
 def _s() -> int:
     return torch.cuda.current_stream().cuda_stream
 

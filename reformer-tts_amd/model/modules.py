@@ -78,9 +78,17 @@ class EncoderPreNet(nn.Module):
                        (f"dropout{i}", nn.Dropout(dropout))]
         self.convolutions = nn.Sequential(OrderedDict(layers))
 
+    use_fused = True
+
     def forward(self, input_):
         c = self.convolutions
         x = c.dropout0(self.embed(input_))                      # (B, L, C) channels-last throughout
+        if self.use_fused and self.training and x.is_cuda and self.embedding_dim % 128 == 0 and (x.shape[0] * x.shape[1]) % 64 == 0:
+            from ..edges import ConvStackFn, encoder_prenet_stack
+            if getattr(self, "_stack", None) is None:
+                self._stack = encoder_prenet_stack(self)
+            z = ConvStackFn.apply(x.to(torch.bfloat16), self._stack, True)
+            return _bf16_linear(z, self.projection).float()
         for conv, bn, drop in ((c.conv1, c.bn1, c.dropout1), (c.conv2, c.bn2, c.dropout2), (c.conv3, c.bn3, c.dropout3)):
             x = drop(F.relu(batch_norm_rows(conv1d_k5_rows(x, conv), bn)))
         return _bf16_linear(x, self.projection).float()

@@ -31,9 +31,12 @@ class Decoder(nn.Module):
         self.mel_linear = nn.Linear(embedding_dim, num_mel_coeffs)
         self.stop_linear = nn.Linear(embedding_dim, 1)
 
-    def forward(self, input_, keys, key_padding_mask=None, input_mask=None):
+    def hidden(self, input_, keys, key_padding_mask=None, input_mask=None):
         x = self.positional_encoding(self.prenet(input_))
-        x, attention_matrices = self.reformer(x, keys=keys, key_padding_mask=key_padding_mask, input_mask=input_mask)
+        return self.reformer(x, keys=keys, key_padding_mask=key_padding_mask, input_mask=input_mask)
+
+    def forward(self, input_, keys, key_padding_mask=None, input_mask=None):
+        x, attention_matrices = self.hidden(input_, keys, key_padding_mask=key_padding_mask, input_mask=input_mask)
         return self.mel_linear(x), self.stop_linear(x), attention_matrices
 
 
@@ -56,6 +59,22 @@ class ReformerTTS(nn.Module):
                            prenet_kwargs=dec_prenet_kwargs, reformer_kwargs=dec_reformer_kwargs)
         self.pad_base = pad_base
         self.postnet = PostConvNet(mel_size=num_mel_coeffs, num_hidden=embedding_dim, **postnet_kwargs)
+
+    def _encode_inputs(self, phonemes, spectrogram, spectrogram_mask):
+        dev = spectrogram.device
+        pad_phonemes = pad_to_multiple(phonemes.unsqueeze(-1), self.pad_base).squeeze(-1).to(dev)
+        phoneme_mask = pad_phonemes != 0
+        if spectrogram_mask is None:
+            spectrogram_mask = torch.ones(spectrogram.shape[:2], device=dev)
+        spectrogram_mask = pad_to_multiple(spectrogram_mask.unsqueeze(-1).to(dev), self.pad_base).squeeze(-1).to(torch.bool)
+        return pad_phonemes, phoneme_mask, spectrogram_mask, pad_to_multiple(spectrogram, self.pad_base)
+
+    def decoder_hidden(self, phonemes, spectrogram, spectrogram_mask=None):
+        """Decoder output (B, T_padded, d) in front of the mel/stop heads: the training step feeds it to the
+        fused heads + postnet + loss executor (``edges.PostnetLoss``)."""
+        pad_phonemes, phoneme_mask, spectrogram_mask, pad_spec = self._encode_inputs(phonemes, spectrogram, spectrogram_mask)
+        keys = self.enc(pad_phonemes, input_mask=phoneme_mask)
+        return self.dec.hidden(pad_spec, keys=keys, key_padding_mask=~phoneme_mask, input_mask=spectrogram_mask)[0]
 
     def forward(self, phonemes: torch.LongTensor, spectrogram: torch.Tensor,
                 spectrogram_mask: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, list]:

@@ -132,9 +132,20 @@ class Trainer:
         return hook
 
     # ------------------------------------------------------------------ step pieces
+    use_fused_edges = True
+
     def forward_loss(self, batch):
         """``wrappers.py:53-72``: input frames [0, L-1), targets [1, L), mask = loss_mask.mean(-1)."""
         spec = batch["spectrogram"]
+        lm = spec.shape[1] - 1
+        if (self.use_fused_edges and self.device.type == "cuda" and self.model.training and lm % self.model.pad_base == 0
+                and (spec.shape[0] * lm) % 64 == 0):
+            from ..edges import PostnetLoss
+            if getattr(self, "_postnet_loss", None) is None:
+                self._postnet_loss = PostnetLoss(self.model, self.loss)
+            y = self.model.decoder_hidden(batch["phonemes"], spec[:, :-1], spectrogram_mask=batch["loss_mask"].mean(dim=-1))
+            losses = self._postnet_loss.apply(y, spec[:, 1:], batch["stop_tokens"], batch["loss_mask"])
+            return losses[0], losses[1], losses[2], losses[3]
         raw, post, stop, _ = self.model(batch["phonemes"], spec[:, :-1], spectrogram_mask=batch["loss_mask"].mean(dim=-1))
         return self.loss(raw, post, stop.view(stop.shape[0], -1), spec[:, 1:], batch["stop_tokens"], batch["loss_mask"])
 
@@ -174,6 +185,8 @@ class Trainer:
         _lib.call("rtts_adamw_step", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
                   self.flat_v.data_ptr(), self.decay_mask.data_ptr(), n, self.ws_scale.data_ptr(), lr, 0.9, 0.999, 1e-6,
                   float(self.cfg.weight_decay), self.global_step, stream)
+        from ..engine import WEIGHT_EPOCH
+        WEIGHT_EPOCH[0] += 1
         self.refresh_mirror()
 
     def lr_now_for(self, step: int) -> float:

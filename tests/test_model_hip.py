@@ -266,3 +266,46 @@ def test_fused_engine_matches_general_path(gpu):
         if rel > worst[1]:
             worst = (n, rel)
     assert worst[1] < 6e-2, worst
+
+
+def test_fused_edges_match_general_path(gpu):
+    """Fused conv/BatchNorm/heads/postnet/loss executors (edges.py) against the ATen modules: same
+    losses (1e-3 rel) and gradients (rel-L2 <= 6e-2) on a 2+2-layer model without dropout."""
+    from reformer_tts_amd.model.config import TTSTrainingConfig, model_config_from_dict
+    from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
+    cfg = model_ref.small_cfg()
+    cfg["enc_reformer_kwargs"]["attn_kwargs"]["implementation"] = "hip"
+    cfg["dec_reformer_kwargs"]["self_attn_kwargs"]["implementation"] = "hip"
+    batch = synthetic_batch(2, 100, 256, device=gpu)
+    res = []
+    for fused in (True, False):
+        model = build_model(model_config_from_dict(cfg), gpu)
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        model.load_state_dict(synth.synth_state_dict(shapes, seed=9), strict=False)
+        for layer in _lsh_layers(model):
+            layer.forced_rotations = torch.randn(1, 64, 4, layer_buckets(layer, model, batch) // 2,
+                                                 generator=torch.Generator().manual_seed(3))
+        tr = Trainer(model, TTSTrainingConfig(batch_size=2), gpu)
+        tr.use_fused_edges = fused
+        model.enc.prenet.use_fused = fused
+        model.train()
+        tr.zero_grad()
+        losses = tr.forward_loss(batch)
+        losses[0].backward()
+        torch.cuda.synchronize()
+        res.append(([float(x) for x in losses], {n: tr.flat_g[s:e].clone() for n, (s, e) in tr.offsets.items()},
+                    {k: v.clone() for k, v in model.state_dict().items() if "running" in k}))
+    (lf, gf, rf), (lg, gg, rg) = res
+    np.testing.assert_allclose(lf, lg, rtol=2e-3)
+    for k in rg:
+        torch.testing.assert_close(rf[k], rg[k], rtol=2e-2, atol=2e-3, msg=k)
+    for n in gg:
+        if gg[n].norm().item() < 1e-3:
+            continue
+        rel = ((gf[n] - gg[n]).norm() / gg[n].norm()).item()
+        assert rel < 6e-2, (n, rel)
+
+
+def layer_buckets(layer, model, batch):
+    t = 128 if not layer.causal else 256      # text 100 -> 128, mel 256 at pad_base 128
+    return t // layer.bucket_size
