@@ -309,3 +309,46 @@ def test_fused_edges_match_general_path(gpu):
 def layer_buckets(layer, model, batch):
     t = 128 if not layer.causal else 256      # text 100 -> 128, mel 256 at pad_base 128
     return t // layer.bucket_size
+
+
+@pytest.mark.parametrize("act,p", [(1, 0.0), (2, 0.3), (1, 0.1)])
+def test_bn_act_dropout_kernels_vs_autograd(gpu, act, p):
+    """rtts_bn_stats / rtts_bn_act_fwd / rtts_bn_act_bwd against torch autograd, with the dropout mask the
+    forward kernel actually drew (recovered from its output) held fixed in the reference."""
+    from reformer_tts_amd import _lib
+    g = torch.Generator().manual_seed(act * 10 + int(p * 10))
+    m, c = 768, 256
+    y = (torch.randn(m, c, generator=g) * 1.5 + 0.3).to(gpu)
+    gamma = (1 + 0.1 * torch.randn(c, generator=g)).to(gpu)
+    beta = (0.1 * torch.randn(c, generator=g)).to(gpu)
+    dz = torch.randn(m, c, generator=g).bfloat16().to(gpu)
+    mean, rstd = torch.empty(c, device=gpu), torch.empty(c, device=gpu)
+    rm, rv = torch.zeros(c, device=gpu), torch.ones(c, device=gpu)
+    ws = torch.empty((2 * 256 + 2) * c, device=gpu)
+    s = torch.cuda.current_stream().cuda_stream
+    seed = 12345
+    _lib.call("rtts_bn_stats", y.data_ptr(), m, c, mean.data_ptr(), rstd.data_ptr(), rm.data_ptr(), rv.data_ptr(), ws.data_ptr(), s)
+    z = torch.empty(m, c, dtype=torch.bfloat16, device=gpu)
+    _lib.call("rtts_bn_act_fwd", y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act, p, seed, m, c,
+              z.data_ptr(), s)
+    dy = torch.empty(m, c, dtype=torch.bfloat16, device=gpu)
+    dgam, dbet = torch.zeros(c, device=gpu), torch.zeros(c, device=gpu)
+    _lib.call("rtts_bn_act_bwd", y.data_ptr(), dz.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act, p,
+              seed, m, c, dy.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), ws.data_ptr(), s)
+    torch.cuda.synchronize()
+    yr = y.clone().requires_grad_()
+    gr, br = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    pre = torch.nn.functional.batch_norm(yr, None, None, gr, br, True, 0.1, 1e-5)
+    a = torch.relu(pre) if act == 1 else torch.tanh(pre)
+    if p > 0:
+        keep = (z.float() != 0) | (a.detach().abs() < 1e-3)       # dropped <=> kernel output is exactly 0
+        frac = keep.float().mean().item()
+        assert abs(frac - (1 - p)) < 0.03 or act == 1, frac           # relu zeros blur the estimate
+        a = a * keep / (1 - p)
+    torch.testing.assert_close(z.float(), a.detach(), rtol=1e-2, atol=1e-2)
+    a.backward(dz.float())
+    torch.testing.assert_close(mean, y.mean(0), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rv, 0.9 + 0.1 * y.var(0, unbiased=True), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dy.float(), yr.grad, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(dgam, gr.grad, rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(dbet, br.grad, rtol=1e-3, atol=1e-2)
