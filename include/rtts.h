@@ -168,6 +168,10 @@ int rtts_tts_loss(const float* raw, const float* post, int64_t ld_mel, const flo
                   int64_t ld_stop, const float* tstop, int rows, int NM, int kind, float pos_weight, float w_raw, float w_post,
                   float w_stop, float* d_raw, float* d_post, float* d_stop, float* losses, float* partial_ws, void* stream);
 
+/* dE[id] += sum of dx rows whose id matches (nn.Embedding backward, reference modules.py:17,56); padding_idx skipped */
+int rtts_embedding_bwd(const int64_t* ids, const float* dx, int rows, int C, int n_embeddings, int padding_idx, float* dE,
+                       void* stream);
+
 /* ---- weight-gradient GEMM, split over the token dimension ------------------------------------
  * c[N][K] (fp32, stride ldc) (+)= sum_m a[m][N] * b[m][K]   (a, b bf16 with strides lda, ldb)
  * = dW of a Linear layer y = x W^T (reference modules.py:195-207, reformer.py:161-217 via autograd).

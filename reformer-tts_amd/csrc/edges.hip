@@ -153,14 +153,35 @@ __global__ __launch_bounds__(ED_THREADS) void col_partial_kernel(const float* __
     }
 }
 
+// column sums of the two partial planes: a block owns 64 channels, its 4 waves each sum every 4th partial row
+// (coalesced 256-B reads), then the 4 wave sums are combined in wave order (deterministic)
+__device__ __forceinline__ void ed_reduce_partials(const float* __restrict__ partial, int nrows, int C, int c, float& s, float& q,
+                                                   float (*red)[4][64]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float a = 0.f, b = 0.f;
+    if (c < C) {
+#pragma unroll 4
+        for (int r = wave; r < nrows; r += 4) {
+            a += partial[(size_t)r * 2 * C + c];
+            b += partial[(size_t)r * 2 * C + C + c];
+        }
+    }
+    red[0][wave][lane] = a;
+    red[1][wave][lane] = b;
+    __syncthreads();
+    s = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+    q = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+}
+
 // mean/rstd from the partials (+ running statistics, momentum 0.1, unbiased variance)
 __global__ __launch_bounds__(ED_THREADS) void bn_finalize_stats_kernel(const float* __restrict__ partial, int nrows, int M, int C,
                                                                        float* __restrict__ mean, float* __restrict__ rstd,
                                                                        float* __restrict__ run_mean, float* __restrict__ run_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f, q = 0.f;
-    for (int r = 0; r < nrows; ++r) { s += partial[(size_t)r * 2 * C + c]; q += partial[(size_t)r * 2 * C + C + c]; }
+    __shared__ float red[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    float s, q;
+    ed_reduce_partials(partial, nrows, C, c, s, q, red);
+    if (threadIdx.x >= 64 || c >= C) return;
     const float mu = s / M;
     const float var = fmaxf(q / M - mu * mu, 0.f);
     mean[c] = mu;
@@ -171,14 +192,15 @@ __global__ __launch_bounds__(ED_THREADS) void bn_finalize_stats_kernel(const flo
     }
 }
 
-// sums of the backward partials: out_a[c] (+)= sum partial a ; out_b[c] (+)= sum partial b ; also raw sums to sums[2C]
+// sums of the backward partials: sums[0..C) = sum g, sums[C..2C) = sum g*yhat; dbeta += , dgamma +=
 __global__ __launch_bounds__(ED_THREADS) void bn_finalize_bwd_kernel(const float* __restrict__ partial, int nrows, int C,
                                                                      float* __restrict__ sums, float* __restrict__ dgamma,
                                                                      float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f, q = 0.f;
-    for (int r = 0; r < nrows; ++r) { s += partial[(size_t)r * 2 * C + c]; q += partial[(size_t)r * 2 * C + C + c]; }
+    __shared__ float red[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    float s, q;
+    ed_reduce_partials(partial, nrows, C, c, s, q, red);
+    if (threadIdx.x >= 64 || c >= C) return;
     sums[c] = s;
     sums[C + c] = q;
     dbeta[c] += s;
@@ -310,6 +332,20 @@ __global__ void tts_loss_finalize_kernel(const float* __restrict__ partial, int 
     losses[1] = a; losses[2] = b; losses[3] = c;
 }
 
+// ------------------------------------------------------------------ embedding backward (padding_idx rows get no gradient)
+// dE[id] += sum over rows with ids[row] == id of dx[row]: one block per (id, 256-channel group); the block scans the id list
+// (a few thousand entries) and adds matching rows in row order => deterministic, no atomics
+__global__ __launch_bounds__(ED_THREADS) void embedding_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dx, int rows,
+                                                                   int C, int padding_idx, float* __restrict__ dE) {
+    const int id = blockIdx.x;
+    const int c = blockIdx.y * ED_THREADS + threadIdx.x;
+    if (id == padding_idx || c >= C) return;
+    float acc = 0.f;
+    for (int r = 0; r < rows; ++r)
+        if (ids[r] == id) acc += dx[(size_t)r * C + c];
+    dE[(size_t)id * C + c] += acc;
+}
+
 // ------------------------------------------------------------------ host side
 static inline unsigned ed_grid(size_t items) {
     size_t b = (items + ED_THREADS - 1) / ED_THREADS;
@@ -364,7 +400,7 @@ extern "C" int rtts_bn_stats(const float* y, int M, int C, float* mean, float* r
     const dim3 grid = ed_col_grid(M, C);
     hipLaunchKernelGGL((col_partial_kernel<0>), grid, dim3(ED_THREADS), 0, (hipStream_t)stream, y, (const bf16_t*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0u, 0u, 1.f, M, C, partial_ws);
-    hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((C + ED_THREADS - 1) / ED_THREADS), dim3(ED_THREADS), 0, (hipStream_t)stream, partial_ws,
+    hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((C + 63) / 64), dim3(ED_THREADS), 0, (hipStream_t)stream, partial_ws,
                        (int)grid.x, M, C, mean, rstd, run_mean, run_var);
     RTTS_LAUNCH_CHECK("rtts_bn_stats");
     return 0;
@@ -392,7 +428,7 @@ extern "C" int rtts_bn_act_bwd(const float* y, const void* dz, const float* mean
     float* sums = partial_ws + (size_t)ED_PBLOCKS * 2 * C;
     hipLaunchKernelGGL((col_partial_kernel<1>), grid, dim3(ED_THREADS), 0, (hipStream_t)stream, y, (const bf16_t*)dz, mean, rstd, gamma, beta, act,
                        seed, th, ds, M, C, partial_ws);
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + ED_THREADS - 1) / ED_THREADS), dim3(ED_THREADS), 0, (hipStream_t)stream, partial_ws,
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 63) / 64), dim3(ED_THREADS), 0, (hipStream_t)stream, partial_ws,
                        (int)grid.x, C, sums, dgamma, dbeta);
     const size_t n4 = (size_t)M * C / 4;
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ed_grid(n4)), dim3(ED_THREADS), 0, (hipStream_t)stream, y, (const bf16_t*)dz, mean, rstd,
@@ -413,5 +449,14 @@ extern "C" int rtts_tts_loss(const float* raw, const float* post, int64_t ld_mel
     hipLaunchKernelGGL(tts_loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_ws, blocks, 1.f / ((float)rows * NM),
                        1.f / (float)rows, w_raw, w_post, w_stop, losses);
     RTTS_LAUNCH_CHECK("rtts_tts_loss");
+    return 0;
+}
+
+extern "C" int rtts_embedding_bwd(const int64_t* ids, const float* dx, int rows, int C, int n_embeddings, int padding_idx, float* dE,
+                                  void* stream) {
+    RTTS_REQUIRE(ids && dx && dE && rows > 0 && C > 0 && n_embeddings > 0, "rtts_embedding_bwd: bad arguments");
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(n_embeddings, (C + ED_THREADS - 1) / ED_THREADS), dim3(ED_THREADS), 0, (hipStream_t)stream,
+                       ids, dx, rows, C, padding_idx, dE);
+    RTTS_LAUNCH_CHECK("rtts_embedding_bwd");
     return 0;
 }

@@ -63,6 +63,27 @@ def _bf16_linear(x, lin: nn.Linear):
     return F.linear(x.to(torch.bfloat16), lin.weight.to(torch.bfloat16), b)
 
 
+class _EmbeddingFn(torch.autograd.Function):
+    """nn.Embedding lookup whose backward is the deterministic per-id row sum of csrc/edges.hip."""
+
+    @staticmethod
+    def forward(ctx, ids, weight, padding_idx):
+        ctx.save_for_backward(ids)
+        ctx.shape, ctx.padding_idx = weight.shape, padding_idx
+        return weight[ids]
+
+    @staticmethod
+    def backward(ctx, dx):
+        from .. import _lib
+        (ids,) = ctx.saved_tensors
+        n, c = ctx.shape
+        dw = torch.zeros(n, c, dtype=torch.float32, device=dx.device)
+        dx2 = dx.reshape(-1, c).float().contiguous()
+        _lib.call("rtts_embedding_bwd", ids.reshape(-1).contiguous().data_ptr(), dx2.data_ptr(), dx2.shape[0], c, n,
+                  -1 if ctx.padding_idx is None else ctx.padding_idx, dw.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        return None, dw, None
+
+
 class EncoderPreNet(nn.Module):
     """``modules.py:8-61``: embedding -> 3 x [dropout, conv k5, BatchNorm, ReLU] -> dropout -> linear."""
 
@@ -82,7 +103,10 @@ class EncoderPreNet(nn.Module):
 
     def forward(self, input_):
         c = self.convolutions
-        x = c.dropout0(self.embed(input_))                      # (B, L, C) channels-last throughout
+        if self.use_fused and self.training and input_.is_cuda:
+            x = c.dropout0(_EmbeddingFn.apply(input_, self.embed.weight, self.embed.padding_idx))
+        else:
+            x = c.dropout0(self.embed(input_))                  # (B, L, C) channels-last throughout
         if self.use_fused and self.training and x.is_cuda and self.embedding_dim % 128 == 0 and (x.shape[0] * x.shape[1]) % 64 == 0:
             from ..edges import ConvStackFn, encoder_prenet_stack
             if getattr(self, "_stack", None) is None:
