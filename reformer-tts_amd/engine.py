@@ -23,6 +23,11 @@ from . import _lib, ops
 from .model.lsh_attention import LSHSelfAttention
 
 
+# Reversible recompute with a selective stash: the attention cores' outputs (bf16 (B,T,d) + one fp32 logsumexp per
+# token.head, ~13 MB per decoder layer at the baseline shape) are kept from the forward, so the backward's recompute of
+# f(x) = to_out(attention(LN x)) re-runs only LayerNorm and the projections, not the attention forward.  Bitwise the same
+# result (the kernels are deterministic); HBM capacity traded for time.  False = the reference's pure recompute.
+STASH_ATTENTION = True
 WEIGHT_EPOCH = [0]   # bumped by the trainer after every optimizer step (its kernels write parameters through raw pointers)
 
 
@@ -125,6 +130,7 @@ class LSHExec:
         self.norm = withnorm.norm
         self.layer: LSHSelfAttention = withnorm.fn.layer
         self.st = None
+        self.stash = None     # (out, lse_tot) of the forward when STASH_ATTENTION: the recompute skips the attention forward
 
     @staticmethod
     def supported(withnorm) -> bool:
@@ -144,7 +150,7 @@ class LSHExec:
             return torch.as_strided(ga, (2 * ga.shape[0], ga.shape[1]), (ga.shape[1], 1)), None
         return None, (ga, gb)
 
-    def _internals(self, inp, b, t, mask, st):
+    def _internals(self, inp, b, t, mask, st, stash=None):
         lyr = self.layer
         e = lyr.dim
         if t <= lyr.full_attn_thres:
@@ -156,21 +162,25 @@ class LSHExec:
             rot = lyr._rotations(qkv, t // lyr.bucket_size)
             st, _, _ = ops.lsh_hash_sort(qkv[..., :e], rot, lyr.heads, lyr.bucket_size)
         lyr.last_st = st
-        o, lse = ops.lsh_attn_fwd(qkv[..., :e], qkv[..., e:], st, lyr.heads, lyr.bucket_size, lyr.causal, mask)
-        out, lse_tot = ops.lsh_combine_fwd(o, lse, b, lyr.heads)
+        if stash is not None:
+            out, lse_tot = stash
+        else:
+            o, lse = ops.lsh_attn_fwd(qkv[..., :e], qkv[..., e:], st, lyr.heads, lyr.bucket_size, lyr.causal, mask)
+            out, lse_tot = ops.lsh_combine_fwd(o, lse, b, lyr.heads)
         g = torch.mm(out.view(b * t, e), _bf16(lyr.to_out.weight).t())
         return xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g
 
     def forward(self, acc, inp, b, t, mask=None, **_):
-        *_, st, _, _, g = self._internals(inp, b, t, mask, None)
+        *_, st, out, lse_tot, g = self._internals(inp, b, t, mask, None)
         self.st = st
+        self.stash = (out, lse_tot) if STASH_ATTENTION else None
         residual(acc, g, self.layer.to_out.bias, 1.0)
 
     def backward(self, acc, inp, d_acc, d_inp, b, t, mask=None, **_):
         lyr = self.layer
         e = lyr.dim
-        xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g = self._internals(inp, b, t, mask, self.st)
-        self.st = None
+        xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g = self._internals(inp, b, t, mask, self.st, self.stash)
+        self.st = self.stash = None
         residual(acc, g, lyr.to_out.bias, -1.0)                               # reconstruct the stream
         dyb = cast_colsum(d_acc, _grad(lyr.to_out.bias))
         out2 = out.view(b * t, e)
@@ -233,13 +243,14 @@ class XAttnExec:
     def __init__(self, withnorm):
         self.norm = withnorm.norm
         self.mha = withnorm.fn.layer
+        self.stash = None
 
     @staticmethod
     def supported(withnorm) -> bool:
         m = withnorm.fn.layer
         return m.dropout == 0.0 and m.bias_k is None and not m.add_zero_attn and m._qkv_same_embed_dim
 
-    def _internals(self, inp, b, t, keys_bf16, kvalid):
+    def _internals(self, inp, b, t, keys_bf16, kvalid, stash=None):
         m = self.mha
         e, h = m.embed_dim, m.num_heads
         tk = keys_bf16.shape[0] // b
@@ -247,21 +258,26 @@ class XAttnExec:
         xn, mean, rstd = ln_fwd(inp, self.norm)
         q = torch.addmm(bias[:e], xn, w[:e].t())
         kv = torch.addmm(bias[e:], keys_bf16, w[e:].t())
-        o = torch.empty(b * t, e, dtype=torch.bfloat16, device=inp.device)
-        lse = torch.empty(b * h, t, dtype=torch.float32, device=inp.device)
-        _lib.call("rtts_xattn_fwd", q.data_ptr(), e, kv.data_ptr(), 2 * e, None if kvalid is None else kvalid.data_ptr(), b, h, t,
-                  tk, e // h, o.data_ptr(), e, lse.data_ptr(), _s())
+        if stash is not None:
+            o, lse = stash
+        else:
+            o = torch.empty(b * t, e, dtype=torch.bfloat16, device=inp.device)
+            lse = torch.empty(b * h, t, dtype=torch.float32, device=inp.device)
+            _lib.call("rtts_xattn_fwd", q.data_ptr(), e, kv.data_ptr(), 2 * e, None if kvalid is None else kvalid.data_ptr(), b, h, t,
+                      tk, e // h, o.data_ptr(), e, lse.data_ptr(), _s())
         g = torch.mm(o, _bf16(m.out_proj.weight).t())
         return xn, mean, rstd, w, q, kv, o, lse, g, tk
 
     def forward(self, acc, inp, b, t, keys_bf16=None, kvalid=None, **_):
-        *_, g, _ = self._internals(inp, b, t, keys_bf16, kvalid)
+        *_, o, lse, g, _ = self._internals(inp, b, t, keys_bf16, kvalid)
+        self.stash = (o, lse) if STASH_ATTENTION else None
         residual(acc, g, self.mha.out_proj.bias, 1.0)
 
     def backward(self, acc, inp, d_acc, d_inp, b, t, keys_bf16=None, kvalid=None, dkeys=None, **_):
         m = self.mha
         e, h = m.embed_dim, m.num_heads
-        xn, mean, rstd, w, q, kv, o, lse, g, tk = self._internals(inp, b, t, keys_bf16, kvalid)
+        xn, mean, rstd, w, q, kv, o, lse, g, tk = self._internals(inp, b, t, keys_bf16, kvalid, self.stash)
+        self.stash = None
         residual(acc, g, m.out_proj.bias, -1.0)
         dyb = cast_colsum(d_acc, _grad(m.out_proj.bias))
         wgrad(_grad(m.out_proj.weight), dyb, o)

@@ -356,3 +356,30 @@ def test_bn_act_dropout_kernels_vs_autograd(gpu, act, p):
     torch.testing.assert_close(dy.float(), yr.grad, rtol=2e-2, atol=2e-2)
     torch.testing.assert_close(dgam, gr.grad, rtol=1e-3, atol=1e-2)
     torch.testing.assert_close(dbet, br.grad, rtol=1e-3, atol=1e-2)
+
+
+def test_attention_stash_is_bitwise_equal_to_pure_recompute(gpu):
+    """STASH_ATTENTION keeps the attention outputs of the forward for the backward instead of recomputing them:
+    gradients must be IDENTICAL (deterministic kernels), not just close."""
+    from reformer_tts_amd import engine
+    from reformer_tts_amd.model.config import TTSTrainingConfig, model_config_from_dict
+    from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
+    cfg = model_ref.small_cfg()
+    cfg["enc_reformer_kwargs"]["attn_kwargs"]["implementation"] = "hip"
+    cfg["dec_reformer_kwargs"]["self_attn_kwargs"]["implementation"] = "hip"
+    batch = synthetic_batch(2, 100, 256, device=gpu)
+    grads = []
+    old = engine.STASH_ATTENTION
+    try:
+        for stash in (True, False):
+            engine.STASH_ATTENTION = stash
+            model = build_model(model_config_from_dict(cfg), gpu)
+            tr = Trainer(model, TTSTrainingConfig(batch_size=2), gpu)
+            model.train()
+            tr.zero_grad()
+            tr.forward_loss(batch)[0].backward()
+            torch.cuda.synchronize()
+            grads.append(tr.flat_g.clone())
+    finally:
+        engine.STASH_ATTENTION = old
+    assert torch.equal(grads[0], grads[1])
