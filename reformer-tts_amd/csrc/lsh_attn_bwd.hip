@@ -6,7 +6,7 @@
 //     out[q] = sum_{r,k} exp(s_rqk - LSE[q]) v[k],   LSE = logsumexp over rounds and keys,
 // so with P' = exp(s - LSE) and delta[q] = out[q].dout[q]:
 //     dV[k] += P'^T dout      dS = P' * (dout V^T - delta)   (0 where the logit was replaced
-//     by the self constant)   dQ = (dS * kscale) K     G = dS^T Q,   dK = kscale (G - k^ (k^.G))
+//     by the self constant)   dS' = dS * kscale   dQ = dS' K     G' = dS'^T Q,   dK = G' - k^ (k^.G')
 // where kscale[k] = dh^-1/2 / |k| is the key normalisation folded into the logits.
 //
 // Layout: KEY ON THE LANE.  Wave w owns keys [32w, 32w+32) of the chunk's 2*BS keys for all BS
@@ -50,8 +50,8 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
     unsigned char* Ds = Os + BS * AB_ROWB;                     // [NK][DSROW] dS'^T
     float* kscale = reinterpret_cast<float*>(Ds + NK * DSROW);
     int* kpos = reinterpret_cast<int*>(kscale + NK);
-    int* kval = kpos + NK;
-    float* qlse = reinterpret_cast<float*>(kval + NK);
+    int* kpe = kpos + NK;                                      // effective position: dead <=> kpe[key] > qpe[query]
+    float* qlse = reinterpret_cast<float*>(kpe + NK);          // lse_tot * log2(e)
     float* qdel = qlse + BS;
 
     const int nb = T / BS;
@@ -116,9 +116,10 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
         if (piece == 0) {
             kscale[row] = 0.125f * __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));   // dh^-1/2 / max(|k|, 1e-12)
             kpos[row] = trow[it];
-            kval[row] = MASKED ? (int)mask[(size_t)b * T + trow[it]] : 1;
+            const int valid = MASKED ? (int)mask[(size_t)b * T + trow[it]] : 1;
+            kpe[row] = valid ? (CAUSAL ? trow[it] : 0) : 0x40000000;
             if (row < BS) {
-                qlse[row] = lse_tot[(size_t)bh * T + trow[it]];
+                qlse[row] = lse_tot[(size_t)bh * T + trow[it]] * 1.4426950408889634f;
                 qdel[row] = delta[(size_t)bh * T + trow[it]];
             }
         }
@@ -129,14 +130,14 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
     // ---- this wave's key-side constants -----------------------------------------------------
     bf16x8 kf[KT2][4];
     float ksc[KT2];
-    int kvl[KT2];
+    int kpk[KT2];
 #pragma unroll
     for (int k2 = 0; k2 < KT2; ++k2) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
             kf[k2][ks] = *reinterpret_cast<const bf16x8*>(Ks + myrow[k2] * AB_ROWB + (ks * 16 + 8 * hh) * 2);
         ksc[k2] = kscale[myrow[k2]];
-        kvl[k2] = kval[myrow[k2]];
+        kpk[k2] = kpe[myrow[k2]];
     }
 
     f32x16 dvacc[KT2][2], gacc[KT2][2];   // [key tile][dh tile]: rows = dh, lane = key
@@ -176,28 +177,32 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[k2][ks], sacc, 0, 0, 0);    // S[q][key]
                 pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof[ks], vf[k2][ks], pacc, 0, 0, 0);   // dP[q][key]
             }
+            // P' = exp2(s*ksc*log2e - lse*log2e); dS' = P' (dP - delta) ksc  (0 at the self logit: it was a constant).
+            // ksc multiplies dS' once here: G' = dS'^T Q then gives dK = G' - k^ (k^ . G'), and dQ^T = K^T dS'^T.
             float pp[16], ds[16];
+            const float ksc2 = ksc[k2] * 1.4426950408889634f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int q0 = qt * 32 + 8 * g + 4 * hh;
                 const float4 l4 = *reinterpret_cast<const float4*>(qlse + q0);
                 const float4 d4 = *reinterpret_cast<const float4*>(qdel + q0);
                 const int4 p4 = *reinterpret_cast<const int4*>(kpos + q0);
-                const int4 v4 = *reinterpret_cast<const int4*>(kval + q0);
+                const int4 e4 = *reinterpret_cast<const int4*>(kpe + q0);
                 const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv_[4] = {d4.x, d4.y, d4.z, d4.w};
-                const int pv[4] = {p4.x, p4.y, p4.z, p4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+                const int pv[4] = {p4.x, p4.y, p4.z, p4.w}, ev[4] = {e4.x, e4.y, e4.z, e4.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int i = 4 * g + j;
                     const bool self = pv[j] == mypos[k2];
-                    bool dead = false;
-                    if (MASKED) dead = !(vv[j] && kvl[k2]);
-                    if (CAUSAL) dead = dead || (pv[j] < mypos[k2]);
-                    float x = sacc[i] * ksc[k2];
-                    if (self) x = -5e4f;
-                    const float p = (dead && !self) ? 0.f : __expf(x - lv[j]);
+                    // an invalid query (kpe == BIG) sees nothing but itself: its effective position is below every key's
+                    const int qpe = (ev[j] == 0x40000000) ? -1 : ev[j];
+                    const bool dead = kpk[k2] > qpe;
+                    float x = sacc[i] * ksc2;
+                    x = self ? (-5e4f * 1.4426950408889634f) : x;
+                    float p = __builtin_amdgcn_exp2f(x - lv[j]);
+                    p = (dead && !self) ? 0.f : p;
                     pp[i] = p;
-                    ds[i] = self ? 0.f : p * (pacc[i] - dv_[j]);
+                    ds[i] = self ? 0.f : p * (pacc[i] - dv_[j]) * ksc[k2];
                 }
             }
 #pragma unroll
@@ -214,12 +219,12 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
                     gacc[k2][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[s2][dt], db, gacc[k2][dt], 0, 0, 0);
                 }
             }
-            // dS'^T[key][q] = dS * kscale[key]  (bf16), 4 consecutive queries per 8-byte store
+            // dS'^T[key][q] (bf16), 4 consecutive queries per 8-byte store
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 uint2 pk;
-                pk.x = pack_bf16x2(ds[4 * g] * ksc[k2], ds[4 * g + 1] * ksc[k2]);
-                pk.y = pack_bf16x2(ds[4 * g + 2] * ksc[k2], ds[4 * g + 3] * ksc[k2]);
+                pk.x = pack_bf16x2(ds[4 * g], ds[4 * g + 1]);
+                pk.y = pack_bf16x2(ds[4 * g + 2], ds[4 * g + 3]);
                 *reinterpret_cast<uint2*>(Ds + myrow[k2] * DSROW + (qt * 32 + 8 * g + 4 * hh) * 2) = pk;
             }
         }
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
             for (int g = 0; g < 4; ++g) {
                 float dk[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) dk[j] = ksc[k2] * (gacc[k2][dt][4 * g + j] - kv_[dt][4 * g + j] * dot);
+                for (int j = 0; j < 4; ++j) dk[j] = gacc[k2][dt][4 * g + j] - kv_[dt][4 * g + j] * dot;
                 uint2 pk;
                 pk.x = pack_bf16x2(dk[0], dk[1]);
                 pk.y = pack_bf16x2(dk[2], dk[3]);
