@@ -163,9 +163,8 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            bf16x8 pf;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pf[j] = (__bf16)acc[8 * s2 + j];
+            const int o8 = 8 * s2;
+            const bf16x8 pf = cvt_bf16x8(acc[o8], acc[o8 + 1], acc[o8 + 2], acc[o8 + 3], acc[o8 + 4], acc[o8 + 5], acc[o8 + 6], acc[o8 + 7]);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
                 const int keyb = kt * 32 + 16 * s2 + 4 * hh + trq;

@@ -43,8 +43,20 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float x) {
     return __builtin_bit_cast(bf16_t, b);
 }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+// two floats -> one dword of bf16 (one v_cvt_pk_bf16_f32)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+// eight floats -> one MFMA fragment (four v_cvt_pk_bf16_f32)
+__device__ __forceinline__ bf16x8 cvt_bf16x8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+    const f32x8 v = {a0, a1, a2, a3, a4, a5, a6, a7};
+    return __builtin_convertvector(v, bf16x8);
 }
 
 // XCD-aware bijective remap of a linear workgroup id: the hardware deals workgroups

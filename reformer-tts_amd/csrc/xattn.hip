@@ -114,9 +114,9 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const bf16_t* __restrict
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            bf16x8 pf;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[kt][8 * s2 + j];
+            const int o8 = 8 * s2;
+            const bf16x8 pf = cvt_bf16x8(s[kt][o8], s[kt][o8 + 1], s[kt][o8 + 2], s[kt][o8 + 3], s[kt][o8 + 4], s[kt][o8 + 5],
+                                         s[kt][o8 + 6], s[kt][o8 + 7]);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
                 const int keyb = kt * 32 + 16 * s2 + 4 * hh + trq;
@@ -252,12 +252,10 @@ __global__ __launch_bounds__(TK) void xattn_bwd_kernel(const bf16_t* __restrict_
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                bf16x8 pb, db;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    pb[j] = (__bf16)pp[8 * s2 + j];
-                    db[j] = (__bf16)ds[8 * s2 + j];
-                }
+                const float* pq = pp + 8 * s2;
+                const float* dq_ = ds + 8 * s2;
+                const bf16x8 pb = cvt_bf16x8(pq[0], pq[1], pq[2], pq[3], pq[4], pq[5], pq[6], pq[7]);
+                const bf16x8 db = cvt_bf16x8(dq_[0], dq_[1], dq_[2], dq_[3], dq_[4], dq_[5], dq_[6], dq_[7]);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     dvacc[k2][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[s2][dt], pb, dvacc[k2][dt], 0, 0, 0);
