@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--text-len", type=int, default=200)
     ap.add_argument("--config", default="baseline", choices=["baseline", "long"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     return ap.parse_args()
 
@@ -105,17 +106,25 @@ def main():
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
     note(f"model built ({trainer.n_params} parameters), warming up")
+    use_graph = not args.no_graph
+    if use_graph:
+        trainer.capture(batch)          # whole step (fwd, bwd, all-reduce, clip, AdamW) as one hipGraph
+        step_fn = trainer.replay
+        note("step captured into a hipGraph")
+    else:
+        step_fn = lambda: trainer.train_step(batch)   # noqa: E731
     for i in range(args.warmup):
-        trainer.train_step(batch)
+        step_fn()
         torch.cuda.synchronize()
         note(f"warm-up step {i} done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ops.TIMING.enable("rtts_lsh_attn_bwd/bs128")
+    if not use_graph:
+        ops.TIMING.enable("rtts_lsh_attn_bwd/bs128")
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = trainer.train_step(batch)[0]
+        loss = step_fn()[0]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -126,6 +135,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     note(f"timed region done: {1e3 * elapsed / args.steps:.2f} ms/step")
+    if use_graph:
+        # HIP events cannot be read back from inside a replayed graph: time the dominant kernel on the same stream over
+        # the same number of eager steps of the same workload, directly after the timed region
+        ops.TIMING.enable("rtts_lsh_attn_bwd/bs128")
+        for _ in range(args.steps):
+            trainer.train_step(batch)
+        torch.cuda.synchronize()
     avg_ms, launches, flops_per_launch = ops.TIMING.summary("rtts_lsh_attn_bwd/bs128")
     ops.TIMING.disable()
 
@@ -140,7 +156,8 @@ def main():
                                    f"LSH 8 rounds, buckets 64/128), per-GPU batch {args.batch}, text {args.text_len}->256, "
                                    f"mel {args.mel_len}x80" if args.config == "baseline" else
                                    f"config/bucket-size-64-18-06.yml, per-GPU batch {args.batch}, mel {args.mel_len}",
-                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(float(loss), 4)},
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(float(loss), 4),
+                       "launch": "hipGraph replay" if use_graph else "eager"},
         }
         if launches:
             ach = flops_per_launch / (avg_ms * 1e-3) / 1e12

@@ -92,12 +92,14 @@ int rtts_lsh_bwd_reduce(const void* dqk_part, const void* dv_part, int B, int H,
  *   rtts_grad_clip_scale: scale_out[0] = grad_mult * min(1, max_norm / (grad_mult*|g| + 1e-6)),
  *        scale_out[1] = grad_mult*|g|;  partial_ws: >= 2048 floats.  grad_mult = 1/world_size
  *        after a sum all-reduce.  max_norm <= 0 disables clipping.
- *   rtts_adamw_step: grads are multiplied by scale[0] on the fly (scale may be NULL = 1). */
+ *   rtts_adamw_step: grads are multiplied by scale[0] on the fly (scale may be NULL = 1);
+ *        hyper (device) = {lr, lr*sqrt(1-beta2^t)/(1-beta1^t)} for the current step t, read by the kernel so that
+ *        a captured hipGraph replays with the values the host wrote before the replay. */
 int rtts_grad_clip_scale(const float* grads, int64_t n, float grad_mult, float max_norm, float* partial_ws,
                          float* scale_out, void* stream);
 int rtts_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* decay_mask,
-                    int64_t n, const float* scale, float lr, float beta1, float beta2, float eps,
-                    float weight_decay, int step, void* stream);
+                    int64_t n, const float* scale, const float* hyper, float beta1, float beta2, float eps,
+                    float weight_decay, void* stream);
 
 /* ---- row-wise fused kernels around the GEMMs of a reversible block --------------------------
  * Replace the ATen chains of WithNorm / FeedForward / residual adds (reference

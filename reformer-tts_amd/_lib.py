@@ -41,7 +41,7 @@ SIGNATURES = {
     "rtts_tts_loss": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp],
     "rtts_embedding_bwd": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],
     "rtts_gemm_tn": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _i32, _vp, _i64, _vp],
-    "rtts_adamw_step": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _i32, _vp],
+    "rtts_adamw_step": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _f32, _f32, _vp],
 }
 
 _lib = None

@@ -57,9 +57,11 @@ __global__ __launch_bounds__(OPT_THREADS) void clip_scale_kernel(const float* __
 
 __global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                             float* __restrict__ v, const uint8_t* __restrict__ decay, size_t n,
-                                                            const float* __restrict__ scale, float lr, float b1, float b2,
-                                                            float eps, float wd, float step_size) {
+                                                            const float* __restrict__ scale, const float* __restrict__ hyper,
+                                                            float b1, float b2, float eps, float wd) {
+    // hyper = {lr, lr * sqrt(1-b2^t) / (1-b1^t)} lives in device memory so that a captured graph replays with fresh values
     const float gs = scale ? scale[0] : 1.f;
+    const float lr = hyper[0], step_size = hyper[1];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float gi = g[i] * gs;
         const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -87,15 +89,13 @@ extern "C" int rtts_grad_clip_scale(const float* grads, int64_t n, float grad_mu
 }
 
 extern "C" int rtts_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* decay_mask,
-                               int64_t n, const float* scale, float lr, float beta1, float beta2, float eps,
-                               float weight_decay, int step, void* stream) {
-    RTTS_REQUIRE(params && grads && exp_avg && exp_avg_sq && decay_mask && n > 0 && step >= 1, "rtts_adamw_step: bad arguments");
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    const float step_size = (float)((double)lr * sqrt(bc2) / bc1);
+                               int64_t n, const float* scale, const float* hyper, float beta1, float beta2, float eps,
+                               float weight_decay, void* stream) {
+    RTTS_REQUIRE(params && grads && exp_avg && exp_avg_sq && decay_mask && hyper && n > 0, "rtts_adamw_step: bad arguments");
     int blocks = (int)((n + OPT_THREADS - 1) / OPT_THREADS);
     if (blocks > OPT_MAX_BLOCKS) blocks = OPT_MAX_BLOCKS;
     hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(OPT_THREADS), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
-                       decay_mask, (size_t)n, scale, lr, beta1, beta2, eps, weight_decay, step_size);
+                       decay_mask, (size_t)n, scale, hyper, beta1, beta2, eps, weight_decay);
     RTTS_LAUNCH_CHECK("rtts_adamw_step");
     return 0;
 }

@@ -89,6 +89,8 @@ class Trainer:
         if dev.type == "cuda":
             self.ws_partial = torch.zeros(2048, dtype=torch.float32, device=dev)
             self.ws_scale = torch.zeros(2, dtype=torch.float32, device=dev)
+            self.hyper = torch.zeros(2, dtype=torch.float32, device=dev)        # {lr, bias-corrected step size} of the step
+            self.hyper_host = torch.zeros(2, dtype=torch.float32).pin_memory()
             # bf16 mirror of every parameter, refreshed by ONE cast launch per optimizer step; modules see views
             self.flat_pb = torch.zeros(total + pad, dtype=torch.bfloat16, device=dev)
             for n, p in named:
@@ -172,19 +174,28 @@ class Trainer:
             lr *= min(1.0, float(self.global_step + 1) / self.cfg.warmup_steps)
         return lr
 
-    def optimizer_step(self):
+    def set_step_hyper(self, step_index: int):
+        """Host -> device copy of this step's {lr, lr*sqrt(1-b2^t)/(1-b1^t)} (t = step_index + 1); outside any graph."""
+        lr = self.lr_now_for(step_index)
+        t = step_index + 1
+        self.hyper_host[0] = lr
+        self.hyper_host[1] = lr * math.sqrt(1.0 - 0.999 ** t) / (1.0 - 0.9 ** t)
+        self.hyper.copy_(self.hyper_host, non_blocking=True)
+
+    def optimizer_step(self, update_hyper: bool = True):
         """Clip by global norm (after the all-reduce, on averaged gradients) + HF-AdamW."""
-        self.global_step += 1
-        lr = self.lr_now_for(self.global_step - 1)
-        n = self.flat_p.numel()
         if self.device.type != "cuda":
             raise _lib.RttsError("optimizer_step runs on the GPU only (no CPU fallback for the HIP path)")
+        if update_hyper:
+            self.set_step_hyper(self.global_step)
+        self.global_step += 1
+        n = self.flat_p.numel()
         stream = torch.cuda.current_stream().cuda_stream
         _lib.call("rtts_grad_clip_scale", self.flat_g.data_ptr(), n, 1.0 / self.world, float(self.cfg.gradient_clip_val),
                   self.ws_partial.data_ptr(), self.ws_scale.data_ptr(), stream)
         _lib.call("rtts_adamw_step", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
-                  self.flat_v.data_ptr(), self.decay_mask.data_ptr(), n, self.ws_scale.data_ptr(), lr, 0.9, 0.999, 1e-6,
-                  float(self.cfg.weight_decay), self.global_step, stream)
+                  self.flat_v.data_ptr(), self.decay_mask.data_ptr(), n, self.ws_scale.data_ptr(), self.hyper.data_ptr(), 0.9, 0.999,
+                  1e-6, float(self.cfg.weight_decay), stream)
         from ..engine import WEIGHT_EPOCH
         WEIGHT_EPOCH[0] += 1
         self.refresh_mirror()
@@ -195,11 +206,40 @@ class Trainer:
             lr *= min(1.0, float(step + 1) / self.cfg.warmup_steps)
         return lr
 
-    def train_step(self, batch):
+    def train_step(self, batch, update_hyper: bool = True):
         """One micro-batch: forward + loss + backward (+ all-reduce) + optimizer step."""
         self.model.train()
         self.zero_grad()
         total, raw_l, post_l, stop_l = self.forward_loss(batch)
         self.backward(total)
-        self.optimizer_step()
+        self.optimizer_step(update_hyper)
         return total.detach(), raw_l.detach(), post_l.detach(), stop_l.detach()
+
+    # ------------------------------------------------------------------ hipGraph replay of the whole step
+    def capture(self, batch):
+        """Capture forward + backward + all-reduce + clip + AdamW + mirror refresh for THIS batch buffer into a hipGraph.
+        Afterwards ``replay()`` runs one full step per call: the host only writes {lr, step size} for the step into device
+        memory and launches the graph.  Rotations and dropout draw from the graph-safe default generator."""
+        from ..model.lsh_attention import LSHSelfAttention
+        for m in self.model.modules():
+            if isinstance(m, LSHSelfAttention):
+                m.use_default_generator = True
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):                           # warm-up on a side stream (allocator, lazy attributes)
+                self.train_step(batch)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        self.set_step_hyper(self.global_step)
+        with torch.cuda.graph(self._graph):
+            self._graph_out = self.train_step(batch, update_hyper=False)
+        return self._graph_out
+
+    def replay(self):
+        self.set_step_hyper(self.global_step)
+        self.global_step += 1
+        self._graph.replay()
+        return self._graph_out
+

@@ -138,8 +138,10 @@ def test_optimizer_kernels_vs_oracle(gpu):
     world, max_norm, lr, wd, step = 4, 1.0, 3e-4, 1e-2, 7
     stream = torch.cuda.current_stream().cuda_stream
     _lib.call("rtts_grad_clip_scale", gd.data_ptr(), n + pad, 1.0 / world, max_norm, ws.data_ptr(), sc.data_ptr(), stream)
+    import math
+    hyper = torch.tensor([lr, lr * math.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)], device=gpu)
     _lib.call("rtts_adamw_step", pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), kd.data_ptr(), n + pad,
-              sc.data_ptr(), lr, 0.9, 0.999, 1e-6, wd, step, stream)
+              sc.data_ptr(), hyper.data_ptr(), 0.9, 0.999, 1e-6, wd, stream)
     torch.cuda.synchronize()
     g_avg = grad / world
     coef = optim_ref.clip_coef([g_avg], max_norm)
@@ -384,3 +386,35 @@ def test_attention_stash_matches_pure_recompute(gpu):
     finally:
         engine.STASH_ATTENTION = old
     assert ((grads[0] - grads[1]).norm() / grads[1].norm()).item() < 1e-2
+
+
+def test_graph_replay_matches_eager_steps(gpu):
+    """A captured hipGraph of the whole step replays with fresh {lr, step size}: losses follow the eager trajectory."""
+    from reformer_tts_amd.model.config import TTSTrainingConfig, model_config_from_dict
+    from reformer_tts_amd.model.lsh_attention import LSHSelfAttention
+    from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
+    cfg = model_ref.small_cfg()
+    cfg["enc_reformer_kwargs"]["attn_kwargs"]["implementation"] = "hip"
+    cfg["dec_reformer_kwargs"]["self_attn_kwargs"]["implementation"] = "hip"
+    batch = synthetic_batch(2, 100, 256, device=gpu)
+    traj = []
+    for graph in (False, True):
+        torch.manual_seed(1)
+        model = build_model(model_config_from_dict(cfg), gpu)
+        for m in model.modules():
+            if isinstance(m, LSHSelfAttention):
+                m.forced_rotations = torch.randn(1, 64, 4, (128 if not m.causal else 256) // 64 // 2,
+                                                 generator=torch.Generator().manual_seed(5))
+        tr = Trainer(model, TTSTrainingConfig(batch_size=2, learning_rate=1e-3, warmup_steps=4, gradient_clip_val=1.0), gpu)
+        losses = []
+        if graph:
+            tr.capture(batch)             # 2 warm-up steps + the captured one = steps 0..2
+            losses = [None, None, float(tr._graph_out[0])]
+            for _ in range(3):
+                losses.append(float(tr.replay()[0]))
+        else:
+            for _ in range(6):
+                losses.append(float(tr.train_step(batch)[0]))
+        traj.append(losses)
+    np.testing.assert_allclose(traj[1][2:], traj[0][2:], rtol=2e-2)
+    assert traj[1][-1] < traj[1][2]
