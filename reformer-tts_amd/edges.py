@@ -167,6 +167,7 @@ class PostnetLoss:
         self.layers = [ConvBNAct(getattr(pn, f"conv{i}"), getattr(pn, f"bn{i}"), 2, getattr(pn, f"dropout{i}").p) for i in range(depth)]
         self.convend = ConvK5(pn.convend)
         self.nm = model.num_mel_coeffs
+        self.pos_weight = float(loss_mod.pos_weight)      # host copy: no device read inside a captured step
         self._wh = None
 
     def _heads_weight(self):
@@ -216,7 +217,7 @@ class _PostnetLossFn(torch.autograd.Function):
         kind = 0 if isinstance(lm.spectrogram_loss, torch.nn.MSELoss) else 1
         pw = torch.empty(512 * 3, dtype=torch.float32, device=dev)
         _lib.call("rtts_tts_loss", heads.data_ptr(), post.data_ptr(), 128, true_mel.contiguous().data_ptr(), true_mask.contiguous().data_ptr(),
-                  heads[:, nm:].data_ptr(), 128, true_stop.contiguous().data_ptr(), m, nm, kind, float(lm.pos_weight),
+                  heads[:, nm:].data_ptr(), 128, true_stop.contiguous().data_ptr(), m, nm, kind, ex.pos_weight,
                   float(lm.raw_pred_loss_weight), float(lm.post_pred_loss_weight), float(lm.stop_loss_weight), g_raw.data_ptr(),
                   g_post.data_ptr(), g_stop.data_ptr(), losses.data_ptr(), pw.data_ptr(), _s())
         d_raw[:, :nm] = g_raw

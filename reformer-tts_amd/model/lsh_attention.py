@@ -80,7 +80,9 @@ class LSHSelfAttention(nn.Module):
 
     def _rotations(self, x, n_buckets):
         if self.forced_rotations is not None:
-            return self.forced_rotations.to(device=x.device, dtype=torch.float32).contiguous()
+            if self.forced_rotations.device != x.device or self.forced_rotations.dtype != torch.float32:
+                self.forced_rotations = self.forced_rotations.to(device=x.device, dtype=torch.float32).contiguous()
+            return self.forced_rotations
         rows = x.shape[0] * self.heads if self.random_rotations_per_head else 1
         shape = (rows, self.dim // self.heads, self.n_hashes, n_buckets // 2)
         if getattr(self, "use_default_generator", False):     # hipGraph capture: the default generator is graph-safe
