@@ -235,6 +235,7 @@ class Trainer:
         self.set_step_hyper(self.global_step)
         with torch.cuda.graph(self._graph):
             self._graph_out = self.train_step(batch, update_hyper=False)
+        self.global_step -= 1                            # capturing does not execute: the captured step has not run yet
         return self._graph_out
 
     def replay(self):

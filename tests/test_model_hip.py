@@ -408,9 +408,9 @@ def test_graph_replay_matches_eager_steps(gpu):
         tr = Trainer(model, TTSTrainingConfig(batch_size=2, learning_rate=1e-3, warmup_steps=4, gradient_clip_val=1.0), gpu)
         losses = []
         if graph:
-            tr.capture(batch)             # 2 warm-up steps + the captured one = steps 0..2
-            losses = [None, None, float(tr._graph_out[0])]
-            for _ in range(3):
+            tr.capture(batch)             # 2 eager warm-up steps (0, 1); capturing itself executes nothing
+            losses = [None, None]
+            for _ in range(4):
                 losses.append(float(tr.replay()[0]))
         else:
             for _ in range(6):
