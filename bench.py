@@ -83,8 +83,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("RTTS_DIST_BACKEND", "nccl")     # "gloo": single-GPU rehearsal of the N>1 code path
+    if backend == "gloo":
+        local_rank %= max(torch.cuda.device_count(), 1)
+        args.no_graph = True                                     # gloo collectives are host-side: not capturable
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -145,6 +152,8 @@ def main():
     avg_ms, launches, flops_per_launch = ops.TIMING.summary("rtts_lsh_attn_bwd/bs128")
     ops.TIMING.disable()
 
+    if not (float(loss) == float(loss)):
+        raise RuntimeError("training loss is not finite")
     if rank == 0:
         frames = world * args.batch * args.mel_len * args.steps
         out = {

@@ -20,3 +20,12 @@ for i in range(4):
         bad = [n for n, (s, e) in tr.offsets.items() if torch.isnan(tr.flat_g[s:e]).any()]
         print(" nan grads in", bad[:8], len(bad))
         break
+for i in range(12):
+    out = tr.replay()
+torch.cuda.synchronize()
+print("after 16 replays", [float(x) for x in out], bool(torch.isnan(tr.flat_p).any()))
+loss = out[0]
+for i in range(3):
+    o2 = tr.train_step(batch)
+    torch.cuda.synchronize()
+    print("eager after graph", i, [float(x) for x in o2], "static loss now:", float(loss), "param nan:", bool(torch.isnan(tr.flat_p).any()))
