@@ -113,7 +113,8 @@ def main():
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
     note(f"model built ({trainer.n_params} parameters), warming up")
-    use_graph = not args.no_graph
+    # N>1: RCCL collectives inside a captured graph are opt-in (RTTS_GRAPH_DP=1); the default there is eager launches
+    use_graph = not args.no_graph and (world == 1 or os.environ.get("RTTS_GRAPH_DP") == "1")
     if use_graph:
         trainer.capture(batch)          # whole step (fwd, bwd, all-reduce, clip, AdamW) as one hipGraph
         step_fn = trainer.replay
