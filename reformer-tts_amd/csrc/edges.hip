@@ -333,17 +333,24 @@ __global__ void tts_loss_finalize_kernel(const float* __restrict__ partial, int 
 }
 
 // ------------------------------------------------------------------ embedding backward (padding_idx rows get no gradient)
-// dE[id] += sum over rows with ids[row] == id of dx[row]: one block per (id, 256-channel group); the block scans the id list
-// (a few thousand entries) and adds matching rows in row order => deterministic, no atomics
+// dE[id] += sum over rows with ids[row] == id of dx[row]: one block per (id, 64-channel group); its 4 waves scan
+// interleaved quarters of the id list and add matching rows in row order; the 4 wave sums are combined in wave
+// order => deterministic, no atomics
 __global__ __launch_bounds__(ED_THREADS) void embedding_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dx, int rows,
                                                                    int C, int padding_idx, float* __restrict__ dE) {
+    __shared__ float red[4][64];
     const int id = blockIdx.x;
-    const int c = blockIdx.y * ED_THREADS + threadIdx.x;
-    if (id == padding_idx || c >= C) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + lane;
+    if (id == padding_idx) return;
     float acc = 0.f;
-    for (int r = 0; r < rows; ++r)
-        if (ids[r] == id) acc += dx[(size_t)r * C + c];
-    dE[(size_t)id * C + c] += acc;
+    if (c < C) {
+        for (int r = wave; r < rows; r += 4)
+            if (ids[r] == id) acc += dx[(size_t)r * C + c];
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && c < C) dE[(size_t)id * C + c] += (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // ------------------------------------------------------------------ host side
@@ -455,7 +462,7 @@ extern "C" int rtts_tts_loss(const float* raw, const float* post, int64_t ld_mel
 extern "C" int rtts_embedding_bwd(const int64_t* ids, const float* dx, int rows, int C, int n_embeddings, int padding_idx, float* dE,
                                   void* stream) {
     RTTS_REQUIRE(ids && dx && dE && rows > 0 && C > 0 && n_embeddings > 0, "rtts_embedding_bwd: bad arguments");
-    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(n_embeddings, (C + ED_THREADS - 1) / ED_THREADS), dim3(ED_THREADS), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(n_embeddings, (C + 63) / 64), dim3(ED_THREADS), 0, (hipStream_t)stream,
                        ids, dx, rows, C, padding_idx, dE);
     RTTS_LAUNCH_CHECK("rtts_embedding_bwd");
     return 0;
