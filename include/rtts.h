@@ -84,6 +84,20 @@ int rtts_lsh_attn_bwd(const void* qk, const void* v, int64_t ld, const int32_t* 
 int rtts_lsh_bwd_reduce(const void* dqk_part, const void* dv_part, int B, int H, int T, int dh, int n_hashes,
                         void* dqk, void* dv, int64_t ld_d, void* stream);
 
+/* ---- backward of steps 4-11, ring form: one persistent workgroup per (head, round) walks the chunks in sorted
+ * order, gathers every row once, and writes COMPLETE per-round gradients: 3 slots of (B*H, n_hashes, T, dh) bf16
+ * (dq, dk, dv) plus two halo buffers (B*H, n_hashes, bucket_size, dh) holding the contribution of a round's first
+ * chunk to the previous round's last chunk.  rtts_lsh_bwd_reduce_ring sums rounds and folds the halo in through
+ * `undo` (token -> sorted slot within its round, from rtts_lsh_hash_sort).  Same replaced reference lines as
+ * rtts_lsh_attn_bwd. */
+int rtts_lsh_attn_bwd_ring(const void* qk, const void* v, int64_t ld, const int32_t* st, const uint8_t* mask,
+                           const void* dout, int64_t ld_dout, const float* lse_tot, const float* delta,
+                           int B, int H, int T, int dh, int n_hashes, int bucket_size, int causal,
+                           void* dq_part, void* dk_part, void* dv_part, void* halo_dk, void* halo_dv, void* stream);
+int rtts_lsh_bwd_reduce_ring(const void* dq_part, const void* dk_part, const void* dv_part, const void* halo_dk,
+                             const void* halo_dv, const int32_t* undo, int B, int H, int T, int dh, int n_hashes,
+                             int bucket_size, void* dqk, void* dv, int64_t ld_d, void* stream);
+
 /* ---- optimizer step over the flat parameter buffer --------------------------------------
  * Replaces clip_grad_norm_ (pytorch-lightning gradient_clip_val, reference
  * reformer_tts/training/train.py:77-89) and transformers.optimization.AdamW.step as configured

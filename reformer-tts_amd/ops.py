@@ -127,8 +127,12 @@ def lsh_combine_fwd(o, lse, batch: int, heads: int, out: Optional[torch.Tensor] 
 
 
 def lsh_attn_bwd(qk, v, st, out, dout, lse_tot, heads: int, bucket_size: int, causal: bool, mask=None,
-                 dqkv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
-    """Backward of hash-sorted attention + round combine.  -> dqk, dv (B,T,H*dh) bf16."""
+                 dqkv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, undo: Optional[torch.Tensor] = None):
+    """Backward of hash-sorted attention + round combine.  -> dqk, dv (B,T,H*dh) bf16.
+    With ``undo`` (token -> sorted slot, from ``lsh_hash_sort(want_undo=True)``) the ring kernels run (each row
+    gathered once, 3 complete gradient slots); without it the per-chunk kernels with 5 partial slots."""
+    if undo is not None:
+        return _lsh_attn_bwd_ring(qk, v, st, undo, out, dout, lse_tot, heads, bucket_size, causal, mask, dqkv)
     ld = _check_rows(qk, "qk")
     if _check_rows(v, "v") != ld:
         raise ValueError("qk and v must share a row stride")
@@ -158,4 +162,39 @@ def lsh_attn_bwd(qk, v, st, out, dout, lse_tot, heads: int, bucket_size: int, ca
         raise ValueError("dqk and dv must share a row stride")
     _lib.call("rtts_lsh_bwd_reduce", dqk_part.data_ptr(), dv_part.data_ptr(), b, heads, t, dh, n_hashes, dqk.data_ptr(),
               dv.data_ptr(), ld_d, _stream())
+    return dqk, dv
+
+
+def _lsh_attn_bwd_ring(qk, v, st, undo, out, dout, lse_tot, heads, bucket_size, causal, mask, dqkv):
+    ld = _check_rows(qk, "qk")
+    if _check_rows(v, "v") != ld:
+        raise ValueError("qk and v must share a row stride")
+    ld_out, ld_do = _check_rows(out, "out"), _check_rows(dout, "dout")
+    b, t, d = qk.shape
+    dh = d // heads
+    n_hashes = st.shape[1]
+    if undo.shape != st.shape or undo.dtype != torch.int32 or not undo.is_contiguous():
+        raise ValueError("undo: expected contiguous int32 (B*H, n_hashes, T)")
+    mask = _check_mask(mask, b, t, qk.device)
+    dev = qk.device
+    delta = torch.empty(b * heads, t, dtype=torch.float32, device=dev)
+    _lib.call("rtts_lsh_bwd_delta", out.data_ptr(), ld_out, dout.data_ptr(), ld_do, b, heads, t, dh, delta.data_ptr(), _stream())
+    parts = torch.empty(3, b * heads, n_hashes, t, dh, dtype=torch.bfloat16, device=dev)
+    halo = torch.empty(2, b * heads, n_hashes, bucket_size, dh, dtype=torch.bfloat16, device=dev)
+    ev = TIMING.start(f"rtts_lsh_attn_bwd/bs{bucket_size}")
+    _lib.call("rtts_lsh_attn_bwd_ring", qk.data_ptr(), v.data_ptr(), ld, st.data_ptr(), _ptr(mask), dout.data_ptr(), ld_do,
+              lse_tot.data_ptr(), delta.data_ptr(), b, heads, t, dh, n_hashes, bucket_size, int(causal), parts[0].data_ptr(),
+              parts[1].data_ptr(), parts[2].data_ptr(), halo[0].data_ptr(), halo[1].data_ptr(), _stream())
+    # five MFMA products of 2*bs*(2bs)*dh FLOP per chunk, n_hashes*T/bs chunks per head
+    TIMING.stop(ev, 5.0 * 2.0 * bucket_size * (2 * bucket_size) * dh * (n_hashes * t // bucket_size) * b * heads)
+    if dqkv is None:
+        dqk = torch.empty(b, t, d, dtype=torch.bfloat16, device=dev)
+        dv = torch.empty(b, t, d, dtype=torch.bfloat16, device=dev)
+    else:
+        dqk, dv = dqkv
+    ld_d = _check_rows(dqk, "dqk")
+    if _check_rows(dv, "dv") != ld_d:
+        raise ValueError("dqk and dv must share a row stride")
+    _lib.call("rtts_lsh_bwd_reduce_ring", parts[0].data_ptr(), parts[1].data_ptr(), parts[2].data_ptr(), halo[0].data_ptr(),
+              halo[1].data_ptr(), undo.data_ptr(), b, heads, t, dh, n_hashes, bucket_size, dqk.data_ptr(), dv.data_ptr(), ld_d, _stream())
     return dqk, dv

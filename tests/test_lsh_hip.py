@@ -84,6 +84,7 @@ def test_hash_sort_rejects_bad_length(ops):
 CASES = [
     # b, h, t, bs, nh, causal, masked
     (2, 2, 128, 64, 4, False, False),
+    (1, 2, 4096, 64, 8, True, True),          # BASELINE config #4 shape: 64 buckets per round
     (2, 2, 256, 64, 4, True, True),
     (1, 3, 512, 128, 2, True, False),
     (2, 2, 512, 128, 8, False, True),
@@ -104,11 +105,11 @@ def _run_fwd(ops, b, h, t, bs, nh, causal, masked, seed=0):
             mask[1, t // 2:] = False
     qkv_d = qkv.cuda()
     qk_d, v_d = qkv_d[..., :h * dh], qkv_d[..., h * dh:]
-    st, _, _ = ops.lsh_hash_sort(qk_d, rot.cuda(), h, bs)
+    st, _, undo = ops.lsh_hash_sort(qk_d, rot.cuda(), h, bs, want_undo=True)
     o, lse = ops.lsh_attn_fwd(qk_d, v_d, st, h, bs, causal, None if mask is None else mask.cuda())
     out, lse_tot = ops.lsh_combine_fwd(o, lse, b, h)
     torch.cuda.synchronize()
-    return dict(qkv=qkv, qk_d=qk_d, v_d=v_d, st=st, o=o, lse=lse, out=out, lse_tot=lse_tot, mask=mask, dh=dh)
+    return dict(qkv=qkv, qk_d=qk_d, v_d=v_d, st=st, undo=undo, o=o, lse=lse, out=out, lse_tot=lse_tot, mask=mask, dh=dh)
 
 
 @pytest.mark.parametrize("b,h,t,bs,nh,causal,masked", CASES)
@@ -138,8 +139,9 @@ def test_attention_forward_vs_oracle(ops, b, h, t, bs, nh, causal, masked):
 
 
 # ------------------------------------------------------------------ attention backward
+@pytest.mark.parametrize("ring", [True, False])
 @pytest.mark.parametrize("b,h,t,bs,nh,causal,masked", CASES)
-def test_attention_backward_vs_oracle_autograd(ops, b, h, t, bs, nh, causal, masked):
+def test_attention_backward_vs_oracle_autograd(ops, b, h, t, bs, nh, causal, masked, ring):
     """Gradients of sum(out * dout) w.r.t. qk and v against autograd through the oracle on the same
     permutation.  bf16 partials (16 per token) and bf16 P/dS operands bound the error at ~2%
     of the gradient scale."""
@@ -148,7 +150,7 @@ def test_attention_backward_vs_oracle_autograd(ops, b, h, t, bs, nh, causal, mas
     g = torch.Generator().manual_seed(11)
     dout = torch.randn(b, t, h * dh, generator=g).bfloat16()
     dqk, dv = ops.lsh_attn_bwd(r["qk_d"], r["v_d"], r["st"], r["out"], dout.cuda(), r["lse_tot"], h, bs, causal,
-                               None if r["mask"] is None else r["mask"].cuda())
+                               None if r["mask"] is None else r["mask"].cuda(), undo=r["undo"] if ring else None)
     torch.cuda.synchronize()
     qk = _heads_first(r["qkv"][..., :h * dh], b, t, h, dh).requires_grad_()
     v = _heads_first(r["qkv"][..., h * dh:], b, t, h, dh).requires_grad_()
