@@ -216,8 +216,8 @@ class FFNExec:
 
     def _internals(self, inp):
         xn, mean, rstd = ln_fwd(inp, self.norm)
-        h = torch.mm(xn, _bf16(self.l1.weight).t())
-        _lib.call("rtts_bias_act", h.data_ptr(), self.l1.bias.data_ptr(), h.shape[0], h.shape[1], 1, _s())
+        # bias + ReLU ride in the library GEMM's epilogue (fp32 accumulate, one rounding to bf16)
+        h = torch._addmm_activation(_bf16(self.l1.bias), xn, _bf16(self.l1.weight).t(), use_gelu=False)
         g = torch.mm(h, _bf16(self.l2.weight).t())
         return xn, mean, rstd, h, g
 
