@@ -124,7 +124,8 @@ int rtts_adamw_step(float* params, const float* grads, float* exp_avg, float* ex
  *   rtts_ln_fwd            xn(bf16) = LayerNorm(x; eps 1e-5) * gamma + beta; keeps mean, rstd (M)
  *   rtts_ln_bwd            dx_io += dLN(dxn); dgamma += ..., dbeta += ...
  *   rtts_cast_colsum       dyb(bf16) = dy(fp32); dbias += colsum(dy)   (dbias may be NULL)
- *   rtts_colsum_bf16       dbias += colsum(dh); relu_gate: dh *= (h > 0) in place first
+ *   rtts_colsum_bf16       dbias += colsum(dh); relu_gate: dh *= (h > 0) * gate_scale in place first (gate_scale = 1/(1-p)
+ *                          when h went through dropout_p after the ReLU)
  *   rtts_residual_epilogue y = x + sign * (g(bf16) + bias)    (bias may be NULL)
  *   rtts_bias_act          h(bf16) = [relu](h + bias) in place
  *   rtts_cast_f32_bf16     flat cast (n % 4 == 0): the per-step bf16 mirror of all parameters */
@@ -134,7 +135,7 @@ int rtts_ln_bwd(const void* dxn, const float* x, const float* mean, const float*
                 float* dx_io, float* dgamma, float* dbeta, float* partial_ws, int M, int d, void* stream);
 int rtts_cast_colsum(const float* dy, void* dyb, float* dbias, float* partial_ws, int M, int d, void* stream);
 int rtts_colsum_bf16(void* dh, const void* h, int64_t ld, float* dbias, float* partial_ws, int M, int d,
-                     int relu_gate, void* stream);
+                     int relu_gate, float gate_scale, void* stream);
 int rtts_residual_epilogue(const float* x, const void* g, const float* bias, float sign, float* y,
                            int64_t M, int d, void* stream);
 int rtts_bias_act(void* h, const float* bias, int64_t M, int d, int relu, void* stream);
@@ -183,6 +184,14 @@ int rtts_bn_act_bwd(const float* y, const void* dz, const float* mean, const flo
 int rtts_tts_loss(const float* raw, const float* post, int64_t ld_mel, const float* tgt, const float* mask, const float* stop,
                   int64_t ld_stop, const float* tstop, int rows, int NM, int kind, float pos_weight, float w_raw, float w_post,
                   float w_stop, float* d_raw, float* d_post, float* d_stop, float* losses, float* partial_ws, void* stream);
+
+/* Scaled positional encoding (reference modules.py:172-192): out = y + alpha * dropout_p(table[t]), the mask shared over the
+ * batch; dalpha += sum dy * dropout_p(table).  relu_drop: h = dropout_p(relu(h)) in place (decoder prenet, modules.py:82-100). */
+int rtts_pe_add(const void* y, const float* table, const float* alpha, float drop_p, uint32_t seed, int T, int64_t M, int d,
+                float* out, void* stream);
+int rtts_pe_dalpha(const float* dy, const float* table, float drop_p, uint32_t seed, int T, int64_t M, int d, float* dalpha,
+                   float* partial_ws, void* stream);
+int rtts_relu_drop(void* h, float drop_p, uint32_t seed, int64_t n, void* stream);
 
 /* dE[id] += sum of dx rows whose id matches (nn.Embedding backward, reference modules.py:17,56); padding_idx skipped */
 int rtts_embedding_bwd(const int64_t* ids, const float* dx, int rows, int C, int n_embeddings, int padding_idx, float* dE,

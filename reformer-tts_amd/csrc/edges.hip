@@ -353,6 +353,78 @@ __global__ __launch_bounds__(ED_THREADS) void embedding_bwd_kernel(const int64_t
     if (wave == 0 && c < C) dE[(size_t)id * C + c] += (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
+// ------------------------------------------------------------------ scaled positional encoding (modules.py:172-192)
+// out[m][c] = y[m][c] + alpha * dropout_p(table[m % T][c]); the mask depends on (t, c) only: shared over the batch
+__global__ __launch_bounds__(ED_THREADS) void pe_add_kernel(const bf16_t* __restrict__ y, const float* __restrict__ table,
+                                                            const float* __restrict__ alpha, uint32_t seed, uint32_t thresh, float dscale,
+                                                            int T, size_t n4, int d, float* __restrict__ out) {
+    const float a = alpha[0];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * 4;
+        const int c = (int)(e % d);
+        const int t = (int)((e / d) % T);
+        const uint2 yv = reinterpret_cast<const uint2*>(y)[i];
+        const float4 tv = *reinterpret_cast<const float4*>(table + (size_t)t * d + c);
+        const float tt[4] = {tv.x, tv.y, tv.z, tv.w};
+        const float yy[4] = {__uint_as_float(yv.x << 16), __uint_as_float(yv.x & 0xffff0000u), __uint_as_float(yv.y << 16),
+                             __uint_as_float(yv.y & 0xffff0000u)};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o[j] = yy[j] + a * tt[j] * (thresh ? ed_drop(seed, (uint32_t)(t * d + c + j), thresh, dscale) : 1.f);
+        reinterpret_cast<float4*>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// partial[blk] = sum over this block's elements of dy * dropout(table)
+__global__ __launch_bounds__(ED_THREADS) void pe_dalpha_partial_kernel(const float* __restrict__ dy, const float* __restrict__ table,
+                                                                       uint32_t seed, uint32_t thresh, float dscale, int T, size_t n4, int d,
+                                                                       float* __restrict__ partial) {
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * 4;
+        const int c = (int)(e % d);
+        const int t = (int)((e / d) % T);
+        const float4 dv = reinterpret_cast<const float4*>(dy)[i];
+        const float4 tv = *reinterpret_cast<const float4*>(table + (size_t)t * d + c);
+        const float dd[4] = {dv.x, dv.y, dv.z, dv.w}, tt[4] = {tv.x, tv.y, tv.z, tv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            s = __builtin_fmaf(dd[j], tt[j] * (thresh ? ed_drop(seed, (uint32_t)(t * d + c + j), thresh, dscale) : 1.f), s);
+    }
+    __shared__ float red[ED_THREADS / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void pe_dalpha_final_kernel(const float* __restrict__ partial, int n, float* __restrict__ dalpha) {
+    if (threadIdx.x != 0) return;
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += partial[i];
+    dalpha[0] += s;
+}
+
+// h = dropout_p(relu(h)) in place (bf16), 8 elements per thread; the backward gate is (h_out > 0) * 1/(1-p)
+__global__ __launch_bounds__(ED_THREADS) void relu_drop_kernel(bf16_t* __restrict__ h, uint32_t seed, uint32_t thresh, float dscale, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        uint4 t = reinterpret_cast<uint4*>(h)[i];
+        uint32_t u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float lo = fmaxf(__uint_as_float(u[j] << 16), 0.f), hi = fmaxf(__uint_as_float(u[j] & 0xffff0000u), 0.f);
+            if (thresh) {
+                lo *= ed_drop(seed, (uint32_t)(i * 8 + 2 * j), thresh, dscale);
+                hi *= ed_drop(seed, (uint32_t)(i * 8 + 2 * j + 1), thresh, dscale);
+            }
+            u[j] = pack_bf16x2(lo, hi);
+        }
+        t.x = u[0]; t.y = u[1]; t.z = u[2]; t.w = u[3];
+        reinterpret_cast<uint4*>(h)[i] = t;
+    }
+}
+
 // ------------------------------------------------------------------ host side
 static inline unsigned ed_grid(size_t items) {
     size_t b = (items + ED_THREADS - 1) / ED_THREADS;
@@ -465,5 +537,36 @@ extern "C" int rtts_embedding_bwd(const int64_t* ids, const float* dx, int rows,
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3(n_embeddings, (C + 63) / 64), dim3(ED_THREADS), 0, (hipStream_t)stream,
                        ids, dx, rows, C, padding_idx, dE);
     RTTS_LAUNCH_CHECK("rtts_embedding_bwd");
+    return 0;
+}
+
+extern "C" int rtts_pe_add(const void* y, const float* table, const float* alpha, float drop_p, uint32_t seed, int T, int64_t M, int d,
+                           float* out, void* stream) {
+    RTTS_REQUIRE(y && table && alpha && out && T > 0 && M > 0 && d > 0 && d % 4 == 0 && M % T == 0 && drop_p >= 0.f && drop_p < 1.f,
+                 "rtts_pe_add: bad arguments");
+    const size_t n4 = (size_t)M * d / 4;
+    hipLaunchKernelGGL(pe_add_kernel, dim3(ed_grid(n4)), dim3(ED_THREADS), 0, (hipStream_t)stream, (const bf16_t*)y, table, alpha, seed,
+                       ed_thresh(drop_p), 1.f / (1.f - drop_p), T, n4, d, out);
+    RTTS_LAUNCH_CHECK("rtts_pe_add");
+    return 0;
+}
+
+extern "C" int rtts_pe_dalpha(const float* dy, const float* table, float drop_p, uint32_t seed, int T, int64_t M, int d, float* dalpha,
+                              float* partial_ws, void* stream) {
+    RTTS_REQUIRE(dy && table && dalpha && partial_ws && T > 0 && M > 0 && d % 4 == 0 && M % T == 0, "rtts_pe_dalpha: bad arguments");
+    const size_t n4 = (size_t)M * d / 4;
+    const int blocks = 512;
+    hipLaunchKernelGGL(pe_dalpha_partial_kernel, dim3(blocks), dim3(ED_THREADS), 0, (hipStream_t)stream, dy, table, seed, ed_thresh(drop_p),
+                       1.f / (1.f - drop_p), T, n4, d, partial_ws);
+    hipLaunchKernelGGL(pe_dalpha_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_ws, blocks, dalpha);
+    RTTS_LAUNCH_CHECK("rtts_pe_dalpha");
+    return 0;
+}
+
+extern "C" int rtts_relu_drop(void* h, float drop_p, uint32_t seed, int64_t n, void* stream) {
+    RTTS_REQUIRE(h && n > 0 && n % 8 == 0 && drop_p >= 0.f && drop_p < 1.f, "rtts_relu_drop: bad arguments");
+    hipLaunchKernelGGL(relu_drop_kernel, dim3(ed_grid((size_t)n / 8)), dim3(ED_THREADS), 0, (hipStream_t)stream, (bf16_t*)h, seed,
+                       ed_thresh(drop_p), 1.f / (1.f - drop_p), (size_t)n / 8);
+    RTTS_LAUNCH_CHECK("rtts_relu_drop");
     return 0;
 }

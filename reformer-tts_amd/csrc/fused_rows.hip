@@ -209,7 +209,7 @@ __global__ __launch_bounds__(FR_THREADS) void cast_colsum_kernel(const float* __
 // RELU: dh = dh * (h > 0) written back in place, then summed
 template <int EPL, int VEC, bool RELU>
 __global__ __launch_bounds__(FR_THREADS) void colsum_bf16_kernel(bf16_t* __restrict__ dh, const bf16_t* __restrict__ h,
-                                                                 int64_t ld, float* __restrict__ partial, int M) {
+                                                                 int64_t ld, float* __restrict__ partial, int M, float gate_scale) {
     constexpr int D = EPL * 64;
     constexpr int AV = (EPL % 4 == 0) ? 4 : 2;
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(FR_THREADS) void colsum_bf16_kernel(bf16_t* __restr
             float hv[EPL];
             load_row_bf16<EPL, VEC>(h + (size_t)row * ld, lane, hv);
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) v[e] = hv[e] > 0.f ? v[e] : 0.f;
+            for (int e = 0; e < EPL; ++e) v[e] = hv[e] > 0.f ? v[e] * gate_scale : 0.f;
             store_row_bf16<EPL, VEC>(dh + (size_t)row * ld, lane, v);
         }
 #pragma unroll
@@ -378,7 +378,7 @@ extern "C" int rtts_cast_colsum(const float* dy, void* dyb, float* dbias, float*
 }
 
 extern "C" int rtts_colsum_bf16(void* dh, const void* h, int64_t ld, float* dbias, float* partial_ws, int M, int d, int relu_gate,
-                                void* stream) {
+                                float gate_scale, void* stream) {
     RTTS_REQUIRE(dh && dbias && partial_ws && M > 0 && (!relu_gate || h), "rtts_colsum_bf16: bad arguments");
     RTTS_REQUIRE(ld >= d && ld % 8 == 0, "rtts_colsum_bf16: bad row stride");
     int blocks = (M + FR_WAVES - 1) / FR_WAVES;
@@ -387,10 +387,10 @@ extern "C" int rtts_colsum_bf16(void* dh, const void* h, int64_t ld, float* dbia
 #define CALL(EPL, VEC)                                                                                                         \
     if (relu_gate)                                                                                                             \
         hipLaunchKernelGGL((colsum_bf16_kernel<EPL, VEC, true>), dim3(blocks), dim3(FR_THREADS), lds, (hipStream_t)stream,     \
-                           (bf16_t*)dh, (const bf16_t*)h, ld, partial_ws, M);                                                  \
+                           (bf16_t*)dh, (const bf16_t*)h, ld, partial_ws, M, gate_scale);                                      \
     else                                                                                                                       \
         hipLaunchKernelGGL((colsum_bf16_kernel<EPL, VEC, false>), dim3(blocks), dim3(FR_THREADS), lds, (hipStream_t)stream,    \
-                           (bf16_t*)dh, (const bf16_t*)h, ld, partial_ws, M)
+                           (bf16_t*)dh, (const bf16_t*)h, ld, partial_ws, M, gate_scale)
     FR_DISPATCH_D(d, CALL)
 #undef CALL
     hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 63) / 64), dim3(FR_THREADS), 0, (hipStream_t)stream,

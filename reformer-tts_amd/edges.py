@@ -236,8 +236,9 @@ class _PostnetLossFn(torch.autograd.Function):
         scale = dlosses[0]
         d_raw, d_post, g_stop = d_raw * scale, d_post * scale, g_stop * scale
         # convend: res = conv(z_last) + bias;  d_res = d_post
-        dresb = cast_colsum(d_post, None)
-        _grad(ex.convend.conv.bias).add_(d_post[:, :nm].sum(0))
+        dbias_pad = torch.zeros(128, dtype=torch.float32, device=dev)
+        dresb = cast_colsum(d_post, dbias_pad)                 # deterministic column sums (no ATen reduction)
+        _grad(ex.convend.conv.bias).add_(dbias_pad[:nm])
         dz = ex.convend.backward(dresb, cols_end, b, lp)
         for layer, s in zip(reversed(ex.layers[1:]), reversed(saved[1:])):
             dz = layer.backward(dz, s, b, lp)
@@ -245,9 +246,9 @@ class _PostnetLossFn(torch.autograd.Function):
         dheads = d_raw + d_post
         dheads[:, :nm] += dx0[:, :nm]
         dheads[:, nm] = g_stop
-        dhb = cast_colsum(dheads, None)
+        bsum = torch.zeros(128, dtype=torch.float32, device=dev)
+        dhb = cast_colsum(dheads, bsum)
         mel, stop = ex.model.dec.mel_linear, ex.model.dec.stop_linear
-        bsum = dheads.sum(0)
         _grad(mel.bias).add_(bsum[:nm])
         _grad(stop.bias).add_(bsum[nm:nm + 1])
         dwh = torch.zeros(128, d, dtype=torch.float32, device=dev)
@@ -262,3 +263,86 @@ def _pad_bias(c: ConvK5, dev):
     bias = torch.zeros(c.cop, dtype=torch.float32, device=dev)
     bias[:c.co] = c.conv.bias.detach()
     return bias
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Linear stacks in front of the reversible stacks: (decoder prenet | encoder projection) + scaled positional encoding
+# ------------------------------------------------------------------------------------------------------------------
+def _seed() -> int:
+    return next(_seed_counter) * 2654435761 % (1 << 32)
+
+
+def _pe_ws(device) -> torch.Tensor:
+    key = ("pe", device)
+    if key not in _WS._cache:
+        _WS._cache[key] = torch.empty(512, dtype=torch.float32, device=device)
+    return _WS._cache[key]
+
+
+class _ProjPEFn(torch.autograd.Function):
+    """z (B,L,K) bf16 -> out (B,L,d) fp32 = z W^T + b + alpha * dropout(table): the Linear that ends a prenet followed
+    by ScaledPositionalEncoding (``modules.py:55-61,96-100,180-192``).  Bias gradient, dalpha and dW use the
+    deterministic two-stage kernels (no ATen reductions, hipGraph-replayable)."""
+
+    @staticmethod
+    def forward(ctx, z, lin, pe):
+        b, l, k = z.shape
+        d = lin.out_features
+        z2 = z.reshape(b * l, k)
+        y = torch.addmm(_bf16(lin.bias), z2, _bf16(lin.weight).t())
+        table = pe.table(l, z.device).contiguous()
+        out = torch.empty(b * l, d, dtype=torch.float32, device=z.device)
+        p = pe.dropout.p if pe.training else 0.0
+        seed = _seed()
+        _lib.call("rtts_pe_add", y.data_ptr(), table.data_ptr(), pe.alpha.data_ptr(), float(p), seed, l, b * l, d, out.data_ptr(), _s())
+        ctx.mods, ctx.state = (lin, pe), (z2, table, p, seed, b, l, k, d)
+        return out.view(b, l, d)
+
+    @staticmethod
+    def backward(ctx, dout):
+        lin, pe = ctx.mods
+        z2, table, p, seed, b, l, k, d = ctx.state
+        dy = dout.reshape(b * l, d).float().contiguous()
+        _lib.call("rtts_pe_dalpha", dy.data_ptr(), table.data_ptr(), float(p), seed, l, b * l, d, _grad(pe.alpha).data_ptr(),
+                  _pe_ws(dy.device).data_ptr(), _s())
+        dyb = cast_colsum(dy, _grad(lin.bias))
+        wgrad(_grad(lin.weight), dyb, z2)
+        dz = torch.mm(dyb, _bf16(lin.weight))
+        return dz.view(b, l, k), None, None
+
+
+def proj_pe(z, lin, pe):
+    return _ProjPEFn.apply(z, lin, pe)
+
+
+class _ReluDropLinearFn(torch.autograd.Function):
+    """x (M,K) bf16 -> dropout_p(relu(x W^T + b)) bf16 (decoder prenet stages fc1/fc2, ``modules.py:82-94``)."""
+
+    @staticmethod
+    def forward(ctx, x, lin, p):
+        h = torch.addmm(_bf16(lin.bias), x, _bf16(lin.weight).t())
+        seed = _seed()
+        _lib.call("rtts_relu_drop", h.data_ptr(), float(p), seed, h.numel(), _s())
+        ctx.lin, ctx.state = lin, (x, h, p)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        from .engine import colsum_bf16
+        lin = ctx.lin
+        x, h, p = ctx.state
+        dh = dh.to(torch.bfloat16).contiguous().clone() if dh.dtype != torch.bfloat16 or not dh.is_contiguous() else dh.clone()
+        colsum_bf16(dh, _grad(lin.bias), h, 1.0 / (1.0 - p))        # gate (h > 0) * 1/(1-p) in place + bias gradient
+        wgrad(_grad(lin.weight), dh, x)
+        return torch.mm(dh, _bf16(lin.weight)), None, None
+
+
+def decoder_prenet_pe(prenet, pe, spec):
+    """DecoderPreNet + ScaledPositionalEncoding on (B, L, n_mels) fp32 -> (B, L, d) fp32."""
+    b, l, nm = spec.shape
+    lyr = prenet.layer
+    x = spec.reshape(b * l, nm).to(torch.bfloat16)
+    training = prenet.training
+    h = _ReluDropLinearFn.apply(x, lyr.fc1, lyr.dropout1.p if training else 0.0)
+    h = _ReluDropLinearFn.apply(h, lyr.fc2, lyr.dropout2.p if training else 0.0)
+    return proj_pe(h.view(b, l, -1), lyr.projection, pe)

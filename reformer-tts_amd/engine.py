@@ -90,10 +90,11 @@ def cast_colsum(dy, dbias: Optional[torch.Tensor]):
     return dyb
 
 
-def colsum_bf16(dh, dbias, h=None):
+def colsum_bf16(dh, dbias, h=None, gate_scale: float = 1.0):
+    """dbias += column sums of dh; with ``h``: dh *= (h > 0) * gate_scale in place first (ReLU [+ dropout] backward)."""
     m, d = dh.shape
     _lib.call("rtts_colsum_bf16", dh.data_ptr(), None if h is None else h.data_ptr(), dh.stride(0), dbias.data_ptr(),
-              _WS.partial(dh.device, d).data_ptr(), m, d, int(h is not None), _s())
+              _WS.partial(dh.device, d).data_ptr(), m, d, int(h is not None), float(gate_scale), _s())
 
 
 def residual(acc, g, bias, sign: float):

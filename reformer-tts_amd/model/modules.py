@@ -101,7 +101,8 @@ class EncoderPreNet(nn.Module):
 
     use_fused = True
 
-    def forward(self, input_):
+    def forward(self, input_, pe=None):
+        """``pe``: when given (training on the GPU), the positional encoding is applied here, fused with the projection."""
         c = self.convolutions
         if self.use_fused and self.training and input_.is_cuda:
             x = c.dropout0(_EmbeddingFn.apply(input_, self.embed.weight, self.embed.padding_idx))
@@ -112,10 +113,14 @@ class EncoderPreNet(nn.Module):
             if getattr(self, "_stack", None) is None:
                 self._stack = encoder_prenet_stack(self)
             z = ConvStackFn.apply(x.to(torch.bfloat16), self._stack, True)
+            if pe is not None:
+                from ..edges import proj_pe
+                return proj_pe(z, self.projection, pe)               # projection + positional encoding fused
             return _bf16_linear(z, self.projection).float()
         for conv, bn, drop in ((c.conv1, c.bn1, c.dropout1), (c.conv2, c.bn2, c.dropout2), (c.conv3, c.bn3, c.dropout3)):
             x = drop(F.relu(batch_norm_rows(conv1d_k5_rows(x, conv), bn)))
-        return _bf16_linear(x, self.projection).float()
+        y = _bf16_linear(x, self.projection).float()
+        return y if pe is None else pe(y)
 
 
 class DecoderPreNet(nn.Module):

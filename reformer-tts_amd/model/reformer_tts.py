@@ -19,7 +19,7 @@ class Encoder(nn.Module):
         self.reformer = ReformerEnc(embedding_dim, **reformer_kwargs)
 
     def forward(self, input_, input_mask=None):
-        return self.reformer(self.positional_encoding(self.prenet(input_)), input_mask=input_mask)
+        return self.reformer(self.prenet(input_, pe=self.positional_encoding), input_mask=input_mask)
 
 
 class Decoder(nn.Module):
@@ -31,8 +31,16 @@ class Decoder(nn.Module):
         self.mel_linear = nn.Linear(embedding_dim, num_mel_coeffs)
         self.stop_linear = nn.Linear(embedding_dim, 1)
 
+    use_fused = True
+
     def hidden(self, input_, keys, key_padding_mask=None, input_mask=None):
-        x = self.positional_encoding(self.prenet(input_))
+        d = self.prenet.output_size
+        if (self.use_fused and self.training and input_.is_cuda and d % 128 == 0 and self.prenet.hidden_size % 128 == 0
+                and (input_.shape[0] * input_.shape[1]) % 64 == 0):
+            from ..edges import decoder_prenet_pe
+            x = decoder_prenet_pe(self.prenet, self.positional_encoding, input_)
+        else:
+            x = self.positional_encoding(self.prenet(input_))
         return self.reformer(x, keys=keys, key_padding_mask=key_padding_mask, input_mask=input_mask)
 
     def forward(self, input_, keys, key_padding_mask=None, input_mask=None):

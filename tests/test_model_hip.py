@@ -290,6 +290,7 @@ def test_fused_edges_match_general_path(gpu):
         tr = Trainer(model, TTSTrainingConfig(batch_size=2), gpu)
         tr.use_fused_edges = fused
         model.enc.prenet.use_fused = fused
+        model.dec.use_fused = fused
         model.train()
         tr.zero_grad()
         losses = tr.forward_loss(batch)
@@ -418,3 +419,27 @@ def test_graph_replay_matches_eager_steps(gpu):
         traj.append(losses)
     np.testing.assert_allclose(traj[1][2:], traj[0][2:], rtol=2e-2)
     assert traj[1][-1] < traj[1][2]
+
+
+def test_decoder_prenet_and_positional_encoding_executors(gpu):
+    """decoder_prenet_pe / proj_pe (explicit kernels) against the ATen modules at the baseline widths (80 -> 256 -> 512 -> 512),
+    dropout off: outputs and every gradient, including dalpha and the bias column sums."""
+    from reformer_tts_amd.edges import decoder_prenet_pe
+    from reformer_tts_amd.model.modules import DecoderPreNet, ScaledPositionalEncoding
+    torch.manual_seed(0)
+    res = []
+    spec = torch.randn(4, 256, 80, device=gpu)
+    dout = torch.randn(4, 256, 512, device=gpu)
+    for fused in (True, False):
+        torch.manual_seed(1)
+        pre = DecoderPreNet(80, 512, hidden_size=256, dropout=0.0).to(gpu).train()
+        pe = ScaledPositionalEncoding(512, 0.0).to(gpu).train()
+        y = decoder_prenet_pe(pre, pe, spec) if fused else pe(pre(spec))
+        y.backward(dout)
+        torch.cuda.synchronize()
+        res.append((y.detach(), {n: p.grad.clone() for n, p in list(pre.named_parameters()) + list(pe.named_parameters())}))
+    (yf, gf), (yg, gg) = res
+    assert ((yf - yg).norm() / yg.norm()).item() < 1e-2
+    for n in gg:
+        rel = ((gf[n] - gg[n]).norm() / gg[n].norm()).item()
+        assert rel < 3e-2, (n, rel)
