@@ -285,7 +285,9 @@ class _ProjPEFn(torch.autograd.Function):
     deterministic two-stage kernels (no ATen reductions, hipGraph-replayable)."""
 
     @staticmethod
-    def forward(ctx, z, lin, pe):
+    def forward(ctx, z, lin, pe, _track):
+        # _track = lin.weight: makes the output require grad even when z does not (parameter gradients are
+        # accumulated by this function itself, so None is returned for it)
         b, l, k = z.shape
         d = lin.out_features
         z2 = z.reshape(b * l, k)
@@ -308,18 +310,18 @@ class _ProjPEFn(torch.autograd.Function):
         dyb = cast_colsum(dy, _grad(lin.bias))
         wgrad(_grad(lin.weight), dyb, z2)
         dz = torch.mm(dyb, _bf16(lin.weight))
-        return dz.view(b, l, k), None, None
+        return dz.view(b, l, k), None, None, None
 
 
 def proj_pe(z, lin, pe):
-    return _ProjPEFn.apply(z, lin, pe)
+    return _ProjPEFn.apply(z, lin, pe, lin.weight)
 
 
 class _ReluDropLinearFn(torch.autograd.Function):
     """x (M,K) bf16 -> dropout_p(relu(x W^T + b)) bf16 (decoder prenet stages fc1/fc2, ``modules.py:82-94``)."""
 
     @staticmethod
-    def forward(ctx, x, lin, p):
+    def forward(ctx, x, lin, p, _track):
         h = torch.addmm(_bf16(lin.bias), x, _bf16(lin.weight).t())
         seed = _seed()
         _lib.call("rtts_relu_drop", h.data_ptr(), float(p), seed, h.numel(), _s())
@@ -334,7 +336,7 @@ class _ReluDropLinearFn(torch.autograd.Function):
         dh = dh.to(torch.bfloat16).contiguous().clone() if dh.dtype != torch.bfloat16 or not dh.is_contiguous() else dh.clone()
         colsum_bf16(dh, _grad(lin.bias), h, 1.0 / (1.0 - p))        # gate (h > 0) * 1/(1-p) in place + bias gradient
         wgrad(_grad(lin.weight), dh, x)
-        return torch.mm(dh, _bf16(lin.weight)), None, None
+        return (torch.mm(dh, _bf16(lin.weight)) if ctx.needs_input_grad[0] else None), None, None, None
 
 
 def decoder_prenet_pe(prenet, pe, spec):
@@ -343,6 +345,6 @@ def decoder_prenet_pe(prenet, pe, spec):
     lyr = prenet.layer
     x = spec.reshape(b * l, nm).to(torch.bfloat16)
     training = prenet.training
-    h = _ReluDropLinearFn.apply(x, lyr.fc1, lyr.dropout1.p if training else 0.0)
-    h = _ReluDropLinearFn.apply(h, lyr.fc2, lyr.dropout2.p if training else 0.0)
+    h = _ReluDropLinearFn.apply(x, lyr.fc1, lyr.dropout1.p if training else 0.0, lyr.fc1.weight)
+    h = _ReluDropLinearFn.apply(h, lyr.fc2, lyr.dropout2.p if training else 0.0, lyr.fc2.weight)
     return proj_pe(h.view(b, l, -1), lyr.projection, pe)

@@ -158,6 +158,26 @@ def test_optimizer_kernels_vs_oracle(gpu):
     torch.testing.assert_close(vd[:n].cpu(), v_ref, rtol=1e-5, atol=1e-7)
 
 
+def test_every_parameter_receives_a_gradient_at_baseline_widths(gpu):
+    """Baseline widths (d=512, decoder prenet 256) take every fused executor: after one backward no parameter
+    gradient may be identically zero except the conv biases in front of a BatchNorm (true gradient zero)."""
+    from reformer_tts_amd.model.config import baseline_model_config, baseline_training_config
+    from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
+    cfg = baseline_model_config()
+    cfg.enc_reformer_kwargs.depth = 1
+    cfg.dec_reformer_kwargs.depth = 1
+    model = build_model(cfg, gpu)
+    tr = Trainer(model, baseline_training_config(), gpu)
+    batch = synthetic_batch(2, 200, 256, device=gpu)
+    model.train()
+    tr.zero_grad()
+    tr.forward_loss(batch)[0].backward()
+    torch.cuda.synchronize()
+    zero = [n for n, (s, e) in tr.offsets.items() if float(tr.flat_g[s:e].abs().max()) == 0.0]
+    allowed = {n for n in tr.offsets if ".conv" in n and n.endswith(".bias") and "convend" not in n}
+    assert set(zero) <= allowed, sorted(set(zero) - allowed)
+
+
 def test_train_steps_reduce_loss(golden_dir, gpu):
     """Three optimizer steps on one synthetic batch: finite, decreasing loss; flat views stay attached."""
     from reformer_tts_amd.model.config import TTSTrainingConfig
