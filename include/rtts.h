@@ -165,7 +165,8 @@ int rtts_sum_slabs(const void* part, int nslabs, int64_t n, void* out, void* str
  *   rtts_conv_dw_unperm dw[co][ci][k] += dwp[co][k][ci]
  *   rtts_bn_stats       per-channel batch mean / rstd (eps 1e-5) of y (M,C) fp32; optional running-stat update
  *   rtts_bn_act_fwd     z(bf16) = dropout_p(act(gamma*(y-mean)*rstd + beta)); act 1 = ReLU, 2 = tanh;
- *                       the dropout mask is a hash of (seed, element index), reproduced by the backward
+ *                       the dropout mask is a hash of (seed + *seed_dev, element index), reproduced by the backward;
+ *                       seed_dev (device u32, may be NULL) lets a captured hipGraph draw fresh masks every replay
  *   rtts_bn_act_bwd     dy(bf16) = BatchNorm(train) backward through act and dropout; dgamma, dbeta accumulate
  *   rtts_tts_loss       losses[4] = {total, raw, post, stop} and d_raw, d_post (rows,NM), d_stop (rows):
  *                       masked MSE (kind 0) / L1 (kind 1) means over ALL elements + BCE-with-logits(pos_weight)
@@ -177,21 +178,21 @@ int rtts_conv_dw_unperm(const float* dwp, int Co, int Ci, int CP, float* dw, voi
 int rtts_bn_stats(const float* y, int M, int C, float* mean, float* rstd, float* run_mean, float* run_var,
                   float* partial_ws, void* stream);
 int rtts_bn_act_fwd(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
-                    float drop_p, uint32_t seed, int M, int C, void* z, void* stream);
+                    float drop_p, uint32_t seed, const uint32_t* seed_dev, int M, int C, void* z, void* stream);
 int rtts_bn_act_bwd(const float* y, const void* dz, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                    int act, float drop_p, uint32_t seed, int M, int C, void* dy, float* dgamma, float* dbeta,
-                    float* partial_ws, void* stream);
+                    int act, float drop_p, uint32_t seed, const uint32_t* seed_dev, int M, int C, void* dy, float* dgamma,
+                    float* dbeta, float* partial_ws, void* stream);
 int rtts_tts_loss(const float* raw, const float* post, int64_t ld_mel, const float* tgt, const float* mask, const float* stop,
                   int64_t ld_stop, const float* tstop, int rows, int NM, int kind, float pos_weight, float w_raw, float w_post,
                   float w_stop, float* d_raw, float* d_post, float* d_stop, float* losses, float* partial_ws, void* stream);
 
 /* Scaled positional encoding (reference modules.py:172-192): out = y + alpha * dropout_p(table[t]), the mask shared over the
  * batch; dalpha += sum dy * dropout_p(table).  relu_drop: h = dropout_p(relu(h)) in place (decoder prenet, modules.py:82-100). */
-int rtts_pe_add(const void* y, const float* table, const float* alpha, float drop_p, uint32_t seed, int T, int64_t M, int d,
-                float* out, void* stream);
-int rtts_pe_dalpha(const float* dy, const float* table, float drop_p, uint32_t seed, int T, int64_t M, int d, float* dalpha,
-                   float* partial_ws, void* stream);
-int rtts_relu_drop(void* h, float drop_p, uint32_t seed, int64_t n, void* stream);
+int rtts_pe_add(const void* y, const float* table, const float* alpha, float drop_p, uint32_t seed, const uint32_t* seed_dev,
+                int T, int64_t M, int d, float* out, void* stream);
+int rtts_pe_dalpha(const float* dy, const float* table, float drop_p, uint32_t seed, const uint32_t* seed_dev, int T, int64_t M,
+                   int d, float* dalpha, float* partial_ws, void* stream);
+int rtts_relu_drop(void* h, float drop_p, uint32_t seed, const uint32_t* seed_dev, int64_t n, void* stream);
 
 /* dE[id] += sum of dx rows whose id matches (nn.Embedding backward, reference modules.py:17,56); padding_idx skipped */
 int rtts_embedding_bwd(const int64_t* ids, const float* dx, int rows, int C, int n_embeddings, int padding_idx, float* dE,

@@ -105,8 +105,9 @@ template <int MODE>   // 0: (y, y*y)   1: (g, g*yhat) with g = dz * act'(.) * dr
 __global__ __launch_bounds__(ED_THREADS) void col_partial_kernel(const float* __restrict__ y, const bf16_t* __restrict__ dz,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta, int act,
-                                                                 uint32_t seed, uint32_t thresh, float dscale, int M, int C,
+                                                                 uint32_t seed, const uint32_t* __restrict__ seed_dev, uint32_t thresh, float dscale, int M, int C,
                                                                  float* __restrict__ partial) {
+    if (seed_dev) seed += seed_dev[0];
     // block = 64 channel-quads x 4 row-lanes; grid.x = row slabs, grid.y = channel groups of 256
     const int cq = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.y * 256 + cq * 4;
@@ -210,8 +211,9 @@ __global__ __launch_bounds__(ED_THREADS) void bn_finalize_bwd_kernel(const float
 // z = dropout(act(gamma*(y-mean)*rstd + beta)) as bf16; 4 channels per thread
 __global__ __launch_bounds__(ED_THREADS) void bn_act_fwd_kernel(const float* __restrict__ y, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                                const float* __restrict__ beta, int act, uint32_t seed, uint32_t thresh,
-                                                                float dscale, size_t n4, int C, bf16_t* __restrict__ z) {
+                                                                const float* __restrict__ beta, int act, uint32_t seed, const uint32_t* __restrict__ seed_dev,
+                                                                uint32_t thresh, float dscale, size_t n4, int C, bf16_t* __restrict__ z) {
+    if (seed_dev) seed += seed_dev[0];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const size_t e = i * 4;
         const int c = (int)(e % C);
@@ -236,9 +238,10 @@ __global__ __launch_bounds__(ED_THREADS) void bn_act_fwd_kernel(const float* __r
 __global__ __launch_bounds__(ED_THREADS) void bn_act_bwd_apply_kernel(const float* __restrict__ y, const bf16_t* __restrict__ dz,
                                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int act,
-                                                                      uint32_t seed, uint32_t thresh, float dscale,
+                                                                      uint32_t seed, const uint32_t* __restrict__ seed_dev, uint32_t thresh, float dscale,
                                                                       const float* __restrict__ sums, float inv_m, size_t n4, int C,
                                                                       bf16_t* __restrict__ dy) {
+    if (seed_dev) seed += seed_dev[0];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const size_t e = i * 4;
         const int c = (int)(e % C);
@@ -356,8 +359,9 @@ __global__ __launch_bounds__(ED_THREADS) void embedding_bwd_kernel(const int64_t
 // ------------------------------------------------------------------ scaled positional encoding (modules.py:172-192)
 // out[m][c] = y[m][c] + alpha * dropout_p(table[m % T][c]); the mask depends on (t, c) only: shared over the batch
 __global__ __launch_bounds__(ED_THREADS) void pe_add_kernel(const bf16_t* __restrict__ y, const float* __restrict__ table,
-                                                            const float* __restrict__ alpha, uint32_t seed, uint32_t thresh, float dscale,
-                                                            int T, size_t n4, int d, float* __restrict__ out) {
+                                                            const float* __restrict__ alpha, uint32_t seed, const uint32_t* __restrict__ seed_dev,
+                                                            uint32_t thresh, float dscale, int T, size_t n4, int d, float* __restrict__ out) {
+    if (seed_dev) seed += seed_dev[0];
     const float a = alpha[0];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const size_t e = i * 4;
@@ -378,8 +382,9 @@ __global__ __launch_bounds__(ED_THREADS) void pe_add_kernel(const bf16_t* __rest
 
 // partial[blk] = sum over this block's elements of dy * dropout(table)
 __global__ __launch_bounds__(ED_THREADS) void pe_dalpha_partial_kernel(const float* __restrict__ dy, const float* __restrict__ table,
-                                                                       uint32_t seed, uint32_t thresh, float dscale, int T, size_t n4, int d,
-                                                                       float* __restrict__ partial) {
+                                                                       uint32_t seed, const uint32_t* __restrict__ seed_dev, uint32_t thresh, float dscale, int T,
+                                                                       size_t n4, int d, float* __restrict__ partial) {
+    if (seed_dev) seed += seed_dev[0];
     float s = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const size_t e = i * 4;
@@ -407,7 +412,9 @@ __global__ void pe_dalpha_final_kernel(const float* __restrict__ partial, int n,
 }
 
 // h = dropout_p(relu(h)) in place (bf16), 8 elements per thread; the backward gate is (h_out > 0) * 1/(1-p)
-__global__ __launch_bounds__(ED_THREADS) void relu_drop_kernel(bf16_t* __restrict__ h, uint32_t seed, uint32_t thresh, float dscale, size_t n8) {
+__global__ __launch_bounds__(ED_THREADS) void relu_drop_kernel(bf16_t* __restrict__ h, uint32_t seed, const uint32_t* __restrict__ seed_dev,
+                                                               uint32_t thresh, float dscale, size_t n8) {
+    if (seed_dev) seed += seed_dev[0];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
         uint4 t = reinterpret_cast<uint4*>(h)[i];
         uint32_t u[4] = {t.x, t.y, t.z, t.w};
@@ -478,7 +485,7 @@ extern "C" int rtts_bn_stats(const float* y, int M, int C, float* mean, float* r
     RTTS_REQUIRE(y && mean && rstd && partial_ws && M > 0 && C > 0 && C % 4 == 0, "rtts_bn_stats: bad arguments");
     const dim3 grid = ed_col_grid(M, C);
     hipLaunchKernelGGL((col_partial_kernel<0>), grid, dim3(ED_THREADS), 0, (hipStream_t)stream, y, (const bf16_t*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0u, 0u, 1.f, M, C, partial_ws);
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0u, (const uint32_t*)nullptr, 0u, 1.f, M, C, partial_ws);
     hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((C + 63) / 64), dim3(ED_THREADS), 0, (hipStream_t)stream, partial_ws,
                        (int)grid.x, M, C, mean, rstd, run_mean, run_var);
     RTTS_LAUNCH_CHECK("rtts_bn_stats");
@@ -486,19 +493,19 @@ extern "C" int rtts_bn_stats(const float* y, int M, int C, float* mean, float* r
 }
 
 extern "C" int rtts_bn_act_fwd(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
-                               float drop_p, uint32_t seed, int M, int C, void* z, void* stream) {
+                               float drop_p, uint32_t seed, const uint32_t* seed_dev, int M, int C, void* z, void* stream) {
     RTTS_REQUIRE(y && mean && rstd && gamma && beta && z && M > 0 && C % 4 == 0 && (act == 1 || act == 2) && drop_p >= 0.f && drop_p < 1.f,
                  "rtts_bn_act_fwd: bad arguments");
     const size_t n4 = (size_t)M * C / 4;
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ed_grid(n4)), dim3(ED_THREADS), 0, (hipStream_t)stream, y, mean, rstd, gamma, beta, act, seed,
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ed_grid(n4)), dim3(ED_THREADS), 0, (hipStream_t)stream, y, mean, rstd, gamma, beta, act, seed, seed_dev,
                        ed_thresh(drop_p), 1.f / (1.f - drop_p), n4, C, (bf16_t*)z);
     RTTS_LAUNCH_CHECK("rtts_bn_act_fwd");
     return 0;
 }
 
 extern "C" int rtts_bn_act_bwd(const float* y, const void* dz, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                               int act, float drop_p, uint32_t seed, int M, int C, void* dy, float* dgamma, float* dbeta, float* partial_ws,
-                               void* stream) {
+                               int act, float drop_p, uint32_t seed, const uint32_t* seed_dev, int M, int C, void* dy, float* dgamma, float* dbeta,
+                               float* partial_ws, void* stream) {
     RTTS_REQUIRE(y && dz && mean && rstd && gamma && beta && dy && dgamma && dbeta && partial_ws && M > 0 && C % 4 == 0 && (act == 1 || act == 2),
                  "rtts_bn_act_bwd: bad arguments");
     const dim3 grid = ed_col_grid(M, C);
@@ -506,12 +513,12 @@ extern "C" int rtts_bn_act_bwd(const float* y, const void* dz, const float* mean
     const float ds = 1.f / (1.f - drop_p);
     float* sums = partial_ws + (size_t)ED_PBLOCKS * 2 * C;
     hipLaunchKernelGGL((col_partial_kernel<1>), grid, dim3(ED_THREADS), 0, (hipStream_t)stream, y, (const bf16_t*)dz, mean, rstd, gamma, beta, act,
-                       seed, th, ds, M, C, partial_ws);
+                       seed, seed_dev, th, ds, M, C, partial_ws);
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 63) / 64), dim3(ED_THREADS), 0, (hipStream_t)stream, partial_ws,
                        (int)grid.x, C, sums, dgamma, dbeta);
     const size_t n4 = (size_t)M * C / 4;
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ed_grid(n4)), dim3(ED_THREADS), 0, (hipStream_t)stream, y, (const bf16_t*)dz, mean, rstd,
-                       gamma, beta, act, seed, th, ds, sums, 1.f / (float)M, n4, C, (bf16_t*)dy);
+                       gamma, beta, act, seed, seed_dev, th, ds, sums, 1.f / (float)M, n4, C, (bf16_t*)dy);
     RTTS_LAUNCH_CHECK("rtts_bn_act_bwd");
     return 0;
 }
@@ -540,32 +547,32 @@ extern "C" int rtts_embedding_bwd(const int64_t* ids, const float* dx, int rows,
     return 0;
 }
 
-extern "C" int rtts_pe_add(const void* y, const float* table, const float* alpha, float drop_p, uint32_t seed, int T, int64_t M, int d,
-                           float* out, void* stream) {
+extern "C" int rtts_pe_add(const void* y, const float* table, const float* alpha, float drop_p, uint32_t seed, const uint32_t* seed_dev,
+                           int T, int64_t M, int d, float* out, void* stream) {
     RTTS_REQUIRE(y && table && alpha && out && T > 0 && M > 0 && d > 0 && d % 4 == 0 && M % T == 0 && drop_p >= 0.f && drop_p < 1.f,
                  "rtts_pe_add: bad arguments");
     const size_t n4 = (size_t)M * d / 4;
-    hipLaunchKernelGGL(pe_add_kernel, dim3(ed_grid(n4)), dim3(ED_THREADS), 0, (hipStream_t)stream, (const bf16_t*)y, table, alpha, seed,
+    hipLaunchKernelGGL(pe_add_kernel, dim3(ed_grid(n4)), dim3(ED_THREADS), 0, (hipStream_t)stream, (const bf16_t*)y, table, alpha, seed, seed_dev,
                        ed_thresh(drop_p), 1.f / (1.f - drop_p), T, n4, d, out);
     RTTS_LAUNCH_CHECK("rtts_pe_add");
     return 0;
 }
 
-extern "C" int rtts_pe_dalpha(const float* dy, const float* table, float drop_p, uint32_t seed, int T, int64_t M, int d, float* dalpha,
-                              float* partial_ws, void* stream) {
+extern "C" int rtts_pe_dalpha(const float* dy, const float* table, float drop_p, uint32_t seed, const uint32_t* seed_dev, int T, int64_t M,
+                              int d, float* dalpha, float* partial_ws, void* stream) {
     RTTS_REQUIRE(dy && table && dalpha && partial_ws && T > 0 && M > 0 && d % 4 == 0 && M % T == 0, "rtts_pe_dalpha: bad arguments");
     const size_t n4 = (size_t)M * d / 4;
     const int blocks = 512;
-    hipLaunchKernelGGL(pe_dalpha_partial_kernel, dim3(blocks), dim3(ED_THREADS), 0, (hipStream_t)stream, dy, table, seed, ed_thresh(drop_p),
+    hipLaunchKernelGGL(pe_dalpha_partial_kernel, dim3(blocks), dim3(ED_THREADS), 0, (hipStream_t)stream, dy, table, seed, seed_dev, ed_thresh(drop_p),
                        1.f / (1.f - drop_p), T, n4, d, partial_ws);
     hipLaunchKernelGGL(pe_dalpha_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_ws, blocks, dalpha);
     RTTS_LAUNCH_CHECK("rtts_pe_dalpha");
     return 0;
 }
 
-extern "C" int rtts_relu_drop(void* h, float drop_p, uint32_t seed, int64_t n, void* stream) {
+extern "C" int rtts_relu_drop(void* h, float drop_p, uint32_t seed, const uint32_t* seed_dev, int64_t n, void* stream) {
     RTTS_REQUIRE(h && n > 0 && n % 8 == 0 && drop_p >= 0.f && drop_p < 1.f, "rtts_relu_drop: bad arguments");
-    hipLaunchKernelGGL(relu_drop_kernel, dim3(ed_grid((size_t)n / 8)), dim3(ED_THREADS), 0, (hipStream_t)stream, (bf16_t*)h, seed,
+    hipLaunchKernelGGL(relu_drop_kernel, dim3(ed_grid((size_t)n / 8)), dim3(ED_THREADS), 0, (hipStream_t)stream, (bf16_t*)h, seed, seed_dev,
                        ed_thresh(drop_p), 1.f / (1.f - drop_p), (size_t)n / 8);
     RTTS_LAUNCH_CHECK("rtts_relu_drop");
     return 0;

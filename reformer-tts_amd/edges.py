@@ -23,6 +23,14 @@ from . import _lib
 from .engine import WEIGHT_EPOCH, _WS, _bf16, _grad, cast_colsum, wgrad
 
 _seed_counter = itertools.count(1)
+_SEED_BASE = {}     # device -> u32 tensor added to every dropout seed inside the kernels (rewritten by the trainer each step,
+                    # so that a replayed hipGraph -- whose per-call seeds are frozen constants -- still draws fresh masks)
+
+
+def seed_base(device) -> torch.Tensor:
+    if device not in _SEED_BASE:
+        _SEED_BASE[device] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _SEED_BASE[device]
 
 
 def _s() -> int:
@@ -112,7 +120,7 @@ class ConvBNAct:
         seed = next(_seed_counter) * 2654435761 % (1 << 32)
         z = torch.empty(m, c, dtype=torch.bfloat16, device=dev)
         _lib.call("rtts_bn_act_fwd", y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), self.act,
-                  self.p, seed, m, c, z.data_ptr(), _s())
+                  self.p, seed, seed_base(dev).data_ptr(), m, c, z.data_ptr(), _s())
         return z, (cols, y, mean, rstd, seed)
 
     def backward(self, dz, saved, b, l, need_dx=True, dx_f32=False):
@@ -121,7 +129,7 @@ class ConvBNAct:
         bn = self.bn
         dy = torch.empty(m, c, dtype=torch.bfloat16, device=y.device)
         _lib.call("rtts_bn_act_bwd", y.data_ptr(), dz.data_ptr(), mean.data_ptr(), rstd.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
-                  self.act, self.p, seed, m, c, dy.data_ptr(), _grad(bn.weight).data_ptr(), _grad(bn.bias).data_ptr(),
+                  self.act, self.p, seed, seed_base(y.device).data_ptr(), m, c, dy.data_ptr(), _grad(bn.weight).data_ptr(), _grad(bn.bias).data_ptr(),
                   _ws(y.device, c).data_ptr(), _s())
         _grad(self.c.conv.bias)       # exists (stays zero: the true gradient of a bias in front of BatchNorm is zero)
         return self.c.backward(dy, cols, b, l, need_dx, dx_f32)
@@ -296,7 +304,8 @@ class _ProjPEFn(torch.autograd.Function):
         out = torch.empty(b * l, d, dtype=torch.float32, device=z.device)
         p = pe.dropout.p if pe.training else 0.0
         seed = _seed()
-        _lib.call("rtts_pe_add", y.data_ptr(), table.data_ptr(), pe.alpha.data_ptr(), float(p), seed, l, b * l, d, out.data_ptr(), _s())
+        _lib.call("rtts_pe_add", y.data_ptr(), table.data_ptr(), pe.alpha.data_ptr(), float(p), seed, seed_base(z.device).data_ptr(), l, b * l, d,
+                  out.data_ptr(), _s())
         ctx.mods, ctx.state = (lin, pe), (z2, table, p, seed, b, l, k, d)
         return out.view(b, l, d)
 
@@ -305,7 +314,7 @@ class _ProjPEFn(torch.autograd.Function):
         lin, pe = ctx.mods
         z2, table, p, seed, b, l, k, d = ctx.state
         dy = dout.reshape(b * l, d).float().contiguous()
-        _lib.call("rtts_pe_dalpha", dy.data_ptr(), table.data_ptr(), float(p), seed, l, b * l, d, _grad(pe.alpha).data_ptr(),
+        _lib.call("rtts_pe_dalpha", dy.data_ptr(), table.data_ptr(), float(p), seed, seed_base(dy.device).data_ptr(), l, b * l, d, _grad(pe.alpha).data_ptr(),
                   _pe_ws(dy.device).data_ptr(), _s())
         dyb = cast_colsum(dy, _grad(lin.bias))
         wgrad(_grad(lin.weight), dyb, z2)
@@ -324,7 +333,7 @@ class _ReluDropLinearFn(torch.autograd.Function):
     def forward(ctx, x, lin, p, _track):
         h = torch.addmm(_bf16(lin.bias), x, _bf16(lin.weight).t())
         seed = _seed()
-        _lib.call("rtts_relu_drop", h.data_ptr(), float(p), seed, h.numel(), _s())
+        _lib.call("rtts_relu_drop", h.data_ptr(), float(p), seed, seed_base(h.device).data_ptr(), h.numel(), _s())
         ctx.lin, ctx.state = lin, (x, h, p)
         return h
 

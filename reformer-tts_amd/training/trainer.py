@@ -91,6 +91,7 @@ class Trainer:
             self.ws_scale = torch.zeros(2, dtype=torch.float32, device=dev)
             self.hyper = torch.zeros(2, dtype=torch.float32, device=dev)        # {lr, bias-corrected step size} of the step
             self.hyper_host = torch.zeros(2, dtype=torch.float32).pin_memory()
+            self._seed_host = torch.zeros(1, dtype=torch.int32).pin_memory()
             # bf16 mirror of every parameter, refreshed by ONE cast launch per optimizer step; modules see views
             self.flat_pb = torch.zeros(total + pad, dtype=torch.bfloat16, device=dev)
             for n, p in named:
@@ -181,6 +182,9 @@ class Trainer:
         self.hyper_host[0] = lr
         self.hyper_host[1] = lr * math.sqrt(1.0 - 0.999 ** t) / (1.0 - 0.9 ** t)
         self.hyper.copy_(self.hyper_host, non_blocking=True)
+        from ..edges import seed_base
+        self._seed_host[0] = (step_index * 2246822519 + 3266489917) % (1 << 31)     # fresh dropout masks every step
+        seed_base(self.device).copy_(self._seed_host, non_blocking=True)
 
     def optimizer_step(self, update_hyper: bool = True):
         """Clip by global norm (after the all-reduce, on averaged gradients) + HF-AdamW."""

@@ -352,12 +352,13 @@ def test_bn_act_dropout_kernels_vs_autograd(gpu, act, p):
     seed = 12345
     _lib.call("rtts_bn_stats", y.data_ptr(), m, c, mean.data_ptr(), rstd.data_ptr(), rm.data_ptr(), rv.data_ptr(), ws.data_ptr(), s)
     z = torch.empty(m, c, dtype=torch.bfloat16, device=gpu)
-    _lib.call("rtts_bn_act_fwd", y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act, p, seed, m, c,
-              z.data_ptr(), s)
+    sd = torch.tensor([77], dtype=torch.int32, device=gpu)      # device part of the seed (what a graph replay refreshes)
+    _lib.call("rtts_bn_act_fwd", y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act, p, seed,
+              sd.data_ptr(), m, c, z.data_ptr(), s)
     dy = torch.empty(m, c, dtype=torch.bfloat16, device=gpu)
     dgam, dbet = torch.zeros(c, device=gpu), torch.zeros(c, device=gpu)
     _lib.call("rtts_bn_act_bwd", y.data_ptr(), dz.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act, p,
-              seed, m, c, dy.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), ws.data_ptr(), s)
+              seed, sd.data_ptr(), m, c, dy.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), ws.data_ptr(), s)
     torch.cuda.synchronize()
     yr = y.clone().requires_grad_()
     gr, br = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
@@ -367,8 +368,8 @@ def test_bn_act_dropout_kernels_vs_autograd(gpu, act, p):
         # the mask itself: same seed and shape on a constant pre-activation of 1 (gamma = 0, beta = 1, ReLU)
         ones = torch.empty(m, c, dtype=torch.bfloat16, device=gpu)
         g0, b1 = torch.zeros(c, device=gpu), torch.ones(c, device=gpu)
-        _lib.call("rtts_bn_act_fwd", y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g0.data_ptr(), b1.data_ptr(), 1, p, seed, m, c,
-                  ones.data_ptr(), s)
+        _lib.call("rtts_bn_act_fwd", y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g0.data_ptr(), b1.data_ptr(), 1, p, seed,
+                  sd.data_ptr(), m, c, ones.data_ptr(), s)
         keep = ones.float() != 0
         assert abs(keep.float().mean().item() - (1 - p)) < 0.01
         a = a * keep / (1 - p)
