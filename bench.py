@@ -170,10 +170,16 @@ def main():
                        "launch": "hipGraph replay" if use_graph else "eager"},
         }
         if launches:
+            traffic = None      # HBM bytes per launch from the committed rocprofv3 PMC passes (collected outside this process)
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_lsh_attn_bwd.json")) as fh:
+                    traffic = json.load(fh)["traffic_bytes"] if (args.batch, args.mel_len, args.config) == (12, 1024, "baseline") else None
+            except OSError:
+                pass
             ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
             out["roofline"] = {"kernel": "lsh_attn_bwd_kernel", "bound": "mfma", "achieved": round(ach, 2),
                                "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
-                               "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches}
+                               "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model_cfg, args.mel_len, args.text_len, args.cpu_budget_s)
         print(json.dumps(out), flush=True)
