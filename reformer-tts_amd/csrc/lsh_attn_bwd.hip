@@ -158,17 +158,17 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
             qf[ks] = *reinterpret_cast<const bf16x8*>(Ks + (qt * 32 + r) * AB_ROWB + (ks * 16 + 8 * hh) * 2);
             dof[ks] = *reinterpret_cast<const bf16x8*>(Os + (qt * 32 + r) * AB_ROWB + (ks * 16 + 8 * hh) * 2);
         }
-        // A fragments of the transposed products: element j <-> query 16*s2 + 8*(j>>2) + 4*hh + (j&3)
-        bf16x8 qtf[2][2], dotf[2][2];   // [s2][dh tile]
+        // q-side row constants of this tile, issued first so that their LDS latency hides behind the MFMAs below
+        float4 l4[4], d4[4];
+        int4 p4[4], e4[4];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const int qb = qt * 32 + 16 * s2 + 4 * hh + trq;
-                const int col = (dt * 32 + 16 * trc + 4 * trp) * 2;
-                qtf[s2][dt] = tr_frag(Ks + qb * AB_ROWB + col, Ks + (qb + 8) * AB_ROWB + col);
-                dotf[s2][dt] = tr_frag(Os + qb * AB_ROWB + col, Os + (qb + 8) * AB_ROWB + col);
-            }
+        for (int g = 0; g < 4; ++g) {
+            const int q0 = qt * 32 + 8 * g + 4 * hh;
+            l4[g] = *reinterpret_cast<const float4*>(qlse + q0);
+            d4[g] = *reinterpret_cast<const float4*>(qdel + q0);
+            p4[g] = *reinterpret_cast<const int4*>(kpos + q0);
+            e4[g] = *reinterpret_cast<const int4*>(kpe + q0);
+        }
 #pragma unroll
         for (int k2 = 0; k2 < KT2; ++k2) {
             f32x16 sacc = {0}, pacc = {0};
@@ -183,13 +183,8 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
             const float ksc2 = ksc[k2] * 1.4426950408889634f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int q0 = qt * 32 + 8 * g + 4 * hh;
-                const float4 l4 = *reinterpret_cast<const float4*>(qlse + q0);
-                const float4 d4 = *reinterpret_cast<const float4*>(qdel + q0);
-                const int4 p4 = *reinterpret_cast<const int4*>(kpos + q0);
-                const int4 e4 = *reinterpret_cast<const int4*>(kpe + q0);
-                const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv_[4] = {d4.x, d4.y, d4.z, d4.w};
-                const int pv[4] = {p4.x, p4.y, p4.z, p4.w}, ev[4] = {e4.x, e4.y, e4.z, e4.w};
+                const float lv[4] = {l4[g].x, l4[g].y, l4[g].z, l4[g].w}, dv_[4] = {d4[g].x, d4[g].y, d4[g].z, d4[g].w};
+                const int pv[4] = {p4[g].x, p4[g].y, p4[g].z, p4[g].w}, ev[4] = {e4[g].x, e4[g].y, e4[g].z, e4[g].w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int i = 4 * g + j;
@@ -205,6 +200,18 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
                     ds[i] = self ? 0.f : p * (pacc[i] - dv_[j]) * ksc[k2];
                 }
             }
+            // A fragments of the transposed products (element j <-> query 16*s2 + 8*(j>>2) + 4*hh + (j&3)): read only now,
+            // so that their registers are free during the softmax arithmetic above
+            bf16x8 qtf[2][2], dotf[2][2];   // [s2][dh tile]
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int qb = qt * 32 + 16 * s2 + 4 * hh + trq;
+                    const int col = (dt * 32 + 16 * trc + 4 * trp) * 2;
+                    qtf[s2][dt] = tr_frag(Ks + qb * AB_ROWB + col, Ks + (qb + 8) * AB_ROWB + col);
+                    dotf[s2][dt] = tr_frag(Os + qb * AB_ROWB + col, Os + (qb + 8) * AB_ROWB + col);
+                }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const float* pq = pp + 8 * s2;

@@ -464,3 +464,33 @@ def test_decoder_prenet_and_positional_encoding_executors(gpu):
     for n in gg:
         rel = ((gf[n] - gg[n]).norm() / gg[n].norm()).item()
         assert rel < 3e-2, (n, rel)
+
+
+def test_long_sequence_config_general_path(gpu):
+    """BASELINE config #4 (config/bucket-size-64-18-06.yml: bucket 64/64, post_attn_dropout 0.15, cross-attention
+    dropout 0.15) at 1+1 layers, mel 4096: active dropout inside the reversible blocks sends the stacks down the
+    general path (nested autograd with per-call RNG capture).  Forward/backward must run, stay finite, reach every
+    parameter, and the recompute must replay the same dropout masks (deterministic gradients for a fixed seed)."""
+    from reformer_tts_amd.model.config import TTSTrainingConfig, long_sequence_model_config
+    from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
+    cfg = long_sequence_model_config()
+    cfg.enc_reformer_kwargs.depth = 1
+    cfg.dec_reformer_kwargs.depth = 1
+    grads = []
+    batch = synthetic_batch(1, 200, 4096, device=gpu)
+    for _ in range(2):
+        model = build_model(cfg, gpu)
+        assert model.dec.reformer.layers.use_fused
+        tr = Trainer(model, TTSTrainingConfig(batch_size=1), gpu)
+        model.train()
+        tr.zero_grad()
+        torch.manual_seed(123)
+        torch.cuda.manual_seed(123)
+        loss = tr.forward_loss(batch)[0]
+        assert model.dec.reformer.layers._program is None          # dropout in the blocks => general path
+        loss.backward()
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss) and torch.isfinite(tr.flat_g).all()
+        grads.append(tr.flat_g.clone())
+    zero = [n for n, (s, e) in tr.offsets.items() if float(grads[0][s:e].abs().max()) == 0.0]
+    assert all(".conv" in n and n.endswith(".bias") for n in zero), zero
