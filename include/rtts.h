@@ -164,11 +164,14 @@ int rtts_sum_slabs(const void* part, int nslabs, int64_t n, void* out, void* str
  *   rtts_conv_w_perm    wp[co][k][ci] (bf16, ci < CP zero padded) = w[co][ci][k] (fp32 master layout of nn.Conv1d)
  *   rtts_conv_dw_unperm dw[co][ci][k] += dwp[co][k][ci]
  *   rtts_bn_stats       per-channel batch mean / rstd (eps 1e-5) of y (M,C) fp32; optional running-stat update
+ *                       (momentum 0.1, unbiased variance; mean_shift[c], may be NULL, is added to the batch mean
+ *                       first: the conv bias that the fused path leaves out of y; *num_batches += 1 if given)
  *   rtts_bn_act_fwd     z(bf16) = dropout_p(act(gamma*(y-mean)*rstd + beta)); act 1 = ReLU, 2 = tanh;
  *                       the dropout mask is a hash of (seed + *seed_dev, element index), reproduced by the backward;
  *                       seed_dev (device u32, may be NULL) lets a captured hipGraph draw fresh masks every replay
  *   rtts_bn_act_bwd     dy(bf16) = BatchNorm(train) backward through act and dropout; dgamma, dbeta accumulate
- *   rtts_tts_loss       losses[4] = {total, raw, post, stop} and d_raw, d_post (rows,NM), d_stop (rows):
+ *   rtts_tts_loss       losses[4] = {total, raw, post, stop} and d_raw, d_post (rows, NM; row stride ld_grad >= NM,
+ *                       the pad columns are written as zero), d_stop (rows):
  *                       masked MSE (kind 0) / L1 (kind 1) means over ALL elements + BCE-with-logits(pos_weight)
  * partial_ws: >= (2*256 + 2)*C floats (bn) / 1536 floats (loss). */
 int rtts_im2col_k5(const void* x, int64_t ldx, int B, int L, int C, int CP, void* cols, void* stream);
@@ -176,7 +179,7 @@ int rtts_col2im_k5(const void* dcols, int B, int L, int C, int CP, void* dx, int
 int rtts_conv_w_perm(const float* w, int Co, int Ci, int CP, void* wp, void* stream);
 int rtts_conv_dw_unperm(const float* dwp, int Co, int Ci, int CP, float* dw, void* stream);
 int rtts_bn_stats(const float* y, int M, int C, float* mean, float* rstd, float* run_mean, float* run_var,
-                  float* partial_ws, void* stream);
+                  const float* mean_shift, int64_t* num_batches, float* partial_ws, void* stream);
 int rtts_bn_act_fwd(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
                     float drop_p, uint32_t seed, const uint32_t* seed_dev, int M, int C, void* z, void* stream);
 int rtts_bn_act_bwd(const float* y, const void* dz, const float* mean, const float* rstd, const float* gamma, const float* beta,
@@ -184,7 +187,8 @@ int rtts_bn_act_bwd(const float* y, const void* dz, const float* mean, const flo
                     float* dbeta, float* partial_ws, void* stream);
 int rtts_tts_loss(const float* raw, const float* post, int64_t ld_mel, const float* tgt, const float* mask, const float* stop,
                   int64_t ld_stop, const float* tstop, int rows, int NM, int kind, float pos_weight, float w_raw, float w_post,
-                  float w_stop, float* d_raw, float* d_post, float* d_stop, float* losses, float* partial_ws, void* stream);
+                  float w_stop, float* d_raw, float* d_post, int64_t ld_grad, float* d_stop, float* losses, float* partial_ws,
+                  void* stream);
 
 /* Scaled positional encoding (reference modules.py:172-192): out = y + alpha * dropout_p(table[t]), the mask shared over the
  * batch; dalpha += sum dy * dropout_p(table).  relu_drop: h = dropout_p(relu(h)) in place (decoder prenet, modules.py:82-100). */
@@ -202,7 +206,9 @@ int rtts_embedding_bwd(const int64_t* ids, const float* dx, int rows, int C, int
  * c[N][K] (fp32, stride ldc) (+)= sum_m a[m][N] * b[m][K]   (a, b bf16 with strides lda, ldb)
  * = dW of a Linear layer y = x W^T (reference modules.py:195-207, reformer.py:161-217 via autograd).
  * N % 128 == 0, K % 128 == 0, M % 64 == 0.  slab_ws (>= N*K*16 floats for full split) holds the
- * per-split partial tiles; they are summed in a fixed order (deterministic).  accumulate=1: += . */
+ * per-split partial tiles; they are summed in a fixed order by a second small launch (deterministic).
+ * (A single-launch variant in which the last workgroup of a tile folds the slabs was measured 6x slower:
+ * the agent-scope release fence every workgroup needs writes back a whole XCD L2.)  accumulate=1: += . */
 int rtts_gemm_tn(const void* a, int64_t lda, const void* b, int64_t ldb, int M, int N, int K, float* c, int64_t ldc,
                  int accumulate, float* slab_ws, int64_t slab_ws_floats, void* stream);
 

@@ -177,18 +177,20 @@ __device__ __forceinline__ void ed_reduce_partials(const float* __restrict__ par
 // mean/rstd from the partials (+ running statistics, momentum 0.1, unbiased variance)
 __global__ __launch_bounds__(ED_THREADS) void bn_finalize_stats_kernel(const float* __restrict__ partial, int nrows, int M, int C,
                                                                        float* __restrict__ mean, float* __restrict__ rstd,
-                                                                       float* __restrict__ run_mean, float* __restrict__ run_var) {
+                                                                       float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                                       const float* __restrict__ mean_shift, long long* __restrict__ num_batches) {
     __shared__ float red[2][4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     float s, q;
     ed_reduce_partials(partial, nrows, C, c, s, q, red);
+    if (num_batches && blockIdx.x == 0 && threadIdx.x == 0) num_batches[0] += 1;
     if (threadIdx.x >= 64 || c >= C) return;
     const float mu = s / M;
     const float var = fmaxf(q / M - mu * mu, 0.f);
     mean[c] = mu;
     rstd[c] = rsqrtf(var + 1e-5f);
     if (run_mean) {
-        run_mean[c] = 0.9f * run_mean[c] + 0.1f * mu;
+        run_mean[c] = 0.9f * run_mean[c] + 0.1f * (mu + (mean_shift ? mean_shift[c] : 0.f));
         run_var[c] = 0.9f * run_var[c] + 0.1f * var * ((float)M / (float)(M > 1 ? M - 1 : 1));
     }
 }
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(ED_THREADS) void tts_loss_kernel(const float* __res
                                                               const float* __restrict__ stop, int64_t ld_stop, const float* __restrict__ tstop,
                                                               int rows, int NM, int kind, float pos_weight, float w_raw, float w_post,
                                                               float w_stop, float* __restrict__ d_raw, float* __restrict__ d_post,
-                                                              float* __restrict__ d_stop, float* __restrict__ partial) {
+                                                              int64_t ld_grad, float* __restrict__ d_stop, float* __restrict__ partial) {
     float s_raw = 0.f, s_post = 0.f, s_stop = 0.f;
     const size_t nel = (size_t)rows * NM;
     const float inv_el = 1.f / (float)nel, inv_rows = 1.f / (float)rows;
@@ -290,14 +292,22 @@ __global__ __launch_bounds__(ED_THREADS) void tts_loss_kernel(const float* __res
         if (kind == 0) {
             s_raw = __builtin_fmaf(r, r, s_raw);
             s_post = __builtin_fmaf(p, p, s_post);
-            d_raw[i] = w_raw * 2.f * r * mk * inv_el;
-            d_post[i] = w_post * 2.f * p * mk * inv_el;
+            d_raw[row * ld_grad + c] = w_raw * 2.f * r * mk * inv_el;
+            d_post[row * ld_grad + c] = w_post * 2.f * p * mk * inv_el;
         } else {
             s_raw += fabsf(r);
             s_post += fabsf(p);
-            d_raw[i] = w_raw * (r > 0.f ? 1.f : (r < 0.f ? -1.f : 0.f)) * mk * inv_el;
-            d_post[i] = w_post * (p > 0.f ? 1.f : (p < 0.f ? -1.f : 0.f)) * mk * inv_el;
+            d_raw[row * ld_grad + c] = w_raw * (r > 0.f ? 1.f : (r < 0.f ? -1.f : 0.f)) * mk * inv_el;
+            d_post[row * ld_grad + c] = w_post * (p > 0.f ? 1.f : (p < 0.f ? -1.f : 0.f)) * mk * inv_el;
         }
+    }
+    // columns NM .. ld_grad of the gradient rows (padding of a 128-wide layout) are zeroed here
+    const int npad = (int)ld_grad - NM;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)rows * npad; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / npad;
+        const int c = NM + (int)(i % npad);
+        d_raw[row * ld_grad + c] = 0.f;
+        d_post[row * ld_grad + c] = 0.f;
     }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)rows; i += (size_t)gridDim.x * blockDim.x) {
         const float x = stop[i * ld_stop], t = tstop[i];
@@ -327,18 +337,25 @@ __global__ __launch_bounds__(ED_THREADS) void tts_loss_kernel(const float* __res
 // losses[0..3] = total, raw, post, stop
 __global__ void tts_loss_finalize_kernel(const float* __restrict__ partial, int nblocks, float inv_el, float inv_rows, float w_raw,
                                          float w_post, float w_stop, float* __restrict__ losses) {
-    if (threadIdx.x != 0) return;
+    // one wave; lane l sums blocks l, l+64, ... in order, then a fixed butterfly: deterministic
     float a = 0.f, b = 0.f, c = 0.f;
-    for (int i = 0; i < nblocks; ++i) { a += partial[i * 3]; b += partial[i * 3 + 1]; c += partial[i * 3 + 2]; }
+    for (int i = threadIdx.x; i < nblocks; i += 64) { a += partial[i * 3]; b += partial[i * 3 + 1]; c += partial[i * 3 + 2]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o);
+        b += __shfl_xor(b, o);
+        c += __shfl_xor(c, o);
+    }
+    if (threadIdx.x != 0) return;
     a *= inv_el; b *= inv_el; c *= inv_rows;
     losses[0] = w_raw * a + w_post * b + w_stop * c;
     losses[1] = a; losses[2] = b; losses[3] = c;
 }
 
 // ------------------------------------------------------------------ embedding backward (padding_idx rows get no gradient)
-// dE[id] += sum over rows with ids[row] == id of dx[row]: one block per (id, 64-channel group); its 4 waves scan
-// interleaved quarters of the id list and add matching rows in row order; the 4 wave sums are combined in wave
-// order => deterministic, no atomics
+// dE[id] += sum over rows with ids[row] == id of dx[row]: one block per (id, 64-channel group).  Wave w scans the
+// 64-row groups w, w+4, ...: the lanes compare 64 ids at once, the ballot lists the matching rows and they are added
+// in row order; the 4 wave sums are combined in wave order => deterministic, no atomics
 __global__ __launch_bounds__(ED_THREADS) void embedding_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dx, int rows,
                                                                    int C, int padding_idx, float* __restrict__ dE) {
     __shared__ float red[4][64];
@@ -347,9 +364,14 @@ __global__ __launch_bounds__(ED_THREADS) void embedding_bwd_kernel(const int64_t
     const int c = blockIdx.y * 64 + lane;
     if (id == padding_idx) return;
     float acc = 0.f;
-    if (c < C) {
-        for (int r = wave; r < rows; r += 4)
-            if (ids[r] == id) acc += dx[(size_t)r * C + c];
+    for (int base = wave * 64; base < rows; base += 4 * 64) {
+        const int r = base + lane;
+        unsigned long long m = __ballot(r < rows && ids[r] == (int64_t)id);
+        while (m) {
+            const int rr = base + __builtin_ctzll(m);
+            m &= m - 1;
+            if (c < C) acc += dx[(size_t)rr * C + c];
+        }
     }
     red[wave][lane] = acc;
     __syncthreads();
@@ -405,10 +427,11 @@ __global__ __launch_bounds__(ED_THREADS) void pe_dalpha_partial_kernel(const flo
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 __global__ void pe_dalpha_final_kernel(const float* __restrict__ partial, int n, float* __restrict__ dalpha) {
-    if (threadIdx.x != 0) return;
     float s = 0.f;
-    for (int i = 0; i < n; ++i) s += partial[i];
-    dalpha[0] += s;
+    for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) dalpha[0] += s;
 }
 
 // h = dropout_p(relu(h)) in place (bf16), 8 elements per thread; the backward gate is (h_out > 0) * 1/(1-p)
@@ -480,14 +503,14 @@ static inline dim3 ed_col_grid(int M, int C) {
     return dim3(slabs, (C + 255) / 256);
 }
 
-extern "C" int rtts_bn_stats(const float* y, int M, int C, float* mean, float* rstd, float* run_mean, float* run_var, float* partial_ws,
-                             void* stream) {
+extern "C" int rtts_bn_stats(const float* y, int M, int C, float* mean, float* rstd, float* run_mean, float* run_var,
+                             const float* mean_shift, int64_t* num_batches, float* partial_ws, void* stream) {
     RTTS_REQUIRE(y && mean && rstd && partial_ws && M > 0 && C > 0 && C % 4 == 0, "rtts_bn_stats: bad arguments");
     const dim3 grid = ed_col_grid(M, C);
     hipLaunchKernelGGL((col_partial_kernel<0>), grid, dim3(ED_THREADS), 0, (hipStream_t)stream, y, (const bf16_t*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0u, (const uint32_t*)nullptr, 0u, 1.f, M, C, partial_ws);
     hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((C + 63) / 64), dim3(ED_THREADS), 0, (hipStream_t)stream, partial_ws,
-                       (int)grid.x, M, C, mean, rstd, run_mean, run_var);
+                       (int)grid.x, M, C, mean, rstd, run_mean, run_var, mean_shift, (long long*)num_batches);
     RTTS_LAUNCH_CHECK("rtts_bn_stats");
     return 0;
 }
@@ -525,13 +548,14 @@ extern "C" int rtts_bn_act_bwd(const float* y, const void* dz, const float* mean
 
 extern "C" int rtts_tts_loss(const float* raw, const float* post, int64_t ld_mel, const float* tgt, const float* mask, const float* stop,
                              int64_t ld_stop, const float* tstop, int rows, int NM, int kind, float pos_weight, float w_raw, float w_post,
-                             float w_stop, float* d_raw, float* d_post, float* d_stop, float* losses, float* partial_ws, void* stream) {
-    RTTS_REQUIRE(raw && post && tgt && mask && stop && tstop && d_raw && d_post && d_stop && losses && partial_ws && rows > 0 && NM > 0,
-                 "rtts_tts_loss: bad arguments");
+                             float w_stop, float* d_raw, float* d_post, int64_t ld_grad, float* d_stop, float* losses, float* partial_ws,
+                             void* stream) {
+    RTTS_REQUIRE(raw && post && tgt && mask && stop && tstop && d_raw && d_post && d_stop && losses && partial_ws && rows > 0 && NM > 0 &&
+                     ld_grad >= NM, "rtts_tts_loss: bad arguments");
     RTTS_REQUIRE(kind == 0 || kind == 1, "rtts_tts_loss: Unsupported loss type: %d", kind);
     const int blocks = 512;
     hipLaunchKernelGGL(tts_loss_kernel, dim3(blocks), dim3(ED_THREADS), 0, (hipStream_t)stream, raw, post, ld_mel, tgt, mask, stop, ld_stop,
-                       tstop, rows, NM, kind, pos_weight, w_raw, w_post, w_stop, d_raw, d_post, d_stop, partial_ws);
+                       tstop, rows, NM, kind, pos_weight, w_raw, w_post, w_stop, d_raw, d_post, ld_grad, d_stop, partial_ws);
     hipLaunchKernelGGL(tts_loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_ws, blocks, 1.f / ((float)rows * NM),
                        1.f / (float)rows, w_raw, w_post, w_stop, losses);
     RTTS_LAUNCH_CHECK("rtts_tts_loss");

@@ -244,9 +244,15 @@ __global__ __launch_bounds__(FR_THREADS) void colsum_bf16_kernel(bf16_t* __restr
 
 // out[c] += sum over the partial rows, in a fixed order: a block owns 64 columns, its 4 waves each
 // sum every 4th partial row (coalesced 256-B reads), then the 4 wave sums are added in wave order
+// (blockIdx.y == 1 selects a second partial buffer / output: the two sums of a LayerNorm backward in one launch)
 __global__ __launch_bounds__(FR_THREADS) void colsum_final_kernel(const float* __restrict__ partial, int nrows, int n,
-                                                                  float* __restrict__ out) {
+                                                                  float* __restrict__ out, const float* __restrict__ partial2,
+                                                                  float* __restrict__ out2) {
     __shared__ float red[FR_WAVES][64];
+    if (blockIdx.y) {
+        partial = partial2;
+        out = out2;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
@@ -355,9 +361,8 @@ extern "C" int rtts_ln_bwd(const void* dxn, const float* x, const float* mean, c
 #define CALL(EPL, VEC) hipLaunchKernelGGL((ln_bwd_kernel<EPL, VEC>), dim3(blocks), dim3(FR_THREADS), lds, (hipStream_t)stream, (const bf16_t*)dxn, x, mean, rstd, gamma, dx_io, pg, pb, M)
     FR_DISPATCH_D(d, CALL)
 #undef CALL
-    const dim3 g2((d + 63) / 64);
-    hipLaunchKernelGGL(colsum_final_kernel, g2, dim3(FR_THREADS), 0, (hipStream_t)stream, pg, blocks, d, dgamma);
-    hipLaunchKernelGGL(colsum_final_kernel, g2, dim3(FR_THREADS), 0, (hipStream_t)stream, pb, blocks, d, dbeta);
+    const dim3 g2((d + 63) / 64, 2);
+    hipLaunchKernelGGL(colsum_final_kernel, g2, dim3(FR_THREADS), 0, (hipStream_t)stream, pg, blocks, d, dgamma, pb, dbeta);
     RTTS_LAUNCH_CHECK("rtts_ln_bwd");
     return 0;
 }
@@ -372,7 +377,7 @@ extern "C" int rtts_cast_colsum(const float* dy, void* dyb, float* dbias, float*
 #undef CALL
     if (dbias)
         hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 63) / 64), dim3(FR_THREADS), 0, (hipStream_t)stream,
-                           partial_ws, blocks, d, dbias);
+                           partial_ws, blocks, d, dbias, (const float*)nullptr, (float*)nullptr);
     RTTS_LAUNCH_CHECK("rtts_cast_colsum");
     return 0;
 }
@@ -394,7 +399,7 @@ extern "C" int rtts_colsum_bf16(void* dh, const void* h, int64_t ld, float* dbia
     FR_DISPATCH_D(d, CALL)
 #undef CALL
     hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 63) / 64), dim3(FR_THREADS), 0, (hipStream_t)stream,
-                       partial_ws, blocks, d, dbias);
+                       partial_ws, blocks, d, dbias, (const float*)nullptr, (float*)nullptr);
     RTTS_LAUNCH_CHECK("rtts_colsum_bf16");
     return 0;
 }

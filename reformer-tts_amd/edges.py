@@ -84,8 +84,8 @@ class ConvK5:
 
     def backward(self, dy: torch.Tensor, cols: torch.Tensor, b: int, l: int, need_dx: bool = True, dx_f32: bool = False):
         """dy bf16 (M, cop) -> accumulates dW, returns dx (M, ci rounded up to 8) bf16/fp32."""
-        dwp = torch.zeros(self.cop, 5 * self.cp, dtype=torch.float32, device=dy.device)
-        wgrad(dwp, dy, cols)
+        dwp = torch.empty(self.cop, 5 * self.cp, dtype=torch.float32, device=dy.device)
+        wgrad(dwp, dy, cols, accumulate=False)
         _lib.call("rtts_conv_dw_unperm", dwp.data_ptr(), self.co, self.ci, self.cp, _grad(self.conv.weight).data_ptr(), _s())
         if not need_dx:
             return None
@@ -110,13 +110,10 @@ class ConvBNAct:
         mean = torch.empty(c, dtype=torch.float32, device=dev)
         rstd = torch.empty(c, dtype=torch.float32, device=dev)
         bn = self.bn
-        with torch.no_grad():
-            rm = torch.empty_like(bn.running_mean)
-            _lib.call("rtts_bn_stats", y.data_ptr(), m, c, mean.data_ptr(), rstd.data_ptr(), rm.data_ptr(), bn.running_var.data_ptr(),
-                      _ws(dev, c).data_ptr(), _s())
-            # running_mean tracks the mean of (y + bias); rtts_bn_stats blended against garbage in rm, redo it exactly
-            bn.running_mean.mul_(1 - bn.momentum).add_(mean + self.c.conv.bias, alpha=bn.momentum)
-            bn.num_batches_tracked += 1
+        # running_mean tracks the mean of (y + conv bias): the bias is left out of y (BatchNorm cancels it) and shifts
+        # only the running mean; num_batches_tracked is bumped by the same launch
+        _lib.call("rtts_bn_stats", y.data_ptr(), m, c, mean.data_ptr(), rstd.data_ptr(), bn.running_mean.data_ptr(),
+                  bn.running_var.data_ptr(), self.c.conv.bias.data_ptr(), bn.num_batches_tracked.data_ptr(), _ws(dev, c).data_ptr(), _s())
         seed = next(_seed_counter) * 2654435761 % (1 << 32)
         z = torch.empty(m, c, dtype=torch.bfloat16, device=dev)
         _lib.call("rtts_bn_act_fwd", y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), self.act,
@@ -215,21 +212,17 @@ class _PostnetLossFn(torch.autograd.Function):
         post = heads[:, :128] + res                                           # cols >= nm are junk and never read
         lm = ex.loss_mod
         losses = torch.empty(4, dtype=torch.float32, device=dev)
-        d_raw = torch.zeros(m, 128, dtype=torch.float32, device=dev)
-        d_post = torch.zeros(m, 128, dtype=torch.float32, device=dev)
+        d_raw = torch.empty(m, 128, dtype=torch.float32, device=dev)       # 128-wide rows; the kernel zeroes the pad columns
+        d_post = torch.empty(m, 128, dtype=torch.float32, device=dev)
         if l != lp:
             raise NotImplementedError("fused postnet+loss needs the mel length to be a multiple of pad_base (synthetic batches are)")
-        g_raw = torch.empty(m, nm, dtype=torch.float32, device=dev)
-        g_post = torch.empty(m, nm, dtype=torch.float32, device=dev)
         g_stop = torch.empty(m, dtype=torch.float32, device=dev)
         kind = 0 if isinstance(lm.spectrogram_loss, torch.nn.MSELoss) else 1
         pw = torch.empty(512 * 3, dtype=torch.float32, device=dev)
         _lib.call("rtts_tts_loss", heads.data_ptr(), post.data_ptr(), 128, true_mel.contiguous().data_ptr(), true_mask.contiguous().data_ptr(),
                   heads[:, nm:].data_ptr(), 128, true_stop.contiguous().data_ptr(), m, nm, kind, ex.pos_weight,
-                  float(lm.raw_pred_loss_weight), float(lm.post_pred_loss_weight), float(lm.stop_loss_weight), g_raw.data_ptr(),
-                  g_post.data_ptr(), g_stop.data_ptr(), losses.data_ptr(), pw.data_ptr(), _s())
-        d_raw[:, :nm] = g_raw
-        d_post[:, :nm] = g_post
+                  float(lm.raw_pred_loss_weight), float(lm.post_pred_loss_weight), float(lm.stop_loss_weight), d_raw.data_ptr(),
+                  d_post.data_ptr(), 128, g_stop.data_ptr(), losses.data_ptr(), pw.data_ptr(), _s())
         ctx.ex, ctx.state = ex, (yb, wh, saved, cur, cols_end, d_raw, d_post, g_stop, b, lp, d)
         return losses
 
@@ -259,8 +252,8 @@ class _PostnetLossFn(torch.autograd.Function):
         mel, stop = ex.model.dec.mel_linear, ex.model.dec.stop_linear
         _grad(mel.bias).add_(bsum[:nm])
         _grad(stop.bias).add_(bsum[nm:nm + 1])
-        dwh = torch.zeros(128, d, dtype=torch.float32, device=dev)
-        wgrad(dwh, dhb, yb)
+        dwh = torch.empty(128, d, dtype=torch.float32, device=dev)
+        wgrad(dwh, dhb, yb, accumulate=False)
         _grad(mel.weight).add_(dwh[:nm])
         _grad(stop.weight).add_(dwh[nm:nm + 1])
         dy = torch.mm(dhb, wh).float().view(b, lp, d)

@@ -107,8 +107,8 @@ def residual(acc, g, bias, sign: float):
 _SLAB_FLOATS = 16 * 1024 * 1024   # 64 MB: 16 splits of a 2048 x 512 gradient
 
 
-def wgrad(grad_view: torch.Tensor, dy: torch.Tensor, x: torch.Tensor):
-    """grad_view (N,K) fp32 += dy(M,N)^T @ x(M,K)   (bf16 operands, fp32 accumulation).
+def wgrad(grad_view: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, accumulate: bool = True):
+    """grad_view (N,K) fp32 (+)= dy(M,N)^T @ x(M,K)   (bf16 operands, fp32 accumulation).
     Split-K kernel of csrc/gemm_tn.hip when the shape tiles (128 | N, 128 | K, 64 | M), else hipBLASLt."""
     m, n = dy.shape
     k = x.shape[1]
@@ -118,9 +118,11 @@ def wgrad(grad_view: torch.Tensor, dy: torch.Tensor, x: torch.Tensor):
             _WS._cache[key] = torch.empty(_SLAB_FLOATS, dtype=torch.float32, device=dy.device)
         ws = _WS._cache[key]
         _lib.call("rtts_gemm_tn", dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), m, n, k, grad_view.data_ptr(),
-                  grad_view.stride(0), 1, ws.data_ptr(), ws.numel(), _s())
-    else:
+                  grad_view.stride(0), int(accumulate), ws.data_ptr(), ws.numel(), _s())
+    elif accumulate:
         grad_view.add_(torch.mm(dy.t(), x, out_dtype=torch.float32))
+    else:
+        grad_view.copy_(torch.mm(dy.t(), x, out_dtype=torch.float32))
 
 
 # ------------------------------------------------------------------------------------------ blocks
@@ -341,14 +343,22 @@ def build_program(seq) -> Optional[List[tuple]]:
     return prog
 
 
-def _step_kwargs(kind, kwargs, extra):
+def _mask_u8(m, cache):
+    """bool (B,T) validity mask -> uint8, converted once per distinct tensor of a stack pass."""
+    if m is None:
+        return None
+    if id(m) not in cache:
+        cache[id(m)] = m.to(torch.uint8).contiguous()
+    return cache[id(m)]
+
+
+def _step_kwargs(kind, kwargs, extra, cache):
     """Reference kwargs routing (reformer.py:89-90,147-153) -> executor keyword arguments."""
     if kind == "block":
-        m = kwargs.get("f_args", {}).get("input_mask")
-        return dict(mask=None if m is None else m.to(torch.uint8).contiguous()), {}
+        return dict(mask=_mask_u8(kwargs.get("f_args", {}).get("input_mask"), cache)), {}
     out = {}
     if "input_mask" in kwargs and kwargs["input_mask"] is not None:
-        out["mask"] = kwargs["input_mask"].to(torch.uint8).contiguous()
+        out["mask"] = _mask_u8(kwargs["input_mask"], cache)
     if "key" in kwargs:
         out.update(extra)
     return out, None
@@ -369,9 +379,9 @@ class FusedStackFn(torch.autograd.Function):
                 kpm = next((k.get("key_padding_mask") for k in kwargs_list if "key" in k), None)
                 extra = dict(keys_bf16=context.detach().reshape(-1, d).to(torch.bfloat16),
                              kvalid=None if kpm is None else (~kpm).to(torch.uint8).contiguous())
-            steps = []
+            steps, mask_cache = [], {}
             for (kind, f, g), kwargs in zip(prog, kwargs_list):
-                kw, kwg = _step_kwargs(kind, kwargs, extra)
+                kw, kwg = _step_kwargs(kind, kwargs, extra, mask_cache)
                 steps.append((kind, f, g, kw))
                 if kind == "swap":
                     s1, s2 = s2, s1

@@ -229,12 +229,12 @@ def test_gemm_tn_vs_fp32_reference(ops, m, n, k, acc):
     c0 = torch.randn(n, k, generator=g).cuda()
     ws = torch.empty(16 * n * k, device="cuda")
     outs = []
-    for _ in range(2):
+    for _ in range(3):
         c = c0.clone()
         _lib.call("rtts_gemm_tn", a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), m, n, k, c.data_ptr(), c.stride(0),
                   int(acc), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         outs.append(c)
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     ref = a.float().t() @ b.float() + (c0 if acc else 0)
     torch.testing.assert_close(outs[0], ref, rtol=2e-4, atol=2e-2)

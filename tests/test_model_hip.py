@@ -350,7 +350,7 @@ def test_bn_act_dropout_kernels_vs_autograd(gpu, act, p):
     ws = torch.empty((2 * 256 + 2) * c, device=gpu)
     s = torch.cuda.current_stream().cuda_stream
     seed = 12345
-    _lib.call("rtts_bn_stats", y.data_ptr(), m, c, mean.data_ptr(), rstd.data_ptr(), rm.data_ptr(), rv.data_ptr(), ws.data_ptr(), s)
+    _lib.call("rtts_bn_stats", y.data_ptr(), m, c, mean.data_ptr(), rstd.data_ptr(), rm.data_ptr(), rv.data_ptr(), None, None, ws.data_ptr(), s)
     z = torch.empty(m, c, dtype=torch.bfloat16, device=gpu)
     sd = torch.tensor([77], dtype=torch.int32, device=gpu)      # device part of the seed (what a graph replay refreshes)
     _lib.call("rtts_bn_act_fwd", y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act, p, seed,
@@ -377,6 +377,17 @@ def test_bn_act_dropout_kernels_vs_autograd(gpu, act, p):
     a.backward(dz.float())
     torch.testing.assert_close(mean, y.mean(0), rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(rv, 0.9 + 0.1 * y.var(0, unbiased=True), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rm, 0.1 * y.mean(0), rtol=1e-4, atol=1e-5)
+    # the fused path keeps the conv bias out of y: it shifts the running mean only, and the launch counts the batch
+    shift, nbt = torch.randn(c, generator=g).to(gpu), torch.tensor(4, dtype=torch.int64, device=gpu)
+    rm2, rv2 = torch.zeros(c, device=gpu), torch.ones(c, device=gpu)
+    _lib.call("rtts_bn_stats", y.data_ptr(), m, c, mean.data_ptr(), rstd.data_ptr(), rm2.data_ptr(), rv2.data_ptr(), shift.data_ptr(),
+              nbt.data_ptr(), ws.data_ptr(), s)
+    bn = torch.nn.BatchNorm1d(c).to(gpu).train()
+    bn(y + shift)
+    torch.testing.assert_close(rm2, bn.running_mean, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rv2, bn.running_var, rtol=1e-4, atol=1e-5)
+    assert int(nbt) == 5
     torch.testing.assert_close(dy.float(), yr.grad, rtol=2e-2, atol=2e-2)
     torch.testing.assert_close(dgam, gr.grad, rtol=1e-3, atol=1e-2)
     torch.testing.assert_close(dbet, br.grad, rtol=1e-3, atol=1e-2)
