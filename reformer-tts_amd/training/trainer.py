@@ -20,7 +20,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.distributed as dist
 
-from .. import _lib
+from .. import _lib, engine
 from ..model import ReformerTTS, TTSLoss
 from ..model.config import ReformerTTSConfig, TTSTrainingConfig, as_kwargs
 
@@ -166,6 +166,7 @@ class Trainer:
 
     def backward(self, loss):
         loss.backward()
+        engine.join_side()
         self.finish_allreduce()
 
     def lr_now(self) -> float:
