@@ -14,12 +14,11 @@
 // B operand of the dV^T and G^T products (contraction over the register/row index), so dV and dK
 // of a key are complete inside one wave, in registers.  Only dS crosses LDS, once, as dS^T, for
 // dQ^T = K^T dS'^T (wave w finishes (query tile w/2, dh half w%2)).  Nothing is accumulated across workgroups:
-// each workgroup writes its rows of three dqk slots / two dv slots at UNSORTED positions
-// (slot 0: query role, slot 1: key role own chunk, slot 2: key role looked-back chunk) and
-// rtts_lsh_bwd_reduce sums slots and rounds -- deterministic, no atomics.
+// each workgroup writes its rows of two dqk slots / two dv slots at UNSORTED positions (slot 0: the own chunk's
+// rows, query role + key role added on chip; slot 1: key role of the looked-back chunk's rows), every row of every
+// slot exactly once, and rtts_lsh_bwd_reduce sums slots and rounds -- deterministic, no atomics.
 #include "rtts_common.h"
 #include <float.h>
-#include <stdlib.h>
 
 #define AB_DH 64
 #define AB_ROWB 144
@@ -38,7 +37,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
     const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v, int64_t ld, const int32_t* __restrict__ st,
     const uint8_t* __restrict__ mask, const bf16_t* __restrict__ dout, int64_t ld_do, const float* __restrict__ lse_tot,
     const float* __restrict__ delta, int H, int T, int n_hashes, bf16_t* __restrict__ dqk_part, bf16_t* __restrict__ dv_part,
-    size_t slot_stride, int dbg_stop) {
+    size_t slot_stride) {
     constexpr int NK = 2 * BS;
     constexpr int NQT = BS / 32;
     constexpr int NTHR = BS * 4;
@@ -125,7 +124,6 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
         }
     }
     __syncthreads();
-    if (dbg_stop == 1) { if (kscale[tid & 63] == 12345.f) dqk_part[0] = 1; return; }
 
     // ---- this wave's key-side constants -----------------------------------------------------
     bf16x8 kf[KT2][4];
@@ -235,52 +233,11 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
         }
     }
 
-    if (dbg_stop == 2) { if (dvacc[0][0][0] + gacc[0][1][3] == 12345.f) dqk_part[0] = 1; return; }
-    // ---- key-side outputs: dV and dK of this wave's 64 keys -----------------------------------
-    const int round = c / nb, round_prev = cprev / nb;
-#pragma unroll
-    for (int k2 = 0; k2 < KT2; ++k2) {
-        const bool own = myrow[k2] < BS;   // wave-uniform
-        const size_t orow = ((size_t)bh * n_hashes + (own ? round : round_prev)) * T + mypos[k2];
-        bf16_t* dvp = dv_part + (own ? 0 : slot_stride) + orow * AB_DH;
-        bf16_t* dkp = dqk_part + (own ? slot_stride : 2 * slot_stride) + orow * AB_DH;
-        // k^ . G over the 64 dh (this lane holds 32 of them, the partner half the other 32)
-        float kv_[2][16];
-        float dot = 0.f;
-        const float inv_norm = ksc[k2] * 8.f;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const uint2 kk = *reinterpret_cast<const uint2*>(Ks + myrow[k2] * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2);
-                kv_[dt][4 * g] = __uint_as_float(kk.x << 16) * inv_norm;
-                kv_[dt][4 * g + 1] = __uint_as_float(kk.x & 0xffff0000u) * inv_norm;
-                kv_[dt][4 * g + 2] = __uint_as_float(kk.y << 16) * inv_norm;
-                kv_[dt][4 * g + 3] = __uint_as_float(kk.y & 0xffff0000u) * inv_norm;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dot = __builtin_fmaf(kv_[dt][4 * g + j], gacc[k2][dt][4 * g + j], dot);
-            }
-        dot += __shfl_xor(dot, 32);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float dk[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dk[j] = gacc[k2][dt][4 * g + j] - kv_[dt][4 * g + j] * dot;
-                uint2 pk;
-                pk.x = pack_bf16x2(dk[0], dk[1]);
-                pk.y = pack_bf16x2(dk[2], dk[3]);
-                *reinterpret_cast<uint2*>(dkp + dt * 32 + 8 * g + 4 * hh) = pk;
-                pk.x = pack_bf16x2(dvacc[k2][dt][4 * g], dvacc[k2][dt][4 * g + 1]);
-                pk.y = pack_bf16x2(dvacc[k2][dt][4 * g + 2], dvacc[k2][dt][4 * g + 3]);
-                *reinterpret_cast<uint2*>(dvp + dt * 32 + 8 * g + 4 * hh) = pk;
-            }
-    }
-    __syncthreads();
+    __syncthreads();   // every dS'^T tile is in Ds; nobody reads Os as dout any more
 
-    if (dbg_stop == 3) return;
-    // ---- dQ^T[dh][q] = K^T dS'^T over all 2*BS keys: wave w finishes (query tile w/2, dh half w%2) ----
+    // ---- dQ^T[dh][q] = K^T dS'^T over all 2*BS keys: wave w finishes (query tile w/2, dh half w%2) and parks it
+    //      (bf16) in the dout image's rows: a chunk row is both a query and an own key, so its query-role and
+    //      key-role gradients are added before they leave the chip
     {
         const int qt = wave >> 1, dt = wave & 1;
         f32x16 dq = {0};
@@ -293,15 +250,89 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
             const bf16x8 afrag = tr_frag(Ks + keyr * AB_ROWB + col, Ks + (keyr + 4) * AB_ROWB + col);
             dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, dq, 0, 0, 0);
         }
-        const int qpos = kpos[qt * 32 + r];
-        bf16_t* dqp = dqk_part + (((size_t)bh * n_hashes + round) * T + qpos) * AB_DH;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             uint2 pk;
             pk.x = pack_bf16x2(dq[4 * g], dq[4 * g + 1]);
             pk.y = pack_bf16x2(dq[4 * g + 2], dq[4 * g + 3]);
-            *reinterpret_cast<uint2*>(dqp + dt * 32 + 8 * g + 4 * hh) = pk;
+            *reinterpret_cast<uint2*>(Os + (qt * 32 + r) * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2) = pk;
         }
+    }
+    __syncthreads();   // dQ parked; Ds is free: it becomes the per-wave staging of the row stores below
+
+    // ---- key-side outputs: dK (+ dQ on own rows) and dV of this wave's 32 keys.  The accumulators hold a key per
+    //      lane and dh down the registers; each tile goes through a [32][144 B] LDS staging so that a row leaves as
+    //      eight 16-byte pieces (full 128-byte lines) instead of sixteen scattered 8-byte stores.
+    const int round = c / nb, round_prev = cprev / nb;
+    static_assert(KT2 == 1, "one key tile per wave");
+    {
+        const bool own = myrow[0] < BS;   // wave-uniform
+        const size_t obase = ((size_t)bh * n_hashes + (own ? round : round_prev)) * T;
+        bf16_t* dkdst = dqk_part + (own ? 0 : slot_stride);
+        bf16_t* dvdst = dv_part + (own ? 0 : slot_stride);
+        unsigned char* stg = Ds + wave * (32 * AB_ROWB);
+        // k^ . G over the 64 dh (this lane holds 32 of them, the partner half the other 32)
+        float kv_[2][16];
+        float dot = 0.f;
+        const float inv_norm = ksc[0] * 8.f;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint2 kk = *reinterpret_cast<const uint2*>(Ks + myrow[0] * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2);
+                kv_[dt][4 * g] = __uint_as_float(kk.x << 16) * inv_norm;
+                kv_[dt][4 * g + 1] = __uint_as_float(kk.x & 0xffff0000u) * inv_norm;
+                kv_[dt][4 * g + 2] = __uint_as_float(kk.y << 16) * inv_norm;
+                kv_[dt][4 * g + 3] = __uint_as_float(kk.y & 0xffff0000u) * inv_norm;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dot = __builtin_fmaf(kv_[dt][4 * g + j], gacc[0][dt][4 * g + j], dot);
+            }
+        dot += __shfl_xor(dot, 32);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float dk[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dk[j] = gacc[0][dt][4 * g + j] - kv_[dt][4 * g + j] * dot;
+                if (own) {
+                    const uint2 dqv = *reinterpret_cast<const uint2*>(Os + myrow[0] * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2);
+                    dk[0] += __uint_as_float(dqv.x << 16);
+                    dk[1] += __uint_as_float(dqv.x & 0xffff0000u);
+                    dk[2] += __uint_as_float(dqv.y << 16);
+                    dk[3] += __uint_as_float(dqv.y & 0xffff0000u);
+                }
+                uint2 pk;
+                pk.x = pack_bf16x2(dk[0], dk[1]);
+                pk.y = pack_bf16x2(dk[2], dk[3]);
+                *reinterpret_cast<uint2*>(stg + r * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2) = pk;
+            }
+        __builtin_amdgcn_wave_barrier();
+        const int srow = lane >> 3, spiece = lane & 7;
+        uint4 rowv[4];
+        int rpos[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rowv[i] = *reinterpret_cast<const uint4*>(stg + (i * 8 + srow) * AB_ROWB + spiece * 16);
+            rpos[i] = kpos[wave * 32 + i * 8 + srow];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dkdst + (obase + rpos[i]) * AB_DH + spiece * 8) = rowv[i];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 pk;
+                pk.x = pack_bf16x2(dvacc[0][dt][4 * g], dvacc[0][dt][4 * g + 1]);
+                pk.y = pack_bf16x2(dvacc[0][dt][4 * g + 2], dvacc[0][dt][4 * g + 3]);
+                *reinterpret_cast<uint2*>(stg + r * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2) = pk;
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rowv[i] = *reinterpret_cast<const uint4*>(stg + (i * 8 + srow) * AB_ROWB + spiece * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dvdst + (obase + rpos[i]) * AB_DH + spiece * 8) = rowv[i];
     }
 }
 
@@ -316,7 +347,6 @@ static int launch_attn_bwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const 
     const dim3 grid(B * H * n_hashes * (T / BS)), block(BS * 4);
     const size_t slot_stride = (size_t)B * H * n_hashes * T * AB_DH;
     const int vi = (causal ? 2 : 0) + (mask ? 1 : 0);
-    static const int dbg_stop = getenv("RTTS_BWD_STOP") ? atoi(getenv("RTTS_BWD_STOP")) : 0;   // diagnostics only
 #define AB_GO(C_, M_)                                                                                                      \
     do {                                                                                                                   \
         auto kern = lsh_attn_bwd_kernel<BS, C_, M_>;                                                                       \
@@ -325,7 +355,7 @@ static int launch_attn_bwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const 
             g_bwd_attr_set[BS == 128][vi] = true;                                                                          \
         }                                                                                                                  \
         hipLaunchKernelGGL(kern, grid, block, lds, stream, qk, v, ld, st, mask, dout, ld_do, lse_tot, delta, H, T, n_hashes, \
-                           dqk_part, dv_part, slot_stride, dbg_stop);                                                      \
+                           dqk_part, dv_part, slot_stride);                                                                \
     } while (0)
     if (causal) {
         if (mask) AB_GO(true, true); else AB_GO(true, false);

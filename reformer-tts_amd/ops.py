@@ -130,7 +130,7 @@ def lsh_attn_bwd(qk, v, st, out, dout, lse_tot, heads: int, bucket_size: int, ca
                  dqkv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, undo: Optional[torch.Tensor] = None):
     """Backward of hash-sorted attention + round combine.  -> dqk, dv (B,T,H*dh) bf16.
     With ``undo`` (token -> sorted slot, from ``lsh_hash_sort(want_undo=True)``) the ring kernels run (each row
-    gathered once, 3 complete gradient slots); without it the per-chunk kernels with 5 partial slots."""
+    gathered once, 3 complete gradient slots); without it the per-chunk kernels with 4 partial slots."""
     if undo is not None:
         return _lsh_attn_bwd_ring(qk, v, st, undo, out, dout, lse_tot, heads, bucket_size, causal, mask, dqkv)
     ld = _check_rows(qk, "qk")
@@ -144,7 +144,7 @@ def lsh_attn_bwd(qk, v, st, out, dout, lse_tot, heads: int, bucket_size: int, ca
     dev = qk.device
     delta = torch.empty(b * heads, t, dtype=torch.float32, device=dev)
     _lib.call("rtts_lsh_bwd_delta", out.data_ptr(), ld_out, dout.data_ptr(), ld_do, b, heads, t, dh, delta.data_ptr(), _stream())
-    dqk_part = torch.empty(3, b * heads, n_hashes, t, dh, dtype=torch.bfloat16, device=dev)
+    dqk_part = torch.empty(2, b * heads, n_hashes, t, dh, dtype=torch.bfloat16, device=dev)
     dv_part = torch.empty(2, b * heads, n_hashes, t, dh, dtype=torch.bfloat16, device=dev)
     ev = TIMING.start(f"rtts_lsh_attn_bwd/bs{bucket_size}")
     _lib.call("rtts_lsh_attn_bwd", qk.data_ptr(), v.data_ptr(), ld, st.data_ptr(), _ptr(mask), dout.data_ptr(), ld_do,

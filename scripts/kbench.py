@@ -60,7 +60,7 @@ def main():
             res["combine"] = (us, f"{tok * (nh * 132 + 132) / us / 1e3:8.1f} GB/s alg")
         if not only or "bwd" in only:
             delta = torch.empty(b * h, t, device=dev)
-            dqk_part = torch.empty(3, b * h, nh, t, dh, dtype=torch.bfloat16, device=dev)
+            dqk_part = torch.empty(2, b * h, nh, t, dh, dtype=torch.bfloat16, device=dev)
             dv_part = torch.empty(2, b * h, nh, t, dh, dtype=torch.bfloat16, device=dev)
             s = torch.cuda.current_stream().cuda_stream
             ld = qkv.stride(1)
@@ -95,7 +95,7 @@ def main():
                 _lib.call("rtts_lsh_bwd_reduce", dqk_part.data_ptr(), dv_part.data_ptr(), b, h, t, dh, nh, dqk.data_ptr(),
                           dv.data_ptr(), dqk.stride(1), s)
             us = timeit(red, args.iters)
-            res["bwd_reduce"] = (us, f"{tok * (5 * nh * 128 + 256) / us / 1e3:8.1f} GB/s alg")
+            res["bwd_reduce"] = (us, f"{tok * (4 * nh * 128 + 256) / us / 1e3:8.1f} GB/s alg")
         for k, (us, extra) in res.items():
             print(f"{name:5s} {k:14s} {us:9.1f} us  {extra}", flush=True)
 
