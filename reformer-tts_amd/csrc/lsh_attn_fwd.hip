@@ -206,10 +206,12 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
     }
 
     // ---- 5. write o, lse at the unsorted position ------------------------------------------
+    // The accumulator holds a query per lane and dh down the registers; the tile goes through a [32][144 B] LDS
+    // staging (the V image is dead by now) so that a row leaves as eight 16-byte pieces = one full 128-byte line.
     const int round = c / nb;
     const float inv_l = 1.f / l;
-    const size_t orow = ((size_t)bh * n_hashes + round) * T + qpos;
-    bf16_t* optr = o + orow * AF_DH;
+    const size_t obase = ((size_t)bh * n_hashes + round) * T;
+    unsigned char* stg = Vs + qt * (32 * AF_ROWB);
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
 #pragma unroll
@@ -217,10 +219,21 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
             uint2 pk;
             pk.x = pack_bf16x2(oacc[dt][4 * g] * inv_l, oacc[dt][4 * g + 1] * inv_l);
             pk.y = pack_bf16x2(oacc[dt][4 * g + 2] * inv_l, oacc[dt][4 * g + 3] * inv_l);
-            *reinterpret_cast<uint2*>(optr + dt * 32 + 8 * g + 4 * hh) = pk;
+            *reinterpret_cast<uint2*>(stg + r * AF_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2) = pk;
         }
     }
-    if (hh == 0) lse[orow] = (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;   // v_log_f32 is log2
+    if (hh == 0) lse[obase + qpos] = (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;   // v_log_f32 is log2
+    __builtin_amdgcn_wave_barrier();
+    const int srow = lane >> 3, spiece = lane & 7;
+    uint4 rowv[4];
+    int rpos[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        rowv[i] = *reinterpret_cast<const uint4*>(stg + (i * 8 + srow) * AF_ROWB + spiece * 16);
+        rpos[i] = kpos[qt * 32 + i * 8 + srow];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(o + (obase + rpos[i]) * AF_DH + spiece * 8) = rowv[i];
 }
 
 static bool g_fwd_attr_set[2][4];
