@@ -212,6 +212,18 @@ int rtts_embedding_bwd(const int64_t* ids, const float* dx, int rows, int C, int
 int rtts_gemm_tn(const void* a, int64_t lda, const void* b, int64_t ldb, int M, int N, int K, float* c, int64_t ldc,
                  int accumulate, float* slab_ws, int64_t slab_ws_floats, void* stream);
 
+/* Up to RTTS_GEMM_TN_MAX_GROUP independent weight gradients in ONE pair of launches (the deferred gradients of a
+ * reversible layer): the grid holds every problem's tiles, so the split factor -- and with it the slab traffic --
+ * drops to what the whole group needs to fill the chip.  Same arithmetic per problem as rtts_gemm_tn. */
+#define RTTS_GEMM_TN_MAX_GROUP 8
+typedef struct {
+    const void* a; int64_t lda;    /* dY (M x N) bf16 */
+    const void* b; int64_t ldb;    /* X  (M x K) bf16 */
+    float* c;      int64_t ldc;    /* dW (N x K) fp32 */
+    int32_t M, N, K, accumulate;
+} rtts_gemm_tn_problem;
+int rtts_gemm_tn_grouped(const rtts_gemm_tn_problem* problems, int n, float* slab_ws, int64_t slab_ws_floats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,14 @@ LIB_PATH = os.path.join(_HERE, "lib", "librtts_hip.so")
 
 _i64, _i32, _vp, _f32, _u32 = C.c_int64, C.c_int, C.c_void_p, C.c_float, C.c_uint32
 
+class GemmTnProblem(C.Structure):
+    """rtts_gemm_tn_problem of include/rtts.h."""
+    _fields_ = [("a", _vp), ("lda", _i64), ("b", _vp), ("ldb", _i64), ("c", _vp), ("ldc", _i64),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("accumulate", C.c_int32)]
+
+
+GEMM_TN_MAX_GROUP = 8
+
 # name -> argtypes, exactly the prototypes of include/rtts.h
 SIGNATURES = {
     "rtts_lsh_hash_sort": [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
@@ -46,6 +54,7 @@ SIGNATURES = {
     "rtts_relu_drop": [_vp, _f32, _u32, _vp, _i64, _vp],
     "rtts_embedding_bwd": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],
     "rtts_gemm_tn": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _i32, _vp, _i64, _vp],
+    "rtts_gemm_tn_grouped": [C.POINTER(GemmTnProblem), _i32, _vp, _i64, _vp],
     "rtts_adamw_step": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _f32, _f32, _vp],
 }
 

@@ -13,6 +13,11 @@
 // ds_read_b64_tr_b16 (hardware transpose), exactly like the dQ phase of lsh_attn_bwd.hip.
 // Staging is register double-buffered: the next 64-row stage is in flight while the current one feeds
 // the MFMAs (issue early / write late).
+//
+// GROUPED launches: the weight gradients of one reversible layer (7 of them in a decoder layer) are leaves of the
+// backward -- nothing reads them before the all-reduce/optimizer -- so the executor defers them and launches them
+// together.  One grid then holds 240 tiles instead of 16..64, the split factor drops from 8..32 to 2, and the fp32
+// slab traffic (split x output size, written and read back) drops ~7x; per-launch ramp-up and tails are paid once.
 #include "rtts_common.h"
 
 #define GT_BN 128      // output rows  (N)
@@ -30,16 +35,42 @@ __device__ __forceinline__ bf16x8 gt_tr_frag(const unsigned char* p0, const unsi
     return __builtin_bit_cast(bf16x8, both);
 }
 
-__global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const bf16_t* __restrict__ a, int64_t lda,
-                                                                const bf16_t* __restrict__ b, int64_t ldb, int M, int N, int K,
-                                                                int split, float* __restrict__ out, int64_t ldo,
-                                                                size_t slab_stride, int accumulate) {
+struct GtProb {
+    const bf16_t* a;
+    const bf16_t* b;
+    float* out;          // split == 1: C itself; else this problem's slab area
+    float* c;
+    int64_t lda, ldb, ldo, ldc;
+    size_t slab_stride;  // N*K
+    int M, N, K, split, accumulate;
+    int wg_start;        // first workgroup of this problem in the main grid
+    int rb_start;        // first block of this problem in the slab-reduce grid
+};
+struct GtGroup {
+    GtProb p[RTTS_GEMM_TN_MAX_GROUP];
+    int n;
+};
+
+__global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const GtGroup grp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem;                          // [2][64][272]
     unsigned char* Bs = smem + 2 * GT_BM * GT_ROWB;    // [2][64][272]
 
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < RTTS_GEMM_TN_MAX_GROUP; ++i)
+        if (i < grp.n && (int)blockIdx.x >= grp.p[i].wg_start) pi = i;
+    const GtProb& P = grp.p[pi];
+    const bf16_t* __restrict__ a = P.a;
+    const bf16_t* __restrict__ b = P.b;
+    float* __restrict__ out = P.out;
+    const int64_t lda = P.lda, ldb = P.ldb, ldo = P.ldo;
+    const int M = P.M, K = P.K, split = P.split, accumulate = P.accumulate;
+    const size_t slab_stride = P.slab_stride;
+    const int blk = (int)blockIdx.x - P.wg_start;
+
     const int tiles_k = K / GT_BK;
-    const int tile = blockIdx.x / split, sp = blockIdx.x % split;
+    const int tile = blk / split, sp = blk % split;
     const int n0 = (tile / tiles_k) * GT_BN, k0 = (tile % tiles_k) * GT_BK;
     const int rows_per = M / split;                    // multiple of 64 (checked on the host)
     const int m_begin = sp * rows_per, nstage = rows_per / GT_BM;
@@ -130,21 +161,27 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const bf16_t* __
         }
 }
 
-// c[n][k] (+)= sum over slabs, fixed order; 4 floats per thread
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int nslabs, size_t slab_stride, int N, int K,
-                                                          float* __restrict__ c, int64_t ldc, int accumulate) {
-    const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total4 = (size_t)N * K / 4;
+// c[n][k] (+)= sum over slabs, fixed order; 4 floats per thread; one launch for every split problem of the group
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const GtGroup grp) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < RTTS_GEMM_TN_MAX_GROUP; ++i)
+        if (i < grp.n && (int)blockIdx.x >= grp.p[i].rb_start) pi = i;
+    const GtProb& P = grp.p[pi];
+    if (P.split == 1) return;                  // wrote C directly (its rb range is empty anyway)
+    const size_t i4 = (size_t)((int)blockIdx.x - P.rb_start) * blockDim.x + threadIdx.x;
+    const size_t total4 = P.slab_stride / 4;
     if (i4 >= total4) return;
     const size_t e = i4 * 4;
-    const int n = (int)(e / K), k = (int)(e % K);
+    const int n = (int)(e / P.K), k = (int)(e % P.K);
+    const float* __restrict__ slabs = P.out;
     float4 s = *reinterpret_cast<const float4*>(slabs + e);
-    for (int t = 1; t < nslabs; ++t) {
-        const float4 v = *reinterpret_cast<const float4*>(slabs + (size_t)t * slab_stride + e);
+    for (int t = 1; t < P.split; ++t) {
+        const float4 v = *reinterpret_cast<const float4*>(slabs + (size_t)t * P.slab_stride + e);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    float4* dst = reinterpret_cast<float4*>(c + (size_t)n * ldc + k);
-    if (accumulate) {
+    float4* dst = reinterpret_cast<float4*>(P.c + (size_t)n * P.ldc + k);
+    if (P.accumulate) {
         const float4 o = *dst;
         s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
     }
@@ -153,38 +190,69 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 
 static bool g_gt_attr = false;
 
-extern "C" int rtts_gemm_tn(const void* a, int64_t lda, const void* b, int64_t ldb, int M, int N, int K, float* c, int64_t ldc,
-                            int accumulate, float* slab_ws, int64_t slab_ws_floats, void* stream) {
-    RTTS_REQUIRE(a && b && c, "rtts_gemm_tn: null pointer");
-    RTTS_REQUIRE(N > 0 && K > 0 && M > 0 && N % GT_BN == 0 && K % GT_BK == 0 && M % GT_BM == 0,
-                 "rtts_gemm_tn: need N %% 128 == 0, K %% 128 == 0, M %% 64 == 0 (got M=%d N=%d K=%d)", M, N, K);
-    RTTS_REQUIRE(lda >= N && ldb >= K && ldc >= K && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "rtts_gemm_tn: bad leading dimensions");
-    RTTS_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0, "rtts_gemm_tn: buffers must be 16-byte aligned");
-    const int tiles = (N / GT_BN) * (K / GT_BK);
-    // split the token range so that the grid is ~2 workgroups per CU, each with >= 4 stages
-    int split = 1;
-    const int stages = M / GT_BM;
-    while (tiles * split < 512 && split * 2 <= stages / 4 && stages % (split * 2) == 0) split *= 2;
-    const size_t slab = (size_t)N * K;
-    if (split > 1 && (!slab_ws || (size_t)slab_ws_floats < slab * split)) {
-        RTTS_REQUIRE(slab_ws != nullptr, "rtts_gemm_tn: split-K needs a slab workspace");
-        while (split > 1 && (size_t)slab_ws_floats < slab * split) split /= 2;
+extern "C" int rtts_gemm_tn_grouped(const rtts_gemm_tn_problem* problems, int n, float* slab_ws, int64_t slab_ws_floats, void* stream) {
+    RTTS_REQUIRE(problems && n > 0 && n <= RTTS_GEMM_TN_MAX_GROUP, "rtts_gemm_tn_grouped: 1..%d problems", RTTS_GEMM_TN_MAX_GROUP);
+    GtGroup grp;
+    grp.n = n;
+    int total_tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        const rtts_gemm_tn_problem& q = problems[i];
+        RTTS_REQUIRE(q.a && q.b && q.c, "rtts_gemm_tn: null pointer");
+        RTTS_REQUIRE(q.N > 0 && q.K > 0 && q.M > 0 && q.N % GT_BN == 0 && q.K % GT_BK == 0 && q.M % GT_BM == 0,
+                     "rtts_gemm_tn: need N %% 128 == 0, K %% 128 == 0, M %% 64 == 0 (got M=%d N=%d K=%d)", q.M, q.N, q.K);
+        RTTS_REQUIRE(q.lda >= q.N && q.ldb >= q.K && q.ldc >= q.K && q.lda % 8 == 0 && q.ldb % 8 == 0 && q.ldc % 4 == 0,
+                     "rtts_gemm_tn: bad leading dimensions");
+        RTTS_REQUIRE((((uintptr_t)q.a | (uintptr_t)q.b | (uintptr_t)q.c) & 15) == 0, "rtts_gemm_tn: buffers must be 16-byte aligned");
+        total_tiles += (q.N / GT_BN) * (q.K / GT_BK);
+    }
+    // one split target for the group: ~2 workgroups per CU over all problems, each workgroup with >= 4 stages
+    int want = 1;
+    while (total_tiles * want * 2 <= 640) want *= 2;
+    int wg = 0, rb = 0;
+    size_t slab_used = 0;
+    bool any_split = false;
+    for (int i = 0; i < n; ++i) {
+        const rtts_gemm_tn_problem& q = problems[i];
+        GtProb& P = grp.p[i];
+        const int tiles = (q.N / GT_BN) * (q.K / GT_BK), stages = q.M / GT_BM;
+        const size_t slab = (size_t)q.N * q.K;
+        int split = 1;
+        while (split < want && split * 2 <= stages / 4 && stages % (split * 2) == 0) split *= 2;
+        while (split > 1 && (!slab_ws || slab_used + slab * split > (size_t)slab_ws_floats)) split /= 2;
+        P.a = (const bf16_t*)q.a; P.b = (const bf16_t*)q.b; P.c = q.c;
+        P.lda = q.lda; P.ldb = q.ldb; P.ldc = q.ldc;
+        P.M = q.M; P.N = q.N; P.K = q.K; P.split = split; P.accumulate = q.accumulate;
+        P.slab_stride = slab;
+        P.wg_start = wg;
+        P.rb_start = rb;
+        wg += tiles * split;
+        if (split > 1) {
+            P.out = slab_ws + slab_used;
+            P.ldo = q.K;
+            slab_used += slab * split;
+            rb += (int)((slab / 4 + 255) / 256);
+            any_split = true;
+        } else {
+            P.out = q.c;
+            P.ldo = q.ldc;
+        }
     }
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = 4 * GT_BM * GT_ROWB;
     if (!g_gt_attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         g_gt_attr = true;
     }
-    if (split == 1) {
-        hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles), dim3(GT_THREADS), lds, s, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, M, N, K, 1,
-                           c, ldc, (size_t)0, accumulate);
-    } else {
-        hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * split), dim3(GT_THREADS), lds, s, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, M, N,
-                           K, split, slab_ws, (int64_t)K, slab, 0);
-        const unsigned blocks = (unsigned)((slab / 4 + 255) / 256);
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, slab_ws, split, slab, N, K, c, ldc, accumulate);
-    }
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(wg), dim3(GT_THREADS), lds, s, grp);
+    if (any_split) hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(256), 0, s, grp);
     RTTS_LAUNCH_CHECK("rtts_gemm_tn");
     return 0;
+}
+
+extern "C" int rtts_gemm_tn(const void* a, int64_t lda, const void* b, int64_t ldb, int M, int N, int K, float* c, int64_t ldc,
+                            int accumulate, float* slab_ws, int64_t slab_ws_floats, void* stream) {
+    rtts_gemm_tn_problem q;
+    q.a = a; q.lda = lda; q.b = b; q.ldb = ldb; q.c = c; q.ldc = ldc;
+    q.M = M; q.N = N; q.K = K; q.accumulate = accumulate;
+    return rtts_gemm_tn_grouped(&q, 1, slab_ws, slab_ws_floats, stream);
 }

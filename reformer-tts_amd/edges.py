@@ -20,7 +20,7 @@ from typing import List
 import torch
 
 from . import _lib
-from .engine import WEIGHT_EPOCH, _WS, _bf16, _grad, cast_colsum, join_side, wgrad
+from .engine import WEIGHT_EPOCH, _WS, _bf16, _grad, cast_colsum, wgrad
 
 _seed_counter = itertools.count(1)
 _SEED_BASE = {}     # device -> u32 tensor added to every dropout seed inside the kernels (rewritten by the trainer each step,
@@ -312,7 +312,6 @@ class _ProjPEFn(torch.autograd.Function):
         dyb = cast_colsum(dy, _grad(lin.bias))
         wgrad(_grad(lin.weight), dyb, z2)
         dz = torch.mm(dyb, _bf16(lin.weight))
-        join_side()
         return dz.view(b, l, k), None, None, None
 
 
@@ -339,9 +338,7 @@ class _ReluDropLinearFn(torch.autograd.Function):
         dh = dh.to(torch.bfloat16).contiguous().clone() if dh.dtype != torch.bfloat16 or not dh.is_contiguous() else dh.clone()
         colsum_bf16(dh, _grad(lin.bias), h, 1.0 / (1.0 - p))        # gate (h > 0) * 1/(1-p) in place + bias gradient
         wgrad(_grad(lin.weight), dh, x)
-        dx = torch.mm(dh, _bf16(lin.weight)) if ctx.needs_input_grad[0] else None
-        join_side()
-        return dx, None, None, None
+        return (torch.mm(dh, _bf16(lin.weight)) if ctx.needs_input_grad[0] else None), None, None, None
 
 
 def decoder_prenet_pe(prenet, pe, spec):

@@ -106,51 +106,67 @@ def residual(acc, g, bias, sign: float):
 
 _SLAB_FLOATS = 16 * 1024 * 1024   # 64 MB: 16 splits of a 2048 x 512 gradient
 
-# Weight gradients are leaves of the backward's dependency graph: nothing downstream reads them before the block's
-# all-reduce / the optimizer.  With SIDE_WGRAD they are launched on a second HIP stream (forked from and joined to the
-# main stream by events, which a captured hipGraph turns into parallel branches); their operands are held until the
-# join.  Measured on MI355X (round 1, B=12, hipGraph replay): 9.35 ms/step against 8.94 ms single-stream -- the
-# cross-branch dependencies of the replayed graph cost more than the overlapped tails recover -- so it is off.
-SIDE_WGRAD = False
+# Weight gradients are leaves of the backward's dependency graph: nothing reads them before the block's all-reduce /
+# the optimizer.  With DEFER_WGRAD they are queued (operands held) and launched together, up to 8 per grouped
+# rtts_gemm_tn_grouped call: one grid of ~240 tiles per decoder layer instead of seven grids of 16..64 tiles, so the
+# split factor and the fp32 slab traffic drop ~7x and launch ramps/tails are paid once per layer.
+DEFER_WGRAD = True
+# (A second HIP stream for the weight gradients, forked/joined by events = parallel branches of the captured hipGraph,
+#  was measured SLOWER on MI355X in round 1: 9.35 vs 8.94 ms/step; the cross-branch dependencies of the replayed graph
+#  cost more than the overlapped tails recover.  Removed.)
+_PENDING = []      # (grad_view, dy, x)
+_FINAL_FLUSH_QUEUED = [False]
 
 
-class _Side:
-    streams = {}
-    pending = []
-
-    @classmethod
-    def stream(cls, device):
-        if device not in cls.streams:
-            cls.streams[device] = torch.cuda.Stream(device=device)
-        return cls.streams[device]
+def _final_flush():
+    _FINAL_FLUSH_QUEUED[0] = False
+    flush_wgrad()
 
 
-def join_side():
-    """Main stream waits for the weight-gradient stream; releases the operands held for it."""
-    if _Side.pending:
-        dev = _Side.pending[0][0].device
-        torch.cuda.current_stream(dev).wait_stream(_Side.stream(dev))
-        _Side.pending.clear()
+def _slab_ws(device):
+    key = ("slab", device)
+    if key not in _WS._cache:
+        _WS._cache[key] = torch.empty(_SLAB_FLOATS, dtype=torch.float32, device=device)
+    return _WS._cache[key]
+
+
+def flush_wgrad():
+    """Launch every queued weight gradient (grouped), release the held operands."""
+    while _PENDING:
+        group = _PENDING[:_lib.GEMM_TN_MAX_GROUP]
+        del _PENDING[:len(group)]
+        arr = (_lib.GemmTnProblem * len(group))()
+        for q, (gv, dy, x) in zip(arr, group):
+            q.a, q.lda, q.b, q.ldb, q.c, q.ldc = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), gv.data_ptr(), gv.stride(0)
+            q.M, q.N, q.K, q.accumulate = dy.shape[0], dy.shape[1], x.shape[1], 1
+        ws = _slab_ws(group[0][1].device)
+        _lib.call("rtts_gemm_tn_grouped", arr, len(group), ws.data_ptr(), ws.numel(), _s())
+
+
+def pending_wgrads() -> int:
+    return len(_PENDING)
 
 
 def wgrad(grad_view: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, accumulate: bool = True):
     """grad_view (N,K) fp32 (+)= dy(M,N)^T @ x(M,K)   (bf16 operands, fp32 accumulation).
-    Split-K kernel of csrc/gemm_tn.hip when the shape tiles (128 | N, 128 | K, 64 | M), else hipBLASLt."""
+    Split-K kernel of csrc/gemm_tn.hip when the shape tiles (128 | N, 128 | K, 64 | M), else hipBLASLt.
+    Accumulating calls are queued under DEFER_WGRAD (see flush_wgrad); dy and x must not be written afterwards."""
     m, n = dy.shape
     k = x.shape[1]
     if n % 128 == 0 and k % 128 == 0 and m % 64 == 0 and dy.stride(1) == 1 and x.stride(1) == 1 and grad_view.stride(1) == 1:
-        key = ("slab", dy.device)
-        if key not in _WS._cache:
-            _WS._cache[key] = torch.empty(_SLAB_FLOATS, dtype=torch.float32, device=dy.device)
-        ws = _WS._cache[key]
-        stream = _s()
-        if SIDE_WGRAD and accumulate:
-            side = _Side.stream(dy.device)
-            side.wait_stream(torch.cuda.current_stream(dy.device))
-            _Side.pending.append((dy, x, grad_view))
-            stream = side.cuda_stream
+        if DEFER_WGRAD and accumulate:
+            _PENDING.append((grad_view, dy, x))
+            if not _FINAL_FLUSH_QUEUED[0]:
+                # whatever is still queued when the running autograd pass ends is launched by the engine's callback
+                try:
+                    torch.autograd.Variable._execution_engine.queue_callback(_final_flush)
+                    _FINAL_FLUSH_QUEUED[0] = True
+                except RuntimeError:          # not inside a backward pass: the caller flushes
+                    pass
+            return
+        ws = _slab_ws(dy.device)
         _lib.call("rtts_gemm_tn", dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), m, n, k, grad_view.data_ptr(),
-                  grad_view.stride(0), int(accumulate), ws.data_ptr(), ws.numel(), stream)
+                  grad_view.stride(0), int(accumulate), ws.data_ptr(), ws.numel(), _s())
     elif accumulate:
         grad_view.add_(torch.mm(dy.t(), x, out_dtype=torch.float32))
     else:
@@ -437,6 +453,7 @@ class FusedStackFn(torch.autograd.Function):
             if has_ctx:
                 dkeys = torch.zeros(extra["keys_bf16"].shape, dtype=torch.float32, device=dout.device)
                 extra = dict(extra, dkeys=dkeys)
+            done = []
             for i in range(len(steps) - 1, -1, -1):
                 kind, f, g, kw = steps[i]
                 if kind == "swap":
@@ -448,9 +465,14 @@ class FusedStackFn(torch.autograd.Function):
                 else:
                     g.backward(s2, s1, g2, g1, b, t)
                     f.backward(s1, s2, g1, g2, b, t, **kw)
-                if seq.block_done_hook is not None:
-                    join_side()                      # the hook all-reduces this block's gradient slices
-                    seq.block_done_hook(seq, i)
-            join_side()
+                done.append(i)
+                if pending_wgrads() >= 7 or i == 0:
+                    # one grouped launch per layer's worth of weight gradients; only then are the finished blocks'
+                    # gradient slices final, so their all-reduce hooks run here
+                    flush_wgrad()
+                    if seq.block_done_hook is not None:
+                        for j in done:
+                            seq.block_done_hook(seq, j)
+                    done.clear()
             dx = (g1 + g2).view(b, t, d)
         return dx, (None if dkeys is None else dkeys.view(b, -1, d)), None, None

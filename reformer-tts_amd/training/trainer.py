@@ -166,7 +166,7 @@ class Trainer:
 
     def backward(self, loss):
         loss.backward()
-        engine.join_side()
+        engine.flush_wgrad()
         self.finish_allreduce()
 
     def lr_now(self) -> float:

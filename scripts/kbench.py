@@ -32,6 +32,22 @@ def main():
     args = ap.parse_args()
     only = set(args.only.split(",")) if args.only else None
     dev = torch.device("cuda:0")
+    if only and "wgrad" in only:
+        # split-K weight-gradient GEMM at the shapes of one decoder layer (M = 12288 tokens; kv: 3072 text rows)
+        from reformer_tts_amd import _lib
+        ws = torch.empty(16 * 1024 * 1024, device=dev)
+        s = torch.cuda.current_stream().cuda_stream
+        for nm, (m, n, k) in dict(to_out=(12288, 512, 512), qkv=(12288, 1024, 512), ffn1=(12288, 2048, 512), ffn2=(12288, 512, 2048),
+                                  xkv=(3072, 1024, 512), enc_qkv=(3072, 1024, 512), enc_ffn=(3072, 2048, 512)).items():
+            a = torch.randn(m, n, device=dev).bfloat16()
+            bb = torch.randn(m, k, device=dev).bfloat16()
+            c = torch.zeros(n, k, device=dev)
+            us = timeit(lambda: _lib.call("rtts_gemm_tn", a.data_ptr(), a.stride(0), bb.data_ptr(), bb.stride(0), m, n, k, c.data_ptr(),
+                                          c.stride(0), 1, ws.data_ptr(), ws.numel(), s), args.iters)
+            us_lib = timeit(lambda: torch.mm(a.t(), bb, out_dtype=torch.float32), args.iters)
+            print(f"wgrad {nm:8s} M={m} N={n} K={k}: gemm_tn+reduce {us:7.1f} us = {2.0 * m * n * k / us / 1e6:7.1f} TFLOP/s   "
+                  f"hipBLASLt TN fp32-out {us_lib:7.1f} us", flush=True)
+        return
     for name, (b, h, t, bs, nh, causal) in dict(dec=(12, 8, 1024, 128, 8, True), enc=(12, 8, 256, 64, 8, False),
                                                  long=(4, 8, 4096, 64, 8, True)).items():
         dh = 64

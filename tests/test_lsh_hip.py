@@ -238,3 +238,33 @@ def test_gemm_tn_vs_fp32_reference(ops, m, n, k, acc):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     ref = a.float().t() @ b.float() + (c0 if acc else 0)
     torch.testing.assert_close(outs[0], ref, rtol=2e-4, atol=2e-2)
+
+
+def test_gemm_tn_grouped_matches_single_launches(ops):
+    """The grouped launch (deferred weight gradients of a layer) against fp32 matmuls of the same bf16 values,
+    different shapes and token counts in one grid, accumulate on and off; bitwise reproducible run to run."""
+    from reformer_tts_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    shapes = [(12288, 512, 512, 1), (12288, 1024, 512, 1), (3072, 1024, 512, 0), (12288, 2048, 512, 1), (12288, 512, 2048, 1),
+              (256, 128, 128, 1), (1024, 512, 512, 0)]
+    ops_ = []
+    for m, n, k, acc in shapes:
+        a = torch.randn(m, n, generator=g).bfloat16().cuda()
+        b = torch.randn(m, k, generator=g).bfloat16().cuda()
+        c0 = torch.randn(n, k, generator=g).cuda()
+        ops_.append((a, b, c0, acc))
+    ws = torch.empty(16 * 1024 * 1024, device="cuda")
+    outs = []
+    for _ in range(2):
+        cs = [c0.clone() for _, _, c0, _ in ops_]
+        arr = (_lib.GemmTnProblem * len(ops_))()
+        for q, (a, b, _, acc), c in zip(arr, ops_, cs):
+            q.a, q.lda, q.b, q.ldb, q.c, q.ldc = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), c.stride(0)
+            q.M, q.N, q.K, q.accumulate = a.shape[0], a.shape[1], b.shape[1], acc
+        _lib.call("rtts_gemm_tn_grouped", arr, len(ops_), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        outs.append(cs)
+    for (a, b, c0, acc), c1, c2 in zip(ops_, outs[0], outs[1]):
+        assert torch.equal(c1, c2)
+        ref = a.float().t() @ b.float() + (c0 if acc else 0)
+        torch.testing.assert_close(c1, ref, rtol=2e-4, atol=2e-2)
