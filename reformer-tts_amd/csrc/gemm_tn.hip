@@ -19,12 +19,11 @@
 // together.  One grid then holds 240 tiles instead of 16..64, the split factor drops from 8..32 to 2, and the fp32
 // slab traffic (split x output size, written and read back) drops ~7x; per-launch ramp-up and tails are paid once.
 #include "rtts_common.h"
+#include <stdlib.h>
 
-#define GT_BN 128      // output rows  (N)
-#define GT_BK 128      // output cols  (K)
 #define GT_BM 64       // contraction rows per stage
-#define GT_ROWB 272    // LDS row stride in bytes: 128 bf16 + 16 B pad
-#define GT_THREADS 256
+#define GT_PAD 32      // bytes of padding per LDS row: a row shift of 8 banks, so the 4 rows x 8 dwords of a 16-lane
+                       // transposed read hit 32 distinct banks (16 B of pad gave 2-way conflicts)
 
 typedef __attribute__((ext_vector_type(8))) short gt_short8;
 
@@ -51,10 +50,23 @@ struct GtGroup {
     int n;
 };
 
-__global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const GtGroup grp) {
+// WN x WK waves, each owning a register tile of TN x TK MFMA tiles (32 x 32 each): the workgroup tile is
+// (32 TN WN) x (32 TK WK).  Every MFMA needs 2 KB of operand fragments from LDS; a TN x TK register tile reuses each
+// fragment, so the LDS bytes per MFMA are (TN + TK) / (TN TK) KB against an LDS rate of 128 B/clk/CU and an MFMA
+// rate of one per 8 clk per CU:
+//   <2,2,2,2>: 128 x 128, 256 threads, 2 workgroups per CU -- any shape that tiles by 128; 1 KB per MFMA = LDS-bound
+//              (measured ~600 TFLOP/s, a 4 x 4-wave 256-tile variant with the same 2 x 2 register tile just as slow)
+//   <4,2,2,4>: 256 x 256, 512 threads, 1 workgroup per CU, 128 accumulator registers -- 0.75 KB per MFMA
+template <int WN, int WK, int TN, int TK>
+__global__ __launch_bounds__(64 * WN * WK) void gemm_tn_kernel(const GtGroup grp) {
+    constexpr int BN = 32 * TN * WN, BK = 32 * TK * WK, NTHR = 64 * WN * WK;
+    constexpr int ROWA = BN * 2 + GT_PAD, ROWB = BK * 2 + GT_PAD;       // LDS row strides (bytes)
+    constexpr int PA = BN / 8, PB = BK / 8;                            // 16-byte pieces per staged row
+    constexpr int ITA = GT_BM * PA / NTHR, ITB = GT_BM * PB / NTHR;    // staging loads per thread and operand
+    static_assert(GT_BM * PA % NTHR == 0 && GT_BM * PB % NTHR == 0, "staging must tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* As = smem;                          // [2][64][272]
-    unsigned char* Bs = smem + 2 * GT_BM * GT_ROWB;    // [2][64][272]
+    unsigned char* As = smem;                          // [2][64][ROWA]
+    unsigned char* Bs = smem + 2 * GT_BM * ROWA;       // [2][64][ROWB]
 
     int pi = 0;
 #pragma unroll
@@ -69,51 +81,51 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const GtGroup gr
     const size_t slab_stride = P.slab_stride;
     const int blk = (int)blockIdx.x - P.wg_start;
 
-    const int tiles_k = K / GT_BK;
+    const int tiles_k = K / BK;
     const int tile = blk / split, sp = blk % split;
-    const int n0 = (tile / tiles_k) * GT_BN, k0 = (tile % tiles_k) * GT_BK;
+    const int n0 = (tile / tiles_k) * BN, k0 = (tile % tiles_k) * BK;
     const int rows_per = M / split;                    // multiple of 64 (checked on the host)
     const int m_begin = sp * rows_per, nstage = rows_per / GT_BM;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave >> 1, wk = wave & 1;           // 2 x 2 waves, 64 x 64 outputs each
+    const int wn = wave / WK, wk = wave % WK;
     const int hh = lane >> 5;
     const int trq = (lane & 15) >> 2, trp = lane & 3, trc = (lane >> 4) & 1;
 
-    // staging map: 64 rows x 16 pieces of 16 B per operand; thread -> (row = it*16 + tid/16, piece = tid%16)
-    const int srow = tid >> 4, spiece = tid & 15;
+    // staging map per operand: thread -> (row = it * (NTHR / P) + tid / P, piece = tid % P)
+    const int arow = tid / PA, apiece = tid % PA, brow = tid / PB, bpiece = tid % PB;
+    static_assert(ITA <= 4 && ITB <= 4, "staging registers");
+    // named scalars, not arrays: arrays written under `if (s + 1 < nstage)` and read after the MFMAs end up in scratch
     uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-#define GT_LOAD_STAGE(stage)                                                                       \
-    do {                                                                                           \
-        const size_t m_ = (size_t)m_begin + (size_t)(stage) * GT_BM + srow;                        \
-        ra0 = *reinterpret_cast<const uint4*>(a + (m_ + 0) * lda + n0 + spiece * 8);               \
-        ra1 = *reinterpret_cast<const uint4*>(a + (m_ + 16) * lda + n0 + spiece * 8);              \
-        ra2 = *reinterpret_cast<const uint4*>(a + (m_ + 32) * lda + n0 + spiece * 8);              \
-        ra3 = *reinterpret_cast<const uint4*>(a + (m_ + 48) * lda + n0 + spiece * 8);              \
-        rb0 = *reinterpret_cast<const uint4*>(b + (m_ + 0) * ldb + k0 + spiece * 8);               \
-        rb1 = *reinterpret_cast<const uint4*>(b + (m_ + 16) * ldb + k0 + spiece * 8);              \
-        rb2 = *reinterpret_cast<const uint4*>(b + (m_ + 32) * ldb + k0 + spiece * 8);              \
-        rb3 = *reinterpret_cast<const uint4*>(b + (m_ + 48) * ldb + k0 + spiece * 8);              \
+#define GT_LD(reg, base, ld, step, it, IT) \
+    if constexpr ((it) < (IT)) reg = *reinterpret_cast<const uint4*>((base) + (size_t)((it) * (step)) * (ld))
+#define GT_ST(reg, base, bstep, it, IT) \
+    if constexpr ((it) < (IT)) *reinterpret_cast<uint4*>((base) + (it) * (bstep)) = reg
+#define GT_LOAD_STAGE(stage)                                                              \
+    do {                                                                                  \
+        const size_t m_ = (size_t)m_begin + (size_t)(stage) * GT_BM;                      \
+        const bf16_t* pa_ = a + (m_ + arow) * lda + n0 + apiece * 8;                      \
+        const bf16_t* pb_ = b + (m_ + brow) * ldb + k0 + bpiece * 8;                      \
+        GT_LD(ra0, pa_, lda, NTHR / PA, 0, ITA); GT_LD(ra1, pa_, lda, NTHR / PA, 1, ITA); \
+        GT_LD(ra2, pa_, lda, NTHR / PA, 2, ITA); GT_LD(ra3, pa_, lda, NTHR / PA, 3, ITA); \
+        GT_LD(rb0, pb_, ldb, NTHR / PB, 0, ITB); GT_LD(rb1, pb_, ldb, NTHR / PB, 1, ITB); \
+        GT_LD(rb2, pb_, ldb, NTHR / PB, 2, ITB); GT_LD(rb3, pb_, ldb, NTHR / PB, 3, ITB); \
     } while (0)
-#define GT_STORE_STAGE(buf)                                                                        \
-    do {                                                                                           \
-        unsigned char* pa_ = As + ((buf) * GT_BM + srow) * GT_ROWB + spiece * 16;                  \
-        unsigned char* pb_ = Bs + ((buf) * GT_BM + srow) * GT_ROWB + spiece * 16;                  \
-        *reinterpret_cast<uint4*>(pa_) = ra0;                                                      \
-        *reinterpret_cast<uint4*>(pa_ + 16 * GT_ROWB) = ra1;                                       \
-        *reinterpret_cast<uint4*>(pa_ + 32 * GT_ROWB) = ra2;                                       \
-        *reinterpret_cast<uint4*>(pa_ + 48 * GT_ROWB) = ra3;                                       \
-        *reinterpret_cast<uint4*>(pb_) = rb0;                                                      \
-        *reinterpret_cast<uint4*>(pb_ + 16 * GT_ROWB) = rb1;                                       \
-        *reinterpret_cast<uint4*>(pb_ + 32 * GT_ROWB) = rb2;                                       \
-        *reinterpret_cast<uint4*>(pb_ + 48 * GT_ROWB) = rb3;                                       \
+#define GT_STORE_STAGE(buf)                                                               \
+    do {                                                                                  \
+        unsigned char* pa_ = As + ((buf) * GT_BM + arow) * ROWA + apiece * 16;            \
+        unsigned char* pb_ = Bs + ((buf) * GT_BM + brow) * ROWB + bpiece * 16;            \
+        GT_ST(ra0, pa_, (NTHR / PA) * ROWA, 0, ITA); GT_ST(ra1, pa_, (NTHR / PA) * ROWA, 1, ITA); \
+        GT_ST(ra2, pa_, (NTHR / PA) * ROWA, 2, ITA); GT_ST(ra3, pa_, (NTHR / PA) * ROWA, 3, ITA); \
+        GT_ST(rb0, pb_, (NTHR / PB) * ROWB, 0, ITB); GT_ST(rb1, pb_, (NTHR / PB) * ROWB, 1, ITB); \
+        GT_ST(rb2, pb_, (NTHR / PB) * ROWB, 2, ITB); GT_ST(rb3, pb_, (NTHR / PB) * ROWB, 3, ITB); \
     } while (0)
 
-    f32x16 acc[2][2];
+    f32x16 acc[TN][TK];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
+        for (int j = 0; j < TK; ++j) acc[i][j] = (f32x16){0};
 
     GT_LOAD_STAGE(0);
     GT_STORE_STAGE(0);
@@ -121,38 +133,62 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const GtGroup gr
     for (int s = 0; s < nstage; ++s) {
         const int buf = s & 1;
         if (s + 1 < nstage) GT_LOAD_STAGE(s + 1);      // in flight during the MFMAs below
-        const unsigned char* Ab = As + buf * GT_BM * GT_ROWB;
-        const unsigned char* Bb = Bs + buf * GT_BM * GT_ROWB;
-#pragma unroll
-        for (int ks = 0; ks < GT_BM / 16; ++ks) {
-            const int mr = ks * 16 + 8 * hh + trq;
-            bf16x8 af[2], bfr[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int ca = (wn * 64 + t * 32 + 16 * trc + 4 * trp) * 2;
-                const int cb = (wk * 64 + t * 32 + 16 * trc + 4 * trp) * 2;
-                af[t] = gt_tr_frag(Ab + mr * GT_ROWB + ca, Ab + (mr + 4) * GT_ROWB + ca);
-                bfr[t] = gt_tr_frag(Bb + mr * GT_ROWB + cb, Bb + (mr + 4) * GT_ROWB + cb);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
+        const unsigned char* Ab = As + buf * GT_BM * ROWA;
+        const unsigned char* Bb = Bs + buf * GT_BM * ROWB;
+        // fragments of step ks+1 are requested before the MFMAs of step ks are issued: without this the wave sits
+        // through a full LDS round trip between every two MFMA bursts
+#define GT_FRAGS(AF, BF, ks_)                                                                   \
+    do {                                                                                        \
+        const int mr_ = (ks_) * 16 + 8 * hh + trq;                                              \
+        _Pragma("unroll") for (int t = 0; t < TN; ++t) {                                        \
+            const int ca_ = (wn * 32 * TN + t * 32 + 16 * trc + 4 * trp) * 2;                   \
+            AF[t] = gt_tr_frag(Ab + mr_ * ROWA + ca_, Ab + (mr_ + 4) * ROWA + ca_);             \
+        }                                                                                       \
+        _Pragma("unroll") for (int t = 0; t < TK; ++t) {                                        \
+            const int cb_ = (wk * 32 * TK + t * 32 + 16 * trc + 4 * trp) * 2;                   \
+            BF[t] = gt_tr_frag(Bb + mr_ * ROWB + cb_, Bb + (mr_ + 4) * ROWB + cb_);             \
+        }                                                                                       \
+    } while (0)
+#define GT_MFMAS(AF, BF)                                                                        \
+    _Pragma("unroll") for (int i = 0; i < TN; ++i)                                              \
+        _Pragma("unroll") for (int j = 0; j < TK; ++j)                                          \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[i], BF[j], acc[i][j], 0, 0, 0)
+        bf16x8 af0[TN], bf0[TK], af1[TN], bf1[TK];
+        // (sched_barrier pins the order: the machine scheduler otherwise sinks every fragment load back to its use)
+        GT_FRAGS(af0, bf0, 0);
+        GT_FRAGS(af1, bf1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        GT_MFMAS(af0, bf0);
+        __builtin_amdgcn_sched_barrier(0);
+        GT_FRAGS(af0, bf0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        GT_MFMAS(af1, bf1);
+        __builtin_amdgcn_sched_barrier(0);
+        GT_FRAGS(af1, bf1, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        GT_MFMAS(af0, bf0);
+        __builtin_amdgcn_sched_barrier(0);
+        GT_MFMAS(af1, bf1);
+        static_assert(GT_BM == 64, "four k-steps per stage");
         if (s + 1 < nstage) GT_STORE_STAGE(buf ^ 1);   // other buffer: its readers passed the previous barrier
         __syncthreads();
     }
+#undef GT_LOAD_STAGE
+#undef GT_STORE_STAGE
+#undef GT_LD
+#undef GT_ST
+#undef GT_FRAGS
+#undef GT_MFMAS
 
     // epilogue: C tile rows n = (i&3) + 8*(i>>2) + 4*hh, cols k = lane&31
     float* dst = out + (split > 1 ? (size_t)sp * slab_stride : 0);
     const bool add = (split == 1) && accumulate;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int nb = n0 + wn * 64 + i * 32 + 4 * hh;
-            const int kc = k0 + wk * 64 + j * 32 + (lane & 31);
+        for (int j = 0; j < TK; ++j) {
+            const int nb = n0 + wn * 32 * TN + i * 32 + 4 * hh;
+            const int kc = k0 + wk * 32 * TK + j * 32 + (lane & 31);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 float* p = dst + (size_t)(nb + (e & 3) + 8 * (e >> 2)) * ldo + kc;
@@ -188,33 +224,55 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const GtGroup grp) {
     *dst = s;
 }
 
-static bool g_gt_attr = false;
+template <int WN, int WK, int TN, int TK>
+static void gt_launch(const GtGroup& grp, int wg, hipStream_t s) {
+    constexpr int BN = 32 * TN * WN, BK = 32 * TK * WK;
+    const size_t lds = 2 * GT_BM * (BN * 2 + GT_PAD) + 2 * GT_BM * (BK * 2 + GT_PAD);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<WN, WK, TN, TK>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_tn_kernel<WN, WK, TN, TK>), dim3(wg), dim3(64 * WN * WK), lds, s, grp);
+}
 
 extern "C" int rtts_gemm_tn_grouped(const rtts_gemm_tn_problem* problems, int n, float* slab_ws, int64_t slab_ws_floats, void* stream) {
     RTTS_REQUIRE(problems && n > 0 && n <= RTTS_GEMM_TN_MAX_GROUP, "rtts_gemm_tn_grouped: 1..%d problems", RTTS_GEMM_TN_MAX_GROUP);
     GtGroup grp;
     grp.n = n;
-    int total_tiles = 0;
+    bool big = getenv("RTTS_GEMM_TN_SMALL_TILES") == nullptr;     // 256 x 256 tiles when every problem tiles by 256
+    long long flops = 0;
     for (int i = 0; i < n; ++i) {
         const rtts_gemm_tn_problem& q = problems[i];
         RTTS_REQUIRE(q.a && q.b && q.c, "rtts_gemm_tn: null pointer");
-        RTTS_REQUIRE(q.N > 0 && q.K > 0 && q.M > 0 && q.N % GT_BN == 0 && q.K % GT_BK == 0 && q.M % GT_BM == 0,
+        RTTS_REQUIRE(q.N > 0 && q.K > 0 && q.M > 0 && q.N % 128 == 0 && q.K % 128 == 0 && q.M % GT_BM == 0,
                      "rtts_gemm_tn: need N %% 128 == 0, K %% 128 == 0, M %% 64 == 0 (got M=%d N=%d K=%d)", q.M, q.N, q.K);
         RTTS_REQUIRE(q.lda >= q.N && q.ldb >= q.K && q.ldc >= q.K && q.lda % 8 == 0 && q.ldb % 8 == 0 && q.ldc % 4 == 0,
                      "rtts_gemm_tn: bad leading dimensions");
         RTTS_REQUIRE((((uintptr_t)q.a | (uintptr_t)q.b | (uintptr_t)q.c) & 15) == 0, "rtts_gemm_tn: buffers must be 16-byte aligned");
-        total_tiles += (q.N / GT_BN) * (q.K / GT_BK);
+        big = big && q.N % 256 == 0 && q.K % 256 == 0;
+        flops += 2LL * q.M * q.N * q.K;
     }
-    // one split target for the group: ~2 workgroups per CU over all problems, each workgroup with >= 4 stages
+    // small groups cannot fill 256 CUs with 256 x 256 tiles without splitting the token range very finely
+    // (measured: one 25.8 GFLOP problem 45 us with 128-tiles / 50 us with 256-tiles; the 87 GFLOP group of a decoder
+    // layer 143 us / 127 us)
+    if (flops < 40000000000LL) big = false;
+    const int bt = big ? 256 : 128;
+    int total_tiles = 0;
+    for (int i = 0; i < n; ++i) total_tiles += (problems[i].N / bt) * (problems[i].K / bt);
+    // one split target for the group: the workgroups of all problems together fill the chip
+    // (2 per CU for the 128-tile kernel, 1 per CU for the 256-tile kernel), each with >= 4 stages
+    const int wg_target = big ? 320 : 640;
     int want = 1;
-    while (total_tiles * want * 2 <= 640) want *= 2;
+    while (total_tiles * want * 2 <= wg_target) want *= 2;
     int wg = 0, rb = 0;
     size_t slab_used = 0;
     bool any_split = false;
     for (int i = 0; i < n; ++i) {
         const rtts_gemm_tn_problem& q = problems[i];
         GtProb& P = grp.p[i];
-        const int tiles = (q.N / GT_BN) * (q.K / GT_BK), stages = q.M / GT_BM;
+        const int tiles = (q.N / bt) * (q.K / bt), stages = q.M / GT_BM;
         const size_t slab = (size_t)q.N * q.K;
         int split = 1;
         while (split < want && split * 2 <= stages / 4 && stages % (split * 2) == 0) split *= 2;
@@ -238,12 +296,7 @@ extern "C" int rtts_gemm_tn_grouped(const rtts_gemm_tn_problem* problems, int n,
         }
     }
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = 4 * GT_BM * GT_ROWB;
-    if (!g_gt_attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        g_gt_attr = true;
-    }
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(wg), dim3(GT_THREADS), lds, s, grp);
+    if (big) gt_launch<4, 2, 2, 4>(grp, wg, s); else gt_launch<2, 2, 2, 2>(grp, wg, s);
     if (any_split) hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(256), 0, s, grp);
     RTTS_LAUNCH_CHECK("rtts_gemm_tn");
     return 0;

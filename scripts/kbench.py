@@ -47,6 +47,18 @@ def main():
             us_lib = timeit(lambda: torch.mm(a.t(), bb, out_dtype=torch.float32), args.iters)
             print(f"wgrad {nm:8s} M={m} N={n} K={k}: gemm_tn+reduce {us:7.1f} us = {2.0 * m * n * k / us / 1e6:7.1f} TFLOP/s   "
                   f"hipBLASLt TN fp32-out {us_lib:7.1f} us", flush=True)
+        # the seven deferred weight gradients of one decoder layer in one grouped launch
+        shapes = [(12288, 512, 512), (12288, 1024, 512), (12288, 512, 512), (12288, 512, 512), (3072, 1024, 512), (12288, 2048, 512),
+                  (12288, 512, 2048)]
+        tens = [(torch.randn(m, n, device=dev).bfloat16(), torch.randn(m, k, device=dev).bfloat16(), torch.zeros(n, k, device=dev))
+                for m, n, k in shapes]
+        arr = (_lib.GemmTnProblem * len(tens))()
+        for q, (a, bb, c) in zip(arr, tens):
+            q.a, q.lda, q.b, q.ldb, q.c, q.ldc = a.data_ptr(), a.stride(0), bb.data_ptr(), bb.stride(0), c.data_ptr(), c.stride(0)
+            q.M, q.N, q.K, q.accumulate = a.shape[0], a.shape[1], bb.shape[1], 1
+        us = timeit(lambda: _lib.call("rtts_gemm_tn_grouped", arr, len(tens), ws.data_ptr(), ws.numel(), s), args.iters)
+        fl = sum(2.0 * m * n * k for m, n, k in shapes)
+        print(f"wgrad decoder-layer group (7 problems, {fl / 1e9:.1f} GFLOP): {us:7.1f} us = {fl / us / 1e6:7.1f} TFLOP/s", flush=True)
         return
     for name, (b, h, t, bs, nh, causal) in dict(dec=(12, 8, 1024, 128, 8, True), enc=(12, 8, 256, 64, 8, False),
                                                  long=(4, 8, 4096, 64, 8, True)).items():
