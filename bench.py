@@ -86,7 +86,6 @@ def main():
     backend = os.environ.get("RTTS_DIST_BACKEND", "nccl")     # "gloo": single-GPU rehearsal of the N>1 code path
     if backend == "gloo":
         local_rank %= max(torch.cuda.device_count(), 1)
-        args.no_graph = True                                     # gloo collectives are host-side: not capturable
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -113,12 +112,15 @@ def main():
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
     note(f"model built ({trainer.n_params} parameters), warming up")
-    # N>1: RCCL collectives inside a captured graph are opt-in (RTTS_GRAPH_DP=1); the default there is eager launches
-    use_graph = not args.no_graph and (world == 1 or os.environ.get("RTTS_GRAPH_DP") == "1")
+    # N == 1: the whole step is one hipGraph.  N > 1: two graphs (fwd+bwd | clip+AdamW) around ONE eager all-reduce of
+    # the flat gradient buffer, so no collective is ever captured; RTTS_GRAPH_DP=1 opts into a single graph with the
+    # per-block RCCL all-reduces captured inside (overlapped with the backward; not exercisable on a 1-GPU box).
+    use_graph = not args.no_graph
+    one_graph = world == 1 or (os.environ.get("RTTS_GRAPH_DP") == "1" and backend == "nccl")
     if use_graph:
-        trainer.capture(batch)          # whole step (fwd, bwd, all-reduce, clip, AdamW) as one hipGraph
+        trainer.capture(batch, segmented=not one_graph)
         step_fn = trainer.replay
-        note("step captured into a hipGraph")
+        note("step captured into " + ("one hipGraph" if one_graph else "two hipGraphs around the gradient all-reduce"))
     else:
         step_fn = lambda: trainer.train_step(batch)   # noqa: E731
     for i in range(args.warmup):
@@ -167,7 +169,8 @@ def main():
                                    f"mel {args.mel_len}x80" if args.config == "baseline" else
                                    f"config/bucket-size-64-18-06.yml, per-GPU batch {args.batch}, mel {args.mel_len}",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(float(loss), 4),
-                       "launch": "hipGraph replay" if use_graph else "eager"},
+                       "launch": ("hipGraph replay" if one_graph else "hipGraph replay (fwd+bwd | all-reduce | optimizer)")
+                       if use_graph else "eager"},
         }
         if launches:
             traffic = None      # HBM bytes per launch from the committed rocprofv3 PMC passes (collected outside this process)

@@ -77,11 +77,15 @@ class ReformerTTS(nn.Module):
         spectrogram_mask = pad_to_multiple(spectrogram_mask.unsqueeze(-1).to(dev), self.pad_base).squeeze(-1).to(torch.bool)
         return pad_phonemes, phoneme_mask, spectrogram_mask, pad_to_multiple(spectrogram, self.pad_base)
 
-    def decoder_hidden(self, phonemes, spectrogram, spectrogram_mask=None):
+    def decoder_hidden(self, phonemes, spectrogram, spectrogram_mask=None, keys_hook=None):
         """Decoder output (B, T_padded, d) in front of the mel/stop heads: the training step feeds it to the
-        fused heads + postnet + loss executor (``edges.PostnetLoss``)."""
+        fused heads + postnet + loss executor (``edges.PostnetLoss``).  ``keys_hook`` (encoder output -> tensor the
+        decoder reads) lets the data-parallel trainer cut the autograd graph between encoder and decoder so that the
+        two halves of the backward are separate launches with a gradient all-reduce in between."""
         pad_phonemes, phoneme_mask, spectrogram_mask, pad_spec = self._encode_inputs(phonemes, spectrogram, spectrogram_mask)
         keys = self.enc(pad_phonemes, input_mask=phoneme_mask)
+        if keys_hook is not None:
+            keys = keys_hook(keys)
         return self.dec.hidden(pad_spec, keys=keys, key_padding_mask=~phoneme_mask, input_mask=spectrogram_mask)[0]
 
     def forward(self, phonemes: torch.LongTensor, spectrogram: torch.Tensor,

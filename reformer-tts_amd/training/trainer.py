@@ -129,7 +129,7 @@ class Trainer:
 
     def _make_hook(self, stack_name):
         def hook(seq, i):
-            if self.world > 1 and (stack_name, i) in self.block_bucket:
+            if self.world > 1 and not self._bulk_allreduce and (stack_name, i) in self.block_bucket:
                 s, e = self.block_bucket[(stack_name, i)]
                 self._pending.append(dist.all_reduce(self.flat_g[s:e], group=self.pg, async_op=True))
         return hook
@@ -137,16 +137,27 @@ class Trainer:
     # ------------------------------------------------------------------ step pieces
     use_fused_edges = True
 
-    def forward_loss(self, batch):
-        """``wrappers.py:53-72``: input frames [0, L-1), targets [1, L), mask = loss_mask.mean(-1)."""
+    def _fused_edges_ok(self, batch) -> bool:
         spec = batch["spectrogram"]
         lm = spec.shape[1] - 1
-        if (self.use_fused_edges and self.device.type == "cuda" and self.model.training and lm % self.model.pad_base == 0
-                and (spec.shape[0] * lm) % 64 == 0):
+        return (self.use_fused_edges and self.device.type == "cuda" and self.model.training and lm % self.model.pad_base == 0
+                and (spec.shape[0] * lm) % 64 == 0)
+
+    def _cut_at_encoder(self, keys):
+        """keys_hook of the split step: the decoder reads a detached copy, the encoder's backward is run later from its grad."""
+        self._enc_out = keys
+        self._enc_in = keys.detach().requires_grad_(True)
+        return self._enc_in
+
+    def forward_loss(self, batch, split: bool = False):
+        """``wrappers.py:53-72``: input frames [0, L-1), targets [1, L), mask = loss_mask.mean(-1)."""
+        spec = batch["spectrogram"]
+        if self._fused_edges_ok(batch):
             from ..edges import PostnetLoss
             if getattr(self, "_postnet_loss", None) is None:
                 self._postnet_loss = PostnetLoss(self.model, self.loss)
-            y = self.model.decoder_hidden(batch["phonemes"], spec[:, :-1], spectrogram_mask=batch["loss_mask"].mean(dim=-1))
+            y = self.model.decoder_hidden(batch["phonemes"], spec[:, :-1], spectrogram_mask=batch["loss_mask"].mean(dim=-1),
+                                          keys_hook=self._cut_at_encoder if split else None)
             losses = self._postnet_loss.apply(y, spec[:, 1:], batch["stop_tokens"], batch["loss_mask"])
             return losses[0], losses[1], losses[2], losses[3]
         raw, post, stop, _ = self.model(batch["phonemes"], spec[:, :-1], spectrogram_mask=batch["loss_mask"].mean(dim=-1))
@@ -157,7 +168,7 @@ class Trainer:
 
     def finish_allreduce(self):
         """Reduce what no block bucket covers (prenets, heads, postnet, ...) and wait for everything."""
-        if self.world > 1:
+        if self.world > 1 and not self._bulk_allreduce:
             for s, e in self.rest:
                 self._pending.append(dist.all_reduce(self.flat_g[s:e], group=self.pg, async_op=True))
             for w in self._pending:
@@ -217,18 +228,38 @@ class Trainer:
         self.zero_grad()
         total, raw_l, post_l, stop_l = self.forward_loss(batch)
         self.backward(total)
+        if self._bulk_allreduce:
+            self.bulk_allreduce()
         self.optimizer_step(update_hyper)
         return total.detach(), raw_l.detach(), post_l.detach(), stop_l.detach()
 
     # ------------------------------------------------------------------ hipGraph replay of the whole step
-    def capture(self, batch):
-        """Capture forward + backward + all-reduce + clip + AdamW + mirror refresh for THIS batch buffer into a hipGraph.
-        Afterwards ``replay()`` runs one full step per call: the host only writes {lr, step size} for the step into device
-        memory and launches the graph.  Rotations and dropout draw from the graph-safe default generator."""
+    _bulk_allreduce = False
+
+    def capture(self, batch, segmented: Optional[bool] = None):
+        """Capture the step for THIS batch buffer into hipGraphs; afterwards ``replay()`` runs one full step per call: the
+        host only writes {lr, step size, dropout seed} for the step into device memory and launches.
+
+        * one process (or ``segmented=False``): ONE graph = forward + backward (+ per-block all-reduce) + clip + AdamW +
+          mirror refresh;
+        * data parallel (default when world > 1): THREE graphs with the gradient exchange between them, no collective
+          inside any capture (nothing is asked of RCCL beyond plain all-reduces):
+              A  zero + forward + loss + backward of postnet, heads, decoder, decoder prenet
+                 -> all-reduce of the decoder-side half of the flat gradient buffer (~59 MB), asynchronous
+              B  backward of the encoder stack and prenet, from d(loss)/d(encoder output) (overlaps that all-reduce)
+                 -> all-reduce of the encoder-side half (~48 MB)
+              C  clip + AdamW + mirror refresh
+          Few, large collectives (what xGMI's per-link-bound ring likes); ~55 % of the bytes hidden behind graph B.
+
+        Rotations and dropout draw from the graph-safe default generator."""
         from ..model.lsh_attention import LSHSelfAttention
+        if segmented is None:
+            segmented = self.world > 1
+        segmented = bool(segmented) and self._fused_edges_ok(batch) if segmented else False
         for m in self.model.modules():
             if isinstance(m, LSHSelfAttention):
                 m.use_default_generator = True
+        self._bulk_allreduce = bool(segmented)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -237,15 +268,51 @@ class Trainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
+        self._graph_enc = self._graph_opt = None
         self.set_step_hyper(self.global_step)
+        if not segmented:
+            with torch.cuda.graph(self._graph):
+                self._graph_out = self.train_step(batch, update_hyper=False)
+            self.global_step -= 1                        # capturing does not execute: the captured step has not run yet
+            return self._graph_out
+        enc_names = [n for n in self.offsets if n.startswith("enc.")]
+        self._enc_end = max(self.offsets[n][1] for n in enc_names)
+        if min(self.offsets[n][0] for n in self.offsets if not n.startswith("enc.")) < self._enc_end:
+            raise RuntimeError("flat buffer: encoder parameters are expected to come first")
         with torch.cuda.graph(self._graph):
-            self._graph_out = self.train_step(batch, update_hyper=False)
-        self.global_step -= 1                            # capturing does not execute: the captured step has not run yet
+            self.model.train()
+            self.zero_grad()
+            total, raw_l, post_l, stop_l = self.forward_loss(batch, split=True)
+            total.backward()
+            engine.flush_wgrad()
+            self._graph_out = (total.detach(), raw_l.detach(), post_l.detach(), stop_l.detach())
+        self._graph_enc = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph_enc, pool=self._graph.pool()):
+            self._enc_out.backward(self._enc_in.grad)
+            engine.flush_wgrad()
+        self._enc_out = self._enc_in = None
+        self._graph_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph_opt, pool=self._graph.pool()):
+            self.optimizer_step(update_hyper=False)
+        self.global_step -= 1
         return self._graph_out
+
+    def bulk_allreduce(self):
+        if self.world > 1:
+            dist.all_reduce(self.flat_g, group=self.pg)
 
     def replay(self):
         self.set_step_hyper(self.global_step)
         self.global_step += 1
         self._graph.replay()
+        if self._graph_opt is not None:
+            works = []
+            if self.world > 1:
+                works.append(dist.all_reduce(self.flat_g[self._enc_end:], group=self.pg, async_op=True))
+            self._graph_enc.replay()
+            if self.world > 1:
+                works.append(dist.all_reduce(self.flat_g[:self._enc_end], group=self.pg, async_op=True))
+            for w in works:
+                w.wait()
+            self._graph_opt.replay()
         return self._graph_out
-

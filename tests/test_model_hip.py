@@ -421,8 +421,10 @@ def test_attention_stash_matches_pure_recompute(gpu):
     assert ((grads[0] - grads[1]).norm() / grads[1].norm()).item() < 1e-2
 
 
-def test_graph_replay_matches_eager_steps(gpu):
-    """A captured hipGraph of the whole step replays with fresh {lr, step size}: losses follow the eager trajectory."""
+@pytest.mark.parametrize("segmented", [False, True])
+def test_graph_replay_matches_eager_steps(gpu, segmented):
+    """A captured hipGraph of the whole step replays with fresh {lr, step size}: losses follow the eager trajectory.
+    segmented = the data-parallel form: [fwd + bwd] and [clip + AdamW] graphs around an eager gradient all-reduce."""
     from reformer_tts_amd.model.config import TTSTrainingConfig, model_config_from_dict
     from reformer_tts_amd.model.lsh_attention import LSHSelfAttention
     from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
@@ -441,7 +443,7 @@ def test_graph_replay_matches_eager_steps(gpu):
         tr = Trainer(model, TTSTrainingConfig(batch_size=2, learning_rate=1e-3, warmup_steps=4, gradient_clip_val=1.0), gpu)
         losses = []
         if graph:
-            tr.capture(batch)             # 2 eager warm-up steps (0, 1); capturing itself executes nothing
+            tr.capture(batch, segmented=segmented)   # 2 eager warm-up steps (0, 1); capturing itself executes nothing
             losses = [None, None]
             for _ in range(4):
                 losses.append(float(tr.replay()[0]))
