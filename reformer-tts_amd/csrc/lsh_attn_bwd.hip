@@ -52,6 +52,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
     int* kpe = kpos + NK;                                      // effective position: dead <=> kpe[key] > qpe[query]
     float* qlse = reinterpret_cast<float*>(kpe + NK);          // lse_tot * log2(e)
     float* qdel = qlse + BS;
+    int* qpe_s = reinterpret_cast<int*>(qdel + BS);            // query-side effective position (-1: an invalid query)
 
     const int nb = T / BS;
     const int C = n_hashes * nb;
@@ -120,6 +121,8 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
             if (row < BS) {
                 qlse[row] = lse_tot[(size_t)bh * T + trow[it]] * 1.4426950408889634f;
                 qdel[row] = delta[(size_t)bh * T + trow[it]];
+                // an invalid query sees nothing but itself: its effective position is below every key's
+                qpe_s[row] = valid ? (CAUSAL ? trow[it] : 0) : -1;
             }
         }
     }
@@ -147,6 +150,8 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
             gacc[a][d] = (f32x16){0};
         }
     const int trq = (lane & 15) >> 2, trp = lane & 3, trc = (lane >> 4) & 1;
+    const bool own_tile = myrow[0] < BS;            // wave-uniform
+    const bool wrap = (cprev / nb) != (c / nb);
 
 #pragma unroll 1
     for (int qt = 0; qt < NQT; ++qt) {
@@ -158,15 +163,18 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
         }
         // q-side row constants of this tile, issued first so that their LDS latency hides behind the MFMAs below
         float4 l4[4], d4[4];
-        int4 p4[4], e4[4];
+        int4 e4[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int q0 = qt * 32 + 8 * g + 4 * hh;
             l4[g] = *reinterpret_cast<const float4*>(qlse + q0);
             d4[g] = *reinterpret_cast<const float4*>(qdel + q0);
-            p4[g] = *reinterpret_cast<const int4*>(kpos + q0);
-            e4[g] = *reinterpret_cast<const int4*>(kpe + q0);
+            e4[g] = *reinterpret_cast<const int4*>(qpe_s + q0);
         }
+        // Can a key of this wave's tile BE one of this tile's queries (the self logit)?  Own keys: only on the diagonal
+        // tile.  Looked-back keys: only when the previous chunk belongs to another hash round (the chunk ring wraps
+        // over rounds, so the same token can then sit in both chunks).  Wave-uniform: the common path skips the test.
+        const bool chk_self = own_tile ? (wave == qt) : wrap;
 #pragma unroll
         for (int k2 = 0; k2 < KT2; ++k2) {
             f32x16 sacc = {0}, pacc = {0};
@@ -179,23 +187,38 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
             // ksc multiplies dS' once here: G' = dS'^T Q then gives dK = G' - k^ (k^ . G'), and dQ^T = K^T dS'^T.
             float pp[16], ds[16];
             const float ksc2 = ksc[k2] * 1.4426950408889634f;
+            if (chk_self) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float lv[4] = {l4[g].x, l4[g].y, l4[g].z, l4[g].w}, dv_[4] = {d4[g].x, d4[g].y, d4[g].z, d4[g].w};
-                const int pv[4] = {p4[g].x, p4[g].y, p4[g].z, p4[g].w}, ev[4] = {e4[g].x, e4[g].y, e4[g].z, e4[g].w};
+                for (int g = 0; g < 4; ++g) {
+                    const float lv[4] = {l4[g].x, l4[g].y, l4[g].z, l4[g].w}, dv_[4] = {d4[g].x, d4[g].y, d4[g].z, d4[g].w};
+                    const int4 p4 = *reinterpret_cast<const int4*>(kpos + qt * 32 + 8 * g + 4 * hh);   // rare path: read here
+                    const int pv[4] = {p4.x, p4.y, p4.z, p4.w}, ev[4] = {e4[g].x, e4[g].y, e4[g].z, e4[g].w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int i = 4 * g + j;
-                    const bool self = pv[j] == mypos[k2];
-                    // an invalid query (kpe == BIG) sees nothing but itself: its effective position is below every key's
-                    const int qpe = (ev[j] == 0x40000000) ? -1 : ev[j];
-                    const bool dead = kpk[k2] > qpe;
-                    float x = sacc[i] * ksc2;
-                    x = self ? (-5e4f * 1.4426950408889634f) : x;
-                    float p = __builtin_amdgcn_exp2f(x - lv[j]);
-                    p = (dead && !self) ? 0.f : p;
-                    pp[i] = p;
-                    ds[i] = self ? 0.f : p * (pacc[i] - dv_[j]) * ksc[k2];
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = 4 * g + j;
+                        const bool self = pv[j] == mypos[k2];
+                        const bool dead = kpk[k2] > ev[j];
+                        float x = sacc[i] * ksc2;
+                        x = self ? (-5e4f * 1.4426950408889634f) : x;
+                        float p = __builtin_amdgcn_exp2f(x - lv[j]);
+                        p = (dead && !self) ? 0.f : p;
+                        pp[i] = p;
+                        ds[i] = self ? 0.f : p * (pacc[i] - dv_[j]) * ksc[k2];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float lv[4] = {l4[g].x, l4[g].y, l4[g].z, l4[g].w}, dv_[4] = {d4[g].x, d4[g].y, d4[g].z, d4[g].w};
+                    const int ev[4] = {e4[g].x, e4[g].y, e4[g].z, e4[g].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = 4 * g + j;
+                        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[i], ksc2, -lv[j]));
+                        p = (kpk[k2] > ev[j]) ? 0.f : p;
+                        pp[i] = p;
+                        ds[i] = p * (pacc[i] - dv_[j]) * ksc[k2];
+                    }
                 }
             }
             // A fragments of the transposed products (element j <-> query 16*s2 + 8*(j>>2) + 4*hh + (j&3)): read only now,
@@ -343,7 +366,7 @@ static int launch_attn_bwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const 
                            const bf16_t* dout, int64_t ld_do, const float* lse_tot, const float* delta, int B, int H, int T,
                            int n_hashes, int causal, bf16_t* dqk_part, bf16_t* dv_part, hipStream_t stream) {
     constexpr int NK = 2 * BS;
-    const size_t lds = NK * AB_ROWB + BS * AB_ROWB + NK * (BS * 2 + 16) + NK * 12 + BS * 8;
+    const size_t lds = NK * AB_ROWB + BS * AB_ROWB + NK * (BS * 2 + 16) + NK * 12 + BS * 12;
     const dim3 grid(B * H * n_hashes * (T / BS)), block(BS * 4);
     const size_t slot_stride = (size_t)B * H * n_hashes * T * AB_DH;
     const int vi = (causal ? 2 : 0) + (mask ? 1 : 0);

@@ -34,7 +34,6 @@ def main():
     dev = torch.device("cuda:0")
     if only and "wgrad" in only:
         # split-K weight-gradient GEMM at the shapes of one decoder layer (M = 12288 tokens; kv: 3072 text rows)
-        from reformer_tts_amd import _lib
         ws = torch.empty(16 * 1024 * 1024, device=dev)
         s = torch.cuda.current_stream().cuda_stream
         for nm, (m, n, k) in dict(to_out=(12288, 512, 512), qkv=(12288, 1024, 512), ffn1=(12288, 2048, 512), ffn2=(12288, 512, 2048),
