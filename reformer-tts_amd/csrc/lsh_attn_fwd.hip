@@ -114,6 +114,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
     const int qpe = (kpe[qrow] == AF_BIGPOS) ? -1 : (CAUSAL ? qpos : 0);
     const int trq = (lane & 15) >> 2, trp = lane & 3, trc = (lane >> 4) & 1;
 
+    const bool wrap = (cprev / nb) != (c / nb);
     float m = AF_NEG, l = 0.f;
     f32x16 oacc[2] = {{0}, {0}};
 #pragma unroll 1
@@ -125,22 +126,43 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc, 0, 0, 0);
         }
         float tmax = AF_NEG;
+        // can a key of this tile BE the query itself?  own keys: only the diagonal tile; looked-back keys: only when the
+        // previous chunk belongs to another hash round.  Wave-uniform: the common path skips the test.
+        const bool chk_self = (kt < NQT) ? (kt == qt) : wrap;
+        if (chk_self) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int key0 = kt * 32 + 8 * g + 4 * hh;
-            const float4 sc = *reinterpret_cast<const float4*>(ksc + key0);
-            const int4 kp = *reinterpret_cast<const int4*>(kpos + key0);
-            const int4 ke = *reinterpret_cast<const int4*>(kpe + key0);
-            const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
-            const int kpv[4] = {kp.x, kp.y, kp.z, kp.w};
-            const int kev[4] = {ke.x, ke.y, ke.z, ke.w};
+            for (int g = 0; g < 4; ++g) {
+                const int key0 = kt * 32 + 8 * g + 4 * hh;
+                const float4 sc = *reinterpret_cast<const float4*>(ksc + key0);
+                const int4 kp = *reinterpret_cast<const int4*>(kpos + key0);
+                const int4 ke = *reinterpret_cast<const int4*>(kpe + key0);
+                const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
+                const int kpv[4] = {kp.x, kp.y, kp.z, kp.w};
+                const int kev[4] = {ke.x, ke.y, ke.z, ke.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float x = acc[4 * g + j] * scv[j];
-                x = (kev[j] > qpe) ? AF_NEG : x;
-                x = (kpv[j] == qpos) ? (-5e4f * AF_LOG2E) : x;
-                acc[4 * g + j] = x;
-                tmax = fmaxf(tmax, x);
+                for (int j = 0; j < 4; ++j) {
+                    float x = acc[4 * g + j] * scv[j];
+                    x = (kev[j] > qpe) ? AF_NEG : x;
+                    x = (kpv[j] == qpos) ? (-5e4f * AF_LOG2E) : x;
+                    acc[4 * g + j] = x;
+                    tmax = fmaxf(tmax, x);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int key0 = kt * 32 + 8 * g + 4 * hh;
+                const float4 sc = *reinterpret_cast<const float4*>(ksc + key0);
+                const int4 ke = *reinterpret_cast<const int4*>(kpe + key0);
+                const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
+                const int kev[4] = {ke.x, ke.y, ke.z, ke.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x = acc[4 * g + j] * scv[j];
+                    x = (kev[j] > qpe) ? AF_NEG : x;
+                    acc[4 * g + j] = x;
+                    tmax = fmaxf(tmax, x);
+                }
             }
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
