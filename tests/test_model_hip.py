@@ -507,3 +507,28 @@ def test_long_sequence_config_general_path(gpu):
         grads.append(tr.flat_g.clone())
     zero = [n for n, (s, e) in tr.offsets.items() if float(grads[0][s:e].abs().max()) == 0.0]
     assert all(".conv" in n and n.endswith(".bias") for n in zero), zero
+
+
+def test_batch_prefetcher_feeds_captured_buffers(gpu):
+    """custom_sequence_padder (pinned) -> BatchPrefetcher: batches arrive in order, on the device, and with ``into`` they
+    land in the SAME device buffers every time (what a captured hipGraph reads)."""
+    from reformer_tts_amd.dataset import BatchPrefetcher, custom_sequence_padder
+    g = torch.Generator().manual_seed(0)
+    hosts = []
+    for k in range(3):
+        items = [dict(phonemes=torch.randint(1, 77, (20,), generator=g), spectrogram=torch.randn(64, 80, generator=g) + k)
+                 for _ in range(2)]
+        hosts.append(custom_sequence_padder(items, pin_memory=True))
+    assert hosts[0]["spectrogram"].is_pinned()
+    into = {k: torch.empty_like(v, device=gpu) for k, v in hosts[0].items()}
+    ptrs = {k: v.data_ptr() for k, v in into.items()}
+    seen = 0
+    for i, batch in enumerate(BatchPrefetcher(hosts, gpu, into=into)):
+        torch.cuda.synchronize()
+        for k, v in batch.items():
+            assert v.data_ptr() == ptrs[k] and torch.equal(v.cpu(), hosts[i][k]), (i, k)
+        seen += 1
+    assert seen == 3
+    fresh = list(BatchPrefetcher(hosts, gpu))
+    torch.cuda.synchronize()
+    assert len(fresh) == 3 and all(torch.equal(fresh[i]["phonemes"].cpu(), hosts[i]["phonemes"]) for i in range(3))

@@ -184,3 +184,19 @@ def test_lsh_integer_stages_vs_huggingface(golden_dir):
         sticker, undo = lsh_ref.sort_buckets(exp, t)
         assert torch.equal(sticker, torch.from_numpy(z[f"{tag}/sorted_idx"].astype(np.int64)).reshape(2 * heads, -1))
         assert torch.equal(undo, torch.from_numpy(z[f"{tag}/undo"].astype(np.int64)).reshape(2 * heads, -1))
+
+
+def test_product_collate_matches_reference_golden(pieces):
+    """The product's custom_sequence_padder (reformer_tts_amd.dataset) against the reference's outputs on ragged inputs
+    (fixture generated by importing /root/reference/reformer_tts/dataset/utils.py:5-42), bit-exact; and the edge cases."""
+    from reformer_tts_amd.dataset import custom_sequence_padder
+    items = [dict(phonemes=_t(pieces, f"collate/in{i}/phonemes"), spectrogram=_t(pieces, f"collate/in{i}/spectrogram")) for i in range(3)]
+    got = custom_sequence_padder(items)
+    for k, v in got.items():
+        ref = _t(pieces, f"collate/out/{k}")
+        assert v.shape == ref.shape and torch.equal(v.to(ref.dtype), ref), k
+    one = custom_sequence_padder(items[:1])                      # a batch of one: nothing is padded
+    assert one["spectrogram"].shape[1] == items[0]["spectrogram"].shape[0] + 1 and float(one["loss_mask"].min()) == 1.0
+    assert float(one["stop_tokens"].sum()) == 1.0 and float(one["stop_tokens"][0, -1]) == 1.0
+    with pytest.raises(ValueError):
+        custom_sequence_padder([])
