@@ -43,6 +43,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
+    ap.add_argument("--recompute", default="stash", choices=["stash", "attention-stash", "full"],
+                    help="what the reversible backward recomputes: 'full' = everything, as the reference does; "
+                         "'attention-stash' = attention outputs kept; 'stash' (default) = attention outputs and block outputs "
+                         "f(x) kept, LayerNorm and the input projections recomputed, streams reconstructed by subtraction")
     return ap.parse_args()
 
 
@@ -95,7 +99,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from reformer_tts_amd import ops
+    from reformer_tts_amd import engine, ops
+    engine.STASH_ATTENTION = args.recompute != "full"
+    engine.STASH_BLOCK_OUTPUT = args.recompute == "stash"
     from reformer_tts_amd.model.config import (baseline_model_config, baseline_training_config,
                                                long_sequence_model_config)
     from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
@@ -168,7 +174,7 @@ def main():
                                    f"LSH 8 rounds, buckets 64/128), per-GPU batch {args.batch}, text {args.text_len}->256, "
                                    f"mel {args.mel_len}x80" if args.config == "baseline" else
                                    f"config/bucket-size-64-18-06.yml, per-GPU batch {args.batch}, mel {args.mel_len}",
-                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(float(loss), 4),
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(float(loss), 4), "reversible_recompute": args.recompute,
                        "launch": ("hipGraph replay" if one_graph else "hipGraph replay (fwd+bwd | all-reduce | optimizer)")
                        if use_graph else "eager"},
         }

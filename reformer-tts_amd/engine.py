@@ -28,6 +28,11 @@ from .model.lsh_attention import LSHSelfAttention
 # f(x) = to_out(attention(LN x)) re-runs only LayerNorm and the projections, not the attention forward.  Bitwise the same
 # result (the kernels are deterministic); HBM capacity traded for time.  False = the reference's pure recompute.
 STASH_ATTENTION = True
+# The same trade one step further: keep f(x) itself (bf16 (B*T, d), 12.6 MB per decoder block at the baseline shape,
+# ~130 MB for the whole model) so that the reconstruction x = y - f(.) subtracts exactly what the forward added and
+# the backward skips the output-projection / second FFN GEMM of the recompute (38.6 of 87 GFLOP per decoder layer).
+# What is still recomputed: LayerNorm, the QKV / q, kv / first FFN projections (their outputs are backward operands).
+STASH_BLOCK_OUTPUT = True
 WEIGHT_EPOCH = [0]   # bumped by the trainer after every optimizer step (its kernels write parameters through raw pointers)
 
 
@@ -182,6 +187,7 @@ class LSHExec:
         self.layer: LSHSelfAttention = withnorm.fn.layer
         self.st = None
         self.stash = None     # (out, lse_tot) of the forward when STASH_ATTENTION: the recompute skips the attention forward
+        self.g_stash = None   # f(x) of the forward when STASH_BLOCK_OUTPUT
 
     @staticmethod
     def supported(withnorm) -> bool:
@@ -201,7 +207,7 @@ class LSHExec:
             return torch.as_strided(ga, (2 * ga.shape[0], ga.shape[1]), (ga.shape[1], 1)), None
         return None, (ga, gb)
 
-    def _internals(self, inp, b, t, mask, st, stash=None):
+    def _internals(self, inp, b, t, mask, st, stash=None, g=None):
         lyr = self.layer
         e = lyr.dim
         if t <= lyr.full_attn_thres:
@@ -218,20 +224,22 @@ class LSHExec:
         else:
             o, lse = ops.lsh_attn_fwd(qkv[..., :e], qkv[..., e:], st, lyr.heads, lyr.bucket_size, lyr.causal, mask)
             out, lse_tot = ops.lsh_combine_fwd(o, lse, b, lyr.heads)
-        g = torch.mm(out.view(b * t, e), _bf16(lyr.to_out.weight).t())
+        if g is None:
+            g = torch.mm(out.view(b * t, e), _bf16(lyr.to_out.weight).t())
         return xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g
 
     def forward(self, acc, inp, b, t, mask=None, **_):
         *_, st, out, lse_tot, g = self._internals(inp, b, t, mask, None)
         self.st = st
         self.stash = (out, lse_tot) if STASH_ATTENTION else None
+        self.g_stash = g if STASH_BLOCK_OUTPUT else None
         residual(acc, g, self.layer.to_out.bias, 1.0)
 
     def backward(self, acc, inp, d_acc, d_inp, b, t, mask=None, **_):
         lyr = self.layer
         e = lyr.dim
-        xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g = self._internals(inp, b, t, mask, self.st, self.stash)
-        self.st = self.stash = None
+        xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g = self._internals(inp, b, t, mask, self.st, self.stash, self.g_stash)
+        self.st = self.stash = self.g_stash = None
         residual(acc, g, lyr.to_out.bias, -1.0)                               # reconstruct the stream
         dyb = cast_colsum(d_acc, _grad(lyr.to_out.bias))
         out2 = out.view(b * t, e)
@@ -259,25 +267,29 @@ class FFNExec:
         wn = mod.fn if hasattr(mod, "chunks") else mod
         self.norm = wn.norm
         self.l1, self.l2 = wn.fn.net[0], wn.fn.net[3]
+        self.g_stash = None
 
     @staticmethod
     def supported(mod) -> bool:
         wn = mod.fn if hasattr(mod, "chunks") else mod
         return wn.fn.net[2].p == 0.0
 
-    def _internals(self, inp):
+    def _internals(self, inp, g=None):
         xn, mean, rstd = ln_fwd(inp, self.norm)
         # bias + ReLU ride in the library GEMM's epilogue (fp32 accumulate, one rounding to bf16)
         h = torch._addmm_activation(_bf16(self.l1.bias), xn, _bf16(self.l1.weight).t(), use_gelu=False)
-        g = torch.mm(h, _bf16(self.l2.weight).t())
+        if g is None:
+            g = torch.mm(h, _bf16(self.l2.weight).t())
         return xn, mean, rstd, h, g
 
     def forward(self, acc, inp, b, t, **_):
         *_, g = self._internals(inp)
+        self.g_stash = g if STASH_BLOCK_OUTPUT else None
         residual(acc, g, self.l2.bias, 1.0)
 
     def backward(self, acc, inp, d_acc, d_inp, b, t, **_):
-        xn, mean, rstd, h, g = self._internals(inp)
+        xn, mean, rstd, h, g = self._internals(inp, self.g_stash)
+        self.g_stash = None
         residual(acc, g, self.l2.bias, -1.0)
         dyb = cast_colsum(d_acc, _grad(self.l2.bias))
         wgrad(_grad(self.l2.weight), dyb, h)
@@ -295,13 +307,14 @@ class XAttnExec:
         self.norm = withnorm.norm
         self.mha = withnorm.fn.layer
         self.stash = None
+        self.g_stash = None
 
     @staticmethod
     def supported(withnorm) -> bool:
         m = withnorm.fn.layer
         return m.dropout == 0.0 and m.bias_k is None and not m.add_zero_attn and m._qkv_same_embed_dim
 
-    def _internals(self, inp, b, t, keys_bf16, kvalid, stash=None):
+    def _internals(self, inp, b, t, keys_bf16, kvalid, stash=None, g=None):
         m = self.mha
         e, h = m.embed_dim, m.num_heads
         tk = keys_bf16.shape[0] // b
@@ -316,19 +329,21 @@ class XAttnExec:
             lse = torch.empty(b * h, t, dtype=torch.float32, device=inp.device)
             _lib.call("rtts_xattn_fwd", q.data_ptr(), e, kv.data_ptr(), 2 * e, None if kvalid is None else kvalid.data_ptr(), b, h, t,
                       tk, e // h, o.data_ptr(), e, lse.data_ptr(), _s())
-        g = torch.mm(o, _bf16(m.out_proj.weight).t())
+        if g is None:
+            g = torch.mm(o, _bf16(m.out_proj.weight).t())
         return xn, mean, rstd, w, q, kv, o, lse, g, tk
 
     def forward(self, acc, inp, b, t, keys_bf16=None, kvalid=None, **_):
         *_, o, lse, g, _ = self._internals(inp, b, t, keys_bf16, kvalid)
         self.stash = (o, lse) if STASH_ATTENTION else None
+        self.g_stash = g if STASH_BLOCK_OUTPUT else None
         residual(acc, g, self.mha.out_proj.bias, 1.0)
 
     def backward(self, acc, inp, d_acc, d_inp, b, t, keys_bf16=None, kvalid=None, dkeys=None, **_):
         m = self.mha
         e, h = m.embed_dim, m.num_heads
-        xn, mean, rstd, w, q, kv, o, lse, g, tk = self._internals(inp, b, t, keys_bf16, kvalid, self.stash)
-        self.stash = None
+        xn, mean, rstd, w, q, kv, o, lse, g, tk = self._internals(inp, b, t, keys_bf16, kvalid, self.stash, self.g_stash)
+        self.stash = self.g_stash = None
         residual(acc, g, m.out_proj.bias, -1.0)
         dyb = cast_colsum(d_acc, _grad(m.out_proj.bias))
         wgrad(_grad(m.out_proj.weight), dyb, o)

@@ -394,9 +394,9 @@ def test_bn_act_dropout_kernels_vs_autograd(gpu, act, p):
 
 
 def test_attention_stash_matches_pure_recompute(gpu):
-    """STASH_ATTENTION keeps the attention outputs of the forward for the backward instead of recomputing them from
-    the RECONSTRUCTED stream (which differs from the forward's stream in the last fp32 bits, so the two modes are not
-    bitwise equal): gradients agree to rounding."""
+    """STASH_ATTENTION / STASH_BLOCK_OUTPUT keep the attention outputs / the block outputs f(x) of the forward for the
+    backward instead of recomputing them from the RECONSTRUCTED stream (which differs from the forward's stream in the
+    last fp32 bits, so the modes are not bitwise equal): gradients agree to rounding with the reference's pure recompute."""
     from reformer_tts_amd import engine
     from reformer_tts_amd.model.config import TTSTrainingConfig, model_config_from_dict
     from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
@@ -405,10 +405,10 @@ def test_attention_stash_matches_pure_recompute(gpu):
     cfg["dec_reformer_kwargs"]["self_attn_kwargs"]["implementation"] = "hip"
     batch = synthetic_batch(2, 100, 256, device=gpu)
     grads = []
-    old = engine.STASH_ATTENTION
+    old = engine.STASH_ATTENTION, engine.STASH_BLOCK_OUTPUT
     try:
-        for stash in (True, False):
-            engine.STASH_ATTENTION = stash
+        for stash, stash_out in ((True, True), (True, False), (False, False)):
+            engine.STASH_ATTENTION, engine.STASH_BLOCK_OUTPUT = stash, stash_out
             model = build_model(model_config_from_dict(cfg), gpu)
             tr = Trainer(model, TTSTrainingConfig(batch_size=2), gpu)
             model.train()
@@ -417,8 +417,9 @@ def test_attention_stash_matches_pure_recompute(gpu):
             torch.cuda.synchronize()
             grads.append(tr.flat_g.clone())
     finally:
-        engine.STASH_ATTENTION = old
-    assert ((grads[0] - grads[1]).norm() / grads[1].norm()).item() < 1e-2
+        engine.STASH_ATTENTION, engine.STASH_BLOCK_OUTPUT = old
+    assert ((grads[0] - grads[2]).norm() / grads[2].norm()).item() < 1e-2
+    assert ((grads[1] - grads[2]).norm() / grads[2].norm()).item() < 1e-2
 
 
 @pytest.mark.parametrize("segmented", [False, True])
