@@ -79,6 +79,8 @@ class LSHSelfAttention(nn.Module):
         self.last_st: Optional[torch.Tensor] = None
 
     def _rotations(self, x, n_buckets):
+        if self.forced_rotations is not None and hasattr(self.forced_rotations, "__next__"):
+            return next(self.forced_rotations).to(device=x.device, dtype=torch.float32).contiguous()   # tests: one per call
         if self.forced_rotations is not None:
             if self.forced_rotations.device != x.device or self.forced_rotations.dtype != torch.float32:
                 self.forced_rotations = self.forced_rotations.to(device=x.device, dtype=torch.float32).contiguous()

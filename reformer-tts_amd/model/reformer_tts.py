@@ -48,6 +48,10 @@ class Decoder(nn.Module):
         return self.mel_linear(x), self.stop_linear(x), attention_matrices
 
 
+def _pad_len(n: int, base: int) -> int:
+    return ((n - 1) // base + 1) * base
+
+
 def pad_to_multiple(tensor, pad_base):
     """Right zero-pad (batch, seq_len, channels) to a multiple of ``pad_base`` on the tensor's own
     device (``reformer_tts.py:224-232`` relies on a process-wide default CUDA tensor type)."""
@@ -104,3 +108,81 @@ class ReformerTTS(nn.Module):
         mel_postnet = mel + self.postnet(mel)
         cutoff = spectrogram.shape[1]
         return mel[:, :cutoff], mel_postnet[:, :cutoff], stop[:, :cutoff], attention_matrices
+
+    # ------------------------------------------------------------------ generation
+    @torch.no_grad()
+    def infer(self, phonemes: torch.LongTensor, combine_strategy: str = "concat", max_len: int = 1024,
+              stop_threshold: float = 0.25, verbose: bool = False, stop_at_stop_token: bool = True,
+              cache_encoder: bool = False, check_every: int = 8) -> Tuple[torch.Tensor, torch.LongTensor]:
+        """``reformer_tts.py:145-221``: autoregressive generation by repeated full forwards over the spectrogram
+        generated so far.  Same arguments, same results -- (spectrogram (B, n_mels, L), stop_idx (B,)) -- including the
+        loop guard ``max(spectrogram.shape) > max_len`` (the shape includes the mel axis: ``max_len < n_mels`` ends
+        after one forward) and ``stop == max_len`` for samples that never stopped.
+
+        MI355X-first differences, none of them visible in the result:
+        * the spectrogram lives in ONE preallocated device buffer (no ``torch.cat`` of a growing tensor per frame);
+        * the stop bookkeeping stays on the device; the host looks at it every ``check_every`` iterations only
+          ("concat": frames generated after every sample has stopped cannot change earlier frames, so the result is cut
+          back to where the reference's loop would have ended; "replace" rewrites every frame and checks every time);
+        * ``cache_encoder=True`` runs the encoder once instead of once per frame.  That IS visible -- the reference
+          re-draws the LSH rotations of the encoder in every forward -- hence off by default."""
+        assert combine_strategy in {"concat", "replace"}
+        assert -1. < stop_threshold < 1.
+        was_training = self.training
+        self.eval()
+        try:
+            dev = self.dec.mel_linear.weight.device
+            phonemes = phonemes.to(dev)
+            b, nm = phonemes.shape[0], self.num_mel_coeffs
+            cap = max(max_len, nm, b) + 2                       # the guard below cannot let the buffer grow past this
+            buf = torch.zeros(b, cap + 1, nm, device=dev)       # frame 0 = the zero start frame
+            cur = 1                                             # frames in the buffer, start frame included
+            stop = torch.zeros(b, dtype=torch.long, device=dev)
+            keys_cache = None
+            if cache_encoder:
+                pad_ph = pad_to_multiple(phonemes.unsqueeze(-1), self.pad_base).squeeze(-1)
+                ph_mask = pad_ph != 0
+                keys_cache = (self.enc(pad_ph, input_mask=ph_mask), ph_mask)
+            every = 1 if combine_strategy == "replace" else max(1, int(check_every))
+            it = 0
+            while True:
+                if stop_at_stop_token and it % every == 0 and bool(torch.all(stop > 0)):
+                    break
+                it += 1
+                iteration = cur
+                still_running = stop == 0
+                if verbose and iteration % 10 == 0:
+                    print(f"reached {iteration=}, number_of_running_samples={int(still_running.sum())}...")
+                spec = buf[:, :cur]
+                if keys_cache is None:
+                    _, generated, stop_pred, _ = self.forward(phonemes, spec)
+                else:
+                    keys, ph_mask = keys_cache
+                    pad_spec = pad_to_multiple(spec, self.pad_base)
+                    sp_mask = pad_to_multiple(torch.ones(b, cur, 1, device=dev), self.pad_base).squeeze(-1).to(torch.bool)
+                    mel, stop_pred, _ = self.dec(pad_spec, keys=keys, key_padding_mask=~ph_mask, input_mask=sp_mask)
+                    generated, stop_pred = (mel + self.postnet(mel))[:, :cur], stop_pred[:, :cur]
+                stop_pred = stop_pred.reshape(b, -1)
+                if combine_strategy == "concat":
+                    buf[:, cur] = generated[:, -1, :]
+                    cur += 1
+                    if stop_at_stop_token:
+                        stops_now = torch.sigmoid(stop_pred[:, -1]) > stop_threshold
+                        stop = torch.where(still_running & stops_now, stops_now.long() * iteration + 1, stop)
+                else:
+                    buf[:, 1:1 + generated.shape[1]] = generated
+                    cur = 1 + generated.shape[1]
+                    if stop_at_stop_token:
+                        stops_now = torch.any(torch.sigmoid(stop_pred) > stop_threshold, dim=1)
+                        stop = torch.where(stops_now & still_running, torch.argmax(stop_pred, dim=1) + 1, stop)
+                if max(b, cur, nm) > max_len:
+                    if verbose:
+                        print(f"stopped at {max_len=}")
+                    break
+            if combine_strategy == "concat" and stop_at_stop_token and bool(torch.all(stop > 0)):
+                cur = min(cur, int(stop.max()))                 # where the reference's per-iteration check ends the loop
+            stop = torch.where(stop == 0, torch.full_like(stop, max_len), stop)
+            return buf[:, 1:cur].transpose(1, 2).contiguous(), stop
+        finally:
+            self.train(was_training)
+

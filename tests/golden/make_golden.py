@@ -17,6 +17,8 @@ Fixtures
                    ``oracle.lsh_ref.LSHSelfAttention`` -- "reference wiring x
                    restated LSH" (SURVEY.md 8c (2)); parameters come from
                    ``oracle.synth`` and are therefore not stored.
+  infer_small.npz  the reference's ReformerTTS.infer (autoregressive loop of full eval-mode forwards) on the same
+                   wiring, three strategies; rotations recorded in call order
   hf_lsh_int.npz   integer stages (hash, stable sort) from HuggingFace's
                    independent implementation of the same paper (cross-check,
                    not the reference)
@@ -194,6 +196,53 @@ def model_small():
     print("model_small.npz: loss", out["out/loss"], "layers", n_fwd)
 
 
+STOP_T = float(os.environ.get("GOLDEN_STOP_T", "0.995"))   # synthetic weights give large stop logits
+
+
+def infer_small():
+    """the reference's own ReformerTTS.infer (reformer_tts.py:145-221) in eval mode with
+    non-trivial BatchNorm running statistics; every rotation the LSH shim draws is recorded in call order."""
+    cfg = small_cfg()
+    torch.manual_seed(7)
+    m = ReformerTTS(**cfg)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=3)
+    m.load_state_dict(sd, strict=False)
+    g = torch.Generator().manual_seed(21)
+    out = {}
+    for name, buf in m.named_buffers():
+        if name.endswith("running_mean"):
+            buf.copy_(0.2 * torch.randn(buf.shape, generator=g))
+        elif name.endswith("running_var"):
+            buf.copy_(0.5 + torch.rand(buf.shape, generator=g))
+        if "running" in name:
+            out[f"buf/{name}"] = npy(buf)
+    m.eval()
+    phonemes = torch.randint(1, 77, (2, 23), generator=g)
+    out["phonemes"] = npy(phonemes)
+    # max_len must exceed n_mels = 80: the loop's guard is max(spectrogram.shape) > max_len (reformer_tts.py:212), and
+    # the shape includes the mel axis, so anything smaller ends after one forward
+    for strategy, cs, kw in (("concat", "concat", dict(max_len=86, stop_at_stop_token=False)),
+                             ("concat_stop", "concat", dict(max_len=90, stop_threshold=STOP_T)),
+                             ("replace", "replace", dict(max_len=82, stop_at_stop_token=False)),
+                             ("replace_stop", "replace", dict(max_len=84, stop_threshold=STOP_T)),
+                             ("short", "concat", dict(max_len=7, stop_at_stop_token=False))):
+        rot_log = []
+        for mod in m.modules():
+            if isinstance(mod, lsh_ref.LSHSelfAttention):
+                mod.rotation_log = rot_log
+        torch.manual_seed(5)
+        with torch.no_grad():
+            spec, stop = m.infer(phonemes, combine_strategy=cs, **kw)
+        out[f"{strategy}/spectrogram"], out[f"{strategy}/stop"] = npy(spec), npy(stop)
+        for i, r in enumerate(rot_log):
+            out[f"{strategy}/rot/{i}"] = npy(r)
+        out[f"{strategy}/n_rot"] = np.array(len(rot_log))
+        out[f"{strategy}/kw"] = np.array([kw["max_len"], kw.get("stop_threshold", 0.25), float(kw.get("stop_at_stop_token", True))])
+        print("infer", strategy, tuple(spec.shape), stop.tolist(), "forwards", len(rot_log) // 2)
+    np.savez_compressed(os.path.join(HERE, "infer_small.npz"), **out)
+
+
 def hf_lsh_int():
     """HuggingFace LSHSelfAttention integer stages on seeded vectors (per-head rotations)."""
     from transformers import ReformerConfig
@@ -222,4 +271,5 @@ if __name__ == "__main__":
     torch.set_num_threads(4)
     pieces()
     model_small()
+    infer_small()
     hf_lsh_int()

@@ -200,3 +200,36 @@ def test_product_collate_matches_reference_golden(pieces):
     assert float(one["stop_tokens"].sum()) == 1.0 and float(one["stop_tokens"][0, -1]) == 1.0
     with pytest.raises(ValueError):
         custom_sequence_padder([])
+
+
+@pytest.fixture(scope="module")
+def infer_golden(golden_dir):
+    return np.load(os.path.join(golden_dir, "infer_small.npz"))
+
+
+def _infer_sd(z):
+    cfg = model_ref.small_cfg()
+    zm = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_small.npz"))   # same module tree
+    shapes = {k[len("shape/"):]: tuple(zm[k]) for k in zm.files if k.startswith("shape/")}
+    sd = synth.synth_state_dict(shapes, seed=3)
+    for k in z.files:
+        if k.startswith("buf/"):
+            sd[k[4:]] = torch.from_numpy(z[k])
+    return cfg, sd
+
+
+@pytest.mark.parametrize("case", ["concat", "concat_stop", "replace", "replace_stop", "short"])
+def test_oracle_infer_matches_reference(infer_golden, case):
+    """oracle.model_ref.infer against the reference's own ReformerTTS.infer (reformer_tts.py:145-221; fixture generated
+    by importing it), eval-mode BatchNorm with non-trivial running statistics, rotations replayed in call order.
+    'short': max_len < n_mels ends after ONE forward -- the loop guard is max(spectrogram.shape) > max_len."""
+    z = infer_golden
+    cfg, sd = _infer_sd(z)
+    max_len, thr, use_stop = z[f"{case}/kw"]
+    rots = [torch.from_numpy(z[f"{case}/rot/{i}"]) for i in range(int(z[f"{case}/n_rot"]))]
+    with torch.no_grad():
+        spec, stop = model_ref.infer(sd, cfg, torch.from_numpy(z["phonemes"]), rots, combine_strategy=case.split("_")[0] if case != "short" else "concat",
+                                     max_len=int(max_len), stop_threshold=float(thr), stop_at_stop_token=bool(use_stop))
+    assert spec.shape == z[f"{case}/spectrogram"].shape
+    assert torch.equal(stop, torch.from_numpy(z[f"{case}/stop"]))
+    torch.testing.assert_close(spec, torch.from_numpy(z[f"{case}/spectrogram"]), rtol=1e-3, atol=1e-3)
