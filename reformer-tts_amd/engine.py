@@ -137,7 +137,8 @@ def _slab_ws(device):
 
 def flush_wgrad():
     """Launch every queued weight gradient (grouped), release the held operands."""
-    while _PENDING:
+    _FINAL_FLUSH_QUEUED[0] = False     # the next deferral queues a fresh end-of-backward callback (extra ones are no-ops);
+    while _PENDING:                    # a backward that died half-way therefore cannot leave the flag stuck
         group = _PENDING[:_lib.GEMM_TN_MAX_GROUP]
         del _PENDING[:len(group)]
         arr = (_lib.GemmTnProblem * len(group))()
