@@ -7,48 +7,77 @@
 // on the same XCD, so 7 of the 8 reads are L2 hits), writes 4 B (+8 B optional) per token.
 // The projection is a k-ordered fp32 fmaf chain, so bucket ids are bit-identical to
 // oracle/lsh_int.c; the sort is a stable counting sort (keys are unique => permutation unique).
+//
+// Hash: a lane owns a row (64 values in registers) and runs the fmaf chains of two buckets per instruction
+// (v_pk_fma_f32: the two halves are independent IEEE fmas, so packing does not change a bit).
+// Sort: per 64-token group the lanes that share a bucket are found with log2(n_buckets) ballots (AND of
+// ballot / ~ballot per bucket-id bit), a lane's stable rank is the popcount of that mask below it, and the
+// per-(wave, bucket) running offsets live in LDS -- O(log n_buckets) wave ops per group instead of O(n_buckets).
 #include "rtts_common.h"
 
-#define HS_THREADS 256
-#define HS_WAVES 4
 #define HS_DH 64
 #define HS_ROWB 144   // LDS row stride in bytes for a staged 64 x 64 bf16 tile (conflict-free b128 reads)
 
 template <int HALF>
 __device__ __forceinline__ int hash_row(const float* q, const float* rot_lds) {
     // rot_lds[f * HALF + i]; returns argmax over [xR, -xR] with the first maximum winning
-    float acc[HALF];
-#pragma unroll
-    for (int i = 0; i < HALF; ++i) acc[i] = 0.f;
-#pragma unroll
-    for (int f = 0; f < HS_DH; ++f) {
-#pragma unroll
-        for (int i = 0; i < HALF; ++i) acc[i] = __builtin_fmaf(q[f], rot_lds[f * HALF + i], acc[i]);
-    }
-    float best = acc[0];
     int idx = 0;
+    float best;
+    if constexpr (HALF >= 2) {
+        f32x2 acc[HALF / 2];
 #pragma unroll
-    for (int i = 1; i < HALF; ++i)
-        if (acc[i] > best) { best = acc[i]; idx = i; }
+        for (int i = 0; i < HALF / 2; ++i) acc[i] = (f32x2){0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < HALF; ++i)
-        if (-acc[i] > best) { best = -acc[i]; idx = HALF + i; }
+        for (int f = 0; f < HS_DH; ++f) {
+            const f32x2 qq = {q[f], q[f]};
+#pragma unroll
+            for (int i = 0; i < HALF / 2; ++i)
+                acc[i] = __builtin_elementwise_fma(qq, *reinterpret_cast<const f32x2*>(rot_lds + f * HALF + 2 * i), acc[i]);
+        }
+        best = acc[0][0];
+#pragma unroll
+        for (int i = 1; i < HALF; ++i)
+            if (acc[i >> 1][i & 1] > best) { best = acc[i >> 1][i & 1]; idx = i; }
+#pragma unroll
+        for (int i = 0; i < HALF; ++i)
+            if (-acc[i >> 1][i & 1] > best) { best = -acc[i >> 1][i & 1]; idx = HALF + i; }
+    } else {
+        float a = 0.f;
+#pragma unroll
+        for (int f = 0; f < HS_DH; ++f) a = __builtin_fmaf(q[f], rot_lds[f], a);
+        best = a;
+        if (-a > best) idx = 1;
+    }
     return idx;
 }
 
-template <int HALF>
-__global__ __launch_bounds__(HS_THREADS) void lsh_hash_sort_kernel(
+// lanes of the wave whose value v (0 <= v < 2^BITS, or -1 = inactive) equals this lane's
+template <int BITS>
+__device__ __forceinline__ unsigned long long match_lanes(int v) {
+    unsigned long long m = __ballot(v >= 0);
+#pragma unroll
+    for (int bit = 0; bit < BITS; ++bit) {
+        const unsigned long long bm = __ballot((v >> bit) & 1);
+        m &= ((v >> bit) & 1) ? bm : ~bm;
+    }
+    return m;
+}
+
+template <int HALF, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void lsh_hash_sort_kernel(
     const bf16_t* __restrict__ qk, int64_t ld, const float* __restrict__ rotations, int rot_rows,
     int H, int T, int n_hashes, int32_t* __restrict__ buckets, int32_t* __restrict__ st, int32_t* __restrict__ undo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // carve: rot [64*HALF] f32 | tile [4 waves][64 rows][144 B] | bkt [T] u16 | cntw [4][64] i32 | tot [64] i32
+    constexpr int NB = 2 * HALF;
+    constexpr int BITS = (NB <= 2) ? 1 : (NB <= 4) ? 2 : (NB <= 8) ? 3 : (NB <= 16) ? 4 : (NB <= 32) ? 5 : 6;
+    constexpr int NTHR = 64 * WAVES;
+    // carve: rot [64*HALF] f32 | tile [WAVES][64 rows][144 B] | bkt [T] u16 | cntw [WAVES][64] i32 | tot [64] i32
     float* rot_lds = reinterpret_cast<float*>(smem);
     unsigned char* tile = smem + ((HS_DH * HALF * 4 + 15) & ~15);
-    uint16_t* bkt = reinterpret_cast<uint16_t*>(tile + HS_WAVES * 64 * HS_ROWB);
+    uint16_t* bkt = reinterpret_cast<uint16_t*>(tile + WAVES * 64 * HS_ROWB);
     int* cntw = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(bkt) + ((T * 2 + 15) & ~15));
-    int* tot = cntw + HS_WAVES * 64;
+    int* tot = cntw + WAVES * 64;
 
-    constexpr int NB = 2 * HALF;
     // work item: round r of head bh; rounds of one bh are 8 ids apart => same XCD (L2 reuse of qk)
     const uint32_t nblk = gridDim.x;
     const uint32_t w = xcd_remap(blockIdx.x, nblk);
@@ -57,21 +86,28 @@ __global__ __launch_bounds__(HS_THREADS) void lsh_hash_sort_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     const float* rot_src = rotations + (size_t)(rot_rows == 1 ? 0 : bh) * HS_DH * n_hashes * HALF;
-    for (int i = tid; i < HS_DH * HALF; i += HS_THREADS) {
+    for (int i = tid; i < HS_DH * HALF; i += NTHR) {
         const int f = i / HALF, k = i % HALF;
         rot_lds[i] = rot_src[((size_t)f * n_hashes + r) * HALF + k];
     }
+    for (int i = tid; i < WAVES * 64; i += NTHR) cntw[i] = 0;
     __syncthreads();
 
-    // ---- hash: each wave stages 64 rows (coalesced 16-B pieces), then one lane hashes one row
+    // ---- hash: each wave stages 64 rows (coalesced 16-B pieces), then one lane hashes one row.
+    //      Wave w hashes the token segment it will sort, so its bucket counts need no other wave's rows.
+    const int seg = T / WAVES;              // multiple of 32 because T % 128 == 0 and WAVES in {4, 8}
+    const int s0 = wave * seg;
     const bf16_t* base = qk + (size_t)b * T * ld + (size_t)h * HS_DH;
     unsigned char* wt = tile + wave * 64 * HS_ROWB;
-    for (int t0 = wave * 64; t0 < T; t0 += HS_WAVES * 64) {
+    for (int t0 = 0; t0 < seg; t0 += 64) {
+        const int rows = min(64, seg - t0);         // 32 or 64
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int row = p * 8 + (lane >> 3), piece = lane & 7;
-            const uint4 val = *reinterpret_cast<const uint4*>(base + (size_t)(t0 + row) * ld + piece * 8);
-            *reinterpret_cast<uint4*>(wt + row * HS_ROWB + piece * 16) = val;
+            if (row < rows) {
+                const uint4 val = *reinterpret_cast<const uint4*>(base + (size_t)(s0 + t0 + row) * ld + piece * 8);
+                *reinterpret_cast<uint4*>(wt + row * HS_ROWB + piece * 16) = val;
+            }
         }
         __builtin_amdgcn_wave_barrier();   // same wave wrote and reads: LDS ops of one wave execute in order
         float q[HS_DH];
@@ -85,46 +121,46 @@ __global__ __launch_bounds__(HS_THREADS) void lsh_hash_sort_kernel(
                 q[p * 8 + 2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u);
             }
         }
-        const int idx = hash_row<HALF>(q, rot_lds);
-        bkt[t0 + lane] = (uint16_t)idx;
-        if (buckets) buckets[((size_t)bh * n_hashes + r) * T + t0 + lane] = idx + r * NB;
+        const int idx = hash_row<HALF>(q, rot_lds);   // lanes >= rows hash stale LDS rows: results dropped below
+        if (lane < rows) {
+            bkt[s0 + t0 + lane] = (uint16_t)idx;
+            atomicAdd(&cntw[wave * 64 + idx], 1);      // integer LDS add: order-free, deterministic
+            if (buckets) buckets[((size_t)bh * n_hashes + r) * T + s0 + t0 + lane] = idx + r * NB;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
 
-    // ---- stable counting sort.  Wave w owns the contiguous token segment [w*T/4, (w+1)*T/4);
-    // lane k of every wave keeps the counter of bucket k (NB <= 64).
-    const int seg = T / HS_WAVES;           // multiple of 32 because T % 128 == 0
-    const int s0 = wave * seg;
-    int cnt = 0;
-    for (int t0 = 0; t0 < seg; t0 += 64) {
-        const bool act = t0 + lane < seg;
-        const int mb = act ? (int)bkt[s0 + t0 + lane] : -1;
-        for (int k = 0; k < NB; ++k) {
-            const unsigned long long m = __ballot(mb == k);
-            if (lane == k) cnt += __popcll(m);
-        }
+    // ---- stable counting sort: first sorted slot of (bucket k, wave w) = tokens in smaller buckets + tokens of
+    //      bucket k in earlier waves' segments
+    if (tid < NB) {
+        int t = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < WAVES; ++w2) t += cntw[w2 * 64 + tid];
+        tot[tid] = t;
     }
-    if (lane < NB) cntw[wave * 64 + lane] = cnt;
     __syncthreads();
-    if (tid < NB) tot[tid] = cntw[tid] + cntw[64 + tid] + cntw[128 + tid] + cntw[192 + tid];
-    __syncthreads();
-    int basek = 0;   // first sorted slot of (bucket = lane, this wave's segment)
+    int basek = 0;
     if (lane < NB) {
         for (int k = 0; k < lane; ++k) basek += tot[k];
         for (int w2 = 0; w2 < wave; ++w2) basek += cntw[w2 * 64 + lane];
     }
+    __syncthreads();                         // every wave has read the counts before they become running offsets
+    int* run = cntw + wave * 64;             // this wave's running offset per bucket
+    if (lane < NB) run[lane] = basek;
+    __builtin_amdgcn_wave_barrier();
     int32_t* st_out = st + ((size_t)bh * n_hashes + r) * T;
     int32_t* undo_out = undo ? undo + ((size_t)bh * n_hashes + r) * T : nullptr;
     for (int t0 = 0; t0 < seg; t0 += 64) {
         const bool act = t0 + lane < seg;
         const int mb = act ? (int)bkt[s0 + t0 + lane] : -1;
+        const unsigned long long m = match_lanes<BITS>(mb);              // lanes of this group in my bucket
+        const unsigned long long below = m & ((1ull << lane) - 1ull);
         int pos = 0;
-        for (int k = 0; k < NB; ++k) {
-            const unsigned long long m = __ballot(mb == k);
-            const int bk = __shfl(basek, k);
-            if (mb == k) pos = bk + __popcll(m & ((1ull << lane) - 1ull));
-            if (lane == k) basek += __popcll(m);
-        }
+        if (act) pos = run[mb] + __popcll(below);
+        __builtin_amdgcn_wave_barrier();
+        if (act && below == 0) run[mb] += __popcll(m);                   // the first lane of each bucket advances it
+        __builtin_amdgcn_wave_barrier();
         if (act) {
             const int t = s0 + t0 + lane;
             st_out[pos] = t;
@@ -133,15 +169,31 @@ __global__ __launch_bounds__(HS_THREADS) void lsh_hash_sort_kernel(
     }
 }
 
-template <int HALF>
-static int launch_hash_sort(const bf16_t* qk, int64_t ld, const float* rot, int rot_rows, int B, int H, int T,
-                            int n_hashes, int32_t* buckets, int32_t* st, int32_t* undo, hipStream_t stream) {
-    const size_t lds = ((HS_DH * HALF * 4 + 15) & ~15) + HS_WAVES * 64 * HS_ROWB + ((T * 2 + 15) & ~15) + (HS_WAVES * 64 + 64) * 4;
+template <int HALF, int WAVES>
+static int launch_hash_sort_w(const bf16_t* qk, int64_t ld, const float* rot, int rot_rows, int B, int H, int T,
+                              int n_hashes, int32_t* buckets, int32_t* st, int32_t* undo, hipStream_t stream) {
+    const size_t lds = ((HS_DH * HALF * 4 + 15) & ~15) + WAVES * 64 * HS_ROWB + ((T * 2 + 15) & ~15) + (WAVES * 64 + 64) * 4;
+    static bool attr = false;
+    if (!attr && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lsh_hash_sort_kernel<HALF, WAVES>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
     const dim3 grid(B * H * n_hashes);
-    hipLaunchKernelGGL(lsh_hash_sort_kernel<HALF>, grid, dim3(HS_THREADS), lds, stream, qk, ld, rot, rot_rows, H, T,
+    hipLaunchKernelGGL((lsh_hash_sort_kernel<HALF, WAVES>), grid, dim3(64 * WAVES), lds, stream, qk, ld, rot, rot_rows, H, T,
                        n_hashes, buckets, st, undo);
     RTTS_LAUNCH_CHECK("rtts_lsh_hash_sort");
     return 0;
+}
+
+// 4 waves per (head, round) for short sequences; 8 from T = 2048 on (one workgroup still owns a whole sort, and a
+// long row has enough tokens to keep 8 waves = 2 per SIMD busy through the fmaf chains)
+template <int HALF>
+static int launch_hash_sort(const bf16_t* qk, int64_t ld, const float* rot, int rot_rows, int B, int H, int T,
+                            int n_hashes, int32_t* buckets, int32_t* st, int32_t* undo, hipStream_t stream) {
+    if (T >= 2048 && T % 256 == 0)
+        return launch_hash_sort_w<HALF, 8>(qk, ld, rot, rot_rows, B, H, T, n_hashes, buckets, st, undo, stream);
+    return launch_hash_sort_w<HALF, 4>(qk, ld, rot, rot_rows, B, H, T, n_hashes, buckets, st, undo, stream);
 }
 
 extern "C" int rtts_lsh_hash_sort(const void* qk, int64_t ld_qk, const float* rotations, int rot_rows, int B, int H,
