@@ -138,6 +138,11 @@ int rtts_colsum_bf16(void* dh, const void* h, int64_t ld, float* dbias, float* p
                      int relu_gate, float gate_scale, void* stream);
 int rtts_residual_epilogue(const float* x, const void* g, const float* bias, float sign, float* y,
                            int64_t M, int d, void* stream);
+/* The same epilogue fused with the NEXT block's LayerNorm: x += sign*(g + bias) in place, then
+ * xn(bf16) = LayerNorm(x)*gamma + beta with mean/rstd per row (reformer.py:25-33 applied to the stream a
+ * reversible block has just updated or reconstructed, reversible.py:56-98). */
+int rtts_residual_ln(float* x, const void* g, const float* bias, float sign, const float* gamma, const float* beta,
+                     void* xn, float* mean, float* rstd, int M, int d, void* stream);
 int rtts_bias_act(void* h, const float* bias, int64_t M, int d, int relu, void* stream);
 int rtts_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 

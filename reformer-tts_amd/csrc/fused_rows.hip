@@ -144,6 +144,53 @@ __global__ __launch_bounds__(FR_THREADS) void ln_fwd_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------- residual epilogue + the NEXT block's LayerNorm
+// x += sign * (g + bias) in place, then xn = LayerNorm(x) * gamma + beta (bf16) with its row statistics: the stream a
+// block has just updated (forward) or reconstructed (backward) is exactly the next block's LayerNorm input, so the
+// row is normalised while it is still in registers instead of being read back by a separate launch.
+template <int EPL, int VEC>
+__global__ __launch_bounds__(FR_THREADS) void residual_ln_kernel(float* __restrict__ x, const bf16_t* __restrict__ g,
+                                                                 const float* __restrict__ bias, float sign,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 bf16_t* __restrict__ xn, float* __restrict__ mean,
+                                                                 float* __restrict__ rstd, int M) {
+    constexpr int D = EPL * 64;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * FR_WAVES + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float v[EPL], gv[EPL], w[EPL];
+    load_row_f32<EPL, VEC>(x + (size_t)row * D, lane, v);
+    load_row_bf16<EPL, VEC>(g + (size_t)row * D, lane, gv);
+    if (bias) {
+        load_row_f32<EPL, VEC>(bias, lane, w);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) gv[e] += w[e];
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) v[e] += sign * gv[e];
+    store_row_f32<EPL, VEC>(x + (size_t)row * D, lane, v);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) s += v[e];
+    const float mu = wave_sum(s) * (1.f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        v[e] -= mu;
+        q = __builtin_fmaf(v[e], v[e], q);
+    }
+    const float rs = rsqrtf(wave_sum(q) * (1.f / D) + 1e-5f);
+    load_row_f32<EPL, VEC>(gamma, lane, gv);
+    load_row_f32<EPL, VEC>(beta, lane, w);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) v[e] = __builtin_fmaf(v[e] * rs, gv[e], w[e]);
+    store_row_bf16<EPL, VEC>(xn + (size_t)row * D, lane, v);
+    if (lane == 0) {
+        mean[row] = mu;
+        rstd[row] = rs;
+    }
+}
+
 // ---------------------------------------------------------------- LayerNorm backward
 // dx_io += rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dxn * gamma;
 // partial_g[blk] = sum_rows dxn * xhat, partial_b[blk] = sum_rows dxn
@@ -411,6 +458,17 @@ extern "C" int rtts_residual_epilogue(const float* x, const void* g, const float
     hipLaunchKernelGGL(residual_epilogue_kernel, dim3(stream_grid(n4)), dim3(FR_THREADS), 0, (hipStream_t)stream, x, (const bf16_t*)g,
                        bias, sign, y, n4, d);
     RTTS_LAUNCH_CHECK("rtts_residual_epilogue");
+    return 0;
+}
+
+extern "C" int rtts_residual_ln(float* x, const void* g, const float* bias, float sign, const float* gamma, const float* beta,
+                                void* xn, float* mean, float* rstd, int M, int d, void* stream) {
+    RTTS_REQUIRE(x && g && gamma && beta && xn && mean && rstd && M > 0, "rtts_residual_ln: bad arguments");
+    const dim3 grid((M + FR_WAVES - 1) / FR_WAVES);
+#define CALL(EPL, VEC) hipLaunchKernelGGL((residual_ln_kernel<EPL, VEC>), grid, dim3(FR_THREADS), 0, (hipStream_t)stream, x, (const bf16_t*)g, bias, sign, gamma, beta, (bf16_t*)xn, mean, rstd, M)
+    FR_DISPATCH_D(d, CALL)
+#undef CALL
+    RTTS_LAUNCH_CHECK("rtts_residual_ln");
     return 0;
 }
 

@@ -102,11 +102,20 @@ def colsum_bf16(dh, dbias, h=None, gate_scale: float = 1.0):
               _WS.partial(dh.device, d).data_ptr(), m, d, int(h is not None), float(gate_scale), _s())
 
 
-def residual(acc, g, bias, sign: float):
-    """acc = acc + sign * (g + bias), in place."""
+def residual(acc, g, bias, sign: float, next_norm=None):
+    """acc = acc + sign * (g + bias), in place.  With ``next_norm`` (the LayerNorm of the block that reads ``acc``
+    next) the row is normalised in the same launch: returns (xn, mean, rstd) of LayerNorm(acc), else None."""
     m, d = acc.shape
-    _lib.call("rtts_residual_epilogue", acc.data_ptr(), g.data_ptr(), None if bias is None else bias.data_ptr(), float(sign),
-              acc.data_ptr(), m, d, _s())
+    if next_norm is None:
+        _lib.call("rtts_residual_epilogue", acc.data_ptr(), g.data_ptr(), None if bias is None else bias.data_ptr(), float(sign),
+                  acc.data_ptr(), m, d, _s())
+        return None
+    xn = torch.empty(m, d, dtype=torch.bfloat16, device=acc.device)
+    mean = torch.empty(m, dtype=torch.float32, device=acc.device)
+    rstd = torch.empty(m, dtype=torch.float32, device=acc.device)
+    _lib.call("rtts_residual_ln", acc.data_ptr(), g.data_ptr(), None if bias is None else bias.data_ptr(), float(sign),
+              next_norm.weight.data_ptr(), next_norm.bias.data_ptr(), xn.data_ptr(), mean.data_ptr(), rstd.data_ptr(), m, d, _s())
+    return xn, mean, rstd
 
 
 _SLAB_FLOATS = 16 * 1024 * 1024   # 64 MB: 16 splits of a 2048 x 512 gradient
@@ -208,12 +217,12 @@ class LSHExec:
             return torch.as_strided(ga, (2 * ga.shape[0], ga.shape[1]), (ga.shape[1], 1)), None
         return None, (ga, gb)
 
-    def _internals(self, inp, b, t, mask, st, stash=None, g=None):
+    def _internals(self, inp, b, t, mask, st, stash=None, g=None, pre=None):
         lyr = self.layer
         e = lyr.dim
         if t <= lyr.full_attn_thres:
             raise NotImplementedError("full-attention shortcut (T <= full_attn_thres) is outside the HIP path")
-        xn, mean, rstd = ln_fwd(inp, self.norm)
+        xn, mean, rstd = pre if pre is not None else ln_fwd(inp, self.norm)
         wqkv = self._wqkv()
         qkv = torch.mm(xn, wqkv.t()).view(b, t, 2 * e)
         if st is None:
@@ -229,19 +238,19 @@ class LSHExec:
             g = torch.mm(out.view(b * t, e), _bf16(lyr.to_out.weight).t())
         return xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g
 
-    def forward(self, acc, inp, b, t, mask=None, **_):
-        *_, st, out, lse_tot, g = self._internals(inp, b, t, mask, None)
+    def forward(self, acc, inp, b, t, mask=None, pre=None, next_norm=None, **_):
+        *_, st, out, lse_tot, g = self._internals(inp, b, t, mask, None, pre=pre)
         self.st = st
         self.stash = (out, lse_tot) if STASH_ATTENTION else None
         self.g_stash = g if STASH_BLOCK_OUTPUT else None
-        residual(acc, g, self.layer.to_out.bias, 1.0)
+        return residual(acc, g, self.layer.to_out.bias, 1.0, next_norm)
 
-    def backward(self, acc, inp, d_acc, d_inp, b, t, mask=None, **_):
+    def backward(self, acc, inp, d_acc, d_inp, b, t, mask=None, pre=None, next_norm=None, **_):
         lyr = self.layer
         e = lyr.dim
-        xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g = self._internals(inp, b, t, mask, self.st, self.stash, self.g_stash)
+        xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g = self._internals(inp, b, t, mask, self.st, self.stash, self.g_stash, pre)
         self.st = self.stash = self.g_stash = None
-        residual(acc, g, lyr.to_out.bias, -1.0)                               # reconstruct the stream
+        post = residual(acc, g, lyr.to_out.bias, -1.0, next_norm)             # reconstruct the stream
         dyb = cast_colsum(d_acc, _grad(lyr.to_out.bias))
         out2 = out.view(b * t, e)
         wgrad(_grad(lyr.to_out.weight), dyb, out2)
@@ -259,6 +268,7 @@ class LSHExec:
             pair[1].add_(full[e:])
         dxn = torch.mm(dqkv2, wqkv)
         ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp)
+        return post
 
 
 class FFNExec:
@@ -275,23 +285,23 @@ class FFNExec:
         wn = mod.fn if hasattr(mod, "chunks") else mod
         return wn.fn.net[2].p == 0.0
 
-    def _internals(self, inp, g=None):
-        xn, mean, rstd = ln_fwd(inp, self.norm)
+    def _internals(self, inp, g=None, pre=None):
+        xn, mean, rstd = pre if pre is not None else ln_fwd(inp, self.norm)
         # bias + ReLU ride in the library GEMM's epilogue (fp32 accumulate, one rounding to bf16)
         h = torch._addmm_activation(_bf16(self.l1.bias), xn, _bf16(self.l1.weight).t(), use_gelu=False)
         if g is None:
             g = torch.mm(h, _bf16(self.l2.weight).t())
         return xn, mean, rstd, h, g
 
-    def forward(self, acc, inp, b, t, **_):
-        *_, g = self._internals(inp)
+    def forward(self, acc, inp, b, t, pre=None, next_norm=None, **_):
+        *_, g = self._internals(inp, pre=pre)
         self.g_stash = g if STASH_BLOCK_OUTPUT else None
-        residual(acc, g, self.l2.bias, 1.0)
+        return residual(acc, g, self.l2.bias, 1.0, next_norm)
 
-    def backward(self, acc, inp, d_acc, d_inp, b, t, **_):
-        xn, mean, rstd, h, g = self._internals(inp, self.g_stash)
+    def backward(self, acc, inp, d_acc, d_inp, b, t, pre=None, next_norm=None, **_):
+        xn, mean, rstd, h, g = self._internals(inp, self.g_stash, pre)
         self.g_stash = None
-        residual(acc, g, self.l2.bias, -1.0)
+        post = residual(acc, g, self.l2.bias, -1.0, next_norm)
         dyb = cast_colsum(d_acc, _grad(self.l2.bias))
         wgrad(_grad(self.l2.weight), dyb, h)
         dh = torch.mm(dyb, _bf16(self.l2.weight))
@@ -299,6 +309,7 @@ class FFNExec:
         wgrad(_grad(self.l1.weight), dh, xn)
         dxn = torch.mm(dh, _bf16(self.l1.weight))
         ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp)
+        return post
 
 
 class XAttnExec:
@@ -315,12 +326,12 @@ class XAttnExec:
         m = withnorm.fn.layer
         return m.dropout == 0.0 and m.bias_k is None and not m.add_zero_attn and m._qkv_same_embed_dim
 
-    def _internals(self, inp, b, t, keys_bf16, kvalid, stash=None, g=None):
+    def _internals(self, inp, b, t, keys_bf16, kvalid, stash=None, g=None, pre=None):
         m = self.mha
         e, h = m.embed_dim, m.num_heads
         tk = keys_bf16.shape[0] // b
         w, bias = _bf16(m.in_proj_weight), _bf16(m.in_proj_bias)
-        xn, mean, rstd = ln_fwd(inp, self.norm)
+        xn, mean, rstd = pre if pre is not None else ln_fwd(inp, self.norm)
         q = torch.addmm(bias[:e], xn, w[:e].t())
         kv = torch.addmm(bias[e:], keys_bf16, w[e:].t())
         if stash is not None:
@@ -334,18 +345,18 @@ class XAttnExec:
             g = torch.mm(o, _bf16(m.out_proj.weight).t())
         return xn, mean, rstd, w, q, kv, o, lse, g, tk
 
-    def forward(self, acc, inp, b, t, keys_bf16=None, kvalid=None, **_):
-        *_, o, lse, g, _ = self._internals(inp, b, t, keys_bf16, kvalid)
+    def forward(self, acc, inp, b, t, keys_bf16=None, kvalid=None, pre=None, next_norm=None, **_):
+        *_, o, lse, g, _ = self._internals(inp, b, t, keys_bf16, kvalid, pre=pre)
         self.stash = (o, lse) if STASH_ATTENTION else None
         self.g_stash = g if STASH_BLOCK_OUTPUT else None
-        residual(acc, g, self.mha.out_proj.bias, 1.0)
+        return residual(acc, g, self.mha.out_proj.bias, 1.0, next_norm)
 
-    def backward(self, acc, inp, d_acc, d_inp, b, t, keys_bf16=None, kvalid=None, dkeys=None, **_):
+    def backward(self, acc, inp, d_acc, d_inp, b, t, keys_bf16=None, kvalid=None, dkeys=None, pre=None, next_norm=None, **_):
         m = self.mha
         e, h = m.embed_dim, m.num_heads
-        xn, mean, rstd, w, q, kv, o, lse, g, tk = self._internals(inp, b, t, keys_bf16, kvalid, self.stash, self.g_stash)
+        xn, mean, rstd, w, q, kv, o, lse, g, tk = self._internals(inp, b, t, keys_bf16, kvalid, self.stash, self.g_stash, pre)
         self.stash = self.g_stash = None
-        residual(acc, g, m.out_proj.bias, -1.0)
+        post = residual(acc, g, m.out_proj.bias, -1.0, next_norm)
         dyb = cast_colsum(d_acc, _grad(m.out_proj.bias))
         wgrad(_grad(m.out_proj.weight), dyb, o)
         do = torch.mm(dyb, _bf16(m.out_proj.weight))
@@ -367,9 +378,46 @@ class XAttnExec:
         dxn = torch.mm(dq, w[:e])
         ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp)
         residual(dkeys, torch.mm(dkv, w[e:]), None, 1.0)                      # dkeys (fp32) += dkv W_kv
+        return post
 
 
 # ------------------------------------------------------------------------------------------ stacks
+# LayerNorm chaining: every executor reads (through its LayerNorm) the stream the previous executor has just updated
+# (forward) or reconstructed (backward), so that executor's residual epilogue also emits the next one's LayerNorm
+# (rtts_residual_ln).  FUSE_RESIDUAL_LN = False launches the two kernels separately.
+FUSE_RESIDUAL_LN = __import__("os").environ.get("RTTS_FUSE_RESIDUAL_LN", "1") != "0"
+
+
+def _flat_calls(steps):
+    """[(executor, step index, "f" | "g")] in forward order."""
+    calls = []
+    for i, (kind, f, g, _) in enumerate(steps):
+        if kind == "half":
+            calls.append((f, i, "f"))
+        elif kind == "block":
+            calls.append((f, i, "f"))
+            calls.append((g, i, "g"))
+    return calls
+
+
+class _Chain:
+    """Carries LayerNorm(acc) from the executor that wrote ``acc`` to the one that reads it next."""
+
+    def __init__(self, calls, reverse: bool):
+        order = list(reversed(calls)) if reverse else calls
+        self.next_norm = {}
+        for (ex, i, w), (nxt, _, _) in zip(order, order[1:]):
+            self.next_norm[(i, w)] = nxt.norm
+        self.pre, self.ptr = None, None
+
+    def args(self, i, which, inp):
+        pre = self.pre if (self.pre is not None and self.ptr == inp.data_ptr()) else None
+        return dict(pre=pre, next_norm=self.next_norm.get((i, which)) if FUSE_RESIDUAL_LN else None)
+
+    def done(self, post, acc):
+        self.pre, self.ptr = post, (acc.data_ptr() if post is not None else None)
+
+
 def build_program(seq) -> Optional[List[tuple]]:
     """Translate a ReversibleSequence into a list of ("f"|"g"|"half"|"swap", executor) steps; None if
     some block needs the general (autograd) path (active dropout inside a block, exotic options)."""
@@ -447,13 +495,15 @@ class FusedStackFn(torch.autograd.Function):
             for (kind, f, g), kwargs in zip(prog, kwargs_list):
                 kw, kwg = _step_kwargs(kind, kwargs, extra, mask_cache)
                 steps.append((kind, f, g, kw))
+            chain = _Chain(_flat_calls(steps), reverse=False)
+            for i, (kind, f, g, kw) in enumerate(steps):
                 if kind == "swap":
                     s1, s2 = s2, s1
                 elif kind == "half":
-                    f.forward(s1, s2, b, t, **kw)
+                    chain.done(f.forward(s1, s2, b, t, **kw, **chain.args(i, "f", s2)), s1)
                 else:
-                    f.forward(s1, s2, b, t, **kw)
-                    g.forward(s2, s1, b, t)
+                    chain.done(f.forward(s1, s2, b, t, **kw, **chain.args(i, "f", s2)), s1)
+                    chain.done(g.forward(s2, s1, b, t, **chain.args(i, "g", s1)), s2)
             out = (s1 + s2).view(b, t, d)
         ctx.state = (s1, s2, steps, extra, b, t, d, context is not None, seq)
         return out
@@ -470,6 +520,7 @@ class FusedStackFn(torch.autograd.Function):
                 dkeys = torch.zeros(extra["keys_bf16"].shape, dtype=torch.float32, device=dout.device)
                 extra = dict(extra, dkeys=dkeys)
             done = []
+            chain = _Chain(_flat_calls(steps), reverse=True)
             for i in range(len(steps) - 1, -1, -1):
                 kind, f, g, kw = steps[i]
                 if kind == "swap":
@@ -477,10 +528,10 @@ class FusedStackFn(torch.autograd.Function):
                 elif kind == "half":
                     if "keys_bf16" in kw:
                         kw = dict(kw, dkeys=dkeys)
-                    f.backward(s1, s2, g1, g2, b, t, **kw)
+                    chain.done(f.backward(s1, s2, g1, g2, b, t, **kw, **chain.args(i, "f", s2)), s1)
                 else:
-                    g.backward(s2, s1, g2, g1, b, t)
-                    f.backward(s1, s2, g1, g2, b, t, **kw)
+                    chain.done(g.backward(s2, s1, g2, g1, b, t, **chain.args(i, "g", s1)), s2)
+                    chain.done(f.backward(s1, s2, g1, g2, b, t, **kw, **chain.args(i, "f", s2)), s1)
                 done.append(i)
                 if pending_wgrads() >= 7 or i == 0:
                     # one grouped launch per layer's worth of weight gradients; only then are the finished blocks'
