@@ -108,12 +108,13 @@ int rtts_lsh_bwd_reduce_ring(const void* dq_part, const void* dk_part, const voi
  *        after a sum all-reduce.  max_norm <= 0 disables clipping.
  *   rtts_adamw_step: grads are multiplied by scale[0] on the fly (scale may be NULL = 1);
  *        hyper (device) = {lr, lr*sqrt(1-beta2^t)/(1-beta1^t)} for the current step t, read by the kernel so that
- *        a captured hipGraph replays with the values the host wrote before the replay. */
+ *        a captured hipGraph replays with the values the host wrote before the replay.  n % 4 == 0 (pad the flat
+ *        buffers); bf16_mirror (may be NULL): the updated parameters rounded to bf16, written in the same pass. */
 int rtts_grad_clip_scale(const float* grads, int64_t n, float grad_mult, float max_norm, float* partial_ws,
                          float* scale_out, void* stream);
 int rtts_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* decay_mask,
                     int64_t n, const float* scale, const float* hyper, float beta1, float beta2, float eps,
-                    float weight_decay, void* stream);
+                    float weight_decay, void* bf16_mirror, void* stream);
 
 /* ---- row-wise fused kernels around the GEMMs of a reversible block --------------------------
  * Replace the ATen chains of WithNorm / FeedForward / residual adds (reference

@@ -14,6 +14,8 @@ MI355X-first mechanics:
 """
 from __future__ import annotations
 
+import contextlib
+import gc
 import math
 from typing import Dict, List, Optional
 
@@ -211,10 +213,9 @@ class Trainer:
                   self.ws_partial.data_ptr(), self.ws_scale.data_ptr(), stream)
         _lib.call("rtts_adamw_step", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
                   self.flat_v.data_ptr(), self.decay_mask.data_ptr(), n, self.ws_scale.data_ptr(), self.hyper.data_ptr(), 0.9, 0.999,
-                  1e-6, float(self.cfg.weight_decay), stream)
+                  1e-6, float(self.cfg.weight_decay), self.flat_pb.data_ptr(), stream)     # writes the bf16 mirror too
         from ..engine import WEIGHT_EPOCH
         WEIGHT_EPOCH[0] += 1
-        self.refresh_mirror()
 
     def lr_now_for(self, step: int) -> float:
         lr = self.cfg.learning_rate
@@ -235,6 +236,26 @@ class Trainer:
 
     # ------------------------------------------------------------------ hipGraph replay of the whole step
     _bulk_allreduce = False
+
+    @staticmethod
+    @contextlib.contextmanager
+    def _capturing(graph, **kw):
+        """``torch.cuda.graph`` with the Python garbage collector held off: a collection that happens to run inside a
+        capture can release device resources (events, blocks that were used on another stream), which HIP refuses while
+        a stream is capturing -- the process then aborts from a destructor.  Seen for real: ``Tensor.backward(grad)``
+        lazily imports ``torch.fx.experimental.symbolic_shapes`` (sympy), whose thousands of allocations trigger a
+        collection in the middle of the second graph.  Both causes are removed: the import happens up front, and
+        automatic collection is off for the duration of the capture."""
+        import torch.fx.experimental.symbolic_shapes  # noqa: F401  (what autograd imports on first use of grad_tensors)
+        gc.collect()
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(graph, **kw):
+                yield
+        finally:
+            if was_enabled:
+                gc.enable()
 
     def capture(self, batch, segmented: Optional[bool] = None):
         """Capture the step for THIS batch buffer into hipGraphs; afterwards ``replay()`` runs one full step per call: the
@@ -271,7 +292,7 @@ class Trainer:
         self._graph_enc = self._graph_opt = None
         self.set_step_hyper(self.global_step)
         if not segmented:
-            with torch.cuda.graph(self._graph):
+            with self._capturing(self._graph):
                 self._graph_out = self.train_step(batch, update_hyper=False)
             self.global_step -= 1                        # capturing does not execute: the captured step has not run yet
             return self._graph_out
@@ -279,7 +300,7 @@ class Trainer:
         self._enc_end = max(self.offsets[n][1] for n in enc_names)
         if min(self.offsets[n][0] for n in self.offsets if not n.startswith("enc.")) < self._enc_end:
             raise RuntimeError("flat buffer: encoder parameters are expected to come first")
-        with torch.cuda.graph(self._graph):
+        with self._capturing(self._graph):
             self.model.train()
             self.zero_grad()
             total, raw_l, post_l, stop_l = self.forward_loss(batch, split=True)
@@ -287,12 +308,12 @@ class Trainer:
             engine.flush_wgrad()
             self._graph_out = (total.detach(), raw_l.detach(), post_l.detach(), stop_l.detach())
         self._graph_enc = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph_enc, pool=self._graph.pool()):
+        with self._capturing(self._graph_enc, pool=self._graph.pool()):
             self._enc_out.backward(self._enc_in.grad)
             engine.flush_wgrad()
         self._enc_out = self._enc_in = None
         self._graph_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph_opt, pool=self._graph.pool()):
+        with self._capturing(self._graph_opt, pool=self._graph.pool()):
             self.optimizer_step(update_hyper=False)
         self.global_step -= 1
         return self._graph_out

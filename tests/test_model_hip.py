@@ -140,9 +140,11 @@ def test_optimizer_kernels_vs_oracle(gpu):
     _lib.call("rtts_grad_clip_scale", gd.data_ptr(), n + pad, 1.0 / world, max_norm, ws.data_ptr(), sc.data_ptr(), stream)
     import math
     hyper = torch.tensor([lr, lr * math.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)], device=gpu)
+    mirror = torch.zeros(n + pad, dtype=torch.bfloat16, device=gpu)
     _lib.call("rtts_adamw_step", pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), kd.data_ptr(), n + pad,
-              sc.data_ptr(), hyper.data_ptr(), 0.9, 0.999, 1e-6, wd, stream)
+              sc.data_ptr(), hyper.data_ptr(), 0.9, 0.999, 1e-6, wd, mirror.data_ptr(), stream)
     torch.cuda.synchronize()
+    assert torch.equal(mirror, pd.bfloat16())          # the bf16 mirror written by the same pass
     g_avg = grad / world
     coef = optim_ref.clip_coef([g_avg], max_norm)
     np.testing.assert_allclose(sc.cpu().numpy(), [coef / world, float(g_avg.norm())], rtol=1e-5)
