@@ -117,16 +117,19 @@ def main():
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
+    dec_bucket = int(model_cfg.dec_reformer_kwargs.self_attn_kwargs.bucket_size)
+    tkey = f"rtts_lsh_attn_bwd/bs{dec_bucket}"        # the decoder's LSH backward: the dominant kernel of the step
     note(f"model built ({trainer.n_params} parameters), warming up")
-    # N == 1: the whole step is one hipGraph.  N > 1: two graphs (fwd+bwd | clip+AdamW) around ONE eager all-reduce of
-    # the flat gradient buffer, so no collective is ever captured; RTTS_GRAPH_DP=1 opts into a single graph with the
-    # per-block RCCL all-reduces captured inside (overlapped with the backward; not exercisable on a 1-GPU box).
+    # N == 1: the whole step is one hipGraph.  N > 1: three graphs (fwd + decoder-side bwd | encoder bwd | clip+AdamW)
+    # around two eager all-reduces of the halves of the flat gradient buffer, so no collective is ever captured;
+    # RTTS_GRAPH_DP=1 opts into a single graph with the per-block RCCL all-reduces captured inside (overlapped with the
+    # backward; not exercisable on a 1-GPU box).
     use_graph = not args.no_graph
     one_graph = world == 1 or (os.environ.get("RTTS_GRAPH_DP") == "1" and backend == "nccl")
     if use_graph:
         trainer.capture(batch, segmented=not one_graph)
         step_fn = trainer.replay
-        note("step captured into " + ("one hipGraph" if one_graph else "two hipGraphs around the gradient all-reduce"))
+        note("step captured into " + ("one hipGraph" if one_graph else "three hipGraphs around the two gradient all-reduces"))
     else:
         step_fn = lambda: trainer.train_step(batch)   # noqa: E731
     for i in range(args.warmup):
@@ -137,7 +140,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     if not use_graph:
-        ops.TIMING.enable("rtts_lsh_attn_bwd/bs128")
+        ops.TIMING.enable(tkey)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step_fn()[0]
@@ -154,11 +157,11 @@ def main():
     if use_graph:
         # HIP events cannot be read back from inside a replayed graph: time the dominant kernel on the same stream over
         # the same number of eager steps of the same workload, directly after the timed region
-        ops.TIMING.enable("rtts_lsh_attn_bwd/bs128")
+        ops.TIMING.enable(tkey)
         for _ in range(args.steps):
             trainer.train_step(batch)
         torch.cuda.synchronize()
-    avg_ms, launches, flops_per_launch = ops.TIMING.summary("rtts_lsh_attn_bwd/bs128")
+    avg_ms, launches, flops_per_launch = ops.TIMING.summary(tkey)
     ops.TIMING.disable()
 
     if not (float(loss) == float(loss)):
@@ -175,7 +178,7 @@ def main():
                                    f"mel {args.mel_len}x80" if args.config == "baseline" else
                                    f"config/bucket-size-64-18-06.yml, per-GPU batch {args.batch}, mel {args.mel_len}",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(float(loss), 4), "reversible_recompute": args.recompute,
-                       "launch": ("hipGraph replay" if one_graph else "hipGraph replay (fwd+bwd | all-reduce | optimizer)")
+                       "launch": ("hipGraph replay" if one_graph else "hipGraph replay (fwd+dec bwd | all-reduce | enc bwd | all-reduce | optimizer)")
                        if use_graph else "eager"},
         }
         if launches:

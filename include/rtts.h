@@ -124,26 +124,31 @@ int rtts_adamw_step(float* params, const float* grads, float* exp_avg, float* ex
  * `partial_ws` (>= 2*256*d floats), deterministically.
  *   rtts_ln_fwd            xn(bf16) = LayerNorm(x; eps 1e-5) * gamma + beta; keeps mean, rstd (M)
  *   rtts_ln_bwd            dx_io += dLN(dxn); dgamma += ..., dbeta += ...
- *   rtts_cast_colsum       dyb(bf16) = dy(fp32); dbias += colsum(dy)   (dbias may be NULL)
+ *   rtts_cast_colsum       dyb(bf16) = dy(fp32); dbias += colsum(dy)   (dbias may be NULL); drop_p > 0: dy is first
+ *                          multiplied by the keep-scale of the dropout that sat on the block's output
  *   rtts_colsum_bf16       dbias += colsum(dh); relu_gate: dh *= (h > 0) * gate_scale in place first (gate_scale = 1/(1-p)
  *                          when h went through dropout_p after the ReLU)
- *   rtts_residual_epilogue y = x + sign * (g(bf16) + bias)    (bias may be NULL)
+ *   rtts_residual_epilogue y = x + sign * dropout_p(g(bf16) + bias)    (bias may be NULL; drop_p = post_attn_dropout of
+ *                          the LSH layer, reformer.py:198-200 knob list; mask = hash(seed + *seed_dev, element), the same
+ *                          in the forward, the reconstruction and the backward)
  *   rtts_bias_act          h(bf16) = [relu](h + bias) in place
  *   rtts_cast_f32_bf16     flat cast (n % 4 == 0): the per-step bf16 mirror of all parameters */
 int rtts_ln_fwd(const float* x, const float* gamma, const float* beta, void* xn, float* mean, float* rstd,
                 int M, int d, void* stream);
 int rtts_ln_bwd(const void* dxn, const float* x, const float* mean, const float* rstd, const float* gamma,
                 float* dx_io, float* dgamma, float* dbeta, float* partial_ws, int M, int d, void* stream);
-int rtts_cast_colsum(const float* dy, void* dyb, float* dbias, float* partial_ws, int M, int d, void* stream);
+int rtts_cast_colsum(const float* dy, void* dyb, float* dbias, float* partial_ws, int M, int d, float drop_p, uint32_t seed,
+                     const uint32_t* seed_dev, void* stream);
 int rtts_colsum_bf16(void* dh, const void* h, int64_t ld, float* dbias, float* partial_ws, int M, int d,
                      int relu_gate, float gate_scale, void* stream);
 int rtts_residual_epilogue(const float* x, const void* g, const float* bias, float sign, float* y,
-                           int64_t M, int d, void* stream);
+                           int64_t M, int d, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
 /* The same epilogue fused with the NEXT block's LayerNorm: x += sign*(g + bias) in place, then
  * xn(bf16) = LayerNorm(x)*gamma + beta with mean/rstd per row (reformer.py:25-33 applied to the stream a
  * reversible block has just updated or reconstructed, reversible.py:56-98). */
 int rtts_residual_ln(float* x, const void* g, const float* bias, float sign, const float* gamma, const float* beta,
-                     void* xn, float* mean, float* rstd, int M, int d, void* stream);
+                     void* xn, float* mean, float* rstd, int M, int d, float drop_p, uint32_t seed, const uint32_t* seed_dev,
+                     void* stream);
 int rtts_bias_act(void* h, const float* bias, int64_t M, int d, int relu, void* stream);
 int rtts_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 
@@ -156,10 +161,14 @@ int rtts_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
  *   backward: delta f32 (B*H,Tq) = rowsum(o*do) (rtts_lsh_bwd_delta), dq bf16 like q,
  *   dkv_part bf16 (Tq/128, B, Tk, 2*H*dh) partial slabs -> rtts_sum_slabs -> dkv (B,Tk,2*H*dh) */
 int rtts_xattn_fwd(const void* q, int64_t ld_q, const void* kv, int64_t ld_kv, const uint8_t* kvalid,
-                   int B, int H, int Tq, int Tk, int dh, void* o, int64_t ld_o, float* lse, void* stream);
+                   int B, int H, int Tq, int Tk, int dh, void* o, int64_t ld_o, float* lse,
+                   float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
 int rtts_xattn_bwd(const void* q, int64_t ld_q, const void* kv, int64_t ld_kv, const uint8_t* kvalid,
                    const void* dout, int64_t ld_dout, const float* lse, const float* delta,
-                   int B, int H, int Tq, int Tk, int dh, void* dq, int64_t ld_dq, void* dkv_part, void* stream);
+                   int B, int H, int Tq, int Tk, int dh, void* dq, int64_t ld_dq, void* dkv_part,
+                   float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
+/* drop_p = nn.MultiheadAttention's dropout on the normalised attention probabilities (config #4: 0.15); the keep
+ * decision of (head, query, key) is hash(seed + *seed_dev, index), identical in the forward and the backward. */
 int rtts_sum_slabs(const void* part, int nslabs, int64_t n, void* out, void* stream);
 
 /* ---- convolutional edges (prenet / postnet) and the loss ------------------------------------------

@@ -33,14 +33,14 @@ SIGNATURES = {
     "rtts_grad_clip_scale": [_vp, _i64, _f32, _f32, _vp, _vp, _vp],
     "rtts_ln_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp],
     "rtts_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp],
-    "rtts_cast_colsum": [_vp, _vp, _vp, _vp, _i32, _i32, _vp],
+    "rtts_cast_colsum": [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _u32, _vp, _vp],
     "rtts_colsum_bf16": [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _f32, _vp],
-    "rtts_residual_epilogue": [_vp, _vp, _vp, _f32, _vp, _i64, _i32, _vp],
-    "rtts_residual_ln": [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp],
+    "rtts_residual_epilogue": [_vp, _vp, _vp, _f32, _vp, _i64, _i32, _f32, _u32, _vp, _vp],
+    "rtts_residual_ln": [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _u32, _vp, _vp],
     "rtts_bias_act": [_vp, _vp, _i64, _i32, _i32, _vp],
     "rtts_cast_f32_bf16": [_vp, _vp, _i64, _vp],
-    "rtts_xattn_fwd": [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp],
-    "rtts_xattn_bwd": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp],
+    "rtts_xattn_fwd": [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _f32, _u32, _vp, _vp],
+    "rtts_xattn_bwd": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _f32, _u32, _vp, _vp],
     "rtts_sum_slabs": [_vp, _i32, _i64, _vp, _vp],
     "rtts_im2col_k5": [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp],
     "rtts_col2im_k5": [_vp, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _vp],

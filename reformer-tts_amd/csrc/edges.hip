@@ -17,15 +17,8 @@
 #define ED_THREADS 256
 #define ED_PBLOCKS 256
 
-__device__ __forceinline__ uint32_t ed_hash(uint32_t seed, uint32_t idx) {
-    uint32_t x = idx * 0x9E3779B1u + seed;
-    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-    return x;
-}
-// keep-scale of element idx: 0 (dropped) or 1/(1-p)
-__device__ __forceinline__ float ed_drop(uint32_t seed, uint32_t idx, uint32_t thresh, float scale) {
-    return ed_hash(seed, idx) >= thresh ? scale : 0.f;
-}
+// keep-scale of element idx: 0 (dropped) or 1/(1-p)   (rtts_common.h)
+#define ed_drop rtts_drop_keep
 
 // ------------------------------------------------------------------ im2col / col2im (k=5, pad=2)
 // cols[(b*L + l)][k*CP + c] = x[b][l + k - 2][c] (zero outside [0,L) and for c >= C); 8 channels per thread

@@ -94,6 +94,10 @@ __device__ __forceinline__ void store_row_bf16(bf16_t* __restrict__ row, int lan
     }
 }
 
+// column of register element e of a row held in the load_row_f32 / load_row_bf16 layout
+template <int VEC>
+__device__ __forceinline__ int row_col(int e, int lane) { return ((e / VEC) * 64 + lane) * VEC + (e % VEC); }
+
 __device__ __forceinline__ float wave_sum(float s) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -153,7 +157,8 @@ __global__ __launch_bounds__(FR_THREADS) void residual_ln_kernel(float* __restri
                                                                  const float* __restrict__ bias, float sign,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  bf16_t* __restrict__ xn, float* __restrict__ mean,
-                                                                 float* __restrict__ rstd, int M) {
+                                                                 float* __restrict__ rstd, int M, uint32_t seed,
+                                                                 const uint32_t* __restrict__ seed_dev, uint32_t thresh, float dscale) {
     constexpr int D = EPL * 64;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * FR_WAVES + (threadIdx.x >> 6);
@@ -165,6 +170,11 @@ __global__ __launch_bounds__(FR_THREADS) void residual_ln_kernel(float* __restri
         load_row_f32<EPL, VEC>(bias, lane, w);
 #pragma unroll
         for (int e = 0; e < EPL; ++e) gv[e] += w[e];
+    }
+    if (thresh) {          // post-attention dropout on f(x) = g + bias (reformer_pytorch's post_attn_dropout)
+        if (seed_dev) seed += seed_dev[0];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) gv[e] *= rtts_drop_keep(seed, (uint32_t)row * D + row_col<VEC>(e, lane), thresh, dscale);
     }
 #pragma unroll
     for (int e = 0; e < EPL; ++e) v[e] += sign * gv[e];
@@ -235,16 +245,22 @@ __global__ __launch_bounds__(FR_THREADS) void ln_bwd_kernel(const bf16_t* __rest
 // ---------------------------------------------------------------- fp32 -> bf16 cast + column sums
 template <int EPL, int VEC>
 __global__ __launch_bounds__(FR_THREADS) void cast_colsum_kernel(const float* __restrict__ dy, bf16_t* __restrict__ dyb,
-                                                                 float* __restrict__ partial, int M) {
+                                                                 float* __restrict__ partial, int M, uint32_t seed,
+                                                                 const uint32_t* __restrict__ seed_dev, uint32_t thresh, float dscale) {
     constexpr int D = EPL * 64;
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     const int lane = threadIdx.x & 63;
     float acc[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+    if (thresh && seed_dev) seed += seed_dev[0];
     for (int row = blockIdx.x * FR_WAVES + (threadIdx.x >> 6); row < M; row += gridDim.x * FR_WAVES) {
         float v[EPL];
         load_row_f32<EPL, VEC>(dy + (size_t)row * D, lane, v);
+        if (thresh) {      // backward of the dropout that sat on this block's output: same (seed, element) decisions
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) v[e] *= rtts_drop_keep(seed, (uint32_t)row * D + row_col<VEC>(e, lane), thresh, dscale);
+        }
 #pragma unroll
         for (int e = 0; e < EPL; ++e) acc[e] += v[e];
         store_row_bf16<EPL, VEC>(dyb + (size_t)row * D, lane, v);
@@ -316,17 +332,26 @@ __global__ __launch_bounds__(FR_THREADS) void colsum_final_kernel(const float* _
 // y = x + sign * (g + bias)        (x, y fp32; g bf16; bias fp32 or null), 4 elements per thread
 __global__ __launch_bounds__(FR_THREADS) void residual_epilogue_kernel(const float* __restrict__ x, const bf16_t* __restrict__ g,
                                                                        const float* __restrict__ bias, float sign,
-                                                                       float* __restrict__ y, size_t n4, int d) {
+                                                                       float* __restrict__ y, size_t n4, int d, uint32_t seed,
+                                                                       const uint32_t* __restrict__ seed_dev, uint32_t thresh,
+                                                                       float dscale) {
+    if (thresh && seed_dev) seed += seed_dev[0];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const float4 xv = reinterpret_cast<const float4*>(x)[i];
         const uint2 gv = reinterpret_cast<const uint2*>(g)[i];
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (bias) bv = *reinterpret_cast<const float4*>(bias + (i * 4) % d);
+        float f[4] = {__uint_as_float(gv.x << 16) + bv.x, __uint_as_float(gv.x & 0xffff0000u) + bv.y,
+                      __uint_as_float(gv.y << 16) + bv.z, __uint_as_float(gv.y & 0xffff0000u) + bv.w};
+        if (thresh) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[j] *= rtts_drop_keep(seed, (uint32_t)(i * 4 + j), thresh, dscale);
+        }
         float4 o;
-        o.x = xv.x + sign * (__uint_as_float(gv.x << 16) + bv.x);
-        o.y = xv.y + sign * (__uint_as_float(gv.x & 0xffff0000u) + bv.y);
-        o.z = xv.z + sign * (__uint_as_float(gv.y << 16) + bv.z);
-        o.w = xv.w + sign * (__uint_as_float(gv.y & 0xffff0000u) + bv.w);
+        o.x = xv.x + sign * f[0];
+        o.y = xv.y + sign * f[1];
+        o.z = xv.z + sign * f[2];
+        o.w = xv.w + sign * f[3];
         reinterpret_cast<float4*>(y)[i] = o;
     }
 }
@@ -414,12 +439,13 @@ extern "C" int rtts_ln_bwd(const void* dxn, const float* x, const float* mean, c
     return 0;
 }
 
-extern "C" int rtts_cast_colsum(const float* dy, void* dyb, float* dbias, float* partial_ws, int M, int d, void* stream) {
-    RTTS_REQUIRE(dy && dyb && partial_ws && M > 0, "rtts_cast_colsum: bad arguments");
+extern "C" int rtts_cast_colsum(const float* dy, void* dyb, float* dbias, float* partial_ws, int M, int d, float drop_p, uint32_t seed,
+                                const uint32_t* seed_dev, void* stream) {
+    RTTS_REQUIRE(dy && dyb && partial_ws && M > 0 && drop_p >= 0.f && drop_p < 1.f, "rtts_cast_colsum: bad arguments");
     int blocks = (M + FR_WAVES - 1) / FR_WAVES;
     if (blocks > FR_PARTIAL_BLOCKS) blocks = FR_PARTIAL_BLOCKS;
     const size_t lds = (size_t)FR_WAVES * d * sizeof(float);
-#define CALL(EPL, VEC) hipLaunchKernelGGL((cast_colsum_kernel<EPL, VEC>), dim3(blocks), dim3(FR_THREADS), lds, (hipStream_t)stream, dy, (bf16_t*)dyb, partial_ws, M)
+#define CALL(EPL, VEC) hipLaunchKernelGGL((cast_colsum_kernel<EPL, VEC>), dim3(blocks), dim3(FR_THREADS), lds, (hipStream_t)stream, dy, (bf16_t*)dyb, partial_ws, M, seed, seed_dev, rtts_drop_thresh(drop_p), 1.f / (1.f - drop_p))
     FR_DISPATCH_D(d, CALL)
 #undef CALL
     if (dbias)
@@ -452,20 +478,21 @@ extern "C" int rtts_colsum_bf16(void* dh, const void* h, int64_t ld, float* dbia
 }
 
 extern "C" int rtts_residual_epilogue(const float* x, const void* g, const float* bias, float sign, float* y, int64_t M, int d,
-                                      void* stream) {
-    RTTS_REQUIRE(x && g && y && M > 0 && d > 0 && d % 4 == 0, "rtts_residual_epilogue: bad arguments");
+                                      float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream) {
+    RTTS_REQUIRE(x && g && y && M > 0 && d > 0 && d % 4 == 0 && drop_p >= 0.f && drop_p < 1.f, "rtts_residual_epilogue: bad arguments");
     const size_t n4 = (size_t)M * d / 4;
     hipLaunchKernelGGL(residual_epilogue_kernel, dim3(stream_grid(n4)), dim3(FR_THREADS), 0, (hipStream_t)stream, x, (const bf16_t*)g,
-                       bias, sign, y, n4, d);
+                       bias, sign, y, n4, d, seed, seed_dev, rtts_drop_thresh(drop_p), 1.f / (1.f - drop_p));
     RTTS_LAUNCH_CHECK("rtts_residual_epilogue");
     return 0;
 }
 
 extern "C" int rtts_residual_ln(float* x, const void* g, const float* bias, float sign, const float* gamma, const float* beta,
-                                void* xn, float* mean, float* rstd, int M, int d, void* stream) {
-    RTTS_REQUIRE(x && g && gamma && beta && xn && mean && rstd && M > 0, "rtts_residual_ln: bad arguments");
+                                void* xn, float* mean, float* rstd, int M, int d, float drop_p, uint32_t seed,
+                                const uint32_t* seed_dev, void* stream) {
+    RTTS_REQUIRE(x && g && gamma && beta && xn && mean && rstd && M > 0 && drop_p >= 0.f && drop_p < 1.f, "rtts_residual_ln: bad arguments");
     const dim3 grid((M + FR_WAVES - 1) / FR_WAVES);
-#define CALL(EPL, VEC) hipLaunchKernelGGL((residual_ln_kernel<EPL, VEC>), grid, dim3(FR_THREADS), 0, (hipStream_t)stream, x, (const bf16_t*)g, bias, sign, gamma, beta, (bf16_t*)xn, mean, rstd, M)
+#define CALL(EPL, VEC) hipLaunchKernelGGL((residual_ln_kernel<EPL, VEC>), grid, dim3(FR_THREADS), 0, (hipStream_t)stream, x, (const bf16_t*)g, bias, sign, gamma, beta, (bf16_t*)xn, mean, rstd, M, seed, seed_dev, rtts_drop_thresh(drop_p), 1.f / (1.f - drop_p))
     FR_DISPATCH_D(d, CALL)
 #undef CALL
     RTTS_LAUNCH_CHECK("rtts_residual_ln");

@@ -66,3 +66,18 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t id, uint32_t n) {
     const uint32_t q = n >> 3, r = n & 7u, x = id & 7u, i = id >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
+
+// Counter-based dropout: element idx of a tensor is kept iff hash(seed, idx) >= thresh, thresh = p * 2^32; the same
+// (seed, idx) gives the same decision in the forward, in the reversible reconstruction and in the backward, so no
+// mask is ever stored.  seed = host constant + a device word the trainer rewrites per step (graph replays draw fresh masks).
+__device__ __forceinline__ uint32_t rtts_drop_hash(uint32_t seed, uint32_t idx) {
+    uint32_t x = idx * 0x9E3779B1u + seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+// keep-scale of element idx: 0 (dropped) or 1/(1-p)
+__device__ __forceinline__ float rtts_drop_keep(uint32_t seed, uint32_t idx, uint32_t thresh, float scale) {
+    return rtts_drop_hash(seed, idx) >= thresh ? scale : 0.f;
+}
+static inline uint32_t rtts_drop_thresh(float p) { return p <= 0.f ? 0u : (uint32_t)((double)p * 4294967296.0); }
+

@@ -31,7 +31,9 @@ __device__ __forceinline__ bf16x8 xa_tr_frag(const unsigned char* p0, const unsi
 template <int TK>
 __global__ __launch_bounds__(256) void xattn_fwd_kernel(const bf16_t* __restrict__ q, int64_t ld_q, const bf16_t* __restrict__ kv,
                                                         int64_t ld_kv, const uint8_t* __restrict__ kvalid, int H, int Tq,
-                                                        bf16_t* __restrict__ o, int64_t ld_o, float* __restrict__ lse) {
+                                                        bf16_t* __restrict__ o, int64_t ld_o, float* __restrict__ lse,
+                                                        uint32_t seed, const uint32_t* __restrict__ seed_dev, uint32_t thresh,
+                                                        float dscale) {
     constexpr int NKT = TK / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Ks = smem;
@@ -107,6 +109,17 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const bf16_t* __restrict
             l += p;
         }
     l += __shfl_xor(l, 32);
+    if (thresh) {
+        // nn.MultiheadAttention(dropout=p): dropout on the NORMALISED probabilities; l above is the full normaliser, the
+        // keep-scale of element (head, query, key) multiplies the unnormalised p before P V
+        if (seed_dev) seed += seed_dev[0];
+        const uint32_t base = ((uint32_t)bh * (uint32_t)Tq + (uint32_t)qrow) * (uint32_t)TK;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                s[kt][i] *= rtts_drop_keep(seed, base + (uint32_t)(kt * 32 + 8 * (i >> 2) + 4 * hh + (i & 3)), thresh, dscale);
+    }
 
     f32x16 oacc[2] = {{0}, {0}};
     const int trq = (lane & 15) >> 2, trp = lane & 3, trc = (lane >> 4) & 1;
@@ -145,8 +158,10 @@ __global__ __launch_bounds__(TK) void xattn_bwd_kernel(const bf16_t* __restrict_
                                                        int64_t ld_kv, const uint8_t* __restrict__ kvalid,
                                                        const bf16_t* __restrict__ dout, int64_t ld_do, const float* __restrict__ lse,
                                                        const float* __restrict__ delta, int H, int Tq, bf16_t* __restrict__ dq,
-                                                       int64_t ld_dq, bf16_t* __restrict__ dkv_part, int B) {
+                                                       int64_t ld_dq, bf16_t* __restrict__ dkv_part, int B, uint32_t seed,
+                                                       const uint32_t* __restrict__ seed_dev, uint32_t thresh, float dscale) {
     constexpr int NTHR = TK;                 // one wave per 64 keys
+    if (thresh && seed_dev) seed += seed_dev[0];
     constexpr int DSROW = XA_QB * 2 + 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Ks = smem;                        // [TK][144]
@@ -246,8 +261,12 @@ __global__ __launch_bounds__(TK) void xattn_bwd_kernel(const bf16_t* __restrict_
                 for (int j = 0; j < 4; ++j) {
                     const int i = 4 * g + j;
                     const float p = kvl[k2] ? __expf(sacc[i] * 0.125f - lv[j]) : 0.f;
-                    pp[i] = p;
-                    ds[i] = p * (pacc[i] - dl[j]) * 0.125f;
+                    // dropout on P: O = (D*P) V  =>  dV += (D*P)^T dO,  dS = P * (D*dP - delta)   (delta = O.dO as ever)
+                    const float keep = thresh ? rtts_drop_keep(seed, ((uint32_t)bh * (uint32_t)Tq + (uint32_t)(qb * XA_QB + q0 + j)) *
+                                                                         (uint32_t)TK + (uint32_t)myrow[k2], thresh, dscale)
+                                              : 1.f;
+                    pp[i] = p * keep;
+                    ds[i] = p * (pacc[i] * keep - dl[j]) * 0.125f;
                 }
             }
 #pragma unroll
@@ -356,8 +375,9 @@ static int xa_check(const char* fn, int B, int H, int Tq, int Tk, int dh, int64_
 }
 
 extern "C" int rtts_xattn_fwd(const void* q, int64_t ld_q, const void* kv, int64_t ld_kv, const uint8_t* kvalid, int B, int H, int Tq,
-                              int Tk, int dh, void* o, int64_t ld_o, float* lse, void* stream) {
-    RTTS_REQUIRE(q && kv && o && lse, "rtts_xattn_fwd: null pointer");
+                              int Tk, int dh, void* o, int64_t ld_o, float* lse, float drop_p, uint32_t seed, const uint32_t* seed_dev,
+                              void* stream) {
+    RTTS_REQUIRE(q && kv && o && lse && drop_p >= 0.f && drop_p < 1.f, "rtts_xattn_fwd: bad arguments");
     if (xa_check("rtts_xattn_fwd", B, H, Tq, Tk, dh, ld_q, ld_kv)) return -1;
     RTTS_REQUIRE(ld_o >= (int64_t)H * dh && ld_o % 8 == 0, "rtts_xattn_fwd: bad ld_o");
     RTTS_REQUIRE((((uintptr_t)q | (uintptr_t)kv | (uintptr_t)o) & 15) == 0, "rtts_xattn_fwd: buffers must be 16-byte aligned");
@@ -371,7 +391,7 @@ extern "C" int rtts_xattn_fwd(const void* q, int64_t ld_q, const void* kv, int64
             g_xa_attr[0][TK_ == 256] = true;                                                                              \
         }                                                                                                                 \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q, ld_q, (const bf16_t*)kv, ld_kv, \
-                           kvalid, H, Tq, (bf16_t*)o, ld_o, lse);                                                         \
+                           kvalid, H, Tq, (bf16_t*)o, ld_o, lse, seed, seed_dev, rtts_drop_thresh(drop_p), 1.f / (1.f - drop_p)); \
     } while (0)
     if (Tk == 256) GO(256); else GO(128);
 #undef GO
@@ -381,8 +401,8 @@ extern "C" int rtts_xattn_fwd(const void* q, int64_t ld_q, const void* kv, int64
 
 extern "C" int rtts_xattn_bwd(const void* q, int64_t ld_q, const void* kv, int64_t ld_kv, const uint8_t* kvalid, const void* dout,
                               int64_t ld_dout, const float* lse, const float* delta, int B, int H, int Tq, int Tk, int dh, void* dq,
-                              int64_t ld_dq, void* dkv_part, void* stream) {
-    RTTS_REQUIRE(q && kv && dout && lse && delta && dq && dkv_part, "rtts_xattn_bwd: null pointer");
+                              int64_t ld_dq, void* dkv_part, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream) {
+    RTTS_REQUIRE(q && kv && dout && lse && delta && dq && dkv_part && drop_p >= 0.f && drop_p < 1.f, "rtts_xattn_bwd: bad arguments");
     if (xa_check("rtts_xattn_bwd", B, H, Tq, Tk, dh, ld_q, ld_kv)) return -1;
     RTTS_REQUIRE(ld_dout >= (int64_t)H * dh && ld_dout % 8 == 0 && ld_dq >= (int64_t)H * dh && ld_dq % 8 == 0,
                  "rtts_xattn_bwd: bad strides");
@@ -398,7 +418,8 @@ extern "C" int rtts_xattn_bwd(const void* q, int64_t ld_q, const void* kv, int64
             g_xa_attr[1][TK_ == 256] = true;                                                                              \
         }                                                                                                                 \
         hipLaunchKernelGGL(kern, grid, dim3(TK_), lds, (hipStream_t)stream, (const bf16_t*)q, ld_q, (const bf16_t*)kv, ld_kv, \
-                           kvalid, (const bf16_t*)dout, ld_dout, lse, delta, H, Tq, (bf16_t*)dq, ld_dq, (bf16_t*)dkv_part, B); \
+                           kvalid, (const bf16_t*)dout, ld_dout, lse, delta, H, Tq, (bf16_t*)dq, ld_dq, (bf16_t*)dkv_part, B,    \
+                           seed, seed_dev, rtts_drop_thresh(drop_p), 1.f / (1.f - drop_p));                               \
     } while (0)
     if (Tk == 256) GO(256); else GO(128);
 #undef GO

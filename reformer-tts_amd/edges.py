@@ -22,15 +22,7 @@ import torch
 from . import _lib
 from .engine import WEIGHT_EPOCH, _WS, _bf16, _grad, cast_colsum, wgrad
 
-_seed_counter = itertools.count(1)
-_SEED_BASE = {}     # device -> u32 tensor added to every dropout seed inside the kernels (rewritten by the trainer each step,
-                    # so that a replayed hipGraph -- whose per-call seeds are frozen constants -- still draws fresh masks)
-
-
-def seed_base(device) -> torch.Tensor:
-    if device not in _SEED_BASE:
-        _SEED_BASE[device] = torch.zeros(1, dtype=torch.int32, device=device)
-    return _SEED_BASE[device]
+from ._seeds import _seed_counter, seed_base  # noqa: E402,F401  (shared with engine.py)
 
 
 def _s() -> int:

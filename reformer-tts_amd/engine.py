@@ -20,6 +20,7 @@ from typing import List, Optional
 import torch
 
 from . import _lib, ops
+from ._seeds import next_seed, seed_base
 from .model.lsh_attention import LSHSelfAttention
 
 
@@ -87,11 +88,13 @@ def ln_bwd(dxn, x, mean, rstd, norm, dx_io):
               m, d, _s())
 
 
-def cast_colsum(dy, dbias: Optional[torch.Tensor]):
+def cast_colsum(dy, dbias: Optional[torch.Tensor], drop=None):
+    """dyb (bf16) = dy [* keep-scale of ``drop`` = (p, seed)]; dbias += column sums of the same."""
     m, d = dy.shape
     dyb = torch.empty(m, d, dtype=torch.bfloat16, device=dy.device)
+    p, seed = drop if drop else (0.0, 0)
     _lib.call("rtts_cast_colsum", dy.data_ptr(), dyb.data_ptr(), None if dbias is None else dbias.data_ptr(),
-              _WS.partial(dy.device, d).data_ptr(), m, d, _s())
+              _WS.partial(dy.device, d).data_ptr(), m, d, float(p), seed, seed_base(dy.device).data_ptr(), _s())
     return dyb
 
 
@@ -102,19 +105,23 @@ def colsum_bf16(dh, dbias, h=None, gate_scale: float = 1.0):
               _WS.partial(dh.device, d).data_ptr(), m, d, int(h is not None), float(gate_scale), _s())
 
 
-def residual(acc, g, bias, sign: float, next_norm=None):
-    """acc = acc + sign * (g + bias), in place.  With ``next_norm`` (the LayerNorm of the block that reads ``acc``
-    next) the row is normalised in the same launch: returns (xn, mean, rstd) of LayerNorm(acc), else None."""
+def residual(acc, g, bias, sign: float, next_norm=None, drop=None):
+    """acc = acc + sign * dropout(g + bias), in place (``drop`` = (p, seed) or None).  With ``next_norm`` (the LayerNorm
+    of the block that reads ``acc`` next) the row is normalised in the same launch: returns (xn, mean, rstd) of
+    LayerNorm(acc), else None."""
     m, d = acc.shape
+    p, seed = drop if drop else (0.0, 0)
+    sb = seed_base(acc.device).data_ptr()
     if next_norm is None:
         _lib.call("rtts_residual_epilogue", acc.data_ptr(), g.data_ptr(), None if bias is None else bias.data_ptr(), float(sign),
-                  acc.data_ptr(), m, d, _s())
+                  acc.data_ptr(), m, d, float(p), seed, sb, _s())
         return None
     xn = torch.empty(m, d, dtype=torch.bfloat16, device=acc.device)
     mean = torch.empty(m, dtype=torch.float32, device=acc.device)
     rstd = torch.empty(m, dtype=torch.float32, device=acc.device)
     _lib.call("rtts_residual_ln", acc.data_ptr(), g.data_ptr(), None if bias is None else bias.data_ptr(), float(sign),
-              next_norm.weight.data_ptr(), next_norm.bias.data_ptr(), xn.data_ptr(), mean.data_ptr(), rstd.data_ptr(), m, d, _s())
+              next_norm.weight.data_ptr(), next_norm.bias.data_ptr(), xn.data_ptr(), mean.data_ptr(), rstd.data_ptr(), m, d,
+              float(p), seed, sb, _s())
     return xn, mean, rstd
 
 
@@ -198,10 +205,11 @@ class LSHExec:
         self.st = None
         self.stash = None     # (out, lse_tot) of the forward when STASH_ATTENTION: the recompute skips the attention forward
         self.g_stash = None   # f(x) of the forward when STASH_BLOCK_OUTPUT
+        self.drop = None      # (p, seed) of the forward's post-attention dropout
 
     @staticmethod
     def supported(withnorm) -> bool:
-        return withnorm.fn.layer.post_attn_dropout.p == 0.0
+        return True      # post_attn_dropout rides in the residual epilogue (counter-hash mask, reproduced by the backward)
 
     def _wqkv(self):
         lyr = self.layer
@@ -243,15 +251,18 @@ class LSHExec:
         self.st = st
         self.stash = (out, lse_tot) if STASH_ATTENTION else None
         self.g_stash = g if STASH_BLOCK_OUTPUT else None
-        return residual(acc, g, self.layer.to_out.bias, 1.0, next_norm)
+        p = self.layer.post_attn_dropout.p if self.layer.training else 0.0
+        self.drop = (p, next_seed()) if p > 0.0 else None
+        return residual(acc, g, self.layer.to_out.bias, 1.0, next_norm, self.drop)
 
     def backward(self, acc, inp, d_acc, d_inp, b, t, mask=None, pre=None, next_norm=None, **_):
         lyr = self.layer
         e = lyr.dim
         xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g = self._internals(inp, b, t, mask, self.st, self.stash, self.g_stash, pre)
         self.st = self.stash = self.g_stash = None
-        post = residual(acc, g, lyr.to_out.bias, -1.0, next_norm)             # reconstruct the stream
-        dyb = cast_colsum(d_acc, _grad(lyr.to_out.bias))
+        drop, self.drop = self.drop, None
+        post = residual(acc, g, lyr.to_out.bias, -1.0, next_norm, drop)       # reconstruct the stream (same dropout mask)
+        dyb = cast_colsum(d_acc, _grad(lyr.to_out.bias), drop)
         out2 = out.view(b * t, e)
         wgrad(_grad(lyr.to_out.weight), dyb, out2)
         dout = torch.mm(dyb, _bf16(lyr.to_out.weight)).view(b, t, e)
@@ -320,13 +331,14 @@ class XAttnExec:
         self.mha = withnorm.fn.layer
         self.stash = None
         self.g_stash = None
+        self.drop = None
 
     @staticmethod
     def supported(withnorm) -> bool:
-        m = withnorm.fn.layer
-        return m.dropout == 0.0 and m.bias_k is None and not m.add_zero_attn and m._qkv_same_embed_dim
+        m = withnorm.fn.layer      # dropout on the attention probabilities runs inside the kernels (counter-hash mask)
+        return m.bias_k is None and not m.add_zero_attn and m._qkv_same_embed_dim
 
-    def _internals(self, inp, b, t, keys_bf16, kvalid, stash=None, g=None, pre=None):
+    def _internals(self, inp, b, t, keys_bf16, kvalid, stash=None, g=None, pre=None, drop=None):
         m = self.mha
         e, h = m.embed_dim, m.num_heads
         tk = keys_bf16.shape[0] // b
@@ -339,14 +351,17 @@ class XAttnExec:
         else:
             o = torch.empty(b * t, e, dtype=torch.bfloat16, device=inp.device)
             lse = torch.empty(b * h, t, dtype=torch.float32, device=inp.device)
+            p, seed = drop if drop else (0.0, 0)
             _lib.call("rtts_xattn_fwd", q.data_ptr(), e, kv.data_ptr(), 2 * e, None if kvalid is None else kvalid.data_ptr(), b, h, t,
-                      tk, e // h, o.data_ptr(), e, lse.data_ptr(), _s())
+                      tk, e // h, o.data_ptr(), e, lse.data_ptr(), float(p), seed, seed_base(inp.device).data_ptr(), _s())
         if g is None:
             g = torch.mm(o, _bf16(m.out_proj.weight).t())
         return xn, mean, rstd, w, q, kv, o, lse, g, tk
 
     def forward(self, acc, inp, b, t, keys_bf16=None, kvalid=None, pre=None, next_norm=None, **_):
-        *_, o, lse, g, _ = self._internals(inp, b, t, keys_bf16, kvalid, pre=pre)
+        p = self.mha.dropout if self.mha.training else 0.0
+        self.drop = (p, next_seed()) if p > 0.0 else None
+        *_, o, lse, g, _ = self._internals(inp, b, t, keys_bf16, kvalid, pre=pre, drop=self.drop)
         self.stash = (o, lse) if STASH_ATTENTION else None
         self.g_stash = g if STASH_BLOCK_OUTPUT else None
         return residual(acc, g, self.mha.out_proj.bias, 1.0, next_norm)
@@ -354,7 +369,8 @@ class XAttnExec:
     def backward(self, acc, inp, d_acc, d_inp, b, t, keys_bf16=None, kvalid=None, dkeys=None, pre=None, next_norm=None, **_):
         m = self.mha
         e, h = m.embed_dim, m.num_heads
-        xn, mean, rstd, w, q, kv, o, lse, g, tk = self._internals(inp, b, t, keys_bf16, kvalid, self.stash, self.g_stash, pre)
+        drop, self.drop = self.drop, None
+        xn, mean, rstd, w, q, kv, o, lse, g, tk = self._internals(inp, b, t, keys_bf16, kvalid, self.stash, self.g_stash, pre, drop)
         self.stash = self.g_stash = None
         post = residual(acc, g, m.out_proj.bias, -1.0, next_norm)
         dyb = cast_colsum(d_acc, _grad(m.out_proj.bias))
@@ -366,8 +382,10 @@ class XAttnExec:
         dq = torch.empty(b * t, e, dtype=torch.bfloat16, device=dev)
         nqb = t // 128
         part = torch.empty(nqb, b * tk, 2 * e, dtype=torch.bfloat16, device=dev)
+        dp, dseed = drop if drop else (0.0, 0)
         _lib.call("rtts_xattn_bwd", q.data_ptr(), e, kv.data_ptr(), 2 * e, None if kvalid is None else kvalid.data_ptr(),
-                  do.data_ptr(), e, lse.data_ptr(), delta.data_ptr(), b, h, t, tk, e // h, dq.data_ptr(), e, part.data_ptr(), _s())
+                  do.data_ptr(), e, lse.data_ptr(), delta.data_ptr(), b, h, t, tk, e // h, dq.data_ptr(), e, part.data_ptr(),
+                  float(dp), dseed, seed_base(dev).data_ptr(), _s())
         dkv = torch.empty(b * tk, 2 * e, dtype=torch.bfloat16, device=dev)
         _lib.call("rtts_sum_slabs", part.data_ptr(), nqb, dkv.numel(), dkv.data_ptr(), _s())
         gb, gw = _grad(m.in_proj_bias), _grad(m.in_proj_weight)

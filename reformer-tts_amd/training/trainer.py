@@ -196,7 +196,7 @@ class Trainer:
         self.hyper_host[0] = lr
         self.hyper_host[1] = lr * math.sqrt(1.0 - 0.999 ** t) / (1.0 - 0.9 ** t)
         self.hyper.copy_(self.hyper_host, non_blocking=True)
-        from ..edges import seed_base
+        from .._seeds import seed_base
         self._seed_host[0] = (step_index * 2246822519 + 3266489917) % (1 << 31)     # fresh dropout masks every step
         seed_base(self.device).copy_(self._seed_host, non_blocking=True)
 

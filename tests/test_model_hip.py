@@ -529,11 +529,13 @@ def test_decoder_prenet_and_positional_encoding_executors(gpu):
         assert rel < 3e-2, (n, rel)
 
 
-def test_long_sequence_config_general_path(gpu):
+def test_long_sequence_config_runs_on_the_executor(gpu):
     """BASELINE config #4 (config/bucket-size-64-18-06.yml: bucket 64/64, post_attn_dropout 0.15, cross-attention
-    dropout 0.15) at 1+1 layers, mel 4096: active dropout inside the reversible blocks sends the stacks down the
-    general path (nested autograd with per-call RNG capture).  Forward/backward must run, stay finite, reach every
-    parameter, and the recompute must replay the same dropout masks (deterministic gradients for a fixed seed)."""
+    dropout 0.15) at 1+1 layers, mel 4096.  Both dropouts run inside the executor's kernels as counter-hash masks that
+    the reconstruction and the backward reproduce, so the stacks stay on the explicit path; with the same seeds two runs
+    give identical gradients, with the block-output stash off (the cross-attention forward is then really re-run with
+    the same mask) they agree to rounding, and different seeds give different ones."""
+    from reformer_tts_amd import _seeds, engine
     from reformer_tts_amd.model.config import TTSTrainingConfig, long_sequence_model_config
     from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
     cfg = long_sequence_model_config()
@@ -541,22 +543,133 @@ def test_long_sequence_config_general_path(gpu):
     cfg.dec_reformer_kwargs.depth = 1
     grads = []
     batch = synthetic_batch(1, 200, 4096, device=gpu)
-    for _ in range(2):
-        model = build_model(cfg, gpu)
-        assert model.dec.reformer.layers.use_fused
-        tr = Trainer(model, TTSTrainingConfig(batch_size=1), gpu)
-        model.train()
-        tr.zero_grad()
-        torch.manual_seed(123)
-        torch.cuda.manual_seed(123)
-        loss = tr.forward_loss(batch)[0]
-        assert model.dec.reformer.layers._program is None          # dropout in the blocks => general path
-        loss.backward()
-        torch.cuda.synchronize()
-        assert torch.isfinite(loss) and torch.isfinite(tr.flat_g).all()
-        grads.append(tr.flat_g.clone())
+    old = engine.STASH_ATTENTION, engine.STASH_BLOCK_OUTPUT
+    try:
+        for seed0, stash in ((0, True), (0, True), (0, False), (1000, True)):
+            engine.STASH_ATTENTION = engine.STASH_BLOCK_OUTPUT = stash
+            _seeds.reset(seed0)
+            torch.manual_seed(123)
+            torch.cuda.manual_seed(123)
+            model = build_model(cfg, gpu)
+            tr = Trainer(model, TTSTrainingConfig(batch_size=1), gpu)
+            model.train()
+            tr.zero_grad()
+            loss = tr.forward_loss(batch)[0]
+            assert model.dec.reformer.layers._program is not None and model.enc.reformer.layers._program is not None
+            loss.backward()
+            torch.cuda.synchronize()
+            assert torch.isfinite(loss) and torch.isfinite(tr.flat_g).all()
+            grads.append(tr.flat_g.clone())
+    finally:
+        engine.STASH_ATTENTION, engine.STASH_BLOCK_OUTPUT = old
     zero = [n for n, (s, e) in tr.offsets.items() if float(grads[0][s:e].abs().max()) == 0.0]
     assert all(".conv" in n and n.endswith(".bias") for n in zero), zero
+    assert torch.equal(grads[0], grads[1])
+    assert float((grads[2] - grads[0]).norm() / grads[0].norm()) < 2e-2
+    assert float((grads[3] - grads[0]).norm() / grads[0].norm()) > 5e-2
+
+
+def _drop_mask_rows(gpu, m, d, p, seed, sd):
+    """keep-scale (0 or 1/(1-p)) of every element of an (m, d) block output, read back through the residual epilogue."""
+    from reformer_tts_amd import _lib
+    x = torch.zeros(m, d, device=gpu)
+    g = torch.ones(m, d, dtype=torch.bfloat16, device=gpu)
+    _lib.call("rtts_residual_epilogue", x.data_ptr(), g.data_ptr(), None, 1.0, x.data_ptr(), m, d, p, seed, sd.data_ptr(),
+              torch.cuda.current_stream().cuda_stream)
+    return x
+
+
+def test_post_attention_dropout_kernels_agree(gpu):
+    """The three kernels that apply the LSH layer's post_attn_dropout -- residual epilogue, residual + LayerNorm, and the
+    backward's cast + column sum -- take the same keep decision for the same (seed, element)."""
+    from reformer_tts_amd import _lib
+    m, d, p, seed = 384, 512, 0.15, 4242
+    sd = torch.tensor([99], dtype=torch.int32, device=gpu)
+    s = torch.cuda.current_stream().cuda_stream
+    keep = _drop_mask_rows(gpu, m, d, p, seed, sd)
+    vals = keep.unique()
+    assert vals.numel() == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1 / (1 - p)) < 1e-6
+    assert abs(float((keep > 0).float().mean()) - (1 - p)) < 5e-3
+    assert not torch.equal(keep, _drop_mask_rows(gpu, m, d, p, seed, torch.tensor([100], dtype=torch.int32, device=gpu)))
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.randn(m, d, generator=g).to(gpu)
+    gg = torch.randn(m, d, generator=g).bfloat16().to(gpu)
+    bias = torch.randn(d, generator=g).to(gpu)
+    gamma, beta = (1 + 0.1 * torch.randn(d, generator=g)).to(gpu), (0.1 * torch.randn(d, generator=g)).to(gpu)
+    want = x0 - (gg.float() + bias) * keep
+    x1 = x0.clone()
+    _lib.call("rtts_residual_epilogue", x1.data_ptr(), gg.data_ptr(), bias.data_ptr(), -1.0, x1.data_ptr(), m, d, p, seed, sd.data_ptr(), s)
+    x2 = x0.clone()
+    xn = torch.empty(m, d, dtype=torch.bfloat16, device=gpu)
+    mean, rstd = torch.empty(m, device=gpu), torch.empty(m, device=gpu)
+    _lib.call("rtts_residual_ln", x2.data_ptr(), gg.data_ptr(), bias.data_ptr(), -1.0, gamma.data_ptr(), beta.data_ptr(), xn.data_ptr(),
+              mean.data_ptr(), rstd.data_ptr(), m, d, p, seed, sd.data_ptr(), s)
+    torch.testing.assert_close(x1, want, rtol=1e-6, atol=1e-6)
+    assert torch.equal(x1, x2)
+    torch.testing.assert_close(xn.float(), torch.nn.functional.layer_norm(want, (d,), gamma, beta, 1e-5), rtol=2e-2, atol=2e-2)
+    dy = torch.randn(m, d, generator=g).to(gpu)
+    dyb = torch.empty(m, d, dtype=torch.bfloat16, device=gpu)
+    dbias = torch.zeros(d, device=gpu)
+    ws = torch.empty(2 * 256 * d, device=gpu)
+    _lib.call("rtts_cast_colsum", dy.data_ptr(), dyb.data_ptr(), dbias.data_ptr(), ws.data_ptr(), m, d, p, seed, sd.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert torch.equal(dyb, (dy * keep).bfloat16())
+    torch.testing.assert_close(dbias, (dy * keep).sum(0), rtol=1e-4, atol=1e-3)
+
+
+def test_cross_attention_dropout_vs_autograd(gpu):
+    """rtts_xattn_fwd / rtts_xattn_bwd with dropout on the probabilities against torch autograd using the mask the kernel
+    drew (read back with Q = K = 0, i.e. uniform probabilities, and V = one 64-key block of the identity at a time)."""
+    from reformer_tts_amd import _lib
+    b, h, t, tk, dh, p, seed = 2, 2, 256, 256, 64, 0.15, 777
+    e = h * dh
+    sd = torch.tensor([5], dtype=torch.int32, device=gpu)
+    s = torch.cuda.current_stream().cuda_stream
+
+    def fwd(q, kv):
+        o = torch.empty(b * t, e, dtype=torch.bfloat16, device=gpu)
+        lse = torch.empty(b * h, t, device=gpu)
+        _lib.call("rtts_xattn_fwd", q.data_ptr(), e, kv.data_ptr(), 2 * e, None, b, h, t, tk, dh, o.data_ptr(), e, lse.data_ptr(),
+                  p, seed, sd.data_ptr(), s)
+        return o, lse
+
+    keep = torch.empty(b, h, t, tk, device=gpu)
+    zq = torch.zeros(b * t, e, dtype=torch.bfloat16, device=gpu)
+    for blk in range(tk // dh):
+        kv = torch.zeros(b * tk, 2 * e, dtype=torch.bfloat16, device=gpu)
+        eye = torch.zeros(tk, dh, device=gpu)
+        eye[blk * dh:(blk + 1) * dh] = torch.eye(dh, device=gpu)
+        kv.view(b, tk, 2, h, dh)[:, :, 1] = eye.view(1, tk, 1, dh).bfloat16()
+        o, _ = fwd(zq, kv)
+        keep[..., blk * dh:(blk + 1) * dh] = o.float().view(b, t, h, dh).transpose(1, 2) * tk
+    vals = keep.round(decimals=2).unique()
+    assert vals.numel() == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1 / (1 - p)) < 2e-2
+    keep = (keep > 0.5).float() / (1 - p)
+    assert abs(float((keep > 0).float().mean()) - (1 - p)) < 5e-3
+
+    g = torch.Generator().manual_seed(1)
+    q = torch.randn(b * t, e, generator=g).bfloat16().to(gpu)
+    kv = torch.randn(b * tk, 2 * e, generator=g).bfloat16().to(gpu)
+    do = torch.randn(b * t, e, generator=g).bfloat16().to(gpu)
+    o, lse = fwd(q, kv)
+    qr = q.float().view(b, t, h, dh).transpose(1, 2).requires_grad_()
+    kr = kv.float().view(b, tk, 2, h, dh)[:, :, 0].transpose(1, 2).requires_grad_()
+    vr = kv.float().view(b, tk, 2, h, dh)[:, :, 1].transpose(1, 2).requires_grad_()
+    pr = torch.softmax(qr @ kr.transpose(-1, -2) / 8.0, dim=-1) * keep
+    oref = pr @ vr
+    torch.testing.assert_close(o.float().view(b, t, h, dh).transpose(1, 2), oref.detach(), rtol=2e-2, atol=2e-2)
+    oref.backward(do.float().view(b, t, h, dh).transpose(1, 2))
+    delta = torch.empty(b * h, t, device=gpu)
+    _lib.call("rtts_lsh_bwd_delta", o.data_ptr(), e, do.data_ptr(), e, b, h, t, dh, delta.data_ptr(), s)
+    dq = torch.empty(b * t, e, dtype=torch.bfloat16, device=gpu)
+    part = torch.empty(t // 128, b * tk, 2 * e, dtype=torch.bfloat16, device=gpu)
+    _lib.call("rtts_xattn_bwd", q.data_ptr(), e, kv.data_ptr(), 2 * e, None, do.data_ptr(), e, lse.data_ptr(), delta.data_ptr(), b, h, t,
+              tk, dh, dq.data_ptr(), e, part.data_ptr(), p, seed, sd.data_ptr(), s)
+    torch.cuda.synchronize()
+    dkv = part.float().sum(0).view(b, tk, 2, h, dh)
+    for got, ref, name in ((dq.float().view(b, t, h, dh).transpose(1, 2), qr.grad, "dq"), (dkv[:, :, 0].transpose(1, 2), kr.grad, "dk"),
+                           (dkv[:, :, 1].transpose(1, 2), vr.grad, "dv")):
+        assert float((got - ref).norm() / ref.norm()) < 3e-2, name
 
 
 def test_batch_prefetcher_feeds_captured_buffers(gpu):
