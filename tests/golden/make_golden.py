@@ -19,6 +19,7 @@ Fixtures
                    ``oracle.synth`` and are therefore not stored.
   infer_small.npz  the reference's ReformerTTS.infer (autoregressive loop of full eval-mode forwards) on the same
                    wiring, three strategies; rotations recorded in call order
+  squeezewave_{small,full}.npz  the reference's SqueezeWave.infer (vocoder)
   hf_lsh_int.npz   integer stages (hash, stable sort) from HuggingFace's
                    independent implementation of the same paper (cross-check,
                    not the reference)
@@ -243,6 +244,56 @@ def infer_small():
     np.savez_compressed(os.path.join(HERE, "infer_small.npz"), **out)
 
 
+def squeezewave():
+    """the reference's SqueezeWave.infer (squeeze_wave/modules.py:334-376), eval mode, weight norm
+    and BatchNorm in place (NOT folded), random non-degenerate parameters; the Gaussian draws come from torch's global
+    generator under a recorded seed.  'small' stores its whole state_dict; 'full' (the default 12-flow / 256-channel
+    configuration, 23.7 M parameters) takes its parameters from oracle.synth by name and stores only the BatchNorm
+    running statistics."""
+    sys.modules.setdefault("dacite", types.ModuleType("dacite"))
+    from reformer_tts.squeeze_wave.config import WNConfig
+    from reformer_tts.squeeze_wave.modules import SqueezeWave
+    from oracle import squeezewave_ref as sw_ref
+    for tag, cfg, mel_len, batch in (("small", sw_ref.small_cfg(), 24, 2), ("full", sw_ref.default_cfg(), 32, 1)):
+        wn = cfg["wn_config"]
+        torch.manual_seed(3)
+        m = SqueezeWave(cfg["n_flows"], cfg["n_audio_channels"], cfg["n_mel_channels"], cfg["early_return_interval"],
+                        cfg["early_return_size"], WNConfig(wn["n_layers"], wn["n_channels"], wn["conv_kernel_size"], wn["mel_upsample_scale"]))
+        g = torch.Generator().manual_seed(17)
+        out = {}
+        sd = m.state_dict()
+        if tag == "full":
+            shapes = {k: tuple(v.shape) for k, v in sd.items()}
+            syn = synth.synth_state_dict(shapes, seed=11)
+            for k in sd:
+                if "inv_conv_layers" in k or "num_batches" in k or k not in syn:
+                    continue                       # keep the orthonormal initialisation (well conditioned inverse)
+                sd[k] = syn[k] * (0.05 if "end_conv" in k else 1.0)      # log-scales near 0: the flow stays finite
+            for k, s_ in shapes.items():
+                out[f"shape/{k}"] = np.array(s_, dtype=np.int64)
+        else:
+            for k, v in sd.items():
+                if v.dtype.is_floating_point and "inv_conv_layers" not in k:
+                    sd[k] = (0.02 if "end_conv" in k else 0.3) * torch.randn(v.shape, generator=g) + \
+                        (1.0 if k.endswith("weight_g") or k.endswith("0.weight") else 0.0)
+        for k in sd:
+            if k.endswith("running_var"):
+                sd[k] = 0.5 + torch.rand(sd[k].shape, generator=g)
+            elif k.endswith("running_mean"):
+                sd[k] = 0.2 * torch.randn(sd[k].shape, generator=g)
+            if tag == "small" or "running" in k or "inv_conv_layers" in k:
+                out[f"sd/{k}"] = npy(sd[k])
+        m.load_state_dict(sd)
+        m.eval()
+        mel = (torch.randn(batch, cfg["n_mel_channels"], mel_len, generator=g) * 2.0 - 5.0).clamp(-11.5, 2.0)
+        torch.manual_seed(99)
+        with torch.no_grad():
+            audio = m.infer(mel, sigma=0.6)
+        out["mel"], out["audio"], out["seed"] = npy(mel), npy(audio), np.array(99)
+        np.savez_compressed(os.path.join(HERE, f"squeezewave_{tag}.npz"), **out)
+        print("squeezewave", tag, tuple(audio.shape), "clamped fraction", float((audio.abs() >= 1).float().mean()))
+
+
 def hf_lsh_int():
     """HuggingFace LSHSelfAttention integer stages on seeded vectors (per-head rotations)."""
     from transformers import ReformerConfig
@@ -272,4 +323,5 @@ if __name__ == "__main__":
     pieces()
     model_small()
     infer_small()
+    squeezewave()
     hf_lsh_int()

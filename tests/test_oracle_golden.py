@@ -233,3 +233,35 @@ def test_oracle_infer_matches_reference(infer_golden, case):
     assert spec.shape == z[f"{case}/spectrogram"].shape
     assert torch.equal(stop, torch.from_numpy(z[f"{case}/stop"]))
     torch.testing.assert_close(spec, torch.from_numpy(z[f"{case}/spectrogram"]), rtol=1e-3, atol=1e-3)
+
+
+# ------------------------------------------------------------------ SqueezeWave vocoder
+def _squeezewave_case(golden_dir, tag):
+    from oracle import squeezewave_ref as sw_ref
+    z = np.load(os.path.join(golden_dir, f"squeezewave_{tag}.npz"))
+    cfg = sw_ref.small_cfg() if tag == "small" else sw_ref.default_cfg()
+    if tag == "small":
+        sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    else:
+        shapes = {k[len("shape/"):]: tuple(z[k]) for k in z.files if k.startswith("shape/")}
+        sd = synth.synth_state_dict(shapes, seed=11)
+        sd = {k: v * (0.05 if "end_conv" in k else 1.0) for k, v in sd.items()}
+        for k in z.files:
+            if k.startswith("sd/"):
+                sd[k[3:]] = torch.from_numpy(z[k])
+    return z, cfg, sd
+
+
+@pytest.mark.parametrize("tag", ["small", "full"])
+def test_oracle_squeezewave_infer_matches_reference(golden_dir, tag):
+    """oracle.squeezewave_ref.infer against the reference's SqueezeWave.infer (squeeze_wave/modules.py:334-376; fixture
+    generated by importing it): weight norm and eval-mode BatchNorm unfolded, same Gaussian draws (global generator,
+    recorded seed).  'full' = the default 12-flow, 256-channel configuration (23.7 M parameters, from oracle.synth)."""
+    from oracle import squeezewave_ref as sw_ref
+    z, cfg, sd = _squeezewave_case(golden_dir, tag)
+    torch.manual_seed(int(z["seed"]))
+    with torch.no_grad():
+        audio = sw_ref.infer(sd, cfg, torch.from_numpy(z["mel"]), sigma=0.6)
+    ref = torch.from_numpy(z["audio"])
+    assert audio.shape == ref.shape == (z["mel"].shape[0], 256 * z["mel"].shape[2])
+    torch.testing.assert_close(audio, ref, rtol=1e-3, atol=1e-3)
