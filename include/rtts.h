@@ -239,6 +239,20 @@ typedef struct {
 } rtts_gemm_tn_problem;
 int rtts_gemm_tn_grouped(const rtts_gemm_tn_problem* problems, int n, float* slab_ws, int64_t slab_ws_floats, void* stream);
 
+/* ---- SqueezeWave vocoder, inference -----------------------------------
+ * Activations are channels-last rows; the 1x1 convolutions are GEMMs outside.  Replaces, per WN layer
+ * (reference reformer_tts/squeeze_wave/modules.py):
+ *   rtts_sw_depthwise_k3  BatchNorm1d(eval, folded into w/bias by the caller) + depthwise Conv1d(k=3, pad 1) (:88-122):
+ *                         x fp32 (B,L,C), w (C,3), bias (C) -> y bf16
+ *   rtts_sw_gate          fused_add_tanh_sigmoid_multiply (:10-24) of the pointwise output pw (B*L, 2C) and the layer's
+ *                         slice [cond_offset, +2C) of the conditioning (B*Lm, ld_cond), nearest-upsampled by `upsample`
+ *                         (nn.Upsample, :216-219) -> acts bf16 (B*L, C)
+ *   rtts_sw_coupling_inv  a1 = (a1 - b) / exp(s) on channels [half, 2*half) of audio (rows, ld_audio), wn_out = [s | b] (:353-359) */
+int rtts_sw_depthwise_k3(const float* x, const float* w, const float* bias, int B, int L, int C, void* y, void* stream);
+int rtts_sw_gate(const void* pw, const void* cond, int64_t ld_cond, int cond_offset, int upsample, int B, int L, int Lm, int C,
+                 void* acts, void* stream);
+int rtts_sw_coupling_inv(float* audio, int64_t ld_audio, const float* wn_out, int64_t rows, int half, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

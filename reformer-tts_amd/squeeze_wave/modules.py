@@ -1,0 +1,229 @@
+"""SqueezeWave vocoder, inference on MI355X.
+
+Module tree, constructor arguments and ``state_dict`` names follow
+``/root/reference/reformer_tts/squeeze_wave/modules.py`` (``SqueezeWave`` :238-290, ``WN`` :125-201,
+``DepthwiseSeparableConv1d`` :88-122, ``InvertibleConv1d`` :27-85) so that the reference's checkpoints load; the
+modules here only HOLD parameters.  ``infer`` (:334-376) runs through an explicit executor:
+
+* activations are channels-last rows ``(B*L, C)``: every 1x1 ``Conv1d`` is one GEMM over rows (hipBLASLt, bf16
+  operands, fp32 accumulate), the WN residual stream and the audio stay fp32;
+* weight norm and the eval-mode BatchNorm in front of each depthwise convolution are folded into plain weights once
+  per parameter version (what ``remove_norms`` :237-248,378-419 does destructively);
+* the mel conditioning of all ``n_layers`` layers of a flow is one GEMM (``cond_layer``), consumed in place by the gate
+  kernel with nearest-neighbour upsampling done by indexing;
+* depthwise k3 + folded BatchNorm, tanh*sigmoid gate and inverse affine coupling are the kernels of
+  ``csrc/squeezewave.hip``; the residual add is the TTS path's ``rtts_residual_epilogue``;
+* the inverse of each invertible 1x1 convolution is cached (fp32) like the reference's ``W_inverse``.
+
+There is no CPU fallback: ``infer`` raises off the GPU."""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from .. import _lib
+from .._graphs import capturing
+from .config import WNConfig
+
+
+def _s() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class InvertibleConv1d(nn.Module):
+    def __init__(self, n_channels: int):
+        super().__init__()
+        self.conv = nn.Conv1d(n_channels, n_channels, kernel_size=1, bias=False)
+        w = torch.linalg.qr(torch.randn(n_channels, n_channels))[0]          # random orthonormal, det +1
+        if torch.det(w) < 0:
+            w[:, 0] = -w[:, 0]
+        self.conv.weight.data = w.reshape(n_channels, n_channels, 1).contiguous()
+
+
+class DepthwiseSeparableConv1d(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int):
+        super().__init__()
+        assert kernel_size % 2 == 1 and in_channels % 2 == 0
+        self.layer = nn.Sequential(nn.BatchNorm1d(in_channels),
+                                   nn.Conv1d(in_channels, in_channels, kernel_size, padding=(kernel_size - 1) // 2, groups=in_channels),
+                                   nn.Conv1d(in_channels, out_channels, 1))
+
+
+class WN(nn.Module):
+    def __init__(self, in_audio_channels: int, in_mel_channels: int, n_layers: int, n_channels: int, conv_kernel_size: int,
+                 mel_upsample_scale: int):
+        super().__init__()
+        assert conv_kernel_size % 2 == 1 and n_channels % 2 == 0
+        self.n_layers, self.n_channels, self.kernel_size, self.upsample_scale = n_layers, n_channels, conv_kernel_size, mel_upsample_scale
+        wn = torch.nn.utils.weight_norm
+        self.cond_layer = wn(nn.Conv1d(in_mel_channels, 2 * n_channels * n_layers, 1), name="weight")
+        self.start_conv = wn(nn.Conv1d(in_audio_channels, n_channels, 1), name="weight")
+        self.end_conv = nn.Conv1d(n_channels, 2 * in_audio_channels, 1)
+        self.end_conv.weight.data.zero_()
+        self.end_conv.bias.data.zero_()
+        self.in_layers = nn.ModuleList(DepthwiseSeparableConv1d(n_channels, 2 * n_channels, conv_kernel_size) for _ in range(n_layers))
+        self.res_skip_layers = nn.ModuleList(wn(nn.Conv1d(n_channels, n_channels, 1), name="weight") for _ in range(n_layers))
+
+
+def _normed(conv) -> torch.Tensor:
+    """(Cout, Cin) fp32 weight of a 1x1 convolution, weight norm applied if it is still attached."""
+    if hasattr(conv, "weight_g"):
+        v, g = conv.weight_v.detach().float(), conv.weight_g.detach().float()
+        w = v * (g / v.flatten(1).norm(dim=1).view(-1, 1, 1))
+    else:
+        w = conv.weight.detach().float()
+    return w.squeeze(-1)
+
+
+class _FoldedWN:
+    """Inference weights of one WN block: bf16 GEMM operands (row-major (Cout, Cin)), fp32 biases, depthwise taps with
+    the eval-mode BatchNorm folded in:  dw(bn(x)) = sum_k (w_k * a) x_{l+k-1} + [b + (sum_k w_k) * c],
+    a = gamma / sqrt(var + eps), c = beta - mean * a.  (Zero padding pads bn(x), i.e. the constant c is NOT added at the
+    borders by the reference; the border rows get the exact correction below.)"""
+
+    def __init__(self, wn: WN):
+        bf = torch.bfloat16
+        self.c, self.nl, self.up = wn.n_channels, wn.n_layers, wn.upsample_scale
+        if wn.kernel_size != 3:
+            raise NotImplementedError("the HIP depthwise kernel is built for conv_kernel_size == 3")
+        self.w_start, self.b_start = _normed(wn.start_conv).to(bf).contiguous(), wn.start_conv.bias.detach().float()
+        self.w_cond, self.b_cond = _normed(wn.cond_layer).to(bf).contiguous(), wn.cond_layer.bias.detach().to(bf)
+        self.w_end, self.b_end = wn.end_conv.weight.detach().float().squeeze(-1).to(bf).contiguous(), wn.end_conv.bias.detach().float()
+        self.dw_w, self.dw_b, self.dw_edge, self.w_pw, self.b_pw, self.w_rs, self.b_rs = [], [], [], [], [], [], []
+        for i in range(wn.n_layers):
+            bn, dw, pw = wn.in_layers[i].layer
+            a = bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)
+            cst = bn.bias.detach().float() - bn.running_mean.float() * a
+            w = dw.weight.detach().float().squeeze(1)                          # (C, 3)
+            self.dw_w.append((w * a[:, None]).contiguous())
+            self.dw_b.append((dw.bias.detach().float() + w.sum(1) * cst).contiguous())
+            # at l = 0 the tap k = 0 sees the zero padding of bn(x), not c; at l = L-1 the tap k = 2 likewise
+            self.dw_edge.append(((w[:, 0] * cst).contiguous(), (w[:, 2] * cst).contiguous()))
+            self.w_pw.append(pw.weight.detach().float().squeeze(-1).to(bf).contiguous())
+            self.b_pw.append(pw.bias.detach().to(bf))
+            self.w_rs.append(_normed(wn.res_skip_layers[i]).to(bf).contiguous())
+            self.b_rs.append(wn.res_skip_layers[i].bias.detach().float().contiguous())
+
+    def forward(self, a0: torch.Tensor, mel_rows: torch.Tensor, b: int, length: int, mel_len: int) -> torch.Tensor:
+        """a0 fp32 (B*L, n_half) rows, mel_rows bf16 (B*Lm, n_mel) -> fp32 (B*L, 2*n_half) = [s | b]."""
+        dev, c = a0.device, self.c
+        m = b * length
+        if a0.shape[1] % 8:      # odd channel counts (tiny test configurations): plain fp32 GEMM
+            h = torch.addmm(self.b_start, a0, self.w_start.float().t())
+        else:
+            h = torch.mm(a0.to(torch.bfloat16), self.w_start.t(), out_dtype=torch.float32) + self.b_start
+        cond = torch.addmm(self.b_cond, mel_rows, self.w_cond.t())                 # (B*Lm, 2c*nl) bf16, all layers at once
+        up = length // mel_len
+        for i in range(self.nl):
+            dw = torch.empty(m, c, dtype=torch.bfloat16, device=dev)
+            _lib.call("rtts_sw_depthwise_k3", h.data_ptr(), self.dw_w[i].data_ptr(), self.dw_b[i].data_ptr(), b, length, c, dw.data_ptr(), _s())
+            lo, hi = self.dw_edge[i]
+            dwv = dw.view(b, length, c)
+            dwv[:, 0] = (dwv[:, 0].float() - lo).to(torch.bfloat16)              # zero padding pads bn(x): undo the constant there
+            dwv[:, -1] = (dwv[:, -1].float() - hi).to(torch.bfloat16)
+            pw = torch.addmm(self.b_pw[i], dw, self.w_pw[i].t())                   # (M, 2c) bf16
+            acts = torch.empty(m, c, dtype=torch.bfloat16, device=dev)
+            _lib.call("rtts_sw_gate", pw.data_ptr(), cond.data_ptr(), cond.stride(0), i * 2 * c, up, b, length, mel_len, c, acts.data_ptr(), _s())
+            rs = torch.mm(acts, self.w_rs[i].t())
+            _lib.call("rtts_residual_epilogue", h.data_ptr(), rs.data_ptr(), self.b_rs[i].data_ptr(), 1.0, h.data_ptr(), m, c, 0.0, 0, None, _s())
+        return torch.mm(h.to(torch.bfloat16), self.w_end.t(), out_dtype=torch.float32) + self.b_end
+
+
+class SqueezeWave(nn.Module):
+    def __init__(self, n_flows: int, n_audio_channels: int, n_mel_channels: int, early_return_interval: int, early_return_size: int,
+                 wn_config: WNConfig):
+        super().__init__()
+        assert n_audio_channels % 2 == 0, "n_audio_channels must be divisible by 2"
+        assert early_return_size % 2 == 0, "early_return_size must be divisible by 2"
+        self.n_flows, self.n_audio_channels, self.early_return_size = n_flows, n_audio_channels, early_return_size
+        self.early_return_interval = early_return_interval
+        self.wn_layers, self.inv_conv_layers = nn.ModuleList(), nn.ModuleList()
+        n_half, n_rem = n_audio_channels // 2, n_audio_channels
+        for k in range(n_flows):
+            if self.return_early(k):
+                n_half -= early_return_size // 2
+                n_rem -= early_return_size
+            self.inv_conv_layers.append(InvertibleConv1d(n_rem))
+            self.wn_layers.append(WN(n_half, n_mel_channels, wn_config.n_layers, wn_config.n_channels, wn_config.conv_kernel_size,
+                                     wn_config.mel_upsample_scale))
+        self.n_remaining_channels = n_rem
+        self._folded: Optional[List[_FoldedWN]] = None
+        self._folded_key = None
+
+    def return_early(self, flow: int) -> bool:
+        return flow % self.early_return_interval == 0 and flow > 0
+
+    def _fold(self):
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + tuple((b.data_ptr(), b._version) for b in self.buffers())
+        if self._folded is None or self._folded_key != key:
+            with torch.no_grad():
+                self._folded = [_FoldedWN(wn) for wn in self.wn_layers]
+                self._winv = [conv.conv.weight.detach().float().squeeze(-1).inverse().contiguous() for conv in self.inv_conv_layers]
+            self._folded_key = key
+        return self._folded
+
+    def noise_shapes(self, batch: int, mel_len: int):
+        """Shapes (reference layout (B, C, L)) of the Gaussian draws of one ``infer`` call, in the order they are consumed."""
+        length = mel_len * (256 // self.n_audio_channels)
+        shapes = [(batch, self.n_remaining_channels, length)]
+        shapes += [(batch, self.early_return_size, length) for k in reversed(range(self.n_flows)) if self.return_early(k)]
+        return shapes
+
+    @torch.no_grad()
+    def infer(self, mel_spectrogram: torch.Tensor, sigma: float = 0.6, noise: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
+        """``modules.py:334-376``: mel (B, n_mel, Lm) -> audio (B, 256 * Lm) in [-1, 1].  ``noise``: the Gaussian draws in
+        the reference's (B, C, L) layout and order (see ``noise_shapes``); drawn on the device when omitted."""
+        dev = self.inv_conv_layers[0].conv.weight.device
+        if dev.type != "cuda":
+            raise _lib.RttsError("SqueezeWave.infer runs on the GPU only (no CPU fallback for the HIP path)")
+        folded = self._fold()
+        mel = mel_spectrogram.to(dev)
+        b, n_mel, mel_len = mel.shape
+        length = mel_len * (256 // self.n_audio_channels)
+        if folded[0].up * mel_len != length:
+            raise ValueError("mel_upsample_scale must equal 256 // n_audio_channels")
+        shapes = self.noise_shapes(b, mel_len)
+        if noise is None:
+            noise = [torch.randn(s, device=dev) for s in shapes]
+        assert [tuple(z.shape) for z in noise] == shapes, "noise tensors do not match noise_shapes()"
+        rows = lambda z: z.to(dev, torch.float32).permute(0, 2, 1).reshape(b * length, -1).contiguous()    # noqa: E731
+        draws = iter(noise)
+        mel_rows = mel.permute(0, 2, 1).reshape(b * mel_len, n_mel).to(torch.bfloat16).contiguous()
+        audio = rows(next(draws))                                                  # (B*L, n_remaining) fp32
+        for k in reversed(range(self.n_flows)):
+            half = audio.shape[1] // 2
+            a0 = audio[:, :half].contiguous()
+            wn_out = folded[k].forward(a0, mel_rows, b, length, mel_len)            # [s | b]
+            _lib.call("rtts_sw_coupling_inv", audio.data_ptr(), audio.stride(0), wn_out.data_ptr(), audio.shape[0], half, _s())
+            audio = torch.mm(audio, self._winv[k].t())                             # inverse 1x1 convolution, fp32
+            if self.return_early(k):
+                audio = torch.cat((sigma * rows(next(draws)), audio), dim=1)
+        return torch.clamp(audio.view(b, length * audio.shape[1]), -1, 1)
+
+    def capture(self, batch: int, mel_len: int, sigma: float = 0.6):
+        """-> ``run(mel) -> audio``: the whole ``infer`` for one (batch, mel_len) shape as ONE hipGraph (~1000 launches
+        replayed without host work; eager inference is launch-bound: 14 ms whether B is 1 or 8).  Per call the mel is
+        copied into the graph's input buffer and fresh Gaussian noise is drawn inside the graph (the default CUDA
+        generator is graph-safe).  The returned audio tensor is the graph's output buffer: copy it before the next call."""
+        dev = self.inv_conv_layers[0].conv.weight.device
+        mel_buf = torch.zeros(batch, self.wn_layers[0].cond_layer.weight_v.shape[1] if hasattr(self.wn_layers[0].cond_layer, "weight_v")
+                              else self.wn_layers[0].cond_layer.weight.shape[1], mel_len, device=dev)
+        shapes = self.noise_shapes(batch, mel_len)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.infer(mel_buf, sigma)                         # warm-up: folding, allocator, lazy attributes
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with capturing(graph):
+            out = self.infer(mel_buf, sigma, noise=[torch.randn(s, device=dev) for s in shapes])
+
+        def run(mel: torch.Tensor) -> torch.Tensor:
+            mel_buf.copy_(mel, non_blocking=True)
+            graph.replay()
+            return out
+        return run
+

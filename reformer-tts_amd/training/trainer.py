@@ -14,8 +14,6 @@ MI355X-first mechanics:
 """
 from __future__ import annotations
 
-import contextlib
-import gc
 import math
 from typing import Dict, List, Optional
 
@@ -23,6 +21,7 @@ import torch
 import torch.distributed as dist
 
 from .. import _lib, engine
+from .._graphs import capturing
 from ..model import ReformerTTS, TTSLoss
 from ..model.config import ReformerTTSConfig, TTSTrainingConfig, as_kwargs
 
@@ -237,25 +236,7 @@ class Trainer:
     # ------------------------------------------------------------------ hipGraph replay of the whole step
     _bulk_allreduce = False
 
-    @staticmethod
-    @contextlib.contextmanager
-    def _capturing(graph, **kw):
-        """``torch.cuda.graph`` with the Python garbage collector held off: a collection that happens to run inside a
-        capture can release device resources (events, blocks that were used on another stream), which HIP refuses while
-        a stream is capturing -- the process then aborts from a destructor.  Seen for real: ``Tensor.backward(grad)``
-        lazily imports ``torch.fx.experimental.symbolic_shapes`` (sympy), whose thousands of allocations trigger a
-        collection in the middle of the second graph.  Both causes are removed: the import happens up front, and
-        automatic collection is off for the duration of the capture."""
-        import torch.fx.experimental.symbolic_shapes  # noqa: F401  (what autograd imports on first use of grad_tensors)
-        gc.collect()
-        was_enabled = gc.isenabled()
-        gc.disable()
-        try:
-            with torch.cuda.graph(graph, **kw):
-                yield
-        finally:
-            if was_enabled:
-                gc.enable()
+    _capturing = staticmethod(capturing)      # torch.cuda.graph with the garbage collector held off (see _graphs.py)
 
     def capture(self, batch, segmented: Optional[bool] = None):
         """Capture the step for THIS batch buffer into hipGraphs; afterwards ``replay()`` runs one full step per call: the
