@@ -113,7 +113,7 @@ class ReformerTTS(nn.Module):
     @torch.no_grad()
     def infer(self, phonemes: torch.LongTensor, combine_strategy: str = "concat", max_len: int = 1024,
               stop_threshold: float = 0.25, verbose: bool = False, stop_at_stop_token: bool = True,
-              cache_encoder: bool = False, check_every: int = 8) -> Tuple[torch.Tensor, torch.LongTensor]:
+              cache_encoder: bool = False, check_every: int = 8, use_graph: bool = False) -> Tuple[torch.Tensor, torch.LongTensor]:
         """``reformer_tts.py:145-221``: autoregressive generation by repeated full forwards over the spectrogram
         generated so far.  Same arguments, same results -- (spectrogram (B, n_mels, L), stop_idx (B,)) -- including the
         loop guard ``max(spectrogram.shape) > max_len`` (the shape includes the mel axis: ``max_len < n_mels`` ends
@@ -125,9 +125,12 @@ class ReformerTTS(nn.Module):
           ("concat": frames generated after every sample has stopped cannot change earlier frames, so the result is cut
           back to where the reference's loop would have ended; "replace" rewrites every frame and checks every time);
         * ``cache_encoder=True`` runs the encoder once instead of once per frame.  That IS visible -- the reference
-          re-draws the LSH rotations of the encoder in every forward -- hence off by default."""
+          re-draws the LSH rotations of the encoder in every forward -- hence off by default;
+        * ``use_graph=True`` ("concat" only): one frame = one hipGraph replay (see ``_infer_graphed``)."""
         assert combine_strategy in {"concat", "replace"}
         assert -1. < stop_threshold < 1.
+        if use_graph and combine_strategy == "concat":
+            return self._infer_graphed(phonemes, max_len, stop_threshold, stop_at_stop_token, cache_encoder, check_every)
         was_training = self.training
         self.eval()
         try:
@@ -183,6 +186,81 @@ class ReformerTTS(nn.Module):
                 cur = min(cur, int(stop.max()))                 # where the reference's per-iteration check ends the loop
             stop = torch.where(stop == 0, torch.full_like(stop, max_len), stop)
             return buf[:, 1:cur].transpose(1, 2).contiguous(), stop
+        finally:
+            self.train(was_training)
+
+    @torch.no_grad()
+    def _infer_graphed(self, phonemes, max_len, stop_threshold, stop_at_stop_token, cache_encoder, check_every):
+        """"concat" generation with ONE hipGraph replay per frame.  The padded input window, its validity mask, the index
+        of the newest frame and the stop bookkeeping are device buffers; the graph runs the decoder (and the encoder
+        unless cached) over the window, picks the output at the newest position with a device index, appends it to the
+        window and advances the index -- the host only replays, looks at the stop flags every ``check_every`` frames and
+        moves to a larger window (a new capture) when the padded length grows by ``pad_base``.  Same results as the
+        eager loop up to the LSH rotations, which are redrawn per forward in both."""
+        from .._graphs import capturing
+        from .lsh_attention import LSHSelfAttention
+        was_training = self.training
+        self.eval()
+        for m in self.modules():
+            if isinstance(m, LSHSelfAttention):
+                m.use_default_generator = True                       # the per-layer generators are not capturable
+        try:
+            dev = self.dec.mel_linear.weight.device
+            phonemes = phonemes.to(dev)
+            b, nm = phonemes.shape[0], self.num_mel_coeffs
+            pad_ph = pad_to_multiple(phonemes.unsqueeze(-1), self.pad_base).squeeze(-1)
+            ph_mask = pad_ph != 0
+            keys_c = self.enc(pad_ph, input_mask=ph_mask) if cache_encoder else None
+            cap = max(max_len, nm, b) + 2
+            total = _pad_len(cap + 1, self.pad_base)
+            spec = torch.zeros(b, total, nm, device=dev)              # frame 0 = the zero start frame
+            mask = torch.zeros(b, total, dtype=torch.bool, device=dev)
+            mask[:, 0] = True
+            pos = torch.zeros(1, dtype=torch.long, device=dev)        # index of the newest frame = cur - 1
+            stop = torch.zeros(b, dtype=torch.long, device=dev)
+            thr = float(stop_threshold)
+
+            def step(t_pad):
+                keys = keys_c if keys_c is not None else self.enc(pad_ph, input_mask=ph_mask)
+                mel, stop_pred, _ = self.dec(spec[:, :t_pad], keys=keys, key_padding_mask=~ph_mask, input_mask=mask[:, :t_pad])
+                gen = (mel + self.postnet(mel)).index_select(1, pos)                    # (B, 1, n_mels) at the newest position
+                if stop_at_stop_token:
+                    stops_now = torch.sigmoid(stop_pred.reshape(b, -1).index_select(1, pos).reshape(b)) > thr
+                    stop.copy_(torch.where((stop == 0) & stops_now, stops_now.long() * (pos + 1) + 1, stop))
+                pos.add_(1)
+                spec.index_copy_(1, pos, gen)
+                mask.index_fill_(1, pos, True)
+
+            graphs = {}
+            cur, it = 1, 0
+            every = max(1, int(check_every))
+            while True:
+                if stop_at_stop_token and it % every == 0 and bool(torch.all(stop > 0)):
+                    break
+                it += 1
+                t_pad = _pad_len(cur, self.pad_base)
+                if t_pad not in graphs:
+                    # warm-up on a side stream (lazy tables, allocator), with the bookkeeping restored afterwards
+                    saved = (spec.clone(), mask.clone(), pos.clone(), stop.clone())
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        step(t_pad)
+                    torch.cuda.current_stream().wait_stream(side)
+                    for dst, src in zip((spec, mask, pos, stop), saved):
+                        dst.copy_(src)
+                    torch.cuda.synchronize()
+                    graphs[t_pad] = torch.cuda.CUDAGraph()
+                    with capturing(graphs[t_pad]):
+                        step(t_pad)
+                graphs[t_pad].replay()
+                cur += 1
+                if max(b, cur, nm) > max_len:
+                    break
+            if stop_at_stop_token and bool(torch.all(stop > 0)):
+                cur = min(cur, int(stop.max()))
+            stop = torch.where(stop == 0, torch.full_like(stop, max_len), stop)
+            return spec[:, 1:cur].transpose(1, 2).contiguous(), stop
         finally:
             self.train(was_training)
 

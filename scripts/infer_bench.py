@@ -30,7 +30,8 @@ def main():
     ph = torch.randint(1, 77, (args.batch, 200), generator=torch.Generator().manual_seed(0))
     out = {"workload": f"config/baseline.yml ReformerTTS.infer, B={args.batch}, 200 phonemes, {args.frames} frames, concat strategy",
            "unit": "mel-frames/s (all utterances)"}
-    for name, kw in (("reference_semantics", dict()), ("cache_encoder", dict(cache_encoder=True))):
+    for name, kw in (("reference_semantics", dict()), ("cache_encoder", dict(cache_encoder=True)),
+                     ("graph_per_frame", dict(use_graph=True)), ("graph_per_frame_cache_encoder", dict(use_graph=True, cache_encoder=True))):
         model.infer(ph, max_len=90, stop_at_stop_token=False, **kw)          # warm-up (allocator, lazy tables)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

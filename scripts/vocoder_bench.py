@@ -71,6 +71,12 @@ def main():
     def e2e():
         spec, _ = tts.infer(ph, max_len=args.tts_frames, stop_at_stop_token=False, cache_encoder=True)
         return sw.infer(spec)
+    def e2e_graph():
+        spec, _ = tts.infer(ph, max_len=args.tts_frames, stop_at_stop_token=False, cache_encoder=True, use_graph=True)
+        return sw.infer(spec)
+    dtg, audio = timed(e2e_graph, 1)
+    out["text_to_audio_B1_graph"] = {"frames": args.tts_frames, "ms": round(1e3 * dtg, 1), "samples_per_s": round(audio.numel() / dtg, 0),
+                                     "x_realtime": round(audio.numel() / dtg / SR, 2), "note": "one hipGraph replay per frame (captures included)"}
     dt, audio = timed(e2e, 1)
     out["text_to_audio_B1"] = {"frames": args.tts_frames, "ms": round(1e3 * dt, 1), "samples_per_s": round(audio.numel() / dt, 0),
                                "x_realtime": round(audio.numel() / dt / SR, 2),

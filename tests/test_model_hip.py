@@ -735,7 +735,7 @@ def test_infer_cached_encoder_and_check_interval(golden_dir, gpu):
     """check_every only moves the host's look at the stop flags: identical output for 1 and 8.  cache_encoder runs the
     encoder once; with rotations held fixed per layer (what makes the two runs comparable) the frames agree closely."""
     outs = []
-    for kw in (dict(check_every=1), dict(check_every=8), dict(cache_encoder=True)):
+    for kw in (dict(check_every=1), dict(check_every=8), dict(cache_encoder=True), dict(use_graph=True), dict(use_graph=True, cache_encoder=True)):
         zi, model = _load_infer(golden_dir, gpu, "concat_stop")
         enc_l, dec_l = _lsh_layers(model)
         enc_l.forced_rotations = torch.from_numpy(zi["concat_stop/rot/0"])      # one tensor: reused by every call
@@ -744,3 +744,25 @@ def test_infer_cached_encoder_and_check_interval(golden_dir, gpu):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert outs[2][0].shape == outs[0][0].shape and torch.equal(outs[2][1], outs[0][1])
     torch.testing.assert_close(outs[2][0], outs[0][0], rtol=2e-2, atol=2e-2)
+    # one hipGraph replay per frame: same frames, same stop indices as the eager loop
+    for o in outs[3:]:
+        assert o[0].shape == outs[0][0].shape and torch.equal(o[1], outs[0][1])
+        torch.testing.assert_close(o[0], outs[0][0], rtol=2e-2, atol=2e-2)
+
+
+def test_infer_graphed_crosses_a_padding_window(golden_dir, gpu):
+    """pad_base = 128 in the small configuration: 140 frames need the 128- and the 256-frame window (two captures); the
+    graphed loop must agree with the eager loop across the switch."""
+    outs = []
+    for kw in (dict(use_graph=False), dict(use_graph=True)):
+        zi, model = _load_infer(golden_dir, gpu, "concat")
+        enc_l, dec_l = _lsh_layers(model)
+        enc_l.forced_rotations = torch.from_numpy(zi["concat/rot/0"])
+        dec_l.forced_rotations = None        # the decoder's bucket count changes with the window: draw per forward
+        torch.manual_seed(3)
+        torch.cuda.manual_seed(3)
+        outs.append(model.infer(torch.from_numpy(zi["phonemes"]), max_len=140, stop_at_stop_token=False, cache_encoder=True, **kw))
+    assert outs[0][0].shape == outs[1][0].shape == (2, 80, 140)
+    assert torch.isfinite(outs[1][0]).all() and torch.equal(outs[0][1], outs[1][1])
+    # different random rotations in the two runs: compare the first frames (one window, short chain) loosely
+    assert float((outs[0][0][:, :, :4] - outs[1][0][:, :, :4]).abs().max()) < 0.2 * float(outs[0][0].abs().max())
