@@ -127,10 +127,23 @@ def main():
     use_graph = not args.no_graph
     one_graph = world == 1 or (os.environ.get("RTTS_GRAPH_DP") == "1" and backend == "nccl")
     if use_graph:
-        trainer.capture(batch, segmented=not one_graph)
+        ok = 1
+        try:
+            trainer.capture(batch, segmented=not one_graph)
+        except Exception as exc:  # noqa: BLE001  (a capture that fails must not cost the whole measurement)
+            ok = 0
+            print(f"[bench] rank {rank}: graph capture failed ({type(exc).__name__}: {exc}); falling back to eager launches",
+                  file=sys.stderr, flush=True)
+        if world > 1:           # every rank takes the same path: collectives are issued outside the graphs
+            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        use_graph = bool(ok)
+    if use_graph:
         step_fn = trainer.replay
         note("step captured into " + ("one hipGraph" if one_graph else "three hipGraphs around the two gradient all-reduces"))
     else:
+        trainer._bulk_allreduce = False               # eager: per-block all-reduce overlapped with the backward
         step_fn = lambda: trainer.train_step(batch)   # noqa: E731
     for i in range(args.warmup):
         step_fn()
