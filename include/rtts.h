@@ -187,7 +187,10 @@ int rtts_sum_slabs(const void* part, int nslabs, int64_t n, void* out, void* str
  *   rtts_bn_act_bwd     dy(bf16) = BatchNorm(train) backward through act and dropout; dgamma, dbeta accumulate
  *   rtts_tts_loss       losses[4] = {total, raw, post, stop} and d_raw, d_post (rows, NM; row stride ld_grad >= NM,
  *                       the pad columns are written as zero), d_stop (rows):
- *                       masked MSE (kind 0) / L1 (kind 1) means over ALL elements + BCE-with-logits(pos_weight)
+ *                       masked MSE (kind 0) / L1 (kind 1) means over ALL elements + BCE-with-logits(pos_weight);
+ *                       predictions / gradients have rows = batch * padded_len (the decoder's length, a multiple of
+ *                       pad_base), targets batch * valid_len rows (reformer_tts.py:141-143 crops the predictions): rows
+ *                       t >= valid_len get zero gradient and do not count
  * partial_ws: >= (2*256 + 2)*C floats (bn) / 1536 floats (loss). */
 int rtts_im2col_k5(const void* x, int64_t ldx, int B, int L, int C, int CP, void* cols, void* stream);
 int rtts_col2im_k5(const void* dcols, int B, int L, int C, int CP, void* dx, int64_t lddx, int out_f32, void* stream);
@@ -203,7 +206,7 @@ int rtts_bn_act_bwd(const float* y, const void* dz, const float* mean, const flo
 int rtts_tts_loss(const float* raw, const float* post, int64_t ld_mel, const float* tgt, const float* mask, const float* stop,
                   int64_t ld_stop, const float* tstop, int rows, int NM, int kind, float pos_weight, float w_raw, float w_post,
                   float w_stop, float* d_raw, float* d_post, int64_t ld_grad, float* d_stop, float* losses, float* partial_ws,
-                  void* stream);
+                  int padded_len, int valid_len, void* stream);
 
 /* Scaled positional encoding (reference modules.py:172-192): out = y + alpha * dropout_p(table[t]), the mask shared over the
  * batch; dalpha += sum dy * dropout_p(table).  relu_drop: h = dropout_p(relu(h)) in place (decoder prenet, modules.py:82-100). */

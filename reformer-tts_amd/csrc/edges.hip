@@ -273,14 +273,25 @@ __global__ __launch_bounds__(ED_THREADS) void tts_loss_kernel(const float* __res
                                                               const float* __restrict__ stop, int64_t ld_stop, const float* __restrict__ tstop,
                                                               int rows, int NM, int kind, float pos_weight, float w_raw, float w_post,
                                                               float w_stop, float* __restrict__ d_raw, float* __restrict__ d_post,
-                                                              int64_t ld_grad, float* __restrict__ d_stop, float* __restrict__ partial) {
+                                                              int64_t ld_grad, float* __restrict__ d_stop, float* __restrict__ partial,
+                                                              int Lp, int Lv) {
+    // predictions / gradients: rows = B*Lp (the decoder's padded length); targets: B*Lv rows (the batch's own length,
+    // reformer_tts.py:141-143 crops the predictions to it).  Rows t >= Lv of a sample get zero gradient and no loss.
     float s_raw = 0.f, s_post = 0.f, s_stop = 0.f;
     const size_t nel = (size_t)rows * NM;
-    const float inv_el = 1.f / (float)nel, inv_rows = 1.f / (float)rows;
+    const size_t vrows = (size_t)(rows / Lp) * Lv;
+    const float inv_el = 1.f / ((float)vrows * NM), inv_rows = 1.f / (float)vrows;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nel; i += (size_t)gridDim.x * blockDim.x) {
         const size_t row = i / NM;
         const int c = (int)(i % NM);
-        const float mk = mask[i], tg = tgt[i];
+        const int t = (int)(row % Lp);
+        if (t >= Lv) {
+            d_raw[row * ld_grad + c] = 0.f;
+            d_post[row * ld_grad + c] = 0.f;
+            continue;
+        }
+        const size_t ti = ((row / Lp) * Lv + t) * NM + c;
+        const float mk = mask[ti], tg = tgt[ti];
         const float r = raw[row * ld_mel + c] * mk - tg, p = post[row * ld_mel + c] * mk - tg;
         if (kind == 0) {
             s_raw = __builtin_fmaf(r, r, s_raw);
@@ -303,7 +314,12 @@ __global__ __launch_bounds__(ED_THREADS) void tts_loss_kernel(const float* __res
         d_post[row * ld_grad + c] = 0.f;
     }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)rows; i += (size_t)gridDim.x * blockDim.x) {
-        const float x = stop[i * ld_stop], t = tstop[i];
+        const int tt = (int)(i % Lp);
+        if (tt >= Lv) {
+            d_stop[i] = 0.f;
+            continue;
+        }
+        const float x = stop[i * ld_stop], t = tstop[(i / Lp) * Lv + tt];
         // BCE with logits, pos_weight pw:  (1-t) x + (1 + (pw-1) t) * softplus(-x)
         const float lw = 1.f + (pos_weight - 1.f) * t;
         const float sp = fmaxf(-x, 0.f) + log1pf(expf(-fabsf(x)));      // softplus(-x)
@@ -542,15 +558,19 @@ extern "C" int rtts_bn_act_bwd(const float* y, const void* dz, const float* mean
 extern "C" int rtts_tts_loss(const float* raw, const float* post, int64_t ld_mel, const float* tgt, const float* mask, const float* stop,
                              int64_t ld_stop, const float* tstop, int rows, int NM, int kind, float pos_weight, float w_raw, float w_post,
                              float w_stop, float* d_raw, float* d_post, int64_t ld_grad, float* d_stop, float* losses, float* partial_ws,
-                             void* stream) {
+                             int padded_len, int valid_len, void* stream) {
     RTTS_REQUIRE(raw && post && tgt && mask && stop && tstop && d_raw && d_post && d_stop && losses && partial_ws && rows > 0 && NM > 0 &&
                      ld_grad >= NM, "rtts_tts_loss: bad arguments");
+    RTTS_REQUIRE(padded_len > 0 && valid_len > 0 && valid_len <= padded_len && rows % padded_len == 0,
+                 "rtts_tts_loss: rows must be batch * padded_len and 0 < valid_len <= padded_len");
     RTTS_REQUIRE(kind == 0 || kind == 1, "rtts_tts_loss: Unsupported loss type: %d", kind);
     const int blocks = 512;
     hipLaunchKernelGGL(tts_loss_kernel, dim3(blocks), dim3(ED_THREADS), 0, (hipStream_t)stream, raw, post, ld_mel, tgt, mask, stop, ld_stop,
-                       tstop, rows, NM, kind, pos_weight, w_raw, w_post, w_stop, d_raw, d_post, ld_grad, d_stop, partial_ws);
-    hipLaunchKernelGGL(tts_loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_ws, blocks, 1.f / ((float)rows * NM),
-                       1.f / (float)rows, w_raw, w_post, w_stop, losses);
+                       tstop, rows, NM, kind, pos_weight, w_raw, w_post, w_stop, d_raw, d_post, ld_grad, d_stop, partial_ws, padded_len,
+                       valid_len);
+    const float vrows = (float)(rows / padded_len) * (float)valid_len;
+    hipLaunchKernelGGL(tts_loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_ws, blocks, 1.f / (vrows * NM),
+                       1.f / vrows, w_raw, w_post, w_stop, losses);
     RTTS_LAUNCH_CHECK("rtts_tts_loss");
     return 0;
 }

@@ -206,15 +206,13 @@ class _PostnetLossFn(torch.autograd.Function):
         losses = torch.empty(4, dtype=torch.float32, device=dev)
         d_raw = torch.empty(m, 128, dtype=torch.float32, device=dev)       # 128-wide rows; the kernel zeroes the pad columns
         d_post = torch.empty(m, 128, dtype=torch.float32, device=dev)
-        if l != lp:
-            raise NotImplementedError("fused postnet+loss needs the mel length to be a multiple of pad_base (synthetic batches are)")
         g_stop = torch.empty(m, dtype=torch.float32, device=dev)
         kind = 0 if isinstance(lm.spectrogram_loss, torch.nn.MSELoss) else 1
         pw = torch.empty(512 * 3, dtype=torch.float32, device=dev)
         _lib.call("rtts_tts_loss", heads.data_ptr(), post.data_ptr(), 128, true_mel.contiguous().data_ptr(), true_mask.contiguous().data_ptr(),
                   heads[:, nm:].data_ptr(), 128, true_stop.contiguous().data_ptr(), m, nm, kind, ex.pos_weight,
                   float(lm.raw_pred_loss_weight), float(lm.post_pred_loss_weight), float(lm.stop_loss_weight), d_raw.data_ptr(),
-                  d_post.data_ptr(), 128, g_stop.data_ptr(), losses.data_ptr(), pw.data_ptr(), _s())
+                  d_post.data_ptr(), 128, g_stop.data_ptr(), losses.data_ptr(), pw.data_ptr(), lp, l, _s())
         ctx.ex, ctx.state = ex, (yb, wh, saved, cur, cols_end, d_raw, d_post, g_stop, b, lp, d)
         return losses
 

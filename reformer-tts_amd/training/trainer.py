@@ -141,8 +141,8 @@ class Trainer:
     def _fused_edges_ok(self, batch) -> bool:
         spec = batch["spectrogram"]
         lm = spec.shape[1] - 1
-        return (self.use_fused_edges and self.device.type == "cuda" and self.model.training and lm % self.model.pad_base == 0
-                and (spec.shape[0] * lm) % 64 == 0)
+        lp = -(-lm // self.model.pad_base) * self.model.pad_base      # the decoder runs on the padded length
+        return self.use_fused_edges and self.device.type == "cuda" and self.model.training and (spec.shape[0] * lp) % 64 == 0
 
     def _cut_at_encoder(self, keys):
         """keys_hook of the split step: the decoder reads a detached copy, the encoder's backward is run later from its grad."""

@@ -339,15 +339,18 @@ def test_fused_engine_matches_general_path(gpu):
     assert worst[1] < 6e-2, worst
 
 
-def test_fused_edges_match_general_path(gpu):
+@pytest.mark.parametrize("mel_len", [256, 200])
+def test_fused_edges_match_general_path(gpu, mel_len):
     """Fused conv/BatchNorm/heads/postnet/loss executors (edges.py) against the ATen modules: same
-    losses (1e-3 rel) and gradients (rel-L2 <= 6e-2) on a 2+2-layer model without dropout."""
+    losses (1e-3 rel) and gradients (rel-L2 <= 6e-2) on a 2+2-layer model without dropout.  mel_len = 200: the batch's
+    own length is not a multiple of pad_base (real data never is) -- the decoder, heads and postnet run on the padded
+    256 rows, the loss on the first 200 of each sample, the padded rows get zero gradient."""
     from reformer_tts_amd.model.config import TTSTrainingConfig, model_config_from_dict
     from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
     cfg = model_ref.small_cfg()
     cfg["enc_reformer_kwargs"]["attn_kwargs"]["implementation"] = "hip"
     cfg["dec_reformer_kwargs"]["self_attn_kwargs"]["implementation"] = "hip"
-    batch = synthetic_batch(2, 100, 256, device=gpu)
+    batch = synthetic_batch(2, 100, mel_len, device=gpu)
     res = []
     for fused in (True, False):
         model = build_model(model_config_from_dict(cfg), gpu)
@@ -362,6 +365,7 @@ def test_fused_edges_match_general_path(gpu):
         model.dec.use_fused = fused
         model.train()
         tr.zero_grad()
+        assert tr._fused_edges_ok(batch) == fused
         losses = tr.forward_loss(batch)
         losses[0].backward()
         torch.cuda.synchronize()
