@@ -233,6 +233,18 @@ class Trainer:
         self.optimizer_step(update_hyper)
         return total.detach(), raw_l.detach(), post_l.detach(), stop_l.detach()
 
+    def fit(self, host_batches, log_every: int = 0):
+        """Eager training over an iterable of HOST batches (the output of ``dataset.custom_sequence_padder``; shapes may
+        vary from batch to batch, which a captured graph cannot follow): the next batch is copied to HBM on a copy stream
+        while the current step runs.  -> list of the total loss per step (device scalars; no per-step host sync)."""
+        from ..dataset import BatchPrefetcher
+        losses = []
+        for i, batch in enumerate(BatchPrefetcher(host_batches, self.device)):
+            losses.append(self.train_step(batch)[0])
+            if log_every and (i + 1) % log_every == 0:
+                print(f"step {self.global_step}: loss {float(losses[-1]):.4f}", flush=True)
+        return losses
+
     # ------------------------------------------------------------------ hipGraph replay of the whole step
     _bulk_allreduce = False
 

@@ -770,3 +770,26 @@ def test_infer_graphed_crosses_a_padding_window(golden_dir, gpu):
     assert torch.isfinite(outs[1][0]).all() and torch.equal(outs[0][1], outs[1][1])
     # different random rotations in the two runs: compare the first frames (one window, short chain) loosely
     assert float((outs[0][0][:, :, :4] - outs[1][0][:, :, :4]).abs().max()) < 0.2 * float(outs[0][0].abs().max())
+
+
+def test_fit_over_ragged_host_batches(gpu):
+    """Trainer.fit: collate (pinned) -> copy-stream prefetch -> eager steps over batches of DIFFERENT shapes (text and
+    mel lengths that are not multiples of pad_base), every batch on the fused edges path; the loss goes down on a
+    repeated batch."""
+    from reformer_tts_amd.dataset import custom_sequence_padder
+    from reformer_tts_amd.model.config import TTSTrainingConfig
+    from reformer_tts_amd.training import Trainer, build_model
+    g = torch.Generator().manual_seed(0)
+
+    def items(n, lp, lm):
+        return [dict(phonemes=torch.randint(1, 77, (int(lp * (0.6 + 0.4 * k / n)),), generator=g),
+                     spectrogram=(torch.randn(int(lm * (0.5 + 0.5 * k / n)), 80, generator=g) * 2 - 5).clamp(-11.5, 2.0)) for k in range(1, n + 1)]
+    first = custom_sequence_padder(items(2, 60, 200), pin_memory=True)
+    batches = [first, custom_sequence_padder(items(2, 90, 150), pin_memory=True), first, first, first]
+    model = build_model(_hip_cfg(), gpu)
+    tr = Trainer(model, TTSTrainingConfig(batch_size=2, learning_rate=1e-3, warmup_steps=None), gpu)
+    model.train()
+    assert all(tr._fused_edges_ok({k: v.to(gpu) for k, v in b.items()}) for b in batches)
+    losses = [float(x) for x in tr.fit(batches)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
