@@ -120,8 +120,9 @@ def main():
     dec_bucket = int(model_cfg.dec_reformer_kwargs.self_attn_kwargs.bucket_size)
     tkey = f"rtts_lsh_attn_bwd/bs{dec_bucket}"        # the decoder's LSH backward: the dominant kernel of the step
     note(f"model built ({trainer.n_params} parameters), warming up")
-    # N == 1: the whole step is one hipGraph.  N > 1: three graphs (fwd + decoder-side bwd | encoder bwd | clip+AdamW)
-    # around two eager all-reduces of the halves of the flat gradient buffer, so no collective is ever captured;
+    # N == 1: the whole step is one hipGraph.  N > 1: four graphs (fwd + decoder-side bwd | encoder stack bwd | encoder
+    # prenet bwd | clip+AdamW) around three eager all-reduces of parts of the flat gradient buffer, so no collective is
+    # ever captured;
     # RTTS_GRAPH_DP=1 opts into a single graph with the per-block RCCL all-reduces captured inside (overlapped with the
     # backward; not exercisable on a 1-GPU box).
     use_graph = not args.no_graph
@@ -141,7 +142,7 @@ def main():
         use_graph = bool(ok)
     if use_graph:
         step_fn = trainer.replay
-        note("step captured into " + ("one hipGraph" if one_graph else "three hipGraphs around the two gradient all-reduces"))
+        note("step captured into " + ("one hipGraph" if one_graph else "four hipGraphs around the three gradient all-reduces"))
     else:
         trainer._bulk_allreduce = False               # eager: per-block all-reduce overlapped with the backward
         step_fn = lambda: trainer.train_step(batch)   # noqa: E731
@@ -191,7 +192,7 @@ def main():
                                    f"mel {args.mel_len}x80" if args.config == "baseline" else
                                    f"config/bucket-size-64-18-06.yml, per-GPU batch {args.batch}, mel {args.mel_len}",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(float(loss), 4), "reversible_recompute": args.recompute,
-                       "launch": ("hipGraph replay" if one_graph else "hipGraph replay (fwd+dec bwd | all-reduce | enc bwd | all-reduce | optimizer)")
+                       "launch": ("hipGraph replay" if one_graph else "hipGraph replay (fwd+dec bwd | all-reduce | enc stack bwd | all-reduce | enc prenet bwd | all-reduce | optimizer)")
                        if use_graph else "eager"},
         }
         if launches:

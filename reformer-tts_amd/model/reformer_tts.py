@@ -18,8 +18,11 @@ class Encoder(nn.Module):
         self.positional_encoding = ScaledPositionalEncoding(embedding_dim, scp_encoding_dropout)
         self.reformer = ReformerEnc(embedding_dim, **reformer_kwargs)
 
-    def forward(self, input_, input_mask=None):
-        return self.reformer(self.prenet(input_, pe=self.positional_encoding), input_mask=input_mask)
+    def forward(self, input_, input_mask=None, stack_hook=None):
+        x = self.prenet(input_, pe=self.positional_encoding)
+        if stack_hook is not None:                    # data-parallel trainer: cut between prenet and reversible stack
+            x = stack_hook(x)
+        return self.reformer(x, input_mask=input_mask)
 
 
 class Decoder(nn.Module):
@@ -81,13 +84,13 @@ class ReformerTTS(nn.Module):
         spectrogram_mask = pad_to_multiple(spectrogram_mask.unsqueeze(-1).to(dev), self.pad_base).squeeze(-1).to(torch.bool)
         return pad_phonemes, phoneme_mask, spectrogram_mask, pad_to_multiple(spectrogram, self.pad_base)
 
-    def decoder_hidden(self, phonemes, spectrogram, spectrogram_mask=None, keys_hook=None):
+    def decoder_hidden(self, phonemes, spectrogram, spectrogram_mask=None, keys_hook=None, enc_stack_hook=None):
         """Decoder output (B, T_padded, d) in front of the mel/stop heads: the training step feeds it to the
         fused heads + postnet + loss executor (``edges.PostnetLoss``).  ``keys_hook`` (encoder output -> tensor the
         decoder reads) lets the data-parallel trainer cut the autograd graph between encoder and decoder so that the
         two halves of the backward are separate launches with a gradient all-reduce in between."""
         pad_phonemes, phoneme_mask, spectrogram_mask, pad_spec = self._encode_inputs(phonemes, spectrogram, spectrogram_mask)
-        keys = self.enc(pad_phonemes, input_mask=phoneme_mask)
+        keys = self.enc(pad_phonemes, input_mask=phoneme_mask, stack_hook=enc_stack_hook)
         if keys_hook is not None:
             keys = keys_hook(keys)
         return self.dec.hidden(pad_spec, keys=keys, key_padding_mask=~phoneme_mask, input_mask=spectrogram_mask)[0]

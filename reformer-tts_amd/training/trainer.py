@@ -150,6 +150,12 @@ class Trainer:
         self._enc_in = keys.detach().requires_grad_(True)
         return self._enc_in
 
+    def _cut_at_enc_stack(self, x):
+        """enc_stack_hook of the split step: cut between the encoder prenet (+ positional encoding) and its stack."""
+        self._pre_out = x
+        self._pre_in = x.detach().requires_grad_(True)
+        return self._pre_in
+
     def forward_loss(self, batch, split: bool = False):
         """``wrappers.py:53-72``: input frames [0, L-1), targets [1, L), mask = loss_mask.mean(-1)."""
         spec = batch["spectrogram"]
@@ -158,7 +164,8 @@ class Trainer:
             if getattr(self, "_postnet_loss", None) is None:
                 self._postnet_loss = PostnetLoss(self.model, self.loss)
             y = self.model.decoder_hidden(batch["phonemes"], spec[:, :-1], spectrogram_mask=batch["loss_mask"].mean(dim=-1),
-                                          keys_hook=self._cut_at_encoder if split else None)
+                                          keys_hook=self._cut_at_encoder if split else None,
+                                          enc_stack_hook=self._cut_at_enc_stack if split else None)
             losses = self._postnet_loss.apply(y, spec[:, 1:], batch["stop_tokens"], batch["loss_mask"])
             return losses[0], losses[1], losses[2], losses[3]
         raw, post, stop, _ = self.model(batch["phonemes"], spec[:, :-1], spectrogram_mask=batch["loss_mask"].mean(dim=-1))
@@ -256,14 +263,16 @@ class Trainer:
 
         * one process (or ``segmented=False``): ONE graph = forward + backward (+ per-block all-reduce) + clip + AdamW +
           mirror refresh;
-        * data parallel (default when world > 1): THREE graphs with the gradient exchange between them, no collective
+        * data parallel (default when world > 1): FOUR graphs with the gradient exchange between them, no collective
           inside any capture (nothing is asked of RCCL beyond plain all-reduces):
-              A  zero + forward + loss + backward of postnet, heads, decoder, decoder prenet
-                 -> all-reduce of the decoder-side half of the flat gradient buffer (~59 MB), asynchronous
-              B  backward of the encoder stack and prenet, from d(loss)/d(encoder output) (overlaps that all-reduce)
-                 -> all-reduce of the encoder-side half (~48 MB)
-              C  clip + AdamW + mirror refresh
-          Few, large collectives (what xGMI's per-link-bound ring likes); ~55 % of the bytes hidden behind graph B.
+              A   zero + forward + loss + backward of postnet, heads, decoder, decoder prenet
+                  -> all-reduce of the decoder-side part of the flat gradient buffer (~59 MB), asynchronous
+              B   backward of the encoder stack, from d(loss)/d(encoder output)         (overlaps that all-reduce)
+                  -> all-reduce of the encoder stack's part (~35 MB), asynchronous
+              B'  backward of the encoder prenet + positional encoding               (overlaps that all-reduce)
+                  -> all-reduce of the prenet's part (~17 MB): the only exposed one
+              C   clip + AdamW + mirror refresh
+          Three large collectives (what xGMI's per-link-bound ring likes); ~85 % of the bytes hidden.
 
         Rotations and dropout draw from the graph-safe default generator."""
         from ..model.lsh_attention import LSHSelfAttention
@@ -282,7 +291,7 @@ class Trainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
-        self._graph_enc = self._graph_opt = None
+        self._graph_enc = self._graph_pre = self._graph_opt = None
         self.set_step_hyper(self.global_step)
         if not segmented:
             with self._capturing(self._graph):
@@ -300,11 +309,19 @@ class Trainer:
             total.backward()
             engine.flush_wgrad()
             self._graph_out = (total.detach(), raw_l.detach(), post_l.detach(), stop_l.detach())
+        stack_names = [n for n in enc_names if n.startswith("enc.reformer.")]
+        self._stack_begin = min(self.offsets[n][0] for n in stack_names)
+        if any(self.offsets[n][0] >= self._stack_begin for n in enc_names if n not in stack_names):
+            raise RuntimeError("flat buffer: the encoder prenet is expected in front of the encoder stack")
         self._graph_enc = torch.cuda.CUDAGraph()
         with self._capturing(self._graph_enc, pool=self._graph.pool()):
             self._enc_out.backward(self._enc_in.grad)
             engine.flush_wgrad()
-        self._enc_out = self._enc_in = None
+        self._graph_pre = torch.cuda.CUDAGraph()
+        with self._capturing(self._graph_pre, pool=self._graph.pool()):
+            self._pre_out.backward(self._pre_in.grad)
+            engine.flush_wgrad()
+        self._enc_out = self._enc_in = self._pre_out = self._pre_in = None
         self._graph_opt = torch.cuda.CUDAGraph()
         with self._capturing(self._graph_opt, pool=self._graph.pool()):
             self.optimizer_step(update_hyper=False)
@@ -325,7 +342,10 @@ class Trainer:
                 works.append(dist.all_reduce(self.flat_g[self._enc_end:], group=self.pg, async_op=True))
             self._graph_enc.replay()
             if self.world > 1:
-                works.append(dist.all_reduce(self.flat_g[:self._enc_end], group=self.pg, async_op=True))
+                works.append(dist.all_reduce(self.flat_g[self._stack_begin:self._enc_end], group=self.pg, async_op=True))
+            self._graph_pre.replay()
+            if self.world > 1:
+                works.append(dist.all_reduce(self.flat_g[:self._stack_begin], group=self.pg, async_op=True))
             for w in works:
                 w.wait()
             self._graph_opt.replay()

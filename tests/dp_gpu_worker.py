@@ -1,7 +1,7 @@
 """Worker of tests/test_dp_gpu.py: one rank of a 2-process gloo job sharing cuda:0.  Runs three training steps of the small
 model in the two data-parallel modes of the trainer and checks (a) replicas stay identical, (b) the modes agree:
     eager      per-block all-reduce issued from the block-done hooks, overlapped with the backward
-    graphs     three hipGraphs (fwd + decoder-side bwd | encoder bwd | clip + AdamW) around two eager all-reduces
+    graphs     four hipGraphs (fwd + decoder-side bwd | encoder stack bwd | encoder prenet bwd | clip + AdamW) around three eager all-reduces
 (parameters after three steps, loss of the third step)."""
 import os
 import sys
@@ -35,7 +35,7 @@ def run(mode, rank, dev):
             losses.append(float(tr.train_step(batch)[0]))
     else:
         tr.capture(batch)                      # two eager steps (bulk all-reduce), then the graphs are captured
-        assert tr._graph_enc is not None and tr._graph_opt is not None
+        assert tr._graph_enc is not None and tr._graph_pre is not None and tr._graph_opt is not None
         losses = [None, None, float(tr.replay()[0])]
     torch.cuda.synchronize()
     return tr, losses

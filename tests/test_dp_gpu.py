@@ -1,5 +1,5 @@
 """Two data-parallel ranks on one MI355X (gloo, both on cuda:0): the trainer's eager per-block all-reduce and its
-three-graph replay keep the replicas identical and agree with each other.  RCCL itself needs one GPU per rank and is
+four-graph replay keep the replicas identical and agree with each other.  RCCL itself needs one GPU per rank and is
 exercised by the driver's multi-GPU bench; everything else of the N > 1 path runs here."""
 import os
 import subprocess
