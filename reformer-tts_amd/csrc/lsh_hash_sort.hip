@@ -9,7 +9,11 @@
 // oracle/lsh_int.c; the sort is a stable counting sort (keys are unique => permutation unique).
 //
 // Hash: a lane owns a row (64 values in registers) and runs the fmaf chains of two buckets per instruction
-// (v_pk_fma_f32: the two halves are independent IEEE fmas, so packing does not change a bit).
+// (v_pk_fma_f32: the two halves are independent IEEE fmas, so packing does not change a bit).  The rotation matrix is
+// broadcast from LDS -- every lane of the 12 waves of a CU fetches the same 4*HALF bytes per row element, which makes
+// LDS bandwidth the floor of this phase (measured by ablation on MI355X, decoder shape: empty kernel 2.0 us, hash phase
+// 13.3 us = 3.3 us per 64-row tile, sort + stores 3.0 us).  Scalar loads of the matrix (constant address space,
+// s_load + SGPR operands) were tried and are slower (20.3 us: the loads serialise on their latency).
 // Sort: per 64-token group the lanes that share a bucket are found with log2(n_buckets) ballots (AND of
 // ballot / ~ballot per bucket-id bit), a lane's stable rank is the popcount of that mask below it, and the
 // per-(wave, bucket) running offsets live in LDS -- O(log n_buckets) wave ops per group instead of O(n_buckets).
@@ -99,35 +103,52 @@ __global__ __launch_bounds__(64 * WAVES) void lsh_hash_sort_kernel(
     const int s0 = wave * seg;
     const bf16_t* base = qk + (size_t)b * T * ld + (size_t)h * HS_DH;
     unsigned char* wt = tile + wave * 64 * HS_ROWB;
-    for (int t0 = 0; t0 < seg; t0 += 64) {
-        const int rows = min(64, seg - t0);         // 32 or 64
+    // Row tiles are fetched PF at a time (all their loads in flight together): with few buckets the fmaf chains are
+    // short and a wave would otherwise sit through one full memory round trip per 64 rows.  PF = 1 where the hash is
+    // long enough to hide the next tile's latency behind it and the registers are needed for the accumulators.
+    constexpr int PF = (HALF <= 8) ? 4 : 1;
+    for (int tb = 0; tb < seg; tb += 64 * PF) {
+        uint4 pre[PF][8];
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int row = p * 8 + (lane >> 3), piece = lane & 7;
-            if (row < rows) {
-                const uint4 val = *reinterpret_cast<const uint4*>(base + (size_t)(s0 + t0 + row) * ld + piece * 8);
-                *reinterpret_cast<uint4*>(wt + row * HS_ROWB + piece * 16) = val;
+        for (int u = 0; u < PF; ++u) {
+            const int t0 = tb + 64 * u;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int row = p * 8 + (lane >> 3), piece = lane & 7;
+                const int tr = min(t0 + row, seg - 1);      // past the end: re-read the last row (never stored)
+                pre[u][p] = *reinterpret_cast<const uint4*>(base + (size_t)(s0 + tr) * ld + piece * 8);
             }
         }
-        __builtin_amdgcn_wave_barrier();   // same wave wrote and reads: LDS ops of one wave execute in order
-        float q[HS_DH];
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const uint4 val = *reinterpret_cast<const uint4*>(wt + lane * HS_ROWB + p * 16);
-            const uint32_t u[4] = {val.x, val.y, val.z, val.w};
+        for (int u = 0; u < PF; ++u) {
+            const int t0 = tb + 64 * u;
+            const int rows = min(64, seg - t0);         // 64, 32, or <= 0 past the end of the segment
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                q[p * 8 + 2 * k] = __uint_as_float(u[k] << 16);
-                q[p * 8 + 2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u);
+            for (int p = 0; p < 8; ++p) {
+                const int row = p * 8 + (lane >> 3), piece = lane & 7;
+                if (row < rows) *reinterpret_cast<uint4*>(wt + row * HS_ROWB + piece * 16) = pre[u][p];
             }
+            if (rows <= 0) continue;           // wave-uniform; (no break: the unrolled body keeps `pre` in registers)
+            __builtin_amdgcn_wave_barrier();   // same wave wrote and reads: LDS ops of one wave execute in order
+            float q[HS_DH];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const uint4 val = *reinterpret_cast<const uint4*>(wt + lane * HS_ROWB + p * 16);
+                const uint32_t uu[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    q[p * 8 + 2 * k] = __uint_as_float(uu[k] << 16);
+                    q[p * 8 + 2 * k + 1] = __uint_as_float(uu[k] & 0xffff0000u);
+                }
+            }
+            const int idx = hash_row<HALF>(q, rot_lds);   // lanes >= rows hash stale LDS rows: results dropped below
+            if (lane < rows) {
+                bkt[s0 + t0 + lane] = (uint16_t)idx;
+                atomicAdd(&cntw[wave * 64 + idx], 1);      // integer LDS add: order-free, deterministic
+                if (buckets) buckets[((size_t)bh * n_hashes + r) * T + s0 + t0 + lane] = idx + r * NB;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        const int idx = hash_row<HALF>(q, rot_lds);   // lanes >= rows hash stale LDS rows: results dropped below
-        if (lane < rows) {
-            bkt[s0 + t0 + lane] = (uint16_t)idx;
-            atomicAdd(&cntw[wave * 64 + idx], 1);      // integer LDS add: order-free, deterministic
-            if (buckets) buckets[((size_t)bh * n_hashes + r) * T + s0 + t0 + lane] = idx + r * NB;
-        }
-        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
 

@@ -12,11 +12,31 @@ import torch  # noqa: E402
 from reformer_tts_amd import _lib, ops  # noqa: E402
 
 
+GRAPH = [False]
+
+
 def timeit(fn, iters):
+    """us per call.  Eager launches are host-bound below ~15 us per call (Python wrapper + ctypes); with --graph the
+    calls are captured into one hipGraph (20 per graph) and the replay is timed: device time only."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if GRAPH[0]:
+        from reformer_tts_amd._graphs import capturing
+        g = torch.cuda.CUDAGraph()
+        with capturing(g):
+            for _ in range(20):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        reps = max(1, iters // 20)
+        a.record()
+        for _ in range(reps):
+            g.replay()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / (reps * 20) * 1e3
     a.record()
     for _ in range(iters):
         fn()
@@ -29,8 +49,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--only", default="")
+    ap.add_argument("--graph", action="store_true", help="time hipGraph replays (device time; eager timing is host-bound for small kernels)")
     args = ap.parse_args()
     only = set(args.only.split(",")) if args.only else None
+    GRAPH[0] = args.graph
     dev = torch.device("cuda:0")
     if only and "wgrad" in only:
         # split-K weight-gradient GEMM at the shapes of one decoder layer (M = 12288 tokens; kv: 3072 text rows)
