@@ -141,6 +141,18 @@ int rtts_cast_colsum(const float* dy, void* dyb, float* dbias, float* partial_ws
                      const uint32_t* seed_dev, void* stream);
 int rtts_colsum_bf16(void* dh, const void* h, int64_t ld, float* dbias, float* partial_ws, int M, int d,
                      int relu_gate, float gate_scale, void* stream);
+/* Deferred finalisation of the column sums: rtts_ln_bwd (dgamma = dbeta = NULL), rtts_cast_colsum / rtts_colsum_bf16
+ * (dbias = NULL) then only write their partial rows -- rtts_colsum_partial_rows(M) rows of d floats; rtts_ln_bwd writes two
+ * such blocks, the second 256*d floats after the first -- and ONE grouped launch adds the sums of up to
+ * RTTS_COLSUM_MAX_GROUP partial buffers into their outputs (same fixed summation order: deterministic). */
+#define RTTS_COLSUM_MAX_GROUP 48
+typedef struct {
+    const float* partial;   /* (nrows, n) fp32 */
+    float* out;             /* (n): += column sums */
+    int32_t nrows, n;
+} rtts_colsum_job;
+int rtts_colsum_partial_rows(int M);
+int rtts_colsum_final_grouped(const rtts_colsum_job* jobs, int n, void* stream);
 int rtts_residual_epilogue(const float* x, const void* g, const float* bias, float sign, float* y,
                            int64_t M, int d, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
 /* The same epilogue fused with the NEXT block's LayerNorm: x += sign*(g + bias) in place, then

@@ -20,6 +20,14 @@ class GemmTnProblem(C.Structure):
 
 GEMM_TN_MAX_GROUP = 8
 
+
+class ColsumJob(C.Structure):
+    """rtts_colsum_job of include/rtts.h."""
+    _fields_ = [("partial", _vp), ("out", _vp), ("nrows", C.c_int32), ("n", C.c_int32)]
+
+
+COLSUM_MAX_GROUP = 48
+
 # name -> argtypes, exactly the prototypes of include/rtts.h
 SIGNATURES = {
     "rtts_lsh_hash_sort": [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
@@ -36,6 +44,8 @@ SIGNATURES = {
     "rtts_cast_colsum": [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _u32, _vp, _vp],
     "rtts_colsum_bf16": [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _f32, _vp],
     "rtts_residual_epilogue": [_vp, _vp, _vp, _f32, _vp, _i64, _i32, _f32, _u32, _vp, _vp],
+    "rtts_colsum_partial_rows": [_i32],
+    "rtts_colsum_final_grouped": [C.POINTER(ColsumJob), _i32, _vp],
     "rtts_residual_ln": [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _u32, _vp, _vp],
     "rtts_bias_act": [_vp, _vp, _i64, _i32, _i32, _vp],
     "rtts_cast_f32_bf16": [_vp, _vp, _i64, _vp],

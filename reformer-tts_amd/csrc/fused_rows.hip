@@ -328,6 +328,37 @@ __global__ __launch_bounds__(FR_THREADS) void colsum_final_kernel(const float* _
     if (wave == 0 && c < n) out[c] += (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
+// The same reduction for up to RTTS_COLSUM_MAX_GROUP (partial buffer, output) pairs in ONE launch: bias / LayerNorm
+// gradients are leaves of the backward, so the executor queues their finalisation and flushes a layer's worth together
+// (a decoder layer has 15 of these 5-us launches otherwise).
+struct CsJob {
+    const float* partial;
+    float* out;
+    int nrows, n, blk_start;
+};
+struct CsGroup {
+    CsJob j[RTTS_COLSUM_MAX_GROUP];
+    int n;
+};
+__global__ __launch_bounds__(FR_THREADS) void colsum_final_grouped_kernel(const CsGroup grp) {
+    __shared__ float red[FR_WAVES][64];
+    int ji = 0;
+#pragma unroll 1
+    for (int i = 1; i < grp.n; ++i)
+        if ((int)blockIdx.x >= grp.j[i].blk_start) ji = i;
+    const CsJob& J = grp.j[ji];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = ((int)blockIdx.x - J.blk_start) * 64 + lane;
+    float s = 0.f;
+    if (c < J.n) {
+#pragma unroll 8
+        for (int r = wave; r < J.nrows; r += FR_WAVES) s += J.partial[(size_t)r * J.n + c];
+    }
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < J.n) J.out[c] += (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
 // ---------------------------------------------------------------- elementwise epilogues
 // y = x + sign * (g + bias)        (x, y fp32; g bf16; bias fp32 or null), 4 elements per thread
 __global__ __launch_bounds__(FR_THREADS) void residual_epilogue_kernel(const float* __restrict__ x, const bf16_t* __restrict__ g,
@@ -424,7 +455,7 @@ extern "C" int rtts_ln_fwd(const float* x, const float* gamma, const float* beta
 
 extern "C" int rtts_ln_bwd(const void* dxn, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx_io,
                            float* dgamma, float* dbeta, float* partial_ws, int M, int d, void* stream) {
-    RTTS_REQUIRE(dxn && x && mean && rstd && gamma && dx_io && dgamma && dbeta && partial_ws && M > 0, "rtts_ln_bwd: bad arguments");
+    RTTS_REQUIRE(dxn && x && mean && rstd && gamma && dx_io && partial_ws && M > 0 && (!dgamma == !dbeta), "rtts_ln_bwd: bad arguments");
     int blocks = (M + FR_WAVES - 1) / FR_WAVES;
     if (blocks > FR_PARTIAL_BLOCKS) blocks = FR_PARTIAL_BLOCKS;
     float* pg = partial_ws;
@@ -433,8 +464,10 @@ extern "C" int rtts_ln_bwd(const void* dxn, const float* x, const float* mean, c
 #define CALL(EPL, VEC) hipLaunchKernelGGL((ln_bwd_kernel<EPL, VEC>), dim3(blocks), dim3(FR_THREADS), lds, (hipStream_t)stream, (const bf16_t*)dxn, x, mean, rstd, gamma, dx_io, pg, pb, M)
     FR_DISPATCH_D(d, CALL)
 #undef CALL
-    const dim3 g2((d + 63) / 64, 2);
-    hipLaunchKernelGGL(colsum_final_kernel, g2, dim3(FR_THREADS), 0, (hipStream_t)stream, pg, blocks, d, dgamma, pb, dbeta);
+    if (dgamma) {       // NULL: the caller finalises the partial rows itself (rtts_colsum_final_grouped)
+        const dim3 g2((d + 63) / 64, 2);
+        hipLaunchKernelGGL(colsum_final_kernel, g2, dim3(FR_THREADS), 0, (hipStream_t)stream, pg, blocks, d, dgamma, pb, dbeta);
+    }
     RTTS_LAUNCH_CHECK("rtts_ln_bwd");
     return 0;
 }
@@ -457,7 +490,7 @@ extern "C" int rtts_cast_colsum(const float* dy, void* dyb, float* dbias, float*
 
 extern "C" int rtts_colsum_bf16(void* dh, const void* h, int64_t ld, float* dbias, float* partial_ws, int M, int d, int relu_gate,
                                 float gate_scale, void* stream) {
-    RTTS_REQUIRE(dh && dbias && partial_ws && M > 0 && (!relu_gate || h), "rtts_colsum_bf16: bad arguments");
+    RTTS_REQUIRE(dh && partial_ws && M > 0 && (!relu_gate || h), "rtts_colsum_bf16: bad arguments");
     RTTS_REQUIRE(ld >= d && ld % 8 == 0, "rtts_colsum_bf16: bad row stride");
     int blocks = (M + FR_WAVES - 1) / FR_WAVES;
     if (blocks > FR_PARTIAL_BLOCKS) blocks = FR_PARTIAL_BLOCKS;
@@ -471,9 +504,34 @@ extern "C" int rtts_colsum_bf16(void* dh, const void* h, int64_t ld, float* dbia
                            (bf16_t*)dh, (const bf16_t*)h, ld, partial_ws, M, gate_scale)
     FR_DISPATCH_D(d, CALL)
 #undef CALL
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 63) / 64), dim3(FR_THREADS), 0, (hipStream_t)stream,
-                       partial_ws, blocks, d, dbias, (const float*)nullptr, (float*)nullptr);
+    if (dbias)
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 63) / 64), dim3(FR_THREADS), 0, (hipStream_t)stream,
+                           partial_ws, blocks, d, dbias, (const float*)nullptr, (float*)nullptr);
     RTTS_LAUNCH_CHECK("rtts_colsum_bf16");
+    return 0;
+}
+
+extern "C" int rtts_colsum_partial_rows(int M) {
+    int blocks = (M + FR_WAVES - 1) / FR_WAVES;
+    return blocks > FR_PARTIAL_BLOCKS ? FR_PARTIAL_BLOCKS : blocks;
+}
+
+extern "C" int rtts_colsum_final_grouped(const rtts_colsum_job* jobs, int n, void* stream) {
+    RTTS_REQUIRE(jobs && n > 0 && n <= RTTS_COLSUM_MAX_GROUP, "rtts_colsum_final_grouped: 1..%d jobs", RTTS_COLSUM_MAX_GROUP);
+    CsGroup grp;
+    grp.n = n;
+    int blk = 0;
+    for (int i = 0; i < n; ++i) {
+        RTTS_REQUIRE(jobs[i].partial && jobs[i].out && jobs[i].nrows > 0 && jobs[i].n > 0, "rtts_colsum_final_grouped: bad job %d", i);
+        grp.j[i].partial = jobs[i].partial;
+        grp.j[i].out = jobs[i].out;
+        grp.j[i].nrows = jobs[i].nrows;
+        grp.j[i].n = jobs[i].n;
+        grp.j[i].blk_start = blk;
+        blk += (jobs[i].n + 63) / 64;
+    }
+    hipLaunchKernelGGL(colsum_final_grouped_kernel, dim3(blk), dim3(FR_THREADS), 0, (hipStream_t)stream, grp);
+    RTTS_LAUNCH_CHECK("rtts_colsum_final_grouped");
     return 0;
 }
 

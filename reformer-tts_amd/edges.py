@@ -228,7 +228,7 @@ class _PostnetLossFn(torch.autograd.Function):
         d_raw, d_post, g_stop = d_raw * scale, d_post * scale, g_stop * scale
         # convend: res = conv(z_last) + bias;  d_res = d_post
         dbias_pad = torch.zeros(128, dtype=torch.float32, device=dev)
-        dresb = cast_colsum(d_post, dbias_pad)                 # deterministic column sums (no ATen reduction)
+        dresb = cast_colsum(d_post, dbias_pad, defer=False)                 # deterministic column sums (no ATen reduction)
         _grad(ex.convend.conv.bias).add_(dbias_pad[:nm])
         dz = ex.convend.backward(dresb, cols_end, b, lp)
         for layer, s in zip(reversed(ex.layers[1:]), reversed(saved[1:])):
@@ -238,7 +238,7 @@ class _PostnetLossFn(torch.autograd.Function):
         dheads[:, :nm] += dx0[:, :nm]
         dheads[:, nm] = g_stop
         bsum = torch.zeros(128, dtype=torch.float32, device=dev)
-        dhb = cast_colsum(dheads, bsum)
+        dhb = cast_colsum(dheads, bsum, defer=False)      # read two lines below
         mel, stop = ex.model.dec.mel_linear, ex.model.dec.stop_linear
         _grad(mel.bias).add_(bsum[:nm])
         _grad(stop.bias).add_(bsum[nm:nm + 1])

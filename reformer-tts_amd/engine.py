@@ -81,18 +81,58 @@ def ln_fwd(x, norm):
     return xn, mean, rstd
 
 
+# Column sums (bias and LayerNorm gradients) are leaves of the backward like the weight gradients: with DEFER_COLSUM the
+# producing kernels only write their per-workgroup partial rows (into a buffer of their own, held until the flush) and ONE
+# grouped launch per layer adds them into the gradients -- a decoder layer otherwise pays fifteen 5-us launches for it.
+DEFER_COLSUM = True
+_PENDING_CS = []      # (partial buffer [kept alive], byte offset of the block, rows, d, out tensor)
+
+
+def _partial_rows(m: int) -> int:
+    return min((m + 3) // 4, 256)
+
+
+def _queue_colsum(partial: torch.Tensor, offset_floats: int, rows: int, d: int, out: torch.Tensor):
+    _PENDING_CS.append((partial, offset_floats, rows, d, out))
+    _queue_final_flush()
+
+
+def flush_colsum():
+    while _PENDING_CS:
+        group = _PENDING_CS[:_lib.COLSUM_MAX_GROUP]
+        del _PENDING_CS[:len(group)]
+        arr = (_lib.ColsumJob * len(group))()
+        for j, (partial, off, rows, d, out) in zip(arr, group):
+            j.partial, j.out, j.nrows, j.n = partial.data_ptr() + 4 * off, out.data_ptr(), rows, d
+        _lib.call("rtts_colsum_final_grouped", arr, len(group), _s())
+
+
 def ln_bwd(dxn, x, mean, rstd, norm, dx_io):
     m, d = x.shape
+    if DEFER_COLSUM:
+        ws = torch.empty(2 * 256 * d, dtype=torch.float32, device=x.device)
+        _lib.call("rtts_ln_bwd", dxn.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), norm.weight.data_ptr(),
+                  dx_io.data_ptr(), None, None, ws.data_ptr(), m, d, _s())
+        rows = _partial_rows(m)
+        _queue_colsum(ws, 0, rows, d, _grad(norm.weight))
+        _queue_colsum(ws, 256 * d, rows, d, _grad(norm.bias))
+        return
     _lib.call("rtts_ln_bwd", dxn.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), norm.weight.data_ptr(),
               dx_io.data_ptr(), _grad(norm.weight).data_ptr(), _grad(norm.bias).data_ptr(), _WS.partial(x.device, d).data_ptr(),
               m, d, _s())
 
 
-def cast_colsum(dy, dbias: Optional[torch.Tensor], drop=None):
+def cast_colsum(dy, dbias: Optional[torch.Tensor], drop=None, defer: bool = True):
     """dyb (bf16) = dy [* keep-scale of ``drop`` = (p, seed)]; dbias += column sums of the same."""
     m, d = dy.shape
     dyb = torch.empty(m, d, dtype=torch.bfloat16, device=dy.device)
     p, seed = drop if drop else (0.0, 0)
+    if DEFER_COLSUM and defer and dbias is not None:
+        ws = torch.empty(256 * d, dtype=torch.float32, device=dy.device)
+        _lib.call("rtts_cast_colsum", dy.data_ptr(), dyb.data_ptr(), None, ws.data_ptr(), m, d, float(p), seed,
+                  seed_base(dy.device).data_ptr(), _s())
+        _queue_colsum(ws, 0, _partial_rows(m), d, dbias)
+        return dyb
     _lib.call("rtts_cast_colsum", dy.data_ptr(), dyb.data_ptr(), None if dbias is None else dbias.data_ptr(),
               _WS.partial(dy.device, d).data_ptr(), m, d, float(p), seed, seed_base(dy.device).data_ptr(), _s())
     return dyb
@@ -101,6 +141,12 @@ def cast_colsum(dy, dbias: Optional[torch.Tensor], drop=None):
 def colsum_bf16(dh, dbias, h=None, gate_scale: float = 1.0):
     """dbias += column sums of dh; with ``h``: dh *= (h > 0) * gate_scale in place first (ReLU [+ dropout] backward)."""
     m, d = dh.shape
+    if DEFER_COLSUM and dbias.is_contiguous():
+        ws = torch.empty(256 * d, dtype=torch.float32, device=dh.device)
+        _lib.call("rtts_colsum_bf16", dh.data_ptr(), None if h is None else h.data_ptr(), dh.stride(0), None, ws.data_ptr(), m, d,
+                  int(h is not None), float(gate_scale), _s())
+        _queue_colsum(ws, 0, _partial_rows(m), d, dbias)
+        return
     _lib.call("rtts_colsum_bf16", dh.data_ptr(), None if h is None else h.data_ptr(), dh.stride(0), dbias.data_ptr(),
               _WS.partial(dh.device, d).data_ptr(), m, d, int(h is not None), float(gate_scale), _s())
 
@@ -151,10 +197,21 @@ def _slab_ws(device):
     return _WS._cache[key]
 
 
+def _queue_final_flush():
+    if not _FINAL_FLUSH_QUEUED[0]:
+        # whatever is still queued when the running autograd pass ends is launched by the engine's callback
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_final_flush)
+            _FINAL_FLUSH_QUEUED[0] = True
+        except RuntimeError:          # not inside a backward pass: the caller flushes
+            pass
+
+
 def flush_wgrad():
-    """Launch every queued weight gradient (grouped), release the held operands."""
+    """Launch every queued weight gradient and column-sum finalisation (grouped), release the held operands."""
     _FINAL_FLUSH_QUEUED[0] = False     # the next deferral queues a fresh end-of-backward callback (extra ones are no-ops);
-    while _PENDING:                    # a backward that died half-way therefore cannot leave the flag stuck
+    flush_colsum()                     # a backward that died half-way therefore cannot leave the flag stuck
+    while _PENDING:
         group = _PENDING[:_lib.GEMM_TN_MAX_GROUP]
         del _PENDING[:len(group)]
         arr = (_lib.GemmTnProblem * len(group))()
@@ -178,13 +235,7 @@ def wgrad(grad_view: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, accumulate
     if n % 128 == 0 and k % 128 == 0 and m % 64 == 0 and dy.stride(1) == 1 and x.stride(1) == 1 and grad_view.stride(1) == 1:
         if DEFER_WGRAD and accumulate:
             _PENDING.append((grad_view, dy, x))
-            if not _FINAL_FLUSH_QUEUED[0]:
-                # whatever is still queued when the running autograd pass ends is launched by the engine's callback
-                try:
-                    torch.autograd.Variable._execution_engine.queue_callback(_final_flush)
-                    _FINAL_FLUSH_QUEUED[0] = True
-                except RuntimeError:          # not inside a backward pass: the caller flushes
-                    pass
+            _queue_final_flush()
             return
         ws = _slab_ws(dy.device)
         _lib.call("rtts_gemm_tn", dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), m, n, k, grad_view.data_ptr(),
