@@ -35,10 +35,9 @@ def conv1d_k5_rows(x, conv: nn.Conv1d):
     xp = F.pad(x.to(torch.bfloat16), (0, 0, 2, 2))
     cols = xp.unfold(1, 5, 1).reshape(b * l, cin * 5)                 # (ci, k) order == weight.view(Cout, Cin*5)
     w = conv.weight.to(torch.bfloat16).reshape(conv.out_channels, cin * 5)
-    if cols.is_cuda:   # fp32 result: the BatchNorm that follows removes the channel mean, which would
-        y = _GemmF32Out.apply(cols, w) + conv.bias                       # otherwise leave bf16 rounding of the MEAN behind
-    else:
-        y = cols.float() @ w.float().t() + conv.bias
+    # fp32 result: the BatchNorm that follows removes the channel mean, which would otherwise leave bf16 rounding of the
+    # MEAN behind
+    y = _GemmF32Out.apply(cols, w) + conv.bias
     return y.view(b, l, conv.out_channels)
 
 

@@ -75,7 +75,15 @@ class ReformerTTS(nn.Module):
         self.pad_base = pad_base
         self.postnet = PostConvNet(mel_size=num_mel_coeffs, num_hidden=embedding_dim, **postnet_kwargs)
 
+    def _require_gpu(self):
+        """The product path is the HIP path: refuse to run anywhere else instead of limping along on ATen CPU kernels."""
+        dev = self.dec.mel_linear.weight.device
+        if dev.type != "cuda":
+            from .._lib import RttsError
+            raise RttsError(f"ReformerTTS runs on the GPU only (model is on {dev}); there is no CPU fallback for the HIP path")
+
     def _encode_inputs(self, phonemes, spectrogram, spectrogram_mask):
+        self._require_gpu()
         dev = spectrogram.device
         pad_phonemes = pad_to_multiple(phonemes.unsqueeze(-1), self.pad_base).squeeze(-1).to(dev)
         phoneme_mask = pad_phonemes != 0
@@ -99,6 +107,7 @@ class ReformerTTS(nn.Module):
                 spectrogram_mask: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, list]:
         """``reformer_tts.py:103-143``: returns (mel, mel_postnet, stop, attention_matrices), all cropped
         to the input spectrogram length."""
+        self._require_gpu()
         dev = spectrogram.device
         pad_phonemes = pad_to_multiple(phonemes.unsqueeze(-1), self.pad_base).squeeze(-1).to(dev)
         phoneme_mask = pad_phonemes != 0

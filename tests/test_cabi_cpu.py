@@ -67,3 +67,20 @@ def test_c_twin_vs_huggingface_fixture(golden_dir):
         st, _ = lsh_int.sort_buckets(exp, t // chunk)
         exp_sorted = z[f"{tag}/sorted_idx"].astype(np.int32).reshape(2 * heads, nh, t) % t
         assert np.array_equal(st, exp_sorted), tag
+
+
+def test_model_refuses_to_run_off_the_gpu():
+    """No CPU fallback: a forward (or generation) on a CPU-resident model raises the library's own error at the door."""
+    import torch
+    from reformer_tts_amd import _lib
+    from reformer_tts_amd.model.config import baseline_model_config
+    from reformer_tts_amd.training import build_model, synthetic_batch
+    cfg = baseline_model_config()
+    cfg.enc_reformer_kwargs.depth = 1
+    cfg.dec_reformer_kwargs.depth = 1
+    model = build_model(cfg)
+    batch = synthetic_batch(1, 20, 256)
+    with pytest.raises(_lib.RttsError, match="GPU only"):
+        model(batch["phonemes"], batch["spectrogram"][:, :-1])
+    with pytest.raises(_lib.RttsError, match="GPU only"):
+        model.infer(batch["phonemes"], max_len=90)
