@@ -14,7 +14,6 @@ HIP path, the C twin (``lsh_int.c``) and this file can be fed identical inputs.
 """
 from __future__ import annotations
 
-import math
 from typing import Optional, Tuple
 
 import torch

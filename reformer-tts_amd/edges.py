@@ -14,7 +14,6 @@ and its (exactly zero) gradient is not computed.
 """
 from __future__ import annotations
 
-import itertools
 from typing import List
 
 import torch

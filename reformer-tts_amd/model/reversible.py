@@ -13,7 +13,7 @@ effect), with these MI355X-first changes:
 """
 from __future__ import annotations
 
-from typing import Callable, List, Optional
+from typing import Callable, Optional
 
 import torch
 from torch import nn
