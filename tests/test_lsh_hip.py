@@ -268,3 +268,34 @@ def test_gemm_tn_grouped_matches_single_launches(ops):
         assert torch.equal(c1, c2)
         ref = a.float().t() @ b.float() + (c0 if acc else 0)
         torch.testing.assert_close(c1, ref, rtol=2e-4, atol=2e-2)
+
+
+def test_c_abi_rejects_bad_arguments_with_a_message(ops):
+    """The C ABI validates shapes before it launches (a wrong shape must never reach a kernel): every rejection returns
+    non-zero and leaves a message in rtts_last_error; the ctypes layer raises RttsError with it."""
+    from reformer_tts_amd import _lib
+    s = torch.cuda.current_stream().cuda_stream
+    qk = torch.zeros(1, 256, 128, dtype=torch.bfloat16, device="cuda")
+    rot = torch.zeros(1, 64, 2, 2, device="cuda")
+    st = torch.zeros(2, 2, 256, dtype=torch.int32, device="cuda")
+    cases = [
+        # dh != 64
+        (("rtts_lsh_hash_sort", qk.data_ptr(), 128, rot.data_ptr(), 1, 1, 4, 256, 32, 2, 64, None, st.data_ptr(), None, s), "dh=32 unsupported"),
+        # T not divisible by 2 * bucket_size (the reference's assertion text)
+        (("rtts_lsh_hash_sort", qk.data_ptr(), 128, rot.data_ptr(), 1, 1, 2, 192, 64, 2, 64, None, st.data_ptr(), None, s), "divisible by target bucket size"),
+        # null output
+        (("rtts_lsh_hash_sort", qk.data_ptr(), 128, rot.data_ptr(), 1, 1, 2, 256, 64, 2, 64, None, None, None, s), "null pointer"),
+        # row stride not a multiple of 8
+        (("rtts_lsh_hash_sort", qk.data_ptr(), 130, rot.data_ptr(), 1, 1, 2, 256, 64, 2, 64, None, st.data_ptr(), None, s), "ld_qk"),
+        # unsupported bucket size in the attention kernels
+        (("rtts_lsh_attn_fwd", qk.data_ptr(), qk.data_ptr(), 128, st.data_ptr(), None, 1, 2, 256, 64, 2, 32, 0, qk.data_ptr(), st.data_ptr(), s), "bucket_size=32"),
+        # weight-gradient GEMM: N not a multiple of 128
+        (("rtts_gemm_tn", qk.data_ptr(), 96, qk.data_ptr(), 128, 256, 96, 128, st.data_ptr(), 128, 1, st.data_ptr(), 1 << 20, s), "128"),
+        # AdamW: n not a multiple of 4
+        (("rtts_adamw_step", st.data_ptr(), st.data_ptr(), st.data_ptr(), st.data_ptr(), st.data_ptr(), 1022, None, st.data_ptr(), 0.9, 0.999, 1e-6,
+          0.0, None, s), "multiple of 4"),
+    ]
+    for args, needle in cases:
+        with pytest.raises(_lib.RttsError, match=needle):
+            _lib.call(*args)
+    torch.cuda.synchronize()
