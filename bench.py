@@ -192,6 +192,7 @@ def main():
                                    f"mel {args.mel_len}x80" if args.config == "baseline" else
                                    f"config/bucket-size-64-18-06.yml, per-GPU batch {args.batch}, mel {args.mel_len}",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(float(loss), 4), "reversible_recompute": args.recompute,
+                       "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2),
                        "launch": ("hipGraph replay" if one_graph else "hipGraph replay (fwd+dec bwd | all-reduce | enc stack bwd | all-reduce | enc prenet bwd | all-reduce | optimizer)")
                        if use_graph else "eager"},
         }
