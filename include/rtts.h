@@ -136,7 +136,10 @@ int rtts_adamw_step(float* params, const float* grads, float* exp_avg, float* ex
 int rtts_ln_fwd(const float* x, const float* gamma, const float* beta, void* xn, float* mean, float* rstd,
                 int M, int d, void* stream);
 int rtts_ln_bwd(const void* dxn, const float* x, const float* mean, const float* rstd, const float* gamma,
-                float* dx_io, float* dgamma, float* dbeta, float* partial_ws, int M, int d, void* stream);
+                float* dx_io, float* dgamma, float* dbeta, float* partial_ws, int M, int d,
+                void* dyb_next, float* partial_next, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
+/* dyb_next (may be NULL): bf16 copy of the completed dx_io, times the keep-scale of (drop_p, seed) -- the next block's
+ * rtts_cast_colsum folded in; partial_next then receives that copy's partial column sums (same layout as partial_ws). */
 int rtts_cast_colsum(const float* dy, void* dyb, float* dbias, float* partial_ws, int M, int d, float drop_p, uint32_t seed,
                      const uint32_t* seed_dev, void* stream);
 int rtts_colsum_bf16(void* dh, const void* h, int64_t ld, float* dbias, float* partial_ws, int M, int d,

@@ -208,14 +208,21 @@ template <int EPL, int VEC>
 __global__ __launch_bounds__(FR_THREADS) void ln_bwd_kernel(const bf16_t* __restrict__ dxn, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, float* __restrict__ dx_io,
-                                                            float* __restrict__ partial_g, float* __restrict__ partial_b, int M) {
+                                                            float* __restrict__ partial_g, float* __restrict__ partial_b, int M,
+                                                            bf16_t* __restrict__ dyb_next, float* __restrict__ partial_next,
+                                                            uint32_t seed, const uint32_t* __restrict__ seed_dev, uint32_t thresh,
+                                                            float dscale) {
+    // dyb_next != null: the gradient stream this kernel has just completed is the NEXT block's output gradient, so its
+    // bf16 copy (times that block's post-attention dropout keep-scale, if any) and the partial column sums for that
+    // block's output bias leave in the same pass -- what a separate rtts_cast_colsum launch would re-read the stream for.
     constexpr int D = EPL * 64;
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     const int lane = threadIdx.x & 63;
-    float gam[EPL], ag[EPL], ab[EPL];
+    float gam[EPL], ag[EPL], ab[EPL], an[EPL];
     load_row_f32<EPL, VEC>(gamma, lane, gam);
+    if (thresh && seed_dev) seed += seed_dev[0];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) ag[e] = ab[e] = 0.f;
+    for (int e = 0; e < EPL; ++e) ag[e] = ab[e] = an[e] = 0.f;
     for (int row = blockIdx.x * FR_WAVES + (threadIdx.x >> 6); row < M; row += gridDim.x * FR_WAVES) {
         float dy[EPL], xv[EPL], dx[EPL];
         load_row_bf16<EPL, VEC>(dxn + (size_t)row * D, lane, dy);
@@ -237,9 +244,19 @@ __global__ __launch_bounds__(FR_THREADS) void ln_bwd_kernel(const bf16_t* __rest
 #pragma unroll
         for (int e = 0; e < EPL; ++e) dx[e] += rs * (dy[e] - s1 - xv[e] * s2);
         store_row_f32<EPL, VEC>(dx_io + (size_t)row * D, lane, dx);
+        if (dyb_next) {
+            if (thresh) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) dx[e] *= rtts_drop_keep(seed, (uint32_t)row * D + row_col<VEC>(e, lane), thresh, dscale);
+            }
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) an[e] += dx[e];
+            store_row_bf16<EPL, VEC>(dyb_next + (size_t)row * D, lane, dx);
+        }
     }
     block_partial<EPL, VEC>(ag, partial_g + (size_t)blockIdx.x * D, lds_f);
     block_partial<EPL, VEC>(ab, partial_b + (size_t)blockIdx.x * D, lds_f);
+    if (dyb_next) block_partial<EPL, VEC>(an, partial_next + (size_t)blockIdx.x * D, lds_f);
 }
 
 // ---------------------------------------------------------------- fp32 -> bf16 cast + column sums
@@ -454,14 +471,17 @@ extern "C" int rtts_ln_fwd(const float* x, const float* gamma, const float* beta
 }
 
 extern "C" int rtts_ln_bwd(const void* dxn, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx_io,
-                           float* dgamma, float* dbeta, float* partial_ws, int M, int d, void* stream) {
+                           float* dgamma, float* dbeta, float* partial_ws, int M, int d, void* dyb_next, float* partial_next,
+                           float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream) {
+    RTTS_REQUIRE(!dyb_next || partial_next, "rtts_ln_bwd: dyb_next needs partial_next");
+    RTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "rtts_ln_bwd: bad drop_p");
     RTTS_REQUIRE(dxn && x && mean && rstd && gamma && dx_io && partial_ws && M > 0 && (!dgamma == !dbeta), "rtts_ln_bwd: bad arguments");
     int blocks = (M + FR_WAVES - 1) / FR_WAVES;
     if (blocks > FR_PARTIAL_BLOCKS) blocks = FR_PARTIAL_BLOCKS;
     float* pg = partial_ws;
     float* pb = partial_ws + (size_t)FR_PARTIAL_BLOCKS * d;
     const size_t lds = (size_t)FR_WAVES * d * sizeof(float);
-#define CALL(EPL, VEC) hipLaunchKernelGGL((ln_bwd_kernel<EPL, VEC>), dim3(blocks), dim3(FR_THREADS), lds, (hipStream_t)stream, (const bf16_t*)dxn, x, mean, rstd, gamma, dx_io, pg, pb, M)
+#define CALL(EPL, VEC) hipLaunchKernelGGL((ln_bwd_kernel<EPL, VEC>), dim3(blocks), dim3(FR_THREADS), lds, (hipStream_t)stream, (const bf16_t*)dxn, x, mean, rstd, gamma, dx_io, pg, pb, M, (bf16_t*)dyb_next, partial_next, seed, seed_dev, rtts_drop_thresh(drop_p), 1.f / (1.f - drop_p))
     FR_DISPATCH_D(d, CALL)
 #undef CALL
     if (dgamma) {       // NULL: the caller finalises the partial rows itself (rtts_colsum_final_grouped)

@@ -107,19 +107,43 @@ def flush_colsum():
         _lib.call("rtts_colsum_final_grouped", arr, len(group), _s())
 
 
-def ln_bwd(dxn, x, mean, rstd, norm, dx_io):
+def ln_bwd(dxn, x, mean, rstd, norm, dx_io, next_cast=None):
+    """dx_io += dLN(dxn); LayerNorm gradients queued (or added).  ``next_cast`` = (drop | None,): the completed dx_io is
+    the next block's output gradient, so its bf16 copy (times that block's dropout keep-scale) and the partial column
+    sums for that block's output bias are produced here -> (dyb, partial buffer, rows), else None."""
     m, d = x.shape
+    dev = x.device
+    nxt = None
+    args_next = (None, None, 0.0, 0, None)
+    if next_cast is not None:
+        drop = next_cast[0]
+        p, seed = drop if drop else (0.0, 0)
+        dyb = torch.empty(m, d, dtype=torch.bfloat16, device=dev)
+        pn = torch.empty(256 * d, dtype=torch.float32, device=dev)
+        args_next = (dyb.data_ptr(), pn.data_ptr(), float(p), seed, seed_base(dev).data_ptr())
+        nxt = (dyb, pn, _partial_rows(m))
     if DEFER_COLSUM:
-        ws = torch.empty(2 * 256 * d, dtype=torch.float32, device=x.device)
+        ws = torch.empty(2 * 256 * d, dtype=torch.float32, device=dev)
         _lib.call("rtts_ln_bwd", dxn.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), norm.weight.data_ptr(),
-                  dx_io.data_ptr(), None, None, ws.data_ptr(), m, d, _s())
+                  dx_io.data_ptr(), None, None, ws.data_ptr(), m, d, *args_next, _s())
         rows = _partial_rows(m)
         _queue_colsum(ws, 0, rows, d, _grad(norm.weight))
         _queue_colsum(ws, 256 * d, rows, d, _grad(norm.bias))
-        return
+        return nxt
     _lib.call("rtts_ln_bwd", dxn.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), norm.weight.data_ptr(),
-              dx_io.data_ptr(), _grad(norm.weight).data_ptr(), _grad(norm.bias).data_ptr(), _WS.partial(x.device, d).data_ptr(),
-              m, d, _s())
+              dx_io.data_ptr(), _grad(norm.weight).data_ptr(), _grad(norm.bias).data_ptr(), _WS.partial(dev, d).data_ptr(),
+              m, d, *args_next, _s())
+    return nxt
+
+
+def _out_grad(d_acc, dbias, drop, pre_cast):
+    """bf16 copy of the block's output gradient (+ its bias gradient): taken from the previous LayerNorm backward when it
+    produced one for this stream (``pre_cast``), else one rtts_cast_colsum launch."""
+    if pre_cast is not None:
+        dyb, pn, rows = pre_cast
+        _queue_colsum(pn, 0, rows, d_acc.shape[1], dbias)
+        return dyb
+    return cast_colsum(d_acc, dbias, drop)
 
 
 def cast_colsum(dy, dbias: Optional[torch.Tensor], drop=None, defer: bool = True):
@@ -306,14 +330,14 @@ class LSHExec:
         self.drop = (p, next_seed()) if p > 0.0 else None
         return residual(acc, g, self.layer.to_out.bias, 1.0, next_norm, self.drop)
 
-    def backward(self, acc, inp, d_acc, d_inp, b, t, mask=None, pre=None, next_norm=None, **_):
+    def backward(self, acc, inp, d_acc, d_inp, b, t, mask=None, pre=None, next_norm=None, pre_cast=None, next_cast=None, **_):
         lyr = self.layer
         e = lyr.dim
         xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g = self._internals(inp, b, t, mask, self.st, self.stash, self.g_stash, pre)
         self.st = self.stash = self.g_stash = None
         drop, self.drop = self.drop, None
         post = residual(acc, g, lyr.to_out.bias, -1.0, next_norm, drop)       # reconstruct the stream (same dropout mask)
-        dyb = cast_colsum(d_acc, _grad(lyr.to_out.bias), drop)
+        dyb = _out_grad(d_acc, _grad(lyr.to_out.bias), drop, pre_cast)
         out2 = out.view(b * t, e)
         wgrad(_grad(lyr.to_out.weight), dyb, out2)
         dout = torch.mm(dyb, _bf16(lyr.to_out.weight)).view(b, t, e)
@@ -329,8 +353,7 @@ class LSHExec:
             pair[0].add_(full[:e])
             pair[1].add_(full[e:])
         dxn = torch.mm(dqkv2, wqkv)
-        ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp)
-        return post
+        return post, ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp, next_cast)
 
 
 class FFNExec:
@@ -360,18 +383,17 @@ class FFNExec:
         self.g_stash = g if STASH_BLOCK_OUTPUT else None
         return residual(acc, g, self.l2.bias, 1.0, next_norm)
 
-    def backward(self, acc, inp, d_acc, d_inp, b, t, pre=None, next_norm=None, **_):
+    def backward(self, acc, inp, d_acc, d_inp, b, t, pre=None, next_norm=None, pre_cast=None, next_cast=None, **_):
         xn, mean, rstd, h, g = self._internals(inp, self.g_stash, pre)
         self.g_stash = None
         post = residual(acc, g, self.l2.bias, -1.0, next_norm)
-        dyb = cast_colsum(d_acc, _grad(self.l2.bias))
+        dyb = _out_grad(d_acc, _grad(self.l2.bias), None, pre_cast)
         wgrad(_grad(self.l2.weight), dyb, h)
         dh = torch.mm(dyb, _bf16(self.l2.weight))
         colsum_bf16(dh, _grad(self.l1.bias), h)                                # relu gate in place + db1
         wgrad(_grad(self.l1.weight), dh, xn)
         dxn = torch.mm(dh, _bf16(self.l1.weight))
-        ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp)
-        return post
+        return post, ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp, next_cast)
 
 
 class XAttnExec:
@@ -382,7 +404,7 @@ class XAttnExec:
         self.mha = withnorm.fn.layer
         self.stash = None
         self.g_stash = None
-        self.drop = None
+        self.pdrop = None     # (p, seed) of the dropout on the attention probabilities (NOT an output dropout)
 
     @staticmethod
     def supported(withnorm) -> bool:
@@ -411,20 +433,21 @@ class XAttnExec:
 
     def forward(self, acc, inp, b, t, keys_bf16=None, kvalid=None, pre=None, next_norm=None, **_):
         p = self.mha.dropout if self.mha.training else 0.0
-        self.drop = (p, next_seed()) if p > 0.0 else None
-        *_, o, lse, g, _ = self._internals(inp, b, t, keys_bf16, kvalid, pre=pre, drop=self.drop)
+        self.pdrop = (p, next_seed()) if p > 0.0 else None
+        *_, o, lse, g, _ = self._internals(inp, b, t, keys_bf16, kvalid, pre=pre, drop=self.pdrop)
         self.stash = (o, lse) if STASH_ATTENTION else None
         self.g_stash = g if STASH_BLOCK_OUTPUT else None
         return residual(acc, g, self.mha.out_proj.bias, 1.0, next_norm)
 
-    def backward(self, acc, inp, d_acc, d_inp, b, t, keys_bf16=None, kvalid=None, dkeys=None, pre=None, next_norm=None, **_):
+    def backward(self, acc, inp, d_acc, d_inp, b, t, keys_bf16=None, kvalid=None, dkeys=None, pre=None, next_norm=None,
+                 pre_cast=None, next_cast=None, **_):
         m = self.mha
         e, h = m.embed_dim, m.num_heads
-        drop, self.drop = self.drop, None
+        drop, self.pdrop = self.pdrop, None
         xn, mean, rstd, w, q, kv, o, lse, g, tk = self._internals(inp, b, t, keys_bf16, kvalid, self.stash, self.g_stash, pre, drop)
         self.stash = self.g_stash = None
         post = residual(acc, g, m.out_proj.bias, -1.0, next_norm)
-        dyb = cast_colsum(d_acc, _grad(m.out_proj.bias))
+        dyb = _out_grad(d_acc, _grad(m.out_proj.bias), None, pre_cast)
         wgrad(_grad(m.out_proj.weight), dyb, o)
         do = torch.mm(dyb, _bf16(m.out_proj.weight))
         dev = inp.device
@@ -445,9 +468,9 @@ class XAttnExec:
         wgrad(gw[:e], dq, xn)
         wgrad(gw[e:], dkv, keys_bf16)
         dxn = torch.mm(dq, w[:e])
-        ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp)
+        nxt = ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp, next_cast)
         residual(dkeys, torch.mm(dkv, w[e:]), None, 1.0)                      # dkeys (fp32) += dkv W_kv
-        return post
+        return post, nxt
 
 
 # ------------------------------------------------------------------------------------------ stacks
@@ -474,10 +497,12 @@ class _Chain:
 
     def __init__(self, calls, reverse: bool):
         order = list(reversed(calls)) if reverse else calls
-        self.next_norm = {}
+        self.next_norm, self.next_exec = {}, {}
         for (ex, i, w), (nxt, _, _) in zip(order, order[1:]):
             self.next_norm[(i, w)] = nxt.norm
+            self.next_exec[(i, w)] = nxt
         self.pre, self.ptr = None, None
+        self.cast, self.cast_ptr = None, None
 
     def args(self, i, which, inp):
         pre = self.pre if (self.pre is not None and self.ptr == inp.data_ptr()) else None
@@ -485,6 +510,17 @@ class _Chain:
 
     def done(self, post, acc):
         self.pre, self.ptr = post, (acc.data_ptr() if post is not None else None)
+
+    # backward only: the gradient stream a LayerNorm backward completes (d_inp) is the output gradient (d_acc) of the
+    # executor that runs next in backward order; its bf16 cast + bias partial sums ride in that LayerNorm backward
+    def grad_args(self, i, which, d_acc):
+        pre_cast = self.cast if (self.cast is not None and self.cast_ptr == d_acc.data_ptr()) else None
+        nxt = self.next_exec.get((i, which)) if FUSE_RESIDUAL_LN else None
+        # .drop = an executor's dropout on its OUTPUT (the LSH layers' post_attn_dropout); only that one masks d_acc
+        return dict(pre_cast=pre_cast, next_cast=None if nxt is None else (getattr(nxt, "drop", None),))
+
+    def grad_done(self, nxt, d_inp):
+        self.cast, self.cast_ptr = nxt, (d_inp.data_ptr() if nxt is not None else None)
 
 
 def build_program(seq) -> Optional[List[tuple]]:
@@ -597,10 +633,16 @@ class FusedStackFn(torch.autograd.Function):
                 elif kind == "half":
                     if "keys_bf16" in kw:
                         kw = dict(kw, dkeys=dkeys)
-                    chain.done(f.backward(s1, s2, g1, g2, b, t, **kw, **chain.args(i, "f", s2)), s1)
+                    post, nxt = f.backward(s1, s2, g1, g2, b, t, **kw, **chain.args(i, "f", s2), **chain.grad_args(i, "f", g1))
+                    chain.done(post, s1)
+                    chain.grad_done(nxt, g2)
                 else:
-                    chain.done(g.backward(s2, s1, g2, g1, b, t, **chain.args(i, "g", s1)), s2)
-                    chain.done(f.backward(s1, s2, g1, g2, b, t, **kw, **chain.args(i, "f", s2)), s1)
+                    post, nxt = g.backward(s2, s1, g2, g1, b, t, **chain.args(i, "g", s1), **chain.grad_args(i, "g", g2))
+                    chain.done(post, s2)
+                    chain.grad_done(nxt, g1)
+                    post, nxt = f.backward(s1, s2, g1, g2, b, t, **kw, **chain.args(i, "f", s2), **chain.grad_args(i, "f", g1))
+                    chain.done(post, s1)
+                    chain.grad_done(nxt, g2)
                 done.append(i)
                 if pending_wgrads() >= 7 or i == 0:
                     # one grouped launch per layer's worth of weight gradients; only then are the finished blocks'
