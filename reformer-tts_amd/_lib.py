@@ -86,6 +86,11 @@ def load() -> C.CDLL:
             raise RttsError(
                 f"{LIB_PATH} is missing: build it with `python reformer-tts_amd/build.py` "
                 "(or __graft_entry__.build()). There is no CPU fallback for the HIP path.")
+        # Load order matters: librtts_hip.so needs libamdhip64.so.7, and PyTorch ships its own copy of the HIP runtime.
+        # With torch imported first the loader binds this library to the runtime torch uses (one runtime per process:
+        # torch's streams and device pointers are what the entry points receive).  Loaded the other way round, the
+        # system copy under /opt/rocm comes in first and the first launch fails with "no ROCm-capable device".
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         lib.rtts_version.restype = C.c_int
         lib.rtts_last_error.restype = C.c_char_p
