@@ -205,10 +205,12 @@ class ReformerTTS(nn.Module):
     def _infer_graphed(self, phonemes, max_len, stop_threshold, stop_at_stop_token, cache_encoder, check_every):
         """"concat" generation with ONE hipGraph replay per frame.  The padded input window, its validity mask, the index
         of the newest frame and the stop bookkeeping are device buffers; the graph runs the decoder (and the encoder
-        unless cached) over the window, picks the output at the newest position with a device index, appends it to the
-        window and advances the index -- the host only replays, looks at the stop flags every ``check_every`` frames and
-        moves to a larger window (a new capture) when the padded length grows by ``pad_base``.  Same results as the
-        eager loop up to the LSH rotations, which are redrawn per forward in both."""
+        unless cached) over the window through the explicit executor, picks the output at the newest position with a
+        device index, appends it to the window and advances the index -- the host only replays, looks at the stop flags
+        every ``check_every`` frames and moves to the next window's graph when the padded length grows by ``pad_base``.
+        Buffers and graphs are kept per (batch, padded text length, capacity, options) and reused by later calls, so
+        only the first utterance of a shape pays for the captures.  Same results as the eager loop up to the LSH
+        rotations, which are redrawn per forward in both."""
         from .._graphs import capturing
         from .lsh_attention import LSHSelfAttention
         was_training = self.training
@@ -216,25 +218,51 @@ class ReformerTTS(nn.Module):
         for m in self.modules():
             if isinstance(m, LSHSelfAttention):
                 m.use_default_generator = True                       # the per-layer generators are not capturable
+        stacks = (self.enc.reformer.layers, self.dec.reformer.layers)
+        for st_ in stacks:
+            st_.fused_in_eval = True                                 # executor forward: ~half the launches per frame
         try:
             dev = self.dec.mel_linear.weight.device
             phonemes = phonemes.to(dev)
             b, nm = phonemes.shape[0], self.num_mel_coeffs
-            pad_ph = pad_to_multiple(phonemes.unsqueeze(-1), self.pad_base).squeeze(-1)
-            ph_mask = pad_ph != 0
-            keys_c = self.enc(pad_ph, input_mask=ph_mask) if cache_encoder else None
+            pad_ph_new = pad_to_multiple(phonemes.unsqueeze(-1), self.pad_base).squeeze(-1)
             cap = max(max_len, nm, b) + 2
             total = _pad_len(cap + 1, self.pad_base)
-            spec = torch.zeros(b, total, nm, device=dev)              # frame 0 = the zero start frame
-            mask = torch.zeros(b, total, dtype=torch.bool, device=dev)
-            mask[:, 0] = True
-            pos = torch.zeros(1, dtype=torch.long, device=dev)        # index of the newest frame = cur - 1
-            stop = torch.zeros(b, dtype=torch.long, device=dev)
             thr = float(stop_threshold)
+            params = tuple(p_.data_ptr() for p_ in self.parameters())   # the graphs read the weights in place: new VALUES are fine
+            key = (b, pad_ph_new.shape[1], total, bool(cache_encoder), bool(stop_at_stop_token), thr, str(dev))
+            cache = self.__dict__.setdefault("_gen_cache", {})
+            g = cache.get(key)
+            if g is None or g["params"] != params:                   # new shape, or the weights moved (other device / storage)
+                g = dict(params=params, graphs={}, pad_ph=torch.zeros_like(pad_ph_new),
+                         spec=torch.zeros(b, total, nm, device=dev),                       # frame 0 = the zero start frame
+                         mask=torch.zeros(b, total, dtype=torch.bool, device=dev),
+                         pos=torch.zeros(1, dtype=torch.long, device=dev),                 # index of the newest frame = cur - 1
+                         stop=torch.zeros(b, dtype=torch.long, device=dev),
+                         keys=None)
+                cache.clear()                                        # one generator state at a time (each pins HBM for its graphs)
+                cache[key] = g
+            spec, mask, pos, stop, pad_ph = g["spec"], g["mask"], g["pos"], g["stop"], g["pad_ph"]
+            pad_ph.copy_(pad_ph_new)
+            ph_mask = g.setdefault("ph_mask", torch.zeros_like(pad_ph, dtype=torch.bool))
+            ph_mask.copy_(pad_ph != 0)
+            spec.zero_()
+            mask.zero_()
+            mask[:, 0] = True
+            pos.zero_()
+            stop.zero_()
+            if cache_encoder:
+                keys_new = self.enc(pad_ph, input_mask=ph_mask)
+                if g["keys"] is None:
+                    g["keys"] = torch.empty_like(keys_new)
+                g["keys"].copy_(keys_new)
+            keys_c = g["keys"] if cache_encoder else None
+            nph_mask = g.setdefault("nph_mask", torch.zeros_like(ph_mask))
+            nph_mask.copy_(~ph_mask)
 
             def step(t_pad):
                 keys = keys_c if keys_c is not None else self.enc(pad_ph, input_mask=ph_mask)
-                mel, stop_pred, _ = self.dec(spec[:, :t_pad], keys=keys, key_padding_mask=~ph_mask, input_mask=mask[:, :t_pad])
+                mel, stop_pred, _ = self.dec(spec[:, :t_pad], keys=keys, key_padding_mask=nph_mask, input_mask=mask[:, :t_pad])
                 gen = (mel + self.postnet(mel)).index_select(1, pos)                    # (B, 1, n_mels) at the newest position
                 if stop_at_stop_token:
                     stops_now = torch.sigmoid(stop_pred.reshape(b, -1).index_select(1, pos).reshape(b)) > thr
@@ -243,7 +271,7 @@ class ReformerTTS(nn.Module):
                 spec.index_copy_(1, pos, gen)
                 mask.index_fill_(1, pos, True)
 
-            graphs = {}
+            graphs = g["graphs"]
             cur, it = 1, 0
             every = max(1, int(check_every))
             while True:
@@ -271,8 +299,9 @@ class ReformerTTS(nn.Module):
                     break
             if stop_at_stop_token and bool(torch.all(stop > 0)):
                 cur = min(cur, int(stop.max()))
-            stop = torch.where(stop == 0, torch.full_like(stop, max_len), stop)
-            return spec[:, 1:cur].transpose(1, 2).contiguous(), stop
+            stop_out = torch.where(stop == 0, torch.full_like(stop, max_len), stop)
+            return spec[:, 1:cur].transpose(1, 2).contiguous(), stop_out
         finally:
+            for st_ in stacks:
+                st_.fused_in_eval = False
             self.train(was_training)
-

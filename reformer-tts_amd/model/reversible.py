@@ -183,13 +183,14 @@ class ReversibleSequence(nn.Module):
         self.blocks = blocks
         self.block_done_hook: Optional[Callable] = None   # (sequence, block index) after its backward_pass
         self.use_fused = True      # training on the GPU: explicit executor (engine.py) when every block supports it
+        self.fused_in_eval = False  # generation: the executor's forward in eval mode too (half the launches of the general path)
         self._program = None
         self._program_built = False
 
     def forward_sum(self, x, kwargs_list=None, context=None):
         """Both streams start as ``x``; returns their sum after the stack (``reformer.py:81-93,139-158``)."""
         kwargs_list = kwargs_list if kwargs_list is not None else [{}] * len(self.blocks)
-        if self.use_fused and self.training and x.is_cuda:
+        if self.use_fused and x.is_cuda and (self.training or (self.fused_in_eval and not torch.is_grad_enabled())):
             if not self._program_built:
                 from ..engine import build_program
                 self._program, self._program_built = build_program(self), True
