@@ -266,7 +266,10 @@ int rtts_gemm_tn_grouped(const rtts_gemm_tn_problem* problems, int n, float* sla
  *                         slice [cond_offset, +2C) of the conditioning (B*Lm, ld_cond), nearest-upsampled by `upsample`
  *                         (nn.Upsample, :216-219) -> acts bf16 (B*L, C)
  *   rtts_sw_coupling_inv  a1 = (a1 - b) / exp(s) on channels [half, 2*half) of audio (rows, ld_audio), wn_out = [s | b] (:353-359) */
-int rtts_sw_depthwise_k3(const float* x, const float* w, const float* bias, int B, int L, int C, void* y, void* stream);
+int rtts_sw_depthwise_k3(const float* x, const float* w, const float* bias, int B, int L, int C, void* y,
+                         const float* edge_lo, const float* edge_hi, void* stream);
+/* edge_lo / edge_hi (C floats, may be NULL) are subtracted at l = 0 / l = L-1: the share of a folded BatchNorm constant
+ * that the zero padding of the reference does not see. */
 int rtts_sw_gate(const void* pw, const void* cond, int64_t ld_cond, int cond_offset, int upsample, int B, int L, int Lm, int C,
                  void* acts, void* stream);
 int rtts_sw_coupling_inv(float* audio, int64_t ld_audio, const float* wn_out, int64_t rows, int half, void* stream);

@@ -14,10 +14,13 @@ static inline unsigned sw_grid(size_t items) {
     return (unsigned)b;
 }
 
-// y[b][l][c] = bias[c] + sum_k w[c][k] * x[b][l + k - 1][c]   (kernel 3, zero padding), x fp32 -> y bf16; 4 channels/thread
+// y[b][l][c] = bias[c] + sum_k w[c][k] * x[b][l + k - 1][c]   (kernel 3, zero padding), x fp32 -> y bf16; 4 channels/thread.
+// edge_lo / edge_hi (may be null): per-channel constants subtracted at l = 0 / l = L-1 -- with an eval-mode BatchNorm folded
+// into w and bias, the reference's zero padding pads bn(x), so the folded constant must not be counted for the missing tap.
 __global__ __launch_bounds__(SW_THREADS) void sw_depthwise_k3_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                      const float* __restrict__ bias, int L, int C, size_t n4,
-                                                                     bf16_t* __restrict__ y) {
+                                                                     bf16_t* __restrict__ y, const float* __restrict__ edge_lo,
+                                                                     const float* __restrict__ edge_hi) {
     const int c4 = C / 4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % c4) * 4;
@@ -33,6 +36,8 @@ __global__ __launch_bounds__(SW_THREADS) void sw_depthwise_k3_kernel(const float
         for (int j = 0; j < 4; ++j) {
             const float* wc = w + (size_t)(c + j) * 3;
             o[j] = __builtin_fmaf(wc[0], a[j], __builtin_fmaf(wc[1], m[j], __builtin_fmaf(wc[2], h[j], bias[c + j])));
+            if (edge_lo && l == 0) o[j] -= edge_lo[c + j];
+            if (edge_hi && l + 1 == L) o[j] -= edge_hi[c + j];
         }
         uint2 pk;
         pk.x = pack_bf16x2(o[0], o[1]);
@@ -83,10 +88,11 @@ __global__ __launch_bounds__(SW_THREADS) void sw_coupling_inv_kernel(float* __re
     }
 }
 
-extern "C" int rtts_sw_depthwise_k3(const float* x, const float* w, const float* bias, int B, int L, int C, void* y, void* stream) {
+extern "C" int rtts_sw_depthwise_k3(const float* x, const float* w, const float* bias, int B, int L, int C, void* y, const float* edge_lo,
+                                    const float* edge_hi, void* stream) {
     RTTS_REQUIRE(x && w && bias && y && B > 0 && L > 0 && C > 0 && C % 4 == 0, "rtts_sw_depthwise_k3: bad arguments (C %% 4 == 0)");
     const size_t n4 = (size_t)B * L * C / 4;
-    hipLaunchKernelGGL(sw_depthwise_k3_kernel, dim3(sw_grid(n4)), dim3(SW_THREADS), 0, (hipStream_t)stream, x, w, bias, L, C, n4, (bf16_t*)y);
+    hipLaunchKernelGGL(sw_depthwise_k3_kernel, dim3(sw_grid(n4)), dim3(SW_THREADS), 0, (hipStream_t)stream, x, w, bias, L, C, n4, (bf16_t*)y, edge_lo, edge_hi);
     RTTS_LAUNCH_CHECK("rtts_sw_depthwise_k3");
     return 0;
 }

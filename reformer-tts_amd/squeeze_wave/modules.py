@@ -118,11 +118,9 @@ class _FoldedWN:
         up = length // mel_len
         for i in range(self.nl):
             dw = torch.empty(m, c, dtype=torch.bfloat16, device=dev)
-            _lib.call("rtts_sw_depthwise_k3", h.data_ptr(), self.dw_w[i].data_ptr(), self.dw_b[i].data_ptr(), b, length, c, dw.data_ptr(), _s())
-            lo, hi = self.dw_edge[i]
-            dwv = dw.view(b, length, c)
-            dwv[:, 0] = (dwv[:, 0].float() - lo).to(torch.bfloat16)              # zero padding pads bn(x): undo the constant there
-            dwv[:, -1] = (dwv[:, -1].float() - hi).to(torch.bfloat16)
+            lo, hi = self.dw_edge[i]                                             # zero padding pads bn(x): no folded constant there
+            _lib.call("rtts_sw_depthwise_k3", h.data_ptr(), self.dw_w[i].data_ptr(), self.dw_b[i].data_ptr(), b, length, c, dw.data_ptr(),
+                      lo.data_ptr(), hi.data_ptr(), _s())
             pw = torch.addmm(self.b_pw[i], dw, self.w_pw[i].t())                   # (M, 2c) bf16
             acts = torch.empty(m, c, dtype=torch.bfloat16, device=dev)
             _lib.call("rtts_sw_gate", pw.data_ptr(), cond.data_ptr(), cond.stride(0), i * 2 * c, up, b, length, mel_len, c, acts.data_ptr(), _s())
