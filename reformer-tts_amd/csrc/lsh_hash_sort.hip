@@ -23,8 +23,10 @@
 #define HS_ROWB 144   // LDS row stride in bytes for a staged 64 x 64 bf16 tile (conflict-free b128 reads)
 
 template <int HALF>
-__device__ __forceinline__ int hash_row(const float* q, const float* rot_lds) {
-    // rot_lds[f * HALF + i]; returns argmax over [xR, -xR] with the first maximum winning
+__device__ __forceinline__ int hash_row(const float* q, const float* rot_lds, int half) {
+    // rot_lds[f * HALF + i], columns i >= half are zero padding (n_buckets / 2 = half need not be a power of two: a
+    // 768-frame mel at bucket size 128 has 6 buckets); returns argmax over [xR, -xR] restricted to the real columns,
+    // the first maximum winning
     int idx = 0;
     float best;
     if constexpr (HALF >= 2) {
@@ -41,10 +43,10 @@ __device__ __forceinline__ int hash_row(const float* q, const float* rot_lds) {
         best = acc[0][0];
 #pragma unroll
         for (int i = 1; i < HALF; ++i)
-            if (acc[i >> 1][i & 1] > best) { best = acc[i >> 1][i & 1]; idx = i; }
+            if (i < half && acc[i >> 1][i & 1] > best) { best = acc[i >> 1][i & 1]; idx = i; }
 #pragma unroll
         for (int i = 0; i < HALF; ++i)
-            if (-acc[i >> 1][i & 1] > best) { best = -acc[i >> 1][i & 1]; idx = HALF + i; }
+            if (i < half && -acc[i >> 1][i & 1] > best) { best = -acc[i >> 1][i & 1]; idx = half + i; }
     } else {
         float a = 0.f;
 #pragma unroll
@@ -70,10 +72,12 @@ __device__ __forceinline__ unsigned long long match_lanes(int v) {
 template <int HALF, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void lsh_hash_sort_kernel(
     const bf16_t* __restrict__ qk, int64_t ld, const float* __restrict__ rotations, int rot_rows,
-    int H, int T, int n_hashes, int32_t* __restrict__ buckets, int32_t* __restrict__ st, int32_t* __restrict__ undo) {
+    int H, int T, int n_hashes, int32_t* __restrict__ buckets, int32_t* __restrict__ st, int32_t* __restrict__ undo, int half) {
+    // HALF = the compile-time column capacity (a power of two >= half), half = n_buckets / 2 of this call
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NB = 2 * HALF;
-    constexpr int BITS = (NB <= 2) ? 1 : (NB <= 4) ? 2 : (NB <= 8) ? 3 : (NB <= 16) ? 4 : (NB <= 32) ? 5 : 6;
+    const int NB = 2 * half;
+    constexpr int NBC = 2 * HALF;
+    constexpr int BITS = (NBC <= 2) ? 1 : (NBC <= 4) ? 2 : (NBC <= 8) ? 3 : (NBC <= 16) ? 4 : (NBC <= 32) ? 5 : 6;
     constexpr int NTHR = 64 * WAVES;
     // carve: rot [64*HALF] f32 | tile [WAVES][64 rows][144 B] | bkt [T] u16 | cntw [WAVES][64] i32 | tot [64] i32
     float* rot_lds = reinterpret_cast<float*>(smem);
@@ -89,10 +93,10 @@ __global__ __launch_bounds__(64 * WAVES) void lsh_hash_sort_kernel(
     const int b = bh / H, h = bh % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    const float* rot_src = rotations + (size_t)(rot_rows == 1 ? 0 : bh) * HS_DH * n_hashes * HALF;
+    const float* rot_src = rotations + (size_t)(rot_rows == 1 ? 0 : bh) * HS_DH * n_hashes * half;
     for (int i = tid; i < HS_DH * HALF; i += NTHR) {
         const int f = i / HALF, k = i % HALF;
-        rot_lds[i] = rot_src[((size_t)f * n_hashes + r) * HALF + k];
+        rot_lds[i] = k < half ? rot_src[((size_t)f * n_hashes + r) * half + k] : 0.f;
     }
     for (int i = tid; i < WAVES * 64; i += NTHR) cntw[i] = 0;
     __syncthreads();
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(64 * WAVES) void lsh_hash_sort_kernel(
                     q[p * 8 + 2 * k + 1] = __uint_as_float(uu[k] & 0xffff0000u);
                 }
             }
-            const int idx = hash_row<HALF>(q, rot_lds);   // lanes >= rows hash stale LDS rows: results dropped below
+            const int idx = hash_row<HALF>(q, rot_lds, half);   // lanes >= rows hash stale LDS rows: results dropped below
             if (lane < rows) {
                 bkt[s0 + t0 + lane] = (uint16_t)idx;
                 atomicAdd(&cntw[wave * 64 + idx], 1);      // integer LDS add: order-free, deterministic
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(64 * WAVES) void lsh_hash_sort_kernel(
 
 template <int HALF, int WAVES>
 static int launch_hash_sort_w(const bf16_t* qk, int64_t ld, const float* rot, int rot_rows, int B, int H, int T,
-                              int n_hashes, int32_t* buckets, int32_t* st, int32_t* undo, hipStream_t stream) {
+                              int n_hashes, int32_t* buckets, int32_t* st, int32_t* undo, int half, hipStream_t stream) {
     const size_t lds = ((HS_DH * HALF * 4 + 15) & ~15) + WAVES * 64 * HS_ROWB + ((T * 2 + 15) & ~15) + (WAVES * 64 + 64) * 4;
     static bool attr = false;
     if (!attr && lds > 64 * 1024) {
@@ -202,7 +206,7 @@ static int launch_hash_sort_w(const bf16_t* qk, int64_t ld, const float* rot, in
     }
     const dim3 grid(B * H * n_hashes);
     hipLaunchKernelGGL((lsh_hash_sort_kernel<HALF, WAVES>), grid, dim3(64 * WAVES), lds, stream, qk, ld, rot, rot_rows, H, T,
-                       n_hashes, buckets, st, undo);
+                       n_hashes, buckets, st, undo, half);
     RTTS_LAUNCH_CHECK("rtts_lsh_hash_sort");
     return 0;
 }
@@ -211,10 +215,10 @@ static int launch_hash_sort_w(const bf16_t* qk, int64_t ld, const float* rot, in
 // long row has enough tokens to keep 8 waves = 2 per SIMD busy through the fmaf chains)
 template <int HALF>
 static int launch_hash_sort(const bf16_t* qk, int64_t ld, const float* rot, int rot_rows, int B, int H, int T,
-                            int n_hashes, int32_t* buckets, int32_t* st, int32_t* undo, hipStream_t stream) {
+                            int n_hashes, int32_t* buckets, int32_t* st, int32_t* undo, int half, hipStream_t stream) {
     if (T >= 2048 && T % 256 == 0)
-        return launch_hash_sort_w<HALF, 8>(qk, ld, rot, rot_rows, B, H, T, n_hashes, buckets, st, undo, stream);
-    return launch_hash_sort_w<HALF, 4>(qk, ld, rot, rot_rows, B, H, T, n_hashes, buckets, st, undo, stream);
+        return launch_hash_sort_w<HALF, 8>(qk, ld, rot, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, stream);
+    return launch_hash_sort_w<HALF, 4>(qk, ld, rot, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, stream);
 }
 
 extern "C" int rtts_lsh_hash_sort(const void* qk, int64_t ld_qk, const float* rotations, int rot_rows, int B, int H,
@@ -233,15 +237,12 @@ extern "C" int rtts_lsh_hash_sort(const void* qk, int64_t ld_qk, const float* ro
     const int half = T / bucket_size / 2;
     hipStream_t s = (hipStream_t)stream;
     const bf16_t* q = (const bf16_t*)qk;
-    switch (half) {
-        case 1: return launch_hash_sort<1>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, s);
-        case 2: return launch_hash_sort<2>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, s);
-        case 4: return launch_hash_sort<4>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, s);
-        case 8: return launch_hash_sort<8>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, s);
-        case 16: return launch_hash_sort<16>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, s);
-        case 32: return launch_hash_sort<32>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, s);
-        default: break;
-    }
-    rtts_set_error("rtts_lsh_hash_sort: n_buckets=%d unsupported (need a power of two in [2,64])", 2 * half);
-    return -1;
+    RTTS_REQUIRE(half >= 1 && half <= 32, "rtts_lsh_hash_sort: n_buckets=%d unsupported (2 .. 64)", 2 * half);
+    // column capacity = next power of two; the extra columns are zero padding that the argmax ignores
+    if (half <= 1) return launch_hash_sort<1>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, s);
+    if (half <= 2) return launch_hash_sort<2>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, s);
+    if (half <= 4) return launch_hash_sort<4>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, s);
+    if (half <= 8) return launch_hash_sort<8>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, s);
+    if (half <= 16) return launch_hash_sort<16>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, s);
+    return launch_hash_sort<32>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, s);
 }

@@ -89,6 +89,9 @@ CASES = [
     (1, 3, 512, 128, 2, True, False),
     (2, 2, 512, 128, 8, False, True),
     (1, 8, 1024, 128, 8, True, True),
+    (2, 2, 768, 128, 4, True, True),          # 6 buckets: not a power of two (a 768-frame mel at bucket size 128)
+    (1, 2, 3840, 64, 4, True, False),         # 60 buckets
+    (1, 2, 384, 64, 4, False, True),          # 6 buckets at bucket size 64
 ]
 
 

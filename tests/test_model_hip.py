@@ -870,3 +870,23 @@ def test_three_training_steps_follow_the_oracle_trajectory(gpu):
     cos = float(torch.nn.functional.cosine_similarity(du_gpu, du_ref, dim=0))
     assert cos > 0.97, cos
     assert abs(float(du_gpu.norm() / du_ref.norm()) - 1.0) < 0.05
+
+
+@pytest.mark.parametrize("b,text,mel", [(5, 130, 700), (1, 37, 129), (3, 256, 512)])
+def test_odd_batch_shapes_on_the_executor(gpu, b, text, mel):
+    """Batch sizes and lengths that are not multiples of anything convenient (the model pads text and mel to pad_base;
+    rows = B * padded length is always a multiple of 128): full-width model with 1+1 layers, three steps on the fused
+    path, finite loss that comes down, finite parameters."""
+    from reformer_tts_amd.model.config import TTSTrainingConfig, baseline_model_config
+    from reformer_tts_amd.training import Trainer, build_model
+    cfg = baseline_model_config()
+    cfg.enc_reformer_kwargs.depth = 1
+    cfg.dec_reformer_kwargs.depth = 1
+    model = build_model(cfg, gpu)
+    tr = Trainer(model, TTSTrainingConfig(batch_size=b, learning_rate=3e-4, warmup_steps=None), gpu)
+    batch = {k: v.to(gpu) for k, v in model_ref.synthetic_batch(b, text, mel, ragged=(b > 1), seed=b).items()}
+    assert tr._fused_edges_ok(batch)
+    losses = [float(tr.train_step(batch)[0]) for _ in range(4)]
+    assert model.dec.reformer.layers._program is not None
+    assert all(np.isfinite(losses)) and min(losses[1:]) < losses[0], losses
+    assert torch.isfinite(tr.flat_p).all()
