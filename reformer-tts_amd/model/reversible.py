@@ -190,7 +190,10 @@ class ReversibleSequence(nn.Module):
     def forward_sum(self, x, kwargs_list=None, context=None):
         """Both streams start as ``x``; returns their sum after the stack (``reformer.py:81-93,139-158``)."""
         kwargs_list = kwargs_list if kwargs_list is not None else [{}] * len(self.blocks)
-        if self.use_fused and x.is_cuda and (self.training or (self.fused_in_eval and not torch.is_grad_enabled())):
+        # the on-chip cross-attention kernels hold 128 or 256 keys (text padded to pad_base = 256); longer texts take the
+        # general path below (torch SDPA) instead of failing
+        keys_ok = context is None or context.shape[1] in (128, 256)
+        if self.use_fused and keys_ok and x.is_cuda and (self.training or (self.fused_in_eval and not torch.is_grad_enabled())):
             if not self._program_built:
                 from ..engine import build_program
                 self._program, self._program_built = build_program(self), True
