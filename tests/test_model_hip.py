@@ -892,3 +892,35 @@ def test_odd_batch_shapes_on_the_executor(gpu, b, text, mel):
     assert model.enc.reformer.layers._program is not None
     assert all(np.isfinite(losses)) and min(losses[1:]) < losses[0], losses
     assert torch.isfinite(tr.flat_p).all()
+
+
+def test_graph_replay_reads_new_batch_contents(gpu):
+    """A captured step is bound to its batch BUFFERS, not to their contents: after new data is copied into the same
+    tensors (what BatchPrefetcher(into=...) does) the replay trains on the new batch -- same loss as an eager step on it."""
+    from reformer_tts_amd.model.config import TTSTrainingConfig, model_config_from_dict
+    from reformer_tts_amd.model.lsh_attention import LSHSelfAttention
+    from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
+    cfg = model_ref.small_cfg()
+    cfg["enc_reformer_kwargs"]["attn_kwargs"]["implementation"] = "hip"
+    cfg["dec_reformer_kwargs"]["self_attn_kwargs"]["implementation"] = "hip"
+    a = synthetic_batch(2, 100, 256, seed=1, device=gpu)
+    b = synthetic_batch(2, 100, 256, seed=2, device=gpu)
+    losses = []
+    for graph in (False, True):
+        torch.manual_seed(1)
+        model = build_model(model_config_from_dict(cfg), gpu)
+        for m in model.modules():
+            if isinstance(m, LSHSelfAttention):
+                m.forced_rotations = torch.randn(1, 64, 4, (128 if not m.causal else 256) // 64 // 2, generator=torch.Generator().manual_seed(5))
+        tr = Trainer(model, TTSTrainingConfig(batch_size=2, learning_rate=1e-3, warmup_steps=4, gradient_clip_val=1.0), gpu)
+        if graph:
+            buf = {k: v.clone() for k, v in a.items()}
+            tr.capture(buf)                                   # two eager steps on A
+            for k in buf:
+                buf[k].copy_(b[k])
+            losses.append(float(tr.replay()[0]))
+        else:
+            tr.train_step(a)
+            tr.train_step(a)
+            losses.append(float(tr.train_step(b)[0]))
+    np.testing.assert_allclose(losses[1], losses[0], rtol=2e-2)
