@@ -240,6 +240,25 @@ class Trainer:
         self.optimizer_step(update_hyper)
         return total.detach(), raw_l.detach(), post_l.detach(), stop_l.detach()
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def state_dict(self) -> dict:
+        """Everything a resumed run needs: the model's own state_dict (reference names: loads into the reference and
+        vice versa), the Adam moments keyed by parameter name, and the step counter (drives warm-up and bias correction)."""
+        moments = {n: (self.flat_m[s:e].detach().clone(), self.flat_v[s:e].detach().clone()) for n, (s, e) in self.offsets.items()}
+        return {"model": {k: v.detach().clone() for k, v in self.model.state_dict().items()}, "adam": moments,
+                "global_step": self.global_step}
+
+    def load_state_dict(self, state: dict) -> None:
+        self.model.load_state_dict(state["model"])             # copies into the flat fp32 buffer the parameters view
+        for n, (m, v) in state["adam"].items():
+            s, e = self.offsets[n]
+            self.flat_m[s:e].copy_(m.reshape(-1))
+            self.flat_v[s:e].copy_(v.reshape(-1))
+        self.global_step = int(state["global_step"])
+        if self.device.type == "cuda":
+            self.refresh_mirror()                              # the bf16 mirror the GEMMs read
+            engine.WEIGHT_EPOCH[0] += 1                        # cached re-layouts of weights (conv permutations) are stale
+
     def fit(self, host_batches, log_every: int = 0):
         """Eager training over an iterable of HOST batches (the output of ``dataset.custom_sequence_padder``; shapes may
         vary from batch to batch, which a captured graph cannot follow): the next batch is copied to HBM on a copy stream

@@ -924,3 +924,39 @@ def test_graph_replay_reads_new_batch_contents(gpu):
             tr.train_step(a)
             losses.append(float(tr.train_step(b)[0]))
     np.testing.assert_allclose(losses[1], losses[0], rtol=2e-2)
+
+
+def test_trainer_checkpoint_resume(gpu):
+    """state_dict() after two steps -> a fresh trainer -> load_state_dict(): the third step (loss, updated parameters) is the
+    same as in the run that never stopped; the model part carries the reference's parameter names."""
+    from reformer_tts_amd.model.config import TTSTrainingConfig, model_config_from_dict
+    from reformer_tts_amd.model.lsh_attention import LSHSelfAttention
+    from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
+    cfg = model_ref.small_cfg()
+    cfg["enc_reformer_kwargs"]["attn_kwargs"]["implementation"] = "hip"
+    cfg["dec_reformer_kwargs"]["self_attn_kwargs"]["implementation"] = "hip"
+    batch = synthetic_batch(2, 100, 256, device=gpu)
+
+    def make(seed):
+        torch.manual_seed(seed)
+        model = build_model(model_config_from_dict(cfg), gpu, seed=seed)
+        for m in model.modules():
+            if isinstance(m, LSHSelfAttention):
+                m.forced_rotations = torch.randn(1, 64, 4, (128 if not m.causal else 256) // 64 // 2, generator=torch.Generator().manual_seed(5))
+        return Trainer(model, TTSTrainingConfig(batch_size=2, learning_rate=1e-3, warmup_steps=4, gradient_clip_val=1.0), gpu)
+    t1 = make(1)
+    t1.train_step(batch)
+    t1.train_step(batch)
+    ckpt = t1.state_dict()
+    assert set(ckpt["model"]) == set(t1.model.state_dict()) and ckpt["global_step"] == 2
+    from reformer_tts_amd import _seeds
+    _seeds.reset(100)
+    l1 = float(t1.train_step(batch)[0])
+    t2 = make(99)                                 # different initial weights: everything must come from the checkpoint
+    t2.load_state_dict(ckpt)
+    _seeds.reset(100)
+    l2 = float(t2.train_step(batch)[0])
+    np.testing.assert_allclose(l2, l1, rtol=1e-5)
+    torch.testing.assert_close(t2.flat_p, t1.flat_p, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(t2.flat_m, t1.flat_m, rtol=1e-5, atol=1e-7)
+
