@@ -130,7 +130,7 @@ class Trainer:
 
     def _make_hook(self, stack_name):
         def hook(seq, i):
-            if self.world > 1 and not self._bulk_allreduce and (stack_name, i) in self.block_bucket:
+            if self.world > 1 and not self._bulk_allreduce and not self._accumulating and (stack_name, i) in self.block_bucket:
                 s, e = self.block_bucket[(stack_name, i)]
                 self._pending.append(dist.all_reduce(self.flat_g[s:e], group=self.pg, async_op=True))
         return hook
@@ -176,7 +176,7 @@ class Trainer:
 
     def finish_allreduce(self):
         """Reduce what no block bucket covers (prenets, heads, postnet, ...) and wait for everything."""
-        if self.world > 1 and not self._bulk_allreduce:
+        if self.world > 1 and not self._bulk_allreduce and not self._accumulating:
             for s, e in self.rest:
                 self._pending.append(dist.all_reduce(self.flat_g[s:e], group=self.pg, async_op=True))
             for w in self._pending:
@@ -240,6 +240,34 @@ class Trainer:
         self.optimizer_step(update_hyper)
         return total.detach(), raw_l.detach(), post_l.detach(), stop_l.detach()
 
+    _accumulating = False
+
+    def train_accumulated(self, batches):
+        """``accumulate_grad_batches`` of the reference's trainer (pytorch-lightning 0.7.6, ``training/train.py:77-89``,
+        5 in ``config/baseline.yml``): the losses of the N micro-batches are scaled by 1/N, their gradients accumulate in
+        the flat buffer, the gradient exchange happens once (with the last micro-batch's backward), then ONE clip + AdamW
+        step; ``global_step`` -- which drives warm-up and bias correction -- counts optimizer steps.
+        -> mean of the micro-batch total losses (device scalar)."""
+        batches = list(batches)
+        n = len(batches)
+        self.model.train()
+        self.zero_grad()
+        total = None
+        for i, batch in enumerate(batches):
+            self._accumulating = i + 1 < n                     # all-reduce only with the last micro-batch
+            loss = self.forward_loss(batch)[0]
+            (loss * (1.0 / n)).backward()
+            engine.flush_wgrad()
+            total = loss.detach() if total is None else total + loss.detach()
+        self._accumulating = False
+        if self.world > 1 and not self._bulk_allreduce:
+            # the per-block hooks of the last backward have reduced the block buckets; what no bucket covers follows
+            self.finish_allreduce()
+        elif self._bulk_allreduce:
+            self.bulk_allreduce()
+        self.optimizer_step(True)
+        return total / n
+
     # ------------------------------------------------------------------ checkpoint / resume
     def state_dict(self) -> dict:
         """Everything a resumed run needs: the model's own state_dict (reference names: loads into the reference and
@@ -262,13 +290,20 @@ class Trainer:
     def fit(self, host_batches, log_every: int = 0):
         """Eager training over an iterable of HOST batches (the output of ``dataset.custom_sequence_padder``; shapes may
         vary from batch to batch, which a captured graph cannot follow): the next batch is copied to HBM on a copy stream
-        while the current step runs.  -> list of the total loss per step (device scalars; no per-step host sync)."""
+        while the current step runs; ``cfg.accumulate_grad_batches`` micro-batches make one optimizer step.
+        -> list of the (mean) total loss per optimizer step (device scalars; no per-step host sync)."""
         from ..dataset import BatchPrefetcher
-        losses = []
-        for i, batch in enumerate(BatchPrefetcher(host_batches, self.device)):
-            losses.append(self.train_step(batch)[0])
-            if log_every and (i + 1) % log_every == 0:
-                print(f"step {self.global_step}: loss {float(losses[-1]):.4f}", flush=True)
+        losses, group = [], []
+        acc = max(1, int(self.cfg.accumulate_grad_batches))
+        for batch in BatchPrefetcher(host_batches, self.device):
+            group.append(batch)
+            if len(group) == acc:
+                losses.append(self.train_step(group[0])[0] if acc == 1 else self.train_accumulated(group))
+                group = []
+                if log_every and len(losses) % log_every == 0:
+                    print(f"step {self.global_step}: loss {float(losses[-1]):.4f}", flush=True)
+        if group:                                              # a trailing partial group still makes a step
+            losses.append(self.train_accumulated(group))
         return losses
 
     # ------------------------------------------------------------------ hipGraph replay of the whole step

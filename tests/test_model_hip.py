@@ -960,3 +960,34 @@ def test_trainer_checkpoint_resume(gpu):
     torch.testing.assert_close(t2.flat_p, t1.flat_p, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(t2.flat_m, t1.flat_m, rtol=1e-5, atol=1e-7)
 
+
+
+def test_gradient_accumulation_semantics(gpu):
+    """accumulate_grad_batches (5 in config/baseline.yml): N micro-batches, losses scaled by 1/N, ONE optimizer step.
+    Accumulating the SAME batch twice must reproduce a plain step on it (the mean of two identical gradients), the step
+    counter advances once, and two different micro-batches give the mean of their losses."""
+    from reformer_tts_amd.model.config import TTSTrainingConfig, model_config_from_dict
+    from reformer_tts_amd.model.lsh_attention import LSHSelfAttention
+    from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
+    cfg = model_ref.small_cfg()
+    cfg["enc_reformer_kwargs"]["attn_kwargs"]["implementation"] = "hip"
+    cfg["dec_reformer_kwargs"]["self_attn_kwargs"]["implementation"] = "hip"
+    a = synthetic_batch(2, 100, 256, seed=1, device=gpu)
+    b = synthetic_batch(2, 100, 256, seed=2, device=gpu)
+
+    def make():
+        model = build_model(model_config_from_dict(cfg), gpu, seed=3)
+        for m in model.modules():
+            if isinstance(m, LSHSelfAttention):
+                m.forced_rotations = torch.randn(1, 64, 4, (128 if not m.causal else 256) // 64 // 2, generator=torch.Generator().manual_seed(5))
+        return Trainer(model, TTSTrainingConfig(batch_size=2, learning_rate=1e-3, warmup_steps=4, gradient_clip_val=1.0), gpu)
+    t1, t2, t3 = make(), make(), make()
+    l1 = float(t1.train_step(a)[0])
+    l2 = float(t2.train_accumulated([a, a]))
+    assert t1.global_step == t2.global_step == 1
+    np.testing.assert_allclose(l2, l1, rtol=1e-5)
+    torch.testing.assert_close(t2.flat_p, t1.flat_p, rtol=1e-4, atol=1e-6)
+    lb = float(make().forward_loss(b)[0].detach())
+    l3 = float(t3.train_accumulated([a, b]))
+    np.testing.assert_allclose(l3, 0.5 * (l1 + lb), rtol=1e-4)
+    assert not torch.allclose(t3.flat_p, t1.flat_p)
