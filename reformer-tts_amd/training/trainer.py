@@ -268,6 +268,25 @@ class Trainer:
         self.optimizer_step(True)
         return total / n
 
+    @torch.no_grad()
+    def validate(self, batch):
+        """``LitReformerTTS.validation_step`` (``wrappers.py:107-140``): teacher-forced forward in eval mode (BatchNorm
+        running statistics, no dropout), the four losses; the stacks run through the explicit executor's forward.
+        -> (total, raw, post, stop) device scalars.  Parameters and optimizer state are untouched."""
+        was_training = self.model.training
+        stacks = (self.model.enc.reformer.layers, self.model.dec.reformer.layers)
+        self.model.eval()
+        for st in stacks:
+            st.fused_in_eval = True
+        try:
+            spec = batch["spectrogram"]
+            raw, post, stop, _ = self.model(batch["phonemes"], spec[:, :-1], spectrogram_mask=batch["loss_mask"].mean(dim=-1))
+            return self.loss(raw, post, stop.view(stop.shape[0], -1), spec[:, 1:], batch["stop_tokens"], batch["loss_mask"])
+        finally:
+            for st in stacks:
+                st.fused_in_eval = False
+            self.model.train(was_training)
+
     # ------------------------------------------------------------------ checkpoint / resume
     def state_dict(self) -> dict:
         """Everything a resumed run needs: the model's own state_dict (reference names: loads into the reference and

@@ -991,3 +991,24 @@ def test_gradient_accumulation_semantics(gpu):
     l3 = float(t3.train_accumulated([a, b]))
     np.testing.assert_allclose(l3, 0.5 * (l1 + lb), rtol=1e-4)
     assert not torch.allclose(t3.flat_p, t1.flat_p)
+
+
+def test_validate_is_side_effect_free_and_tracks_training(gpu):
+    """Trainer.validate: eval-mode teacher-forced losses; leaves parameters, BatchNorm statistics and optimizer state
+    alone, and goes down as training on the same batch proceeds."""
+    from reformer_tts_amd.model.config import TTSTrainingConfig
+    from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
+    model = build_model(_hip_cfg(), gpu)
+    tr = Trainer(model, TTSTrainingConfig(batch_size=2, learning_rate=1e-3, warmup_steps=None), gpu)
+    batch = synthetic_batch(2, 100, 256, device=gpu)
+    for _ in range(2):
+        tr.train_step(batch)                      # gives the BatchNorm running statistics something to hold
+    snap = (tr.flat_p.clone(), tr.flat_m.clone(), {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k})
+    v0 = [float(x) for x in tr.validate(batch)]
+    assert model.training and all(np.isfinite(v0))
+    assert torch.equal(tr.flat_p, snap[0]) and torch.equal(tr.flat_m, snap[1])
+    assert all(torch.equal(model.state_dict()[k], v) for k, v in snap[2].items())
+    for _ in range(6):
+        tr.train_step(batch)
+    assert float(tr.validate(batch)[0]) < v0[0]
+
