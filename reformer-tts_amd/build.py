@@ -33,7 +33,9 @@ def build_hip(force: bool = False, verbose: bool = True) -> str:
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-ffp-contract=on"]
+    flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-ffp-contract=on",
+             # no SLP packing of adjacent f32 ops into v_pk_*_f32: beside MFMAs a packed op costs several times two plain ones
+             "-fno-slp-vectorize"]
     objs, procs = [], []
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s) + ".o")

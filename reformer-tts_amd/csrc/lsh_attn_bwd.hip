@@ -25,11 +25,41 @@
 
 typedef __attribute__((ext_vector_type(8))) short short8v;
 
+// Phase probe (scripts/phase_probe.py builds a private copy of this file with -DAB_PHASE_TIMING): wave 0 of every
+// workgroup records the shader clock at the phase boundaries.  Never defined in the product build.
+#ifdef AB_PHASE_TIMING
+__device__ unsigned long long g_ab_phase[32 * 8192];
+#define AB_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_ab_phase[blockIdx.x * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int rtts_debug_ab_phases(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ab_phase), sizeof(g_ab_phase)); }
+#define AB_WSTAMP(i, w) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 8192) g_ab_phase[blockIdx.x * 32 + (i) + (w)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define AB_STAMP(i) do { } while (0)
+#define AB_WSTAMP(i, w) do { } while (0)
+#endif
+
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0, const unsigned char* p1) {
     const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((RTTS_LDS short4v*)p0);
     const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((RTTS_LDS short4v*)p1);
     const short8v both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, both);
+}
+
+// ---- LDS images ---------------------------------------------------------------------------------------------------
+// K/Q and dout images: [row][128 B], no padding; the eight 16-byte pieces of a row are XOR-swizzled with
+//     sw(row) = row bits (2,1) | (row bit 3 ^ row bit 1) << 2
+// so that BOTH access shapes are bank-conflict free (64 banks x 4 B): ds_read_b128 of one piece from 16 rows (the MFMA
+// A/B fragments) and ds_read_b64_tr_b16 of 4 consecutive rows x 64 B (the transposed fragments).  With 144-byte padded
+// rows the transposed reads were 2-way conflicted (rows j and j+2 overlap in 8 banks).
+__device__ __forceinline__ int ab_sw(int row) { return ((row >> 1) & 3) | ((((row >> 3) ^ (row >> 1)) & 1) << 2); }
+__device__ __forceinline__ int ab_off(int row, int piece) { return row * 128 + ((piece ^ ab_sw(row)) << 4); }
+// dS'^T image: [key][BS queries] bf16, no padding, 8-byte granules (4 queries) XOR-swizzled by the key so that the
+// ds_write_b64 of 16 consecutive keys (banks mod 32) and the transposed read of 4 consecutive keys x 64 B (banks mod 64)
+// are both conflict free (the padded image was 4-way conflicted on the read side: the dQ phase ran at LDS speed / 4).
+template <int BS>
+__device__ __forceinline__ int ab_ds_off(int key, int gran) {
+    const int k0 = key & 1, k1 = (key >> 1) & 1, k2 = (key >> 2) & 1, k3 = (key >> 3) & 1;
+    if (BS == 128) return key * 256 + ((gran ^ ((k1 << 4) | (k0 << 3) | (k1 << 2) | (k2 << 1) | k3)) << 3);
+    return key * 128 + ((gran ^ ((k1 << 3) | (k0 << 2) | (k2 << 1) | k3)) << 3);
 }
 
 template <int BS, bool CAUSAL, bool MASKED>
@@ -41,18 +71,20 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
     constexpr int NK = 2 * BS;
     constexpr int NQT = BS / 32;
     constexpr int NTHR = BS * 4;
-    constexpr int KT2 = 1;                // 32-key tiles owned by one wave
-    constexpr int DSROW = BS * 2 + 16;   // bytes per row of the dS^T image [key][query]
+    constexpr int NW = NTHR / 64;
+    constexpr int DSROW = BS * 2;         // bytes per row of the dS^T image [key][query]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* Ks = smem;                                  // [NK][144]  qk rows (own chunk first)
-    unsigned char* Os = Ks + NK * AB_ROWB;                     // [BS][144]  dout rows of the queries
-    unsigned char* Ds = Os + BS * AB_ROWB;                     // [NK][DSROW] dS'^T
-    float* kscale = reinterpret_cast<float*>(Ds + NK * DSROW);
+    // per-row words first: their addresses then fit the 16-bit offset field of the DS instructions
+    float* kscale = reinterpret_cast<float*>(smem);
     int* kpos = reinterpret_cast<int*>(kscale + NK);
     int* kpe = kpos + NK;                                      // effective position: dead <=> kpe[key] > qpe[query]
     float* qlse = reinterpret_cast<float*>(kpe + NK);          // lse_tot * log2(e)
-    float* qdel = qlse + BS;
+    float* qdel = qlse + BS;                                   // MINUS delta: the dP accumulator starts from it
     int* qpe_s = reinterpret_cast<int*>(qdel + BS);            // query-side effective position (-1: an invalid query)
+    unsigned char* Ks = reinterpret_cast<unsigned char*>(qpe_s + BS);   // [NK][128]  qk rows (own chunk first), swizzled
+    unsigned char* Os = Ks + NK * 128;                         // [BS][128]  dout rows of the queries, swizzled
+    unsigned char* Ds = Os + BS * 128;                         // [NK][DSROW] dS'^T, swizzled
+    unsigned char* Stg = Ds + NK * DSROW;                      // [NW][32][144] per-wave staging of the row stores
 
     const int nb = T / BS;
     const int C = n_hashes * nb;
@@ -60,15 +92,18 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
     const int bh = wi / C, c = wi % C;
     const int b = bh / H, h = bh % H;
     const int cprev = (c == 0) ? C - 1 : c - 1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave: an SGPR
     const int r = lane & 31, hh = lane >> 5;
 
+    AB_STAMP(0);
     const int32_t* st_row = st + (size_t)bh * n_hashes * T;
     const bf16_t* qbase = qk + (size_t)b * T * ld + (size_t)h * AB_DH;
     const bf16_t* vbase = v + (size_t)b * T * ld + (size_t)h * AB_DH;
     const bf16_t* dobase = dout + (size_t)b * T * ld_do + (size_t)h * AB_DH;
 
     // ---- gather K rows (all 2*BS) and dout rows (own chunk) into LDS -----------------------
+    // Two dependent global round trips, not three: everything that is indexed by the token position (rows AND the
+    // per-token words mask / lse / delta) is requested as soon as the positions are known.
     constexpr int ITERS = NK * 8 / NTHR;   // 4
     int trow[ITERS];
 #pragma unroll
@@ -77,31 +112,40 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
         const int slot = (row < BS) ? c * BS + row : cprev * BS + (row - BS);
         trow[it] = st_row[slot];
     }
+    const int myrow = wave * 32 + r;       // this wave owns keys [32*wave, 32*wave+32): one per lane (both halves)
+    const int mypos = st_row[(myrow < BS) ? c * BS + myrow : cprev * BS + (myrow - BS)];
+#ifdef AB_PHASE_TIMING
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the positions are here
+    AB_STAMP(10);
+#endif
     uint4 kreg[ITERS], oreg[ITERS / 2];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) kreg[it] = *reinterpret_cast<const uint4*>(qbase + (size_t)trow[it] * ld + (tid & 7) * 8);
 #pragma unroll
     for (int it = 0; it < ITERS / 2; ++it)   // rows < BS are the first half of the iterations
         oreg[it] = *reinterpret_cast<const uint4*>(dobase + (size_t)trow[it] * ld_do + (tid & 7) * 8);
-    // V fragments of this wave's keys go straight to registers (no other wave needs them)
-    int myrow[KT2];
-    bf16x8 vf[KT2][4];
-    int mypos[KT2];
+    int rvalid[ITERS];
+    float rlse[ITERS / 2], rdel[ITERS / 2];
 #pragma unroll
-    for (int k2 = 0; k2 < KT2; ++k2) {
-        myrow[k2] = wave * (32 * KT2) + 32 * k2 + r;
-        const int row = myrow[k2];
-        const int slot = (row < BS) ? c * BS + row : cprev * BS + (row - BS);
-        mypos[k2] = st_row[slot];
+    for (int it = 0; it < ITERS; ++it) rvalid[it] = MASKED ? (int)mask[(size_t)b * T + trow[it]] : 1;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            vf[k2][ks] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)mypos[k2] * ld + ks * 16 + 8 * hh);
+    for (int it = 0; it < ITERS / 2; ++it) {
+        rlse[it] = lse_tot[(size_t)bh * T + trow[it]];
+        rdel[it] = delta[(size_t)bh * T + trow[it]];
     }
+    // V fragments of this wave's keys go straight to registers (no other wave needs them)
+    bf16x8 vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) vf[ks] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)mypos * ld + ks * 16 + 8 * hh);
+#ifdef AB_PHASE_TIMING
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): rows, words and V fragments are here
+    AB_STAMP(11);
+#endif
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int row = (it * NTHR + tid) >> 3, piece = tid & 7;
-        *reinterpret_cast<uint4*>(Ks + row * AB_ROWB + piece * 16) = kreg[it];
-        if (it < ITERS / 2) *reinterpret_cast<uint4*>(Os + row * AB_ROWB + piece * 16) = oreg[it];
+        *reinterpret_cast<uint4*>(Ks + ab_off(row, piece)) = kreg[it];
+        if (it < ITERS / 2) *reinterpret_cast<uint4*>(Os + ab_off(row, piece)) = oreg[it];
         const uint32_t u[4] = {kreg[it].x, kreg[it].y, kreg[it].z, kreg[it].w};
         float ss = 0.f;
 #pragma unroll
@@ -116,161 +160,217 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
         if (piece == 0) {
             kscale[row] = 0.125f * __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));   // dh^-1/2 / max(|k|, 1e-12)
             kpos[row] = trow[it];
-            const int valid = MASKED ? (int)mask[(size_t)b * T + trow[it]] : 1;
-            kpe[row] = valid ? (CAUSAL ? trow[it] : 0) : 0x40000000;
-            if (row < BS) {
-                qlse[row] = lse_tot[(size_t)bh * T + trow[it]] * 1.4426950408889634f;
-                qdel[row] = delta[(size_t)bh * T + trow[it]];
+            kpe[row] = rvalid[it] ? (CAUSAL ? trow[it] : 0) : 0x40000000;
+            if (it < ITERS / 2) {
+                qlse[row] = rlse[it] * 1.4426950408889634f;
+                qdel[row] = -rdel[it];
                 // an invalid query sees nothing but itself: its effective position is below every key's
-                qpe_s[row] = valid ? (CAUSAL ? trow[it] : 0) : -1;
+                qpe_s[row] = rvalid[it] ? (CAUSAL ? trow[it] : 0) : -1;
             }
         }
     }
+    AB_STAMP(1);
     __syncthreads();
+    AB_STAMP(2);
 
     // ---- this wave's key-side constants -----------------------------------------------------
-    bf16x8 kf[KT2][4];
-    float ksc[KT2];
-    int kpk[KT2];
+    // byte offsets of the A/B fragment pieces (ks*2+hh) of row r inside any 32-row block of a swizzled image
+    int fro[4];
 #pragma unroll
-    for (int k2 = 0; k2 < KT2; ++k2) {
+    for (int ks = 0; ks < 4; ++ks) fro[ks] = ab_off(r, ks * 2 + hh);
+    bf16x8 kf[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            kf[k2][ks] = *reinterpret_cast<const bf16x8*>(Ks + myrow[k2] * AB_ROWB + (ks * 16 + 8 * hh) * 2);
-        ksc[k2] = kscale[myrow[k2]];
-        kpk[k2] = kpe[myrow[k2]];
-    }
+    for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(Ks + wave * (32 * 128) + fro[ks]);
+    const float ksc = kscale[myrow];
+    const int kpk = kpe[myrow];
 
-    f32x16 dvacc[KT2][2], gacc[KT2][2];   // [key tile][dh tile]: rows = dh, lane = key
+    f32x16 dvacc[2], gacc[2];   // [dh tile]: rows = dh, lane = key
 #pragma unroll
-    for (int a = 0; a < KT2; ++a)
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            dvacc[a][d] = (f32x16){0};
-            gacc[a][d] = (f32x16){0};
-        }
+    for (int d = 0; d < 2; ++d) {
+        dvacc[d] = (f32x16){0};
+        gacc[d] = (f32x16){0};
+    }
     const int trq = (lane & 15) >> 2, trp = lane & 3, trc = (lane >> 4) & 1;
-    const bool own_tile = myrow[0] < BS;            // wave-uniform
+    // transposed fragments: lane -> (row 4*hh + trq (+8 for the second read), 8-byte granule dt*8 + 4*trc + trp);
+    // sw(row + 8) = sw(row) ^ 4 and dt toggles the same piece bit, so the second read of tile dt sits at tro[dt ^ 1] + 8 rows
+    int tro[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) tro[dt] = ab_off(4 * hh + trq, dt * 4 + 2 * trc + (trp >> 1)) + 8 * (trp & 1);
+    // dS'^T store offsets of this lane's key row at query tile 0; tile qt is granule + 8*qt = byte offset ^ (qt << 6)
+    // (the row base is a multiple of 128 resp. 256 bytes, so bits 6.. of the offset belong to the granule index alone)
+    int dso[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dso[g] = ab_ds_off<BS>(myrow, 2 * g + hh);
+    const bool own_tile = wave < BS / 32;        // wave-uniform (SGPR)
     const bool wrap = (cprev / nb) != (c / nb);
 
 #pragma unroll 1
     for (int qt = 0; qt < NQT; ++qt) {
+        // dP starts at -delta[q] (read first: the second MFMA below waits for it): the accumulator then holds dP - delta,
+        // one subtraction per logit less on the VALU
+        f32x16 sacc = {0}, pacc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 d4 = *reinterpret_cast<const float4*>(qdel + qt * 32 + 8 * g + 4 * hh);
+            pacc[4 * g] = d4.x;
+            pacc[4 * g + 1] = d4.y;
+            pacc[4 * g + 2] = d4.z;
+            pacc[4 * g + 3] = d4.w;
+        }
         bf16x8 qf[4], dof[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            qf[ks] = *reinterpret_cast<const bf16x8*>(Ks + (qt * 32 + r) * AB_ROWB + (ks * 16 + 8 * hh) * 2);
-            dof[ks] = *reinterpret_cast<const bf16x8*>(Os + (qt * 32 + r) * AB_ROWB + (ks * 16 + 8 * hh) * 2);
+            qf[ks] = *reinterpret_cast<const bf16x8*>(Ks + qt * (32 * 128) + fro[ks]);
+            dof[ks] = *reinterpret_cast<const bf16x8*>(Os + qt * (32 * 128) + fro[ks]);
         }
-        // q-side row constants of this tile, issued first so that their LDS latency hides behind the MFMAs below
-        float4 l4[4], d4[4];
+        // q-side row constants of this tile, issued now so that their LDS latency hides behind the MFMAs below
+        float4 l4[4];
         int4 e4[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int q0 = qt * 32 + 8 * g + 4 * hh;
             l4[g] = *reinterpret_cast<const float4*>(qlse + q0);
-            d4[g] = *reinterpret_cast<const float4*>(qdel + q0);
             e4[g] = *reinterpret_cast<const int4*>(qpe_s + q0);
         }
         // Can a key of this wave's tile BE one of this tile's queries (the self logit)?  Own keys: only on the diagonal
         // tile.  Looked-back keys: only when the previous chunk belongs to another hash round (the chunk ring wraps
         // over rounds, so the same token can then sit in both chunks).  Wave-uniform: the common path skips the test.
         const bool chk_self = own_tile ? (wave == qt) : wrap;
+        // Two waves share a SIMD.  The one inside an MFMA burst gets issue priority: an MFMA needs one issue slot per
+        // 32 cycles of matrix pipe, so the other wave's softmax arithmetic fills the slots in between instead of
+        // starving the matrix pipe (oldest-first arbitration let the VALU-heavy wave win every slot).
+        __builtin_amdgcn_s_setprio(3);
 #pragma unroll
-        for (int k2 = 0; k2 < KT2; ++k2) {
-            f32x16 sacc = {0}, pacc = {0};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[k2][ks], sacc, 0, 0, 0);    // S[q][key]
-                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof[ks], vf[k2][ks], pacc, 0, 0, 0);   // dP[q][key]
-            }
-            // P' = exp2(s*ksc*log2e - lse*log2e); dS' = P' (dP - delta) ksc  (0 at the self logit: it was a constant).
-            // ksc multiplies dS' once here: G' = dS'^T Q then gives dK = G' - k^ (k^ . G'), and dQ^T = K^T dS'^T.
-            float pp[16], ds[16];
-            const float ksc2 = ksc[k2] * 1.4426950408889634f;
-            if (chk_self) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float lv[4] = {l4[g].x, l4[g].y, l4[g].z, l4[g].w}, dv_[4] = {d4[g].x, d4[g].y, d4[g].z, d4[g].w};
-                    const int4 p4 = *reinterpret_cast<const int4*>(kpos + qt * 32 + 8 * g + 4 * hh);   // rare path: read here
-                    const int pv[4] = {p4.x, p4.y, p4.z, p4.w}, ev[4] = {e4[g].x, e4[g].y, e4[g].z, e4[g].w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int i = 4 * g + j;
-                        const bool self = pv[j] == mypos[k2];
-                        const bool dead = kpk[k2] > ev[j];
-                        float x = sacc[i] * ksc2;
-                        x = self ? (-5e4f * 1.4426950408889634f) : x;
-                        float p = __builtin_amdgcn_exp2f(x - lv[j]);
-                        p = (dead && !self) ? 0.f : p;
-                        pp[i] = p;
-                        ds[i] = self ? 0.f : p * (pacc[i] - dv_[j]) * ksc[k2];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float lv[4] = {l4[g].x, l4[g].y, l4[g].z, l4[g].w}, dv_[4] = {d4[g].x, d4[g].y, d4[g].z, d4[g].w};
-                    const int ev[4] = {e4[g].x, e4[g].y, e4[g].z, e4[g].w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int i = 4 * g + j;
-                        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[i], ksc2, -lv[j]));
-                        p = (kpk[k2] > ev[j]) ? 0.f : p;
-                        pp[i] = p;
-                        ds[i] = p * (pacc[i] - dv_[j]) * ksc[k2];
-                    }
-                }
-            }
-            // A fragments of the transposed products (element j <-> query 16*s2 + 8*(j>>2) + 4*hh + (j&3)): read only now,
-            // so that their registers are free during the softmax arithmetic above
-            bf16x8 qtf[2][2], dotf[2][2];   // [s2][dh tile]
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const int qb = qt * 32 + 16 * s2 + 4 * hh + trq;
-                    const int col = (dt * 32 + 16 * trc + 4 * trp) * 2;
-                    qtf[s2][dt] = tr_frag(Ks + qb * AB_ROWB + col, Ks + (qb + 8) * AB_ROWB + col);
-                    dotf[s2][dt] = tr_frag(Os + qb * AB_ROWB + col, Os + (qb + 8) * AB_ROWB + col);
-                }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const float* pq = pp + 8 * s2;
-                const float* dq_ = ds + 8 * s2;
-                const bf16x8 pb = cvt_bf16x8(pq[0], pq[1], pq[2], pq[3], pq[4], pq[5], pq[6], pq[7]);
-                const bf16x8 db = cvt_bf16x8(dq_[0], dq_[1], dq_[2], dq_[3], dq_[4], dq_[5], dq_[6], dq_[7]);
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    dvacc[k2][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[s2][dt], pb, dvacc[k2][dt], 0, 0, 0);
-                    gacc[k2][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[s2][dt], db, gacc[k2][dt], 0, 0, 0);
-                }
-            }
-            // dS'^T[key][q] (bf16), 4 consecutive queries per 8-byte store
+        for (int ks = 0; ks < 4; ++ks) {
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[ks], sacc, 0, 0, 0);    // S[q][key]
+            pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof[ks], vf[ks], pacc, 0, 0, 0);   // dP[q][key] - delta[q]
+        }
+        __builtin_amdgcn_s_setprio(0);
+        // P' = exp2(s*ksc*log2e - lse*log2e); dS' = P' (dP - delta) ksc  (0 at the self logit: it was a constant).
+        // ksc multiplies dS' once here: G' = dS'^T Q then gives dK = G' - k^ (k^ . G'), and dQ^T = K^T dS'^T.
+        float pp[16], ds[16];
+        const float ksc2 = ksc * 1.4426950408889634f;
+        if (chk_self) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                uint2 pk;
-                pk.x = pack_bf16x2(ds[4 * g], ds[4 * g + 1]);
-                pk.y = pack_bf16x2(ds[4 * g + 2], ds[4 * g + 3]);
-                *reinterpret_cast<uint2*>(Ds + myrow[k2] * DSROW + (qt * 32 + 8 * g + 4 * hh) * 2) = pk;
+                const float lv[4] = {l4[g].x, l4[g].y, l4[g].z, l4[g].w};
+                const int4 p4 = *reinterpret_cast<const int4*>(kpos + qt * 32 + 8 * g + 4 * hh);   // rare path: read here
+                const int pv[4] = {p4.x, p4.y, p4.z, p4.w}, ev[4] = {e4[g].x, e4[g].y, e4[g].z, e4[g].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = 4 * g + j;
+                    const bool self = pv[j] == mypos;
+                    const bool dead = kpk > ev[j];
+                    float x = sacc[i] * ksc2;
+                    x = self ? (-5e4f * 1.4426950408889634f) : x;
+                    float p = __builtin_amdgcn_exp2f(x - lv[j]);
+                    p = (dead && !self) ? 0.f : p;
+                    pp[i] = p;
+                    ds[i] = self ? 0.f : p * pacc[i] * ksc;
+                }
             }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float lv[4] = {l4[g].x, l4[g].y, l4[g].z, l4[g].w};
+                const int ev[4] = {e4[g].x, e4[g].y, e4[g].z, e4[g].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = 4 * g + j;
+                    float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[i], ksc2, -lv[j]));
+                    p = (kpk > ev[j]) ? 0.f : p;
+                    pp[i] = p;
+                    ds[i] = p * pacc[i] * ksc;
+                }
+            }
+        }
+        // A fragments of the transposed products (element j <-> query 16*s2 + 8*(j>>2) + 4*hh + (j&3)): read only now,
+        // so that their registers are free during the softmax arithmetic above
+        bf16x8 qtf[2][2], dotf[2][2];   // [s2][dh tile]
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int blk = (qt * 32 + 16 * s2) * 128;
+                qtf[s2][dt] = tr_frag(Ks + blk + tro[dt], Ks + blk + 8 * 128 + tro[dt ^ 1]);
+                dotf[s2][dt] = tr_frag(Os + blk + tro[dt], Os + blk + 8 * 128 + tro[dt ^ 1]);
+            }
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const float* pq = pp + 8 * s2;
+            const float* dq_ = ds + 8 * s2;
+            const bf16x8 pb = cvt_bf16x8(pq[0], pq[1], pq[2], pq[3], pq[4], pq[5], pq[6], pq[7]);
+            const bf16x8 db = cvt_bf16x8(dq_[0], dq_[1], dq_[2], dq_[3], dq_[4], dq_[5], dq_[6], dq_[7]);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[s2][dt], pb, dvacc[dt], 0, 0, 0);
+                gacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[s2][dt], db, gacc[dt], 0, 0, 0);
+            }
+        }
+        // dS'^T[key][q] (bf16), 4 consecutive queries per 8-byte store 
+        const int dsq = qt << 6;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 pk;
+            pk.x = pack_bf16x2(ds[4 * g], ds[4 * g + 1]);
+            pk.y = pack_bf16x2(ds[4 * g + 2], ds[4 * g + 3]);
+            *reinterpret_cast<uint2*>(Ds + (dso[g] ^ dsq)) = pk;
         }
     }
 
+    // ---- row stores.  The accumulators hold a key per lane and dh down the registers; each 32-key tile goes through
+    //      a private [32][144 B] LDS staging so that a row leaves as eight 16-byte pieces (full 128-byte lines) instead
+    //      of sixteen scattered 8-byte stores.  dV is final here: it leaves NOW, before the barrier, so that its HBM
+    //      writes run under the dQ phase of the slower waves.
+    AB_STAMP(3);
+    AB_WSTAMP(16, wave);
+    const int round = c / nb, round_prev = cprev / nb;
+    const size_t obase = ((size_t)bh * n_hashes + (own_tile ? round : round_prev)) * T;
+    unsigned char* stg = Stg + wave * (32 * AB_ROWB);
+    const int srow = lane >> 3, spiece = lane & 7;
+    int rpos[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rpos[i] = kpos[wave * 32 + i * 8 + srow];
+    {
+        bf16_t* dvdst = dv_part + (own_tile ? 0 : slot_stride);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 pk;
+                pk.x = pack_bf16x2(dvacc[dt][4 * g], dvacc[dt][4 * g + 1]);
+                pk.y = pack_bf16x2(dvacc[dt][4 * g + 2], dvacc[dt][4 * g + 3]);
+                *reinterpret_cast<uint2*>(stg + r * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2) = pk;
+            }
+        __builtin_amdgcn_wave_barrier();
+        uint4 rowv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rowv[i] = *reinterpret_cast<const uint4*>(stg + (i * 8 + srow) * AB_ROWB + spiece * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dvdst + (obase + rpos[i]) * AB_DH + spiece * 8) = rowv[i];
+    }
+
+    AB_STAMP(4);
+    AB_WSTAMP(24, wave);
     __syncthreads();   // every dS'^T tile is in Ds; nobody reads Os as dout any more
 
+    AB_STAMP(5);
     // ---- dQ^T[dh][q] = K^T dS'^T over all 2*BS keys: wave w finishes (query tile w/2, dh half w%2) and parks it
     //      (bf16) in the dout image's rows: a chunk row is both a query and an own key, so its query-role and
     //      key-role gradients are added before they leave the chip
     {
         const int qt = wave >> 1, dt = wave & 1;
         f32x16 dq = {0};
-        const int col = (dt * 32 + 16 * trc + 4 * trp) * 2;
-        const int qcol = (qt * 32 + 16 * trc + 4 * trp) * 2;
+        const int rl = 8 * hh + trq;                       // key row inside a 16-key step (second read: +4)
+        const int kpc = dt * 4 + 2 * trc + (trp >> 1);     // 16-byte piece of the K row
+        const int ko0 = ab_off(rl, kpc) + 8 * (trp & 1), ko1 = ab_off(rl + 4, kpc) + 8 * (trp & 1);
+        const int gq = qt * 8 + 4 * trc + trp;             // 8-byte granule of the dS^T row
+        const int do0 = ab_ds_off<BS>(rl, gq), do1 = ab_ds_off<BS>(rl + 4, gq);
 #pragma unroll 4
         for (int kb = 0; kb < NK; kb += 16) {
-            const int keyr = kb + 8 * hh + trq;
-            const bf16x8 bfrag = tr_frag(Ds + keyr * DSROW + qcol, Ds + (keyr + 4) * DSROW + qcol);
-            const bf16x8 afrag = tr_frag(Ks + keyr * AB_ROWB + col, Ks + (keyr + 4) * AB_ROWB + col);
+            const bf16x8 bfrag = tr_frag(Ds + kb * DSROW + do0, Ds + kb * DSROW + do1);
+            const bf16x8 afrag = tr_frag(Ks + kb * 128 + ko0, Ks + kb * 128 + ko1);
             dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, dq, 0, 0, 0);
         }
 #pragma unroll
@@ -278,37 +378,31 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
             uint2 pk;
             pk.x = pack_bf16x2(dq[4 * g], dq[4 * g + 1]);
             pk.y = pack_bf16x2(dq[4 * g + 2], dq[4 * g + 3]);
-            *reinterpret_cast<uint2*>(Os + (qt * 32 + r) * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2) = pk;
+            *reinterpret_cast<uint2*>(Os + ab_off(qt * 32 + r, dt * 4 + g) + 8 * hh) = pk;
         }
     }
-    __syncthreads();   // dQ parked; Ds is free: it becomes the per-wave staging of the row stores below
+    AB_STAMP(6);
+    __syncthreads();   // dQ parked
+    AB_STAMP(7);
 
-    // ---- key-side outputs: dK (+ dQ on own rows) and dV of this wave's 32 keys.  The accumulators hold a key per
-    //      lane and dh down the registers; each tile goes through a [32][144 B] LDS staging so that a row leaves as
-    //      eight 16-byte pieces (full 128-byte lines) instead of sixteen scattered 8-byte stores.
-    const int round = c / nb, round_prev = cprev / nb;
-    static_assert(KT2 == 1, "one key tile per wave");
+    // ---- dK (+ dQ on own rows) of this wave's 32 keys
     {
-        const bool own = myrow[0] < BS;   // wave-uniform
-        const size_t obase = ((size_t)bh * n_hashes + (own ? round : round_prev)) * T;
-        bf16_t* dkdst = dqk_part + (own ? 0 : slot_stride);
-        bf16_t* dvdst = dv_part + (own ? 0 : slot_stride);
-        unsigned char* stg = Ds + wave * (32 * AB_ROWB);
+        bf16_t* dkdst = dqk_part + (own_tile ? 0 : slot_stride);
         // k^ . G over the 64 dh (this lane holds 32 of them, the partner half the other 32)
         float kv_[2][16];
         float dot = 0.f;
-        const float inv_norm = ksc[0] * 8.f;
+        const float inv_norm = ksc * 8.f;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const uint2 kk = *reinterpret_cast<const uint2*>(Ks + myrow[0] * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2);
+                const uint2 kk = *reinterpret_cast<const uint2*>(Ks + ab_off(myrow, dt * 4 + g) + 8 * hh);
                 kv_[dt][4 * g] = __uint_as_float(kk.x << 16) * inv_norm;
                 kv_[dt][4 * g + 1] = __uint_as_float(kk.x & 0xffff0000u) * inv_norm;
                 kv_[dt][4 * g + 2] = __uint_as_float(kk.y << 16) * inv_norm;
                 kv_[dt][4 * g + 3] = __uint_as_float(kk.y & 0xffff0000u) * inv_norm;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) dot = __builtin_fmaf(kv_[dt][4 * g + j], gacc[0][dt][4 * g + j], dot);
+                for (int j = 0; j < 4; ++j) dot = __builtin_fmaf(kv_[dt][4 * g + j], gacc[dt][4 * g + j], dot);
             }
         dot += __shfl_xor(dot, 32);
 #pragma unroll
@@ -317,9 +411,9 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
             for (int g = 0; g < 4; ++g) {
                 float dk[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) dk[j] = gacc[0][dt][4 * g + j] - kv_[dt][4 * g + j] * dot;
-                if (own) {
-                    const uint2 dqv = *reinterpret_cast<const uint2*>(Os + myrow[0] * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2);
+                for (int j = 0; j < 4; ++j) dk[j] = gacc[dt][4 * g + j] - kv_[dt][4 * g + j] * dot;
+                if (own_tile) {
+                    const uint2 dqv = *reinterpret_cast<const uint2*>(Os + ab_off(myrow, dt * 4 + g) + 8 * hh);
                     dk[0] += __uint_as_float(dqv.x << 16);
                     dk[1] += __uint_as_float(dqv.x & 0xffff0000u);
                     dk[2] += __uint_as_float(dqv.y << 16);
@@ -331,32 +425,17 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
                 *reinterpret_cast<uint2*>(stg + r * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2) = pk;
             }
         __builtin_amdgcn_wave_barrier();
-        const int srow = lane >> 3, spiece = lane & 7;
         uint4 rowv[4];
-        int rpos[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            rowv[i] = *reinterpret_cast<const uint4*>(stg + (i * 8 + srow) * AB_ROWB + spiece * 16);
-            rpos[i] = kpos[wave * 32 + i * 8 + srow];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dkdst + (obase + rpos[i]) * AB_DH + spiece * 8) = rowv[i];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 pk;
-                pk.x = pack_bf16x2(dvacc[0][dt][4 * g], dvacc[0][dt][4 * g + 1]);
-                pk.y = pack_bf16x2(dvacc[0][dt][4 * g + 2], dvacc[0][dt][4 * g + 3]);
-                *reinterpret_cast<uint2*>(stg + r * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2) = pk;
-            }
-        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int i = 0; i < 4; ++i) rowv[i] = *reinterpret_cast<const uint4*>(stg + (i * 8 + srow) * AB_ROWB + spiece * 16);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dvdst + (obase + rpos[i]) * AB_DH + spiece * 8) = rowv[i];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dkdst + (obase + rpos[i]) * AB_DH + spiece * 8) = rowv[i];
     }
+    AB_STAMP(8);
+#ifdef AB_PHASE_TIMING
+    __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): the row stores have been acknowledged
+    AB_STAMP(9);
+#endif
 }
 
 static bool g_bwd_attr_set[2][4];
@@ -366,7 +445,7 @@ static int launch_attn_bwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const 
                            const bf16_t* dout, int64_t ld_do, const float* lse_tot, const float* delta, int B, int H, int T,
                            int n_hashes, int causal, bf16_t* dqk_part, bf16_t* dv_part, hipStream_t stream) {
     constexpr int NK = 2 * BS;
-    const size_t lds = NK * AB_ROWB + BS * AB_ROWB + NK * (BS * 2 + 16) + NK * 12 + BS * 12;
+    const size_t lds = NK * 128 + BS * 128 + NK * (BS * 2) + (BS * 4 / 64) * 32 * AB_ROWB + NK * 12 + BS * 12;
     const dim3 grid(B * H * n_hashes * (T / BS)), block(BS * 4);
     const size_t slot_stride = (size_t)B * H * n_hashes * T * AB_DH;
     const int vi = (causal ? 2 : 0) + (mask ? 1 : 0);
