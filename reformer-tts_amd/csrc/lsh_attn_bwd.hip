@@ -141,6 +141,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): rows, words and V fragments are here
     AB_STAMP(11);
 #endif
+    const int cbase = (tid & 7) < 3 ? (tid & 7) * (NK * 4) : 3 * NK * 4 + ((tid & 7) - 3) * (BS * 4);   // word array of this lane
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int row = (it * NTHR + tid) >> 3, piece = tid & 7;
@@ -154,19 +155,21 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
             ss = __builtin_fmaf(a, a, ss);
             ss = __builtin_fmaf(bq, bq, ss);
         }
-        ss += __shfl_xor(ss, 1);
-        ss += __shfl_xor(ss, 2);
-        ss += __shfl_xor(ss, 4);
-        if (piece == 0) {
-            kscale[row] = 0.125f * __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));   // dh^-1/2 / max(|k|, 1e-12)
-            kpos[row] = trow[it];
-            kpe[row] = rvalid[it] ? (CAUSAL ? trow[it] : 0) : 0x40000000;
+        ss = rtts_sum8(ss);
+        // the row's words leave in ONE ds_write_b32: lane `piece` of the row's eight lanes stores word `piece`
+        // (0 kscale, 1 kpos, 2 kpe; query rows also 3 lse*log2e, 4 -delta, 5 query-side effective position)
+        {
+            const int eff = CAUSAL ? trow[it] : 0;
+            int w = __float_as_int(0.125f * __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f)));   // dh^-1/2 / max(|k|, 1e-12)
+            w = piece == 1 ? trow[it] : w;
+            w = piece == 2 ? (rvalid[it] ? eff : 0x40000000) : w;
             if (it < ITERS / 2) {
-                qlse[row] = rlse[it] * 1.4426950408889634f;
-                qdel[row] = -rdel[it];
+                w = piece == 3 ? __float_as_int(rlse[it < ITERS / 2 ? it : 0] * 1.4426950408889634f) : w;
+                w = piece == 4 ? __float_as_int(-rdel[it < ITERS / 2 ? it : 0]) : w;
                 // an invalid query sees nothing but itself: its effective position is below every key's
-                qpe_s[row] = rvalid[it] ? (CAUSAL ? trow[it] : 0) : -1;
+                w = piece == 5 ? (rvalid[it] ? eff : -1) : w;
             }
+            if (piece < (it < ITERS / 2 ? 6 : 3)) *reinterpret_cast<int*>(smem + cbase + row * 4) = w;
         }
     }
     AB_STAMP(1);
@@ -388,30 +391,30 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
     // ---- dK (+ dQ on own rows) of this wave's 32 keys
     {
         bf16_t* dkdst = dqk_part + (own_tile ? 0 : slot_stride);
-        // k^ . G over the 64 dh (this lane holds 32 of them, the partner half the other 32)
-        float kv_[2][16];
+        // dK = G - k^ (k^ . G) with k^ = k / |k| = k * (8 ksc): on the raw bf16 row that is G - k * ((k . G) * (8 ksc)^2);
+        // this lane holds 32 of the 64 dh, the partner half the other 32
+        float kraw[2][16];
         float dot = 0.f;
-        const float inv_norm = ksc * 8.f;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const uint2 kk = *reinterpret_cast<const uint2*>(Ks + ab_off(myrow, dt * 4 + g) + 8 * hh);
-                kv_[dt][4 * g] = __uint_as_float(kk.x << 16) * inv_norm;
-                kv_[dt][4 * g + 1] = __uint_as_float(kk.x & 0xffff0000u) * inv_norm;
-                kv_[dt][4 * g + 2] = __uint_as_float(kk.y << 16) * inv_norm;
-                kv_[dt][4 * g + 3] = __uint_as_float(kk.y & 0xffff0000u) * inv_norm;
+                kraw[dt][4 * g] = __uint_as_float(kk.x << 16);
+                kraw[dt][4 * g + 1] = __uint_as_float(kk.x & 0xffff0000u);
+                kraw[dt][4 * g + 2] = __uint_as_float(kk.y << 16);
+                kraw[dt][4 * g + 3] = __uint_as_float(kk.y & 0xffff0000u);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) dot = __builtin_fmaf(kv_[dt][4 * g + j], gacc[dt][4 * g + j], dot);
+                for (int j = 0; j < 4; ++j) dot = __builtin_fmaf(kraw[dt][4 * g + j], gacc[dt][4 * g + j], dot);
             }
-        dot += __shfl_xor(dot, 32);
+        const float ncoef = -rtts_xhalf_sum(dot) * (ksc * 8.f) * (ksc * 8.f);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float dk[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) dk[j] = gacc[dt][4 * g + j] - kv_[dt][4 * g + j] * dot;
+                for (int j = 0; j < 4; ++j) dk[j] = __builtin_fmaf(kraw[dt][4 * g + j], ncoef, gacc[dt][4 * g + j]);
                 if (own_tile) {
                     const uint2 dqv = *reinterpret_cast<const uint2*>(Os + ab_off(myrow, dt * 4 + g) + 8 * hh);
                     dk[0] += __uint_as_float(dqv.x << 16);

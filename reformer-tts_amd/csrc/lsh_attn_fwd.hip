@@ -88,9 +88,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
                 ss = __builtin_fmaf(a, a, ss);
                 ss = __builtin_fmaf(bq, bq, ss);
             }
-            ss += __shfl_xor(ss, 1);
-            ss += __shfl_xor(ss, 2);
-            ss += __shfl_xor(ss, 4);
+            ss = rtts_sum8(ss);
             if (piece == 0) {
                 const int valid = MASKED ? (int)mask[(size_t)b * T + trow[it]] : 1;
                 ksc[row] = (0.125f * AF_LOG2E) * __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));   // 1 / max(|k|, 1e-12)
@@ -165,7 +163,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
                 }
             }
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        tmax = rtts_xhalf_max(tmax);
         const float mnew = fmaxf(m, tmax);
         const float alpha = __builtin_amdgcn_exp2f(m - mnew);
         m = mnew;
@@ -198,7 +196,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
             }
         }
     }
-    l += __shfl_xor(l, 32);
+    l = rtts_xhalf_sum(l);
 
     // ---- merge the two key halves of a query tile through LDS (aliases the K image) ----------
     float* part = reinterpret_cast<float*>(Ks) + (size_t)qt * 34 * 64;   // [34][64]: 32 x O, m, l per lane

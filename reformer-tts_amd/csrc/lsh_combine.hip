@@ -76,9 +76,7 @@ __global__ __launch_bounds__(256) void lsh_bwd_delta_kernel(const bf16_t* __rest
 #pragma unroll
         for (int k = 0; k < 8; ++k) s = __builtin_fmaf(a[k], g[k], s);
     }
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    s += __shfl_xor(s, 4);
+    s = rtts_sum8(s);
     if (row < rows && piece == 0) delta[row] = s;
 }
 

@@ -59,6 +59,24 @@ __device__ __forceinline__ bf16x8 cvt_bf16x8(float a0, float a1, float a2, float
     return __builtin_convertvector(v, bf16x8);
 }
 
+// Cross-lane reductions without the LDS crossbar (ds_bpermute costs an LDS round trip per step):
+// sum over each aligned group of 8 lanes, result in all 8 (two quad_perm DPP adds + one row_half_mirror)
+__device__ __forceinline__ float rtts_sum8(float x) {
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));    // lane ^ 1
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));    // lane ^ 2
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true));   // 7 - lane: the other quad
+    return x;
+}
+// lane l and lane l ^ 32 combined: v_permlane32_swap (gfx950) leaves {x[l & 31], x[32 + (l & 31)]} in the two results
+__device__ __forceinline__ float rtts_xhalf_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float rtts_xhalf_max(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 // XCD-aware bijective remap of a linear workgroup id: the hardware deals workgroups
 // round-robin over the 8 XCDs, so ids congruent mod 8 share an L2.  Give each XCD a
 // contiguous range of work items so that neighbours (which share gathered rows) hit in L2.

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const bf16_t* __restrict
                 m = fmaxf(m, x);
             }
         }
-    m = fmaxf(m, __shfl_xor(m, 32));
+    m = rtts_xhalf_max(m);
     float l = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const bf16_t* __restrict
             s[kt][i] = p;
             l += p;
         }
-    l += __shfl_xor(l, 32);
+    l = rtts_xhalf_sum(l);
     if (thresh) {
         // nn.MultiheadAttention(dropout=p): dropout on the NORMALISED probabilities; l above is the full normaliser, the
         // keep-scale of element (head, query, key) multiplies the unnormalised p before P V
