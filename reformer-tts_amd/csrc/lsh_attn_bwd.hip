@@ -22,6 +22,12 @@
 
 #define AB_DH 64
 #define AB_ROWB 144
+#ifndef AB_DQ_UNROLL
+#define AB_DQ_UNROLL 16
+#endif
+#ifndef AB_UNROLL
+#define AB_UNROLL 4   // query-tile loop fully unrolled: the tail of tile i (dV, G MFMAs, dS stores) overlaps the head of tile i+1; scripts/phase_probe.py --unroll N measures others
+#endif
 
 typedef __attribute__((ext_vector_type(8))) short short8v;
 
@@ -75,10 +81,10 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
     constexpr int DSROW = BS * 2;         // bytes per row of the dS^T image [key][query]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // per-row words first: their addresses then fit the 16-bit offset field of the DS instructions
-    float* kscale = reinterpret_cast<float*>(smem);
-    int* kpos = reinterpret_cast<int*>(kscale + NK);
-    int* kpe = kpos + NK;                                      // effective position: dead <=> kpe[key] > qpe[query]
-    float* qlse = reinterpret_cast<float*>(kpe + NK);          // lse_tot * log2(e)
+    // (the key-side scale and effective position of a wave's 32 keys live in its registers; word arrays 0 and 2 of
+    // the region are unused)
+    int* kpos = reinterpret_cast<int*>(smem) + NK;             // original position of every row (self test, row stores)
+    float* qlse = reinterpret_cast<float*>(kpos + 2 * NK);     // lse_tot * log2(e)
     float* qdel = qlse + BS;                                   // MINUS delta: the dP accumulator starts from it
     int* qpe_s = reinterpret_cast<int*>(qdel + BS);            // query-side effective position (-1: an invalid query)
     unsigned char* Ks = reinterpret_cast<unsigned char*>(qpe_s + BS);   // [NK][128]  qk rows (own chunk first), swizzled
@@ -118,60 +124,51 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the positions are here
     AB_STAMP(10);
 #endif
-    uint4 kreg[ITERS], oreg[ITERS / 2];
+    // Rows go global -> LDS by DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write pass).  One wave-instruction
+    // fills 8 consecutive 128-byte rows of the image in lane order, so the swizzle goes on the SOURCE side: the lane
+    // that lands on physical piece (lane & 7) of row (lane >> 3) fetches logical piece (lane & 7) ^ sw(row).
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) kreg[it] = *reinterpret_cast<const uint4*>(qbase + (size_t)trow[it] * ld + (tid & 7) * 8);
-#pragma unroll
-    for (int it = 0; it < ITERS / 2; ++it)   // rows < BS are the first half of the iterations
-        oreg[it] = *reinterpret_cast<const uint4*>(dobase + (size_t)trow[it] * ld_do + (tid & 7) * 8);
-    int rvalid[ITERS];
+    for (int it = 0; it < ITERS; ++it) {
+        const int rowb = it * (NTHR / 8) + wave * 8;            // wave-uniform: first row of this instruction
+        const int lp = (lane & 7) ^ ab_sw(rowb + (lane >> 3));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qbase + (size_t)trow[it] * ld + lp * 8),
+                                         (RTTS_LDS void*)(Ks + rowb * 128), 16, 0, 0);
+        if (it < ITERS / 2)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dobase + (size_t)trow[it] * ld_do + lp * 8),
+                                             (RTTS_LDS void*)(Os + rowb * 128), 16, 0, 0);
+    }
+    int rvalid[ITERS / 2];
     float rlse[ITERS / 2], rdel[ITERS / 2];
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) rvalid[it] = MASKED ? (int)mask[(size_t)b * T + trow[it]] : 1;
-#pragma unroll
     for (int it = 0; it < ITERS / 2; ++it) {
+        rvalid[it] = MASKED ? (int)mask[(size_t)b * T + trow[it]] : 1;
         rlse[it] = lse_tot[(size_t)bh * T + trow[it]];
         rdel[it] = delta[(size_t)bh * T + trow[it]];
     }
+    const int myvalid = MASKED ? (int)mask[(size_t)b * T + mypos] : 1;
     // V fragments of this wave's keys go straight to registers (no other wave needs them)
     bf16x8 vf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) vf[ks] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)mypos * ld + ks * 16 + 8 * hh);
 #ifdef AB_PHASE_TIMING
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): rows, words and V fragments are here
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     AB_STAMP(11);
 #endif
-    const int cbase = (tid & 7) < 3 ? (tid & 7) * (NK * 4) : 3 * NK * 4 + ((tid & 7) - 3) * (BS * 4);   // word array of this lane
+    // query-side words: lane `piece` of a row's eight lanes stores word `piece` (3 lse*log2e, 4 -delta, 5 effective
+    // position, 1 position); the key-side words of a wave's own 32 keys never leave its registers
+    const int cbase = (tid & 7) < 3 ? (tid & 7) * (NK * 4) : 3 * NK * 4 + ((tid & 7) - 3) * (BS * 4);
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
+    for (int it = 0; it < ITERS / 2; ++it) {
         const int row = (it * NTHR + tid) >> 3, piece = tid & 7;
-        *reinterpret_cast<uint4*>(Ks + ab_off(row, piece)) = kreg[it];
-        if (it < ITERS / 2) *reinterpret_cast<uint4*>(Os + ab_off(row, piece)) = oreg[it];
-        const uint32_t u[4] = {kreg[it].x, kreg[it].y, kreg[it].z, kreg[it].w};
-        float ss = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float a = __uint_as_float(u[k] << 16), bq = __uint_as_float(u[k] & 0xffff0000u);
-            ss = __builtin_fmaf(a, a, ss);
-            ss = __builtin_fmaf(bq, bq, ss);
-        }
-        ss = rtts_sum8(ss);
-        // the row's words leave in ONE ds_write_b32: lane `piece` of the row's eight lanes stores word `piece`
-        // (0 kscale, 1 kpos, 2 kpe; query rows also 3 lse*log2e, 4 -delta, 5 query-side effective position)
-        {
-            const int eff = CAUSAL ? trow[it] : 0;
-            int w = __float_as_int(0.125f * __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f)));   // dh^-1/2 / max(|k|, 1e-12)
-            w = piece == 1 ? trow[it] : w;
-            w = piece == 2 ? (rvalid[it] ? eff : 0x40000000) : w;
-            if (it < ITERS / 2) {
-                w = piece == 3 ? __float_as_int(rlse[it < ITERS / 2 ? it : 0] * 1.4426950408889634f) : w;
-                w = piece == 4 ? __float_as_int(-rdel[it < ITERS / 2 ? it : 0]) : w;
-                // an invalid query sees nothing but itself: its effective position is below every key's
-                w = piece == 5 ? (rvalid[it] ? eff : -1) : w;
-            }
-            if (piece < (it < ITERS / 2 ? 6 : 3)) *reinterpret_cast<int*>(smem + cbase + row * 4) = w;
-        }
+        const int eff = CAUSAL ? trow[it] : 0;
+        int w = trow[it];
+        w = piece == 3 ? __float_as_int(rlse[it] * 1.4426950408889634f) : w;
+        w = piece == 4 ? __float_as_int(-rdel[it]) : w;
+        // an invalid query sees nothing but itself: its effective position is below every key's
+        w = piece == 5 ? (rvalid[it] ? eff : -1) : w;
+        if (piece == 1 || (piece >= 3 && piece < 6)) *reinterpret_cast<int*>(smem + cbase + row * 4) = w;
     }
+    if (hh == 0 && myrow >= BS) kpos[myrow] = mypos;   // looked-back rows: only this wave reads them back (row stores)
     AB_STAMP(1);
     __syncthreads();
     AB_STAMP(2);
@@ -184,8 +181,24 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
     bf16x8 kf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(Ks + wave * (32 * 128) + fro[ks]);
-    const float ksc = kscale[myrow];
-    const int kpk = kpe[myrow];
+    float ksc;
+    {
+        float ss = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const uint4 u4 = __builtin_bit_cast(uint4, kf[ks]);
+            const uint32_t u[4] = {u4.x, u4.y, u4.z, u4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float a = __uint_as_float(u[k] << 16), bq = __uint_as_float(u[k] & 0xffff0000u);
+                ss = __builtin_fmaf(a, a, ss);
+                ss = __builtin_fmaf(bq, bq, ss);
+            }
+        }
+        ss = rtts_xhalf_sum(ss);
+        ksc = 0.125f * __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));   // dh^-1/2 / max(|k|, 1e-12)
+    }
+    const int kpk = myvalid ? (CAUSAL ? mypos : 0) : 0x40000000;
 
     f32x16 dvacc[2], gacc[2];   // [dh tile]: rows = dh, lane = key
 #pragma unroll
@@ -207,7 +220,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
     const bool own_tile = wave < BS / 32;        // wave-uniform (SGPR)
     const bool wrap = (cprev / nb) != (c / nb);
 
-#pragma unroll 1
+#pragma unroll AB_UNROLL
     for (int qt = 0; qt < NQT; ++qt) {
         // dP starts at -delta[q] (read first: the second MFMA below waits for it): the accumulator then holds dP - delta,
         // one subtraction per logit less on the VALU
@@ -242,13 +255,11 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
         // Two waves share a SIMD.  The one inside an MFMA burst gets issue priority: an MFMA needs one issue slot per
         // 32 cycles of matrix pipe, so the other wave's softmax arithmetic fills the slots in between instead of
         // starving the matrix pipe (oldest-first arbitration let the VALU-heavy wave win every slot).
-        __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[ks], sacc, 0, 0, 0);    // S[q][key]
             pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof[ks], vf[ks], pacc, 0, 0, 0);   // dP[q][key] - delta[q]
         }
-        __builtin_amdgcn_s_setprio(0);
         // P' = exp2(s*ksc*log2e - lse*log2e); dS' = P' (dP - delta) ksc  (0 at the self logit: it was a constant).
         // ksc multiplies dS' once here: G' = dS'^T Q then gives dK = G' - k^ (k^ . G'), and dQ^T = K^T dS'^T.
         float pp[16], ds[16];
@@ -298,7 +309,6 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
                 qtf[s2][dt] = tr_frag(Ks + blk + tro[dt], Ks + blk + 8 * 128 + tro[dt ^ 1]);
                 dotf[s2][dt] = tr_frag(Os + blk + tro[dt], Os + blk + 8 * 128 + tro[dt ^ 1]);
             }
-        __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const float* pq = pp + 8 * s2;
@@ -370,7 +380,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
         const int ko0 = ab_off(rl, kpc) + 8 * (trp & 1), ko1 = ab_off(rl + 4, kpc) + 8 * (trp & 1);
         const int gq = qt * 8 + 4 * trc + trp;             // 8-byte granule of the dS^T row
         const int do0 = ab_ds_off<BS>(rl, gq), do1 = ab_ds_off<BS>(rl + 4, gq);
-#pragma unroll 4
+#pragma unroll AB_DQ_UNROLL
         for (int kb = 0; kb < NK; kb += 16) {
             const bf16x8 bfrag = tr_frag(Ds + kb * DSROW + do0, Ds + kb * DSROW + do1);
             const bf16x8 afrag = tr_frag(Ks + kb * 128 + ko0, Ks + kb * 128 + ko1);

@@ -15,12 +15,13 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "reformer-tts_amd", "csrc")
-PROBE = os.path.join(ROOT, "reformer-tts_amd", "lib", "librtts_probe.so")
+UNROLL = next((sys.argv[i + 1] for i, a in enumerate(sys.argv) if a == "--unroll"), "1")
+PROBE = os.path.join(ROOT, "reformer-tts_amd", "lib", f"librtts_probe_u{UNROLL}.so")
 
 
 def build():
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-ffp-contract=on",
-           "-fno-slp-vectorize", "-DAB_PHASE_TIMING", "-shared", "-x", "hip", os.path.join(CSRC, "lsh_attn_bwd.hip"), os.path.join(CSRC, "rtts_api.cpp"),
+           "-fno-slp-vectorize", "-DAB_PHASE_TIMING", f"-DAB_UNROLL={UNROLL}", "-shared", "-x", "hip", os.path.join(CSRC, "lsh_attn_bwd.hip"), os.path.join(CSRC, "rtts_api.cpp"),
            "-o", PROBE]
     print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
