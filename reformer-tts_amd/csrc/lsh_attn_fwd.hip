@@ -30,6 +30,17 @@
 
 typedef __attribute__((ext_vector_type(8))) short af_short8;
 
+// key-tile loop unroll: 2 for bucket size 64 (4-wave workgroups, registers to spare: -4 %), 1 for 128 (unrolling costs the
+// second workgroup per CU: +35 %); scripts/ab_attn.py --fwd measures others
+#ifndef AF_UNROLL
+#define AF_UNROLL (BS == 64 ? 2 : 1)
+#endif
+// V image: [row][128 B] without padding, the eight 16-byte pieces of a row XOR-swizzled (same function as the backward's
+// images, lsh_attn_bwd.hip) so that the transposed reads (4 consecutive rows x 64 B) are bank-conflict free; it is filled by
+// LDS-DMA, the swizzle applied on the source side.
+__device__ __forceinline__ int af_sw(int row) { return ((row >> 1) & 3) | ((((row >> 3) ^ (row >> 1)) & 1) << 2); }
+__device__ __forceinline__ int af_voff(int row, int piece) { return row * 128 + ((piece ^ af_sw(row)) << 4); }
+
 template <int BS, bool CAUSAL, bool MASKED>
 __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v,
                                                                  int64_t ld, const int32_t* __restrict__ st,
@@ -41,7 +52,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
     constexpr int NQT = BS / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Ks = smem;
-    unsigned char* Vs = Ks + NK * AF_ROWB;
+    unsigned char* Vs = Ks + NK * AF_ROWB;                       // [NK][128] swizzled (the output staging reuses it, padded)
     float* ksc = reinterpret_cast<float*>(Vs + NK * AF_ROWB);   // dh^-1/2 / |k| * log2(e)
     int* kpos = reinterpret_cast<int*>(ksc + NK);                // original position (self test)
     int* kpe = kpos + NK;                                        // effective position for the `dead` compare
@@ -52,7 +63,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
     const int bh = wi / C, c = wi % C;
     const int b = bh / H, h = bh % H;
     const int cprev = (c == 0) ? C - 1 : c - 1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     const int32_t* st_row = st + (size_t)bh * n_hashes * T;
     const bf16_t* qbase = qk + (size_t)b * T * ld + (size_t)h * AF_DH;
@@ -68,18 +79,26 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
             const int slot = (row < BS) ? c * BS + row : cprev * BS + (row - BS);
             trow[it] = st_row[slot];
         }
-        uint4 kreg[ITERS], vreg[ITERS];
+        uint4 kreg[ITERS];
+        int rvalid[ITERS];
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int piece = tid & 7;
             kreg[it] = *reinterpret_cast<const uint4*>(qbase + (size_t)trow[it] * ld + piece * 8);
-            vreg[it] = *reinterpret_cast<const uint4*>(vbase + (size_t)trow[it] * ld + piece * 8);
+            // V rows: global -> LDS by DMA; one wave-instruction fills 8 consecutive rows in lane order, so the lane that
+            // lands on physical piece (lane & 7) of row (lane >> 3) fetches logical piece (lane & 7) ^ sw(row)
+            const int rowb = it * (NTHR / 8) + wave * 8;
+            const int lp = (lane & 7) ^ af_sw(rowb + (lane >> 3));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + (size_t)trow[it] * ld + lp * 8),
+                                             (RTTS_LDS void*)(Vs + rowb * 128), 16, 0, 0);
+            // everything indexed by the position is requested now: two dependent global round trips, not three
+            rvalid[it] = MASKED ? (int)mask[(size_t)b * T + trow[it]] : 1;
         }
+        const int cbase = (tid & 7) * (NK * 4);   // word array of this lane: 0 ksc, 1 kpos, 2 kpe
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int row = (it * NTHR + tid) >> 3, piece = tid & 7;
             *reinterpret_cast<uint4*>(Ks + row * AF_ROWB + piece * 16) = kreg[it];
-            *reinterpret_cast<uint4*>(Vs + row * AF_ROWB + piece * 16) = vreg[it];
             const uint32_t u[4] = {kreg[it].x, kreg[it].y, kreg[it].z, kreg[it].w};
             float ss = 0.f;
 #pragma unroll
@@ -89,13 +108,12 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
                 ss = __builtin_fmaf(bq, bq, ss);
             }
             ss = rtts_sum8(ss);
-            if (piece == 0) {
-                const int valid = MASKED ? (int)mask[(size_t)b * T + trow[it]] : 1;
-                ksc[row] = (0.125f * AF_LOG2E) * __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));   // 1 / max(|k|, 1e-12)
-                kpos[row] = trow[it];
-                // dead <=> kpe > qpe.  causal: positions; otherwise 0.  An invalid key is beyond every query.
-                kpe[row] = valid ? (CAUSAL ? trow[it] : 0) : AF_BIGPOS;
-            }
+            // the row's three words leave in one ds_write_b32: lane `piece` stores word `piece`
+            int w = __float_as_int((0.125f * AF_LOG2E) * __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f)));   // 1 / max(|k|, 1e-12)
+            w = piece == 1 ? trow[it] : w;
+            // dead <=> kpe > qpe.  causal: positions; otherwise 0.  An invalid key is beyond every query.
+            w = piece == 2 ? (rvalid[it] ? (CAUSAL ? trow[it] : 0) : AF_BIGPOS) : w;
+            if (piece < 3) *reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(ksc) + cbase + row * 4) = w;
         }
     }
     __syncthreads();
@@ -112,10 +130,14 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
     const int qpe = (kpe[qrow] == AF_BIGPOS) ? -1 : (CAUSAL ? qpos : 0);
     const int trq = (lane & 15) >> 2, trp = lane & 3, trc = (lane >> 4) & 1;
 
+    int tro[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) tro[dt] = af_voff(4 * hh + trq, dt * 4 + 2 * trc + (trp >> 1)) + 8 * (trp & 1);
+
     const bool wrap = (cprev / nb) != (c / nb);
     float m = AF_NEG, l = 0.f;
     f32x16 oacc[2] = {{0}, {0}};
-#pragma unroll 1
+#pragma unroll AF_UNROLL
     for (int kt = kh * (NKT / 2); kt < (kh + 1) * (NKT / 2); ++kt) {
         f32x16 acc = {0};
 #pragma unroll
@@ -187,10 +209,10 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
             const bf16x8 pf = cvt_bf16x8(acc[o8], acc[o8 + 1], acc[o8 + 2], acc[o8 + 3], acc[o8 + 4], acc[o8 + 5], acc[o8 + 6], acc[o8 + 7]);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                const int keyb = kt * 32 + 16 * s2 + 4 * hh + trq;
-                const int col = dt * 32 + 16 * trc + 4 * trp;
-                const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((RTTS_LDS short4v*)(Vs + keyb * AF_ROWB + col * 2));
-                const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((RTTS_LDS short4v*)(Vs + (keyb + 8) * AF_ROWB + col * 2));
+                // rows 4*hh + trq (+8) of the 16-key block, 8-byte granule dt*8 + 4*trc + trp; sw(row + 8) = sw(row) ^ 4
+                const int blk = (kt * 32 + 16 * s2) * 128;
+                const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((RTTS_LDS short4v*)(Vs + blk + tro[dt]));
+                const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((RTTS_LDS short4v*)(Vs + blk + 8 * 128 + tro[dt ^ 1]));
                 const af_short8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, both), pf, oacc[dt], 0, 0, 0);
             }

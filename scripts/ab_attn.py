@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""A/B timing of lsh_attn_bwd build variants on ONE box (box-to-box spread is larger than most kernel changes).
+"""A/B timing of lsh_attn_bwd (or, with --fwd, lsh_attn_fwd) build variants on ONE box (box-to-box spread is larger than most kernel changes).
 
-    python scripts/ab_bwd.py --build "-DAB_UNROLL=1" "-DAB_UNROLL=2" "-DAB_UNROLL=4"    # here: one private .so per flag set
-    python scripts/ab_bwd.py "-DAB_UNROLL=1" "-DAB_UNROLL=2" "-DAB_UNROLL=4"            # GPU box: interleaved timing
+    python scripts/ab_attn.py --build "-DAB_UNROLL=1" "-DAB_UNROLL=2" "-DAB_UNROLL=4"    # here: one private .so per flag set
+    python scripts/ab_attn.py "-DAB_UNROLL=1" "-DAB_UNROLL=2" "-DAB_UNROLL=4"            # GPU box: interleaved timing
 Each variant is csrc/lsh_attn_bwd.hip + rtts_api.cpp compiled with the product flags plus the given ones; the product
 library is not touched."""
 import ctypes as C
@@ -16,20 +16,23 @@ sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "reformer-tts_amd", "csrc")
 
 
+KERNEL = "fwd" if "--fwd" in sys.argv else "bwd"
+
+
 def lib_path(flags):
-    return os.path.join(ROOT, "reformer-tts_amd", "lib", "librtts_ab_" + hashlib.md5(flags.encode()).hexdigest()[:8] + ".so")
+    return os.path.join(ROOT, "reformer-tts_amd", "lib", "librtts_ab_" + KERNEL + "_" + hashlib.md5(flags.encode()).hexdigest()[:8] + ".so")
 
 
 def build(flags):
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-ffp-contract=on",
-           "-fno-slp-vectorize", *flags.split(), "-shared", "-x", "hip", os.path.join(CSRC, "lsh_attn_bwd.hip"),
+           "-fno-slp-vectorize", *flags.split(), "-shared", "-x", "hip", os.path.join(CSRC, f"lsh_attn_{KERNEL}.hip"),
            os.path.join(CSRC, "rtts_api.cpp"), "-o", lib_path(flags)]
     print(" ".join(cmd[-8:]), flush=True)
     subprocess.check_call(cmd)
 
 
 def main():
-    args = [a for a in sys.argv[1:] if a != "--build"]
+    args = [a for a in sys.argv[1:] if a not in ("--build", "--fwd")]
     if "--build" in sys.argv:
         for f in args:
             build(f)
@@ -40,7 +43,7 @@ def main():
     libs = []
     for f in args:
         lib = C.CDLL(lib_path(f))
-        lib.rtts_lsh_attn_bwd.argtypes = _lib.SIGNATURES["rtts_lsh_attn_bwd"]
+        getattr(lib, f"rtts_lsh_attn_{KERNEL}").argtypes = _lib.SIGNATURES[f"rtts_lsh_attn_{KERNEL}"]
         libs.append(lib)
     for name, (b, h, t, bs, nh, causal) in dict(dec=(12, 8, 1024, 128, 8, True), enc=(12, 8, 256, 64, 8, False),
                                                  long=(4, 8, 4096, 64, 8, True)).items():
@@ -65,8 +68,16 @@ def main():
             for i, lib in enumerate(libs):
                 dqk = torch.zeros(2, b * h, nh, t, dh, dtype=torch.bfloat16, device=dev)
                 dv = torch.zeros(2, b * h, nh, t, dh, dtype=torch.bfloat16, device=dev)
+                if KERNEL == "fwd":
+                    dqk = torch.zeros(b * h, nh, t, dh, dtype=torch.bfloat16, device=dev)   # o
+                    dv = torch.zeros(b * h, nh, t, dtype=torch.float32, device=dev)        # lse
 
                 def run():
+                    if KERNEL == "fwd":
+                        rc = lib.rtts_lsh_attn_fwd(qk.data_ptr(), v.data_ptr(), qkv.stride(1), st.data_ptr(), mask.data_ptr(), b, h, t, dh,
+                                                   nh, bs, int(causal), dqk.data_ptr(), dv.data_ptr(), s)
+                        assert rc == 0
+                        return
                     rc = lib.rtts_lsh_attn_bwd(qk.data_ptr(), v.data_ptr(), qkv.stride(1), st.data_ptr(), mask.data_ptr(),
                                                dout.data_ptr(), dout.stride(1), lse_tot.data_ptr(), delta.data_ptr(), b, h, t, dh, nh,
                                                bs, int(causal), dqk.data_ptr(), dv.data_ptr(), s)
