@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librtts_hip.so")
+# RTTS_LIB: an alternative build of the same library (kernel A/B runs on one box); it must exist, there is no fallback
+LIB_PATH = os.environ.get("RTTS_LIB") or os.path.join(_HERE, "lib", "librtts_hip.so")
 
 _i64, _i32, _vp, _f32, _u32 = C.c_int64, C.c_int, C.c_void_p, C.c_float, C.c_uint32
 

@@ -22,8 +22,10 @@
 #include <stdlib.h>
 
 #define GT_BM 64       // contraction rows per stage
-#define GT_PAD 32      // bytes of padding per LDS row: a row shift of 8 banks, so the 4 rows x 8 dwords of a 16-lane
-                       // transposed read hit 32 distinct banks (16 B of pad gave 2-way conflicts)
+#ifndef GT_PAD
+#define GT_PAD 64      // bytes of padding per LDS row: a row shift of 16 banks, so the 4 rows x 16 dwords of a 32-lane
+#endif                 // transposed read (ds_read_b64_tr_b16 is served in two 32-lane groups over 64 banks) hit 64 distinct
+                       // banks; 32 B of pad left them 2-way conflicted (130.6 -> 127.7 us per decoder-layer group)
 
 typedef __attribute__((ext_vector_type(8))) short gt_short8;
 

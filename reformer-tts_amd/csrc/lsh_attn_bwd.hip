@@ -68,20 +68,29 @@ __device__ __forceinline__ int ab_ds_off(int key, int gran) {
     return key * 128 + ((gran ^ ((k1 << 3) | (k0 << 2) | (k2 << 1) | k3)) << 3);
 }
 
+// AB_KT2 = 32-key tiles owned by one wave.  1: 8 waves per 128-key chunk pair, two waves per SIMD (<= 256 registers each).
+// 2: 4 waves, ONE wave per SIMD with the whole 512-entry register file: a query tile's fragments, per-query words and
+// transposed fragments are read once for two key tiles, and the two tiles' MFMA bursts and softmax arithmetic are
+// independent instruction streams the scheduler can interleave inside one wave.
+#ifndef AB_KT2
+#define AB_KT2 1
+#endif
+
 template <int BS, bool CAUSAL, bool MASKED>
-__global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
+__global__ __launch_bounds__(BS * 4 / AB_KT2, AB_KT2 == 2 ? 1 : 2) void lsh_attn_bwd_kernel(
     const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v, int64_t ld, const int32_t* __restrict__ st,
     const uint8_t* __restrict__ mask, const bf16_t* __restrict__ dout, int64_t ld_do, const float* __restrict__ lse_tot,
     const float* __restrict__ delta, int H, int T, int n_hashes, bf16_t* __restrict__ dqk_part, bf16_t* __restrict__ dv_part,
     size_t slot_stride) {
+    constexpr int KT2 = AB_KT2;
     constexpr int NK = 2 * BS;
     constexpr int NQT = BS / 32;
-    constexpr int NTHR = BS * 4;
-    constexpr int NW = NTHR / 64;
+    constexpr int NW = NK / (32 * KT2);
+    constexpr int NTHR = 64 * NW;
     constexpr int DSROW = BS * 2;         // bytes per row of the dS^T image [key][query]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // per-row words first: their addresses then fit the 16-bit offset field of the DS instructions
-    // (the key-side scale and effective position of a wave's 32 keys live in its registers; word arrays 0 and 2 of
+    // (the key-side scale and effective position of a wave's keys live in its registers; word arrays 0 and 2 of
     // the region are unused)
     int* kpos = reinterpret_cast<int*>(smem) + NK;             // original position of every row (self test, row stores)
     float* qlse = reinterpret_cast<float*>(kpos + 2 * NK);     // lse_tot * log2(e)
@@ -90,7 +99,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
     unsigned char* Ks = reinterpret_cast<unsigned char*>(qpe_s + BS);   // [NK][128]  qk rows (own chunk first), swizzled
     unsigned char* Os = Ks + NK * 128;                         // [BS][128]  dout rows of the queries, swizzled
     unsigned char* Ds = Os + BS * 128;                         // [NK][DSROW] dS'^T, swizzled
-    unsigned char* Stg = Ds + NK * DSROW;                      // [NW][32][144] per-wave staging of the row stores
+    unsigned char* Stg = Ds + NK * DSROW;                      // [NK / 32][32][144] per-key-tile staging of the row stores
 
     const int nb = T / BS;
     const int C = n_hashes * nb;
@@ -110,7 +119,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
     // ---- gather K rows (all 2*BS) and dout rows (own chunk) into LDS -----------------------
     // Two dependent global round trips, not three: everything that is indexed by the token position (rows AND the
     // per-token words mask / lse / delta) is requested as soon as the positions are known.
-    constexpr int ITERS = NK * 8 / NTHR;   // 4
+    constexpr int ITERS = NK * 8 / NTHR;   // 4 (KT2 = 1) or 8
     int trow[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
@@ -118,8 +127,13 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
         const int slot = (row < BS) ? c * BS + row : cprev * BS + (row - BS);
         trow[it] = st_row[slot];
     }
-    const int myrow = wave * 32 + r;       // this wave owns keys [32*wave, 32*wave+32): one per lane (both halves)
-    const int mypos = st_row[(myrow < BS) ? c * BS + myrow : cprev * BS + (myrow - BS)];
+    // this wave owns the KT2 key tiles wave*KT2 + k2, one key per lane (both halves)
+    int myrow[KT2], mypos[KT2];
+#pragma unroll
+    for (int k2 = 0; k2 < KT2; ++k2) {
+        myrow[k2] = (wave * KT2 + k2) * 32 + r;
+        mypos[k2] = st_row[(myrow[k2] < BS) ? c * BS + myrow[k2] : cprev * BS + (myrow[k2] - BS)];
+    }
 #ifdef AB_PHASE_TIMING
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the positions are here
     AB_STAMP(10);
@@ -145,17 +159,21 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
         rlse[it] = lse_tot[(size_t)bh * T + trow[it]];
         rdel[it] = delta[(size_t)bh * T + trow[it]];
     }
-    const int myvalid = MASKED ? (int)mask[(size_t)b * T + mypos] : 1;
     // V fragments of this wave's keys go straight to registers (no other wave needs them)
-    bf16x8 vf[4];
+    int myvalid[KT2];
+    bf16x8 vf[KT2][4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) vf[ks] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)mypos * ld + ks * 16 + 8 * hh);
+    for (int k2 = 0; k2 < KT2; ++k2) {
+        myvalid[k2] = MASKED ? (int)mask[(size_t)b * T + mypos[k2]] : 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) vf[k2][ks] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)mypos[k2] * ld + ks * 16 + 8 * hh);
+    }
 #ifdef AB_PHASE_TIMING
     __builtin_amdgcn_s_waitcnt(0x0F70);
     AB_STAMP(11);
 #endif
     // query-side words: lane `piece` of a row's eight lanes stores word `piece` (3 lse*log2e, 4 -delta, 5 effective
-    // position, 1 position); the key-side words of a wave's own 32 keys never leave its registers
+    // position, 1 position); the key-side words of a wave's own keys never leave its registers
     const int cbase = (tid & 7) < 3 ? (tid & 7) * (NK * 4) : 3 * NK * 4 + ((tid & 7) - 3) * (BS * 4);
 #pragma unroll
     for (int it = 0; it < ITERS / 2; ++it) {
@@ -168,7 +186,9 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
         w = piece == 5 ? (rvalid[it] ? eff : -1) : w;
         if (piece == 1 || (piece >= 3 && piece < 6)) *reinterpret_cast<int*>(smem + cbase + row * 4) = w;
     }
-    if (hh == 0 && myrow >= BS) kpos[myrow] = mypos;   // looked-back rows: only this wave reads them back (row stores)
+#pragma unroll
+    for (int k2 = 0; k2 < KT2; ++k2)   // looked-back rows: only this wave reads them back (row stores)
+        if (hh == 0 && myrow[k2] >= BS) kpos[myrow[k2]] = mypos[k2];
     AB_STAMP(1);
     __syncthreads();
     AB_STAMP(2);
@@ -178,15 +198,17 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
     int fro[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) fro[ks] = ab_off(r, ks * 2 + hh);
-    bf16x8 kf[4];
+    bf16x8 kf[KT2][4];
+    float ksc[KT2];
+    int kpk[KT2];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(Ks + wave * (32 * 128) + fro[ks]);
-    float ksc;
-    {
+    for (int k2 = 0; k2 < KT2; ++k2) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kf[k2][ks] = *reinterpret_cast<const bf16x8*>(Ks + (wave * KT2 + k2) * (32 * 128) + fro[ks]);
         float ss = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const uint4 u4 = __builtin_bit_cast(uint4, kf[ks]);
+            const uint4 u4 = __builtin_bit_cast(uint4, kf[k2][ks]);
             const uint32_t u[4] = {u4.x, u4.y, u4.z, u4.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -196,42 +218,46 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
             }
         }
         ss = rtts_xhalf_sum(ss);
-        ksc = 0.125f * __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));   // dh^-1/2 / max(|k|, 1e-12)
+        ksc[k2] = 0.125f * __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));   // dh^-1/2 / max(|k|, 1e-12)
+        kpk[k2] = myvalid[k2] ? (CAUSAL ? mypos[k2] : 0) : 0x40000000;
     }
-    const int kpk = myvalid ? (CAUSAL ? mypos : 0) : 0x40000000;
 
-    f32x16 dvacc[2], gacc[2];   // [dh tile]: rows = dh, lane = key
+    f32x16 dvacc[KT2][2], gacc[KT2][2];   // [key tile][dh tile]: rows = dh, lane = key
 #pragma unroll
-    for (int d = 0; d < 2; ++d) {
-        dvacc[d] = (f32x16){0};
-        gacc[d] = (f32x16){0};
-    }
+    for (int k2 = 0; k2 < KT2; ++k2)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            dvacc[k2][d] = (f32x16){0};
+            gacc[k2][d] = (f32x16){0};
+        }
     const int trq = (lane & 15) >> 2, trp = lane & 3, trc = (lane >> 4) & 1;
     // transposed fragments: lane -> (row 4*hh + trq (+8 for the second read), 8-byte granule dt*8 + 4*trc + trp);
     // sw(row + 8) = sw(row) ^ 4 and dt toggles the same piece bit, so the second read of tile dt sits at tro[dt ^ 1] + 8 rows
     int tro[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) tro[dt] = ab_off(4 * hh + trq, dt * 4 + 2 * trc + (trp >> 1)) + 8 * (trp & 1);
-    // dS'^T store offsets of this lane's key row at query tile 0; tile qt is granule + 8*qt = byte offset ^ (qt << 6)
+    // dS'^T store offsets of this lane's key rows at query tile 0; tile qt is granule + 8*qt = byte offset ^ (qt << 6)
     // (the row base is a multiple of 128 resp. 256 bytes, so bits 6.. of the offset belong to the granule index alone)
-    int dso[4];
+    int dso[KT2][4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) dso[g] = ab_ds_off<BS>(myrow, 2 * g + hh);
-    const bool own_tile = wave < BS / 32;        // wave-uniform (SGPR)
+    for (int k2 = 0; k2 < KT2; ++k2)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dso[k2][g] = ab_ds_off<BS>(myrow[k2], 2 * g + hh);
+    const bool own_tile = wave * KT2 < BS / 32;  // wave-uniform (SGPR); the KT2 tiles of a wave sit on the same side
     const bool wrap = (cprev / nb) != (c / nb);
 
 #pragma unroll AB_UNROLL
     for (int qt = 0; qt < NQT; ++qt) {
         // dP starts at -delta[q] (read first: the second MFMA below waits for it): the accumulator then holds dP - delta,
         // one subtraction per logit less on the VALU
-        f32x16 sacc = {0}, pacc;
+        f32x16 pinit;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 d4 = *reinterpret_cast<const float4*>(qdel + qt * 32 + 8 * g + 4 * hh);
-            pacc[4 * g] = d4.x;
-            pacc[4 * g + 1] = d4.y;
-            pacc[4 * g + 2] = d4.z;
-            pacc[4 * g + 3] = d4.w;
+            pinit[4 * g] = d4.x;
+            pinit[4 * g + 1] = d4.y;
+            pinit[4 * g + 2] = d4.z;
+            pinit[4 * g + 3] = d4.w;
         }
         bf16x8 qf[4], dof[4];
 #pragma unroll
@@ -248,87 +274,99 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
             l4[g] = *reinterpret_cast<const float4*>(qlse + q0);
             e4[g] = *reinterpret_cast<const int4*>(qpe_s + q0);
         }
-        // Can a key of this wave's tile BE one of this tile's queries (the self logit)?  Own keys: only on the diagonal
-        // tile.  Looked-back keys: only when the previous chunk belongs to another hash round (the chunk ring wraps
-        // over rounds, so the same token can then sit in both chunks).  Wave-uniform: the common path skips the test.
-        const bool chk_self = own_tile ? (wave == qt) : wrap;
-        // Two waves share a SIMD.  The one inside an MFMA burst gets issue priority: an MFMA needs one issue slot per
-        // 32 cycles of matrix pipe, so the other wave's softmax arithmetic fills the slots in between instead of
-        // starving the matrix pipe (oldest-first arbitration let the VALU-heavy wave win every slot).
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[ks], sacc, 0, 0, 0);    // S[q][key]
-            pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof[ks], vf[ks], pacc, 0, 0, 0);   // dP[q][key] - delta[q]
-        }
-        // P' = exp2(s*ksc*log2e - lse*log2e); dS' = P' (dP - delta) ksc  (0 at the self logit: it was a constant).
-        // ksc multiplies dS' once here: G' = dS'^T Q then gives dK = G' - k^ (k^ . G'), and dQ^T = K^T dS'^T.
-        float pp[16], ds[16];
-        const float ksc2 = ksc * 1.4426950408889634f;
-        if (chk_self) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float lv[4] = {l4[g].x, l4[g].y, l4[g].z, l4[g].w};
-                const int4 p4 = *reinterpret_cast<const int4*>(kpos + qt * 32 + 8 * g + 4 * hh);   // rare path: read here
-                const int pv[4] = {p4.x, p4.y, p4.z, p4.w}, ev[4] = {e4[g].x, e4[g].y, e4[g].z, e4[g].w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int i = 4 * g + j;
-                    const bool self = pv[j] == mypos;
-                    const bool dead = kpk > ev[j];
-                    float x = sacc[i] * ksc2;
-                    x = self ? (-5e4f * 1.4426950408889634f) : x;
-                    float p = __builtin_amdgcn_exp2f(x - lv[j]);
-                    p = (dead && !self) ? 0.f : p;
-                    pp[i] = p;
-                    ds[i] = self ? 0.f : p * pacc[i] * ksc;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float lv[4] = {l4[g].x, l4[g].y, l4[g].z, l4[g].w};
-                const int ev[4] = {e4[g].x, e4[g].y, e4[g].z, e4[g].w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int i = 4 * g + j;
-                    float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[i], ksc2, -lv[j]));
-                    p = (kpk > ev[j]) ? 0.f : p;
-                    pp[i] = p;
-                    ds[i] = p * pacc[i] * ksc;
-                }
-            }
-        }
-        // A fragments of the transposed products (element j <-> query 16*s2 + 8*(j>>2) + 4*hh + (j&3)): read only now,
-        // so that their registers are free during the softmax arithmetic above
+        // A fragments of the transposed products (element j <-> query 16*s2 + 8*(j>>2) + 4*hh + (j&3))
         bf16x8 qtf[2][2], dotf[2][2];   // [s2][dh tile]
+        if (KT2 == 2) {                 // read once for both key tiles (at KT2 = 1 they are read late: registers)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const int blk = (qt * 32 + 16 * s2) * 128;
-                qtf[s2][dt] = tr_frag(Ks + blk + tro[dt], Ks + blk + 8 * 128 + tro[dt ^ 1]);
-                dotf[s2][dt] = tr_frag(Os + blk + tro[dt], Os + blk + 8 * 128 + tro[dt ^ 1]);
-            }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const float* pq = pp + 8 * s2;
-            const float* dq_ = ds + 8 * s2;
-            const bf16x8 pb = cvt_bf16x8(pq[0], pq[1], pq[2], pq[3], pq[4], pq[5], pq[6], pq[7]);
-            const bf16x8 db = cvt_bf16x8(dq_[0], dq_[1], dq_[2], dq_[3], dq_[4], dq_[5], dq_[6], dq_[7]);
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[s2][dt], pb, dvacc[dt], 0, 0, 0);
-                gacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[s2][dt], db, gacc[dt], 0, 0, 0);
-            }
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int blk = (qt * 32 + 16 * s2) * 128;
+                    qtf[s2][dt] = tr_frag(Ks + blk + tro[dt], Ks + blk + 8 * 128 + tro[dt ^ 1]);
+                    dotf[s2][dt] = tr_frag(Os + blk + tro[dt], Os + blk + 8 * 128 + tro[dt ^ 1]);
+                }
         }
-        // dS'^T[key][q] (bf16), 4 consecutive queries per 8-byte store 
-        const int dsq = qt << 6;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            uint2 pk;
-            pk.x = pack_bf16x2(ds[4 * g], ds[4 * g + 1]);
-            pk.y = pack_bf16x2(ds[4 * g + 2], ds[4 * g + 3]);
-            *reinterpret_cast<uint2*>(Ds + (dso[g] ^ dsq)) = pk;
+        for (int k2 = 0; k2 < KT2; ++k2) {
+            // Can a key of this tile BE one of this tile's queries (the self logit)?  Own keys: only on the diagonal
+            // tile.  Looked-back keys: only when the previous chunk belongs to another hash round (the chunk ring wraps
+            // over rounds, so the same token can then sit in both chunks).  Wave-uniform: the common path skips the test.
+            const bool chk_self = own_tile ? (wave * KT2 + k2 == qt) : wrap;
+            f32x16 sacc = {0}, pacc = pinit;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[k2][ks], sacc, 0, 0, 0);    // S[q][key]
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof[ks], vf[k2][ks], pacc, 0, 0, 0);   // dP[q][key] - delta[q]
+            }
+            // P' = exp2(s*ksc*log2e - lse*log2e); dS' = P' (dP - delta) ksc  (0 at the self logit: it was a constant).
+            // ksc multiplies dS' once here: G' = dS'^T Q then gives dK = G' - k^ (k^ . G'), and dQ^T = K^T dS'^T.
+            float pp[16], ds[16];
+            const float ksc2 = ksc[k2] * 1.4426950408889634f;
+            if (chk_self) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float lv[4] = {l4[g].x, l4[g].y, l4[g].z, l4[g].w};
+                    const int4 p4 = *reinterpret_cast<const int4*>(kpos + qt * 32 + 8 * g + 4 * hh);   // rare path: read here
+                    const int pv[4] = {p4.x, p4.y, p4.z, p4.w}, ev[4] = {e4[g].x, e4[g].y, e4[g].z, e4[g].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = 4 * g + j;
+                        const bool self = pv[j] == mypos[k2];
+                        const bool dead = kpk[k2] > ev[j];
+                        float x = sacc[i] * ksc2;
+                        x = self ? (-5e4f * 1.4426950408889634f) : x;
+                        float p = __builtin_amdgcn_exp2f(x - lv[j]);
+                        p = (dead && !self) ? 0.f : p;
+                        pp[i] = p;
+                        ds[i] = self ? 0.f : p * pacc[i] * ksc[k2];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float lv[4] = {l4[g].x, l4[g].y, l4[g].z, l4[g].w};
+                    const int ev[4] = {e4[g].x, e4[g].y, e4[g].z, e4[g].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = 4 * g + j;
+                        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[i], ksc2, -lv[j]));
+                        p = (kpk[k2] > ev[j]) ? 0.f : p;
+                        pp[i] = p;
+                        ds[i] = p * pacc[i] * ksc[k2];
+                    }
+                }
+            }
+            if (KT2 == 1) {   // read only now, so that their registers are free during the softmax arithmetic above
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const int blk = (qt * 32 + 16 * s2) * 128;
+                        qtf[s2][dt] = tr_frag(Ks + blk + tro[dt], Ks + blk + 8 * 128 + tro[dt ^ 1]);
+                        dotf[s2][dt] = tr_frag(Os + blk + tro[dt], Os + blk + 8 * 128 + tro[dt ^ 1]);
+                    }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const float* pq = pp + 8 * s2;
+                const float* dq_ = ds + 8 * s2;
+                const bf16x8 pb = cvt_bf16x8(pq[0], pq[1], pq[2], pq[3], pq[4], pq[5], pq[6], pq[7]);
+                const bf16x8 db = cvt_bf16x8(dq_[0], dq_[1], dq_[2], dq_[3], dq_[4], dq_[5], dq_[6], dq_[7]);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dvacc[k2][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[s2][dt], pb, dvacc[k2][dt], 0, 0, 0);
+                    gacc[k2][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[s2][dt], db, gacc[k2][dt], 0, 0, 0);
+                }
+            }
+            // dS'^T[key][q] (bf16), 4 consecutive queries per 8-byte store
+            const int dsq = qt << 6;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 pk;
+                pk.x = pack_bf16x2(ds[4 * g], ds[4 * g + 1]);
+                pk.y = pack_bf16x2(ds[4 * g + 2], ds[4 * g + 3]);
+                *reinterpret_cast<uint2*>(Ds + (dso[k2][g] ^ dsq)) = pk;
+            }
         }
     }
 
@@ -340,20 +378,21 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
     AB_WSTAMP(16, wave);
     const int round = c / nb, round_prev = cprev / nb;
     const size_t obase = ((size_t)bh * n_hashes + (own_tile ? round : round_prev)) * T;
-    unsigned char* stg = Stg + wave * (32 * AB_ROWB);
     const int srow = lane >> 3, spiece = lane & 7;
-    int rpos[4];
+    int rpos[KT2][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rpos[i] = kpos[wave * 32 + i * 8 + srow];
-    {
+    for (int k2 = 0; k2 < KT2; ++k2) {
+        unsigned char* stg = Stg + (wave * KT2 + k2) * (32 * AB_ROWB);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rpos[k2][i] = kpos[(wave * KT2 + k2) * 32 + i * 8 + srow];
         bf16_t* dvdst = dv_part + (own_tile ? 0 : slot_stride);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 uint2 pk;
-                pk.x = pack_bf16x2(dvacc[dt][4 * g], dvacc[dt][4 * g + 1]);
-                pk.y = pack_bf16x2(dvacc[dt][4 * g + 2], dvacc[dt][4 * g + 3]);
+                pk.x = pack_bf16x2(dvacc[k2][dt][4 * g], dvacc[k2][dt][4 * g + 1]);
+                pk.y = pack_bf16x2(dvacc[k2][dt][4 * g + 2], dvacc[k2][dt][4 * g + 3]);
                 *reinterpret_cast<uint2*>(stg + r * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2) = pk;
             }
         __builtin_amdgcn_wave_barrier();
@@ -361,7 +400,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i) rowv[i] = *reinterpret_cast<const uint4*>(stg + (i * 8 + srow) * AB_ROWB + spiece * 16);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dvdst + (obase + rpos[i]) * AB_DH + spiece * 8) = rowv[i];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dvdst + (obase + rpos[k2][i]) * AB_DH + spiece * 8) = rowv[i];
     }
 
     AB_STAMP(4);
@@ -369,37 +408,55 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
     __syncthreads();   // every dS'^T tile is in Ds; nobody reads Os as dout any more
 
     AB_STAMP(5);
-    // ---- dQ^T[dh][q] = K^T dS'^T over all 2*BS keys: wave w finishes (query tile w/2, dh half w%2) and parks it
+    // ---- dQ^T[dh][q] = K^T dS'^T over all 2*BS keys: the 2*NQT (query tile, dh half) outputs are dealt over the waves
+    //      (KT2 = 1: one each; KT2 = 2: both dh halves of query tile `wave`, sharing the dS'^T fragments) and parked
     //      (bf16) in the dout image's rows: a chunk row is both a query and an own key, so its query-role and
     //      key-role gradients are added before they leave the chip
     {
-        const int qt = wave >> 1, dt = wave & 1;
-        f32x16 dq = {0};
+        const int qt = (KT2 == 2) ? wave : (wave >> 1);
+        f32x16 dq[KT2];
+#pragma unroll
+        for (int di = 0; di < KT2; ++di) dq[di] = (f32x16){0};
         const int rl = 8 * hh + trq;                       // key row inside a 16-key step (second read: +4)
-        const int kpc = dt * 4 + 2 * trc + (trp >> 1);     // 16-byte piece of the K row
-        const int ko0 = ab_off(rl, kpc) + 8 * (trp & 1), ko1 = ab_off(rl + 4, kpc) + 8 * (trp & 1);
+        int ko0[KT2], ko1[KT2];
+#pragma unroll
+        for (int di = 0; di < KT2; ++di) {
+            const int dt = (KT2 == 2) ? di : (wave & 1);
+            const int kpc = dt * 4 + 2 * trc + (trp >> 1);     // 16-byte piece of the K row
+            ko0[di] = ab_off(rl, kpc) + 8 * (trp & 1);
+            ko1[di] = ab_off(rl + 4, kpc) + 8 * (trp & 1);
+        }
         const int gq = qt * 8 + 4 * trc + trp;             // 8-byte granule of the dS^T row
         const int do0 = ab_ds_off<BS>(rl, gq), do1 = ab_ds_off<BS>(rl + 4, gq);
 #pragma unroll AB_DQ_UNROLL
         for (int kb = 0; kb < NK; kb += 16) {
             const bf16x8 bfrag = tr_frag(Ds + kb * DSROW + do0, Ds + kb * DSROW + do1);
-            const bf16x8 afrag = tr_frag(Ks + kb * 128 + ko0, Ks + kb * 128 + ko1);
-            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, dq, 0, 0, 0);
+#pragma unroll
+            for (int di = 0; di < KT2; ++di) {
+                const bf16x8 afrag = tr_frag(Ks + kb * 128 + ko0[di], Ks + kb * 128 + ko1[di]);
+                dq[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, dq[di], 0, 0, 0);
+            }
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            uint2 pk;
-            pk.x = pack_bf16x2(dq[4 * g], dq[4 * g + 1]);
-            pk.y = pack_bf16x2(dq[4 * g + 2], dq[4 * g + 3]);
-            *reinterpret_cast<uint2*>(Os + ab_off(qt * 32 + r, dt * 4 + g) + 8 * hh) = pk;
+        for (int di = 0; di < KT2; ++di) {
+            const int dt = (KT2 == 2) ? di : (wave & 1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 pk;
+                pk.x = pack_bf16x2(dq[di][4 * g], dq[di][4 * g + 1]);
+                pk.y = pack_bf16x2(dq[di][4 * g + 2], dq[di][4 * g + 3]);
+                *reinterpret_cast<uint2*>(Os + ab_off(qt * 32 + r, dt * 4 + g) + 8 * hh) = pk;
+            }
         }
     }
     AB_STAMP(6);
     __syncthreads();   // dQ parked
     AB_STAMP(7);
 
-    // ---- dK (+ dQ on own rows) of this wave's 32 keys
-    {
+    // ---- dK (+ dQ on own rows) of this wave's keys
+#pragma unroll
+    for (int k2 = 0; k2 < KT2; ++k2) {
+        unsigned char* stg = Stg + (wave * KT2 + k2) * (32 * AB_ROWB);
         bf16_t* dkdst = dqk_part + (own_tile ? 0 : slot_stride);
         // dK = G - k^ (k^ . G) with k^ = k / |k| = k * (8 ksc): on the raw bf16 row that is G - k * ((k . G) * (8 ksc)^2);
         // this lane holds 32 of the 64 dh, the partner half the other 32
@@ -409,24 +466,24 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const uint2 kk = *reinterpret_cast<const uint2*>(Ks + ab_off(myrow, dt * 4 + g) + 8 * hh);
+                const uint2 kk = *reinterpret_cast<const uint2*>(Ks + ab_off(myrow[k2], dt * 4 + g) + 8 * hh);
                 kraw[dt][4 * g] = __uint_as_float(kk.x << 16);
                 kraw[dt][4 * g + 1] = __uint_as_float(kk.x & 0xffff0000u);
                 kraw[dt][4 * g + 2] = __uint_as_float(kk.y << 16);
                 kraw[dt][4 * g + 3] = __uint_as_float(kk.y & 0xffff0000u);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) dot = __builtin_fmaf(kraw[dt][4 * g + j], gacc[dt][4 * g + j], dot);
+                for (int j = 0; j < 4; ++j) dot = __builtin_fmaf(kraw[dt][4 * g + j], gacc[k2][dt][4 * g + j], dot);
             }
-        const float ncoef = -rtts_xhalf_sum(dot) * (ksc * 8.f) * (ksc * 8.f);
+        const float ncoef = -rtts_xhalf_sum(dot) * (ksc[k2] * 8.f) * (ksc[k2] * 8.f);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float dk[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) dk[j] = __builtin_fmaf(kraw[dt][4 * g + j], ncoef, gacc[dt][4 * g + j]);
+                for (int j = 0; j < 4; ++j) dk[j] = __builtin_fmaf(kraw[dt][4 * g + j], ncoef, gacc[k2][dt][4 * g + j]);
                 if (own_tile) {
-                    const uint2 dqv = *reinterpret_cast<const uint2*>(Os + ab_off(myrow, dt * 4 + g) + 8 * hh);
+                    const uint2 dqv = *reinterpret_cast<const uint2*>(Os + ab_off(myrow[k2], dt * 4 + g) + 8 * hh);
                     dk[0] += __uint_as_float(dqv.x << 16);
                     dk[1] += __uint_as_float(dqv.x & 0xffff0000u);
                     dk[2] += __uint_as_float(dqv.y << 16);
@@ -442,7 +499,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i) rowv[i] = *reinterpret_cast<const uint4*>(stg + (i * 8 + srow) * AB_ROWB + spiece * 16);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dkdst + (obase + rpos[i]) * AB_DH + spiece * 8) = rowv[i];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dkdst + (obase + rpos[k2][i]) * AB_DH + spiece * 8) = rowv[i];
     }
     AB_STAMP(8);
 #ifdef AB_PHASE_TIMING
@@ -458,8 +515,8 @@ static int launch_attn_bwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const 
                            const bf16_t* dout, int64_t ld_do, const float* lse_tot, const float* delta, int B, int H, int T,
                            int n_hashes, int causal, bf16_t* dqk_part, bf16_t* dv_part, hipStream_t stream) {
     constexpr int NK = 2 * BS;
-    const size_t lds = NK * 128 + BS * 128 + NK * (BS * 2) + (BS * 4 / 64) * 32 * AB_ROWB + NK * 12 + BS * 12;
-    const dim3 grid(B * H * n_hashes * (T / BS)), block(BS * 4);
+    const size_t lds = NK * 128 + BS * 128 + NK * (BS * 2) + (NK / 32) * 32 * AB_ROWB + NK * 12 + BS * 12;
+    const dim3 grid(B * H * n_hashes * (T / BS)), block(BS * 4 / AB_KT2);
     const size_t slot_stride = (size_t)B * H * n_hashes * T * AB_DH;
     const int vi = (causal ? 2 : 0) + (mask ? 1 : 0);
 #define AB_GO(C_, M_)                                                                                                      \
