@@ -199,7 +199,7 @@ def main():
         if launches:
             traffic = None      # HBM bytes per launch from the committed rocprofv3 PMC passes (collected outside this process)
             try:
-                with open(os.path.join(ROOT, "profiles", "r01c_pmc_lsh_attn_bwd.json")) as fh:
+                with open(os.path.join(ROOT, "profiles", "r01k_pmc_lsh_attn_bwd.json")) as fh:
                     traffic = json.load(fh)["traffic_bytes"] if (args.batch, args.mel_len, args.config) == (12, 1024, "baseline") else None
             except OSError:
                 pass
