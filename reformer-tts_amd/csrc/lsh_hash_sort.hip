@@ -20,6 +20,12 @@
 #include "rtts_common.h"
 
 #define HS_DH 64
+#ifndef HS_PF32
+#define HS_PF32 1
+#endif
+#ifndef HS_W8_MIN_T
+#define HS_W8_MIN_T 2048   // sequences from this length on get 8 waves per (head, round)
+#endif
 #define HS_ROWB 144   // LDS row stride in bytes for a staged 64 x 64 bf16 tile (conflict-free b128 reads)
 
 template <int HALF>
@@ -101,6 +107,11 @@ __global__ __launch_bounds__(64 * WAVES) void lsh_hash_sort_kernel(
     for (int i = tid; i < WAVES * 64; i += NTHR) cntw[i] = 0;
     __syncthreads();
 
+    float rot_reg[HALF == 32 ? 32 : 1];      // MFMA path: R^T fragments, rot_reg[j] = R[2j + (lane >> 5)][lane & 31]
+    if constexpr (HALF == 32) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) rot_reg[j] = rot_lds[(2 * j + (lane >> 5)) * HALF + (lane & 31)];
+    }
     // ---- hash: each wave stages 64 rows (coalesced 16-B pieces), then one lane hashes one row.
     //      Wave w hashes the token segment it will sort, so its bucket counts need no other wave's rows.
     const int seg = T / WAVES;              // multiple of 32 because T % 128 == 0 and WAVES in {4, 8}
@@ -110,7 +121,7 @@ __global__ __launch_bounds__(64 * WAVES) void lsh_hash_sort_kernel(
     // Row tiles are fetched PF at a time (all their loads in flight together): with few buckets the fmaf chains are
     // short and a wave would otherwise sit through one full memory round trip per 64 rows.  PF = 1 where the hash is
     // long enough to hide the next tile's latency behind it and the registers are needed for the accumulators.
-    constexpr int PF = (HALF <= 8) ? 4 : 1;
+    constexpr int PF = (HALF <= 8) ? 4 : (HALF == 32) ? HS_PF32 : 1;   // MFMA path: deeper prefetch measured neutral (A/B, 1/2/4)
     for (int tb = 0; tb < seg; tb += 64 * PF) {
         uint4 pre[PF][8];
 #pragma unroll
@@ -134,6 +145,58 @@ __global__ __launch_bounds__(64 * WAVES) void lsh_hash_sort_kernel(
             }
             if (rows <= 0) continue;           // wave-uniform; (no break: the unrolled body keeps `pre` in registers)
             __builtin_amdgcn_wave_barrier();   // same wave wrote and reads: LDS ops of one wave execute in order
+            if constexpr (HALF == 32) {
+                // 33..64 buckets: the projections go to the matrix pipe.  v_mfma_f32_32x32x2_f32 is bit for bit a k-ordered
+                // f32 fmaf chain (one rounding per product, no wider accumulation), i.e. exactly the chain of
+                // oracle/lsh_int.c, at the f32 vector rate but with the rotation matrix resident in 32 registers instead
+                // of being broadcast from LDS for every row element.  D[bucket][token] = sum_k R[k][bucket] q[token][k]:
+                // A = R^T (lane: bucket l & 31, k = 2j + (l >> 5)), B = q^T (lane: token l & 31, same k), so a lane ends
+                // up with 16 of its token's 32 projections and the argmax stays in registers but for one half swap.
+                const int hh = lane >> 5;
+                int idx2[2];
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub) {
+                    f32x16 acc = {0};
+                    const unsigned char* rowp = wt + (32 * sub + (lane & 31)) * HS_ROWB;
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) {
+                        const uint4 val = *reinterpret_cast<const uint4*>(rowp + p * 16);
+                        const uint32_t uu[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float bq = __uint_as_float(hh ? (uu[k] & 0xffff0000u) : (uu[k] << 16));   // q[token][2j + hh]
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rot_reg[p * 4 + k], bq, acc, 0, 0, 0);
+                        }
+                    }
+                    // this lane's 16 buckets: 8 * (i >> 2) + 4 * hh + (i & 3), ascending in i; [xR, -xR], first maximum wins
+                    float best = -__builtin_inff();
+                    int bi = 0;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int m = 8 * (i >> 2) + 4 * hh + (i & 3);
+                        if (m < half && acc[i] > best) { best = acc[i]; bi = m; }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int m = 8 * (i >> 2) + 4 * hh + (i & 3);
+                        if (m < half && -acc[i] > best) { best = -acc[i]; bi = half + m; }
+                    }
+                    // the partner half holds the other 16 buckets of the same token: larger value wins, the smaller index on a tie
+                    const auto sv = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+                    const auto si = __builtin_amdgcn_permlane32_swap((unsigned)bi, (unsigned)bi, false, false);
+                    const float ob = __uint_as_float(hh ? sv[0] : sv[1]);
+                    const int oi = (int)(hh ? si[0] : si[1]);
+                    idx2[sub] = (ob > best || (ob == best && oi < bi)) ? oi : bi;
+                }
+                const int idx = hh ? idx2[1] : idx2[0];     // lane <-> row of the 64-row tile again
+                if (lane < rows) {
+                    bkt[s0 + t0 + lane] = (uint16_t)idx;
+                    atomicAdd(&cntw[wave * 64 + idx], 1);      // integer LDS add: order-free, deterministic
+                    if (buckets) buckets[((size_t)bh * n_hashes + r) * T + s0 + t0 + lane] = idx + r * NB;
+                }
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
             float q[HS_DH];
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
@@ -216,7 +279,7 @@ static int launch_hash_sort_w(const bf16_t* qk, int64_t ld, const float* rot, in
 template <int HALF>
 static int launch_hash_sort(const bf16_t* qk, int64_t ld, const float* rot, int rot_rows, int B, int H, int T,
                             int n_hashes, int32_t* buckets, int32_t* st, int32_t* undo, int half, hipStream_t stream) {
-    if (T >= 2048 && T % 256 == 0)
+    if (T >= HS_W8_MIN_T && T % 256 == 0)
         return launch_hash_sort_w<HALF, 8>(qk, ld, rot, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, stream);
     return launch_hash_sort_w<HALF, 4>(qk, ld, rot, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, stream);
 }

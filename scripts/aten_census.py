@@ -31,7 +31,11 @@ class Census(TorchDispatchMode):
                 if "reformer-tts_amd" in fr.filename or "reformer_tts_amd" in fr.filename:
                     where = f"{os.path.basename(fr.filename)}:{fr.lineno}"
                     break
-            self.c[(name, where)] += 1
+            big = 0
+            for a in list(args) + list((kwargs or {}).values()):
+                if isinstance(a, torch.Tensor):
+                    big = max(big, a.numel() * a.element_size())
+            self.c[(name, where, big)] += 1
         return func(*args, **(kwargs or {}))
 
 
@@ -46,5 +50,5 @@ torch.cuda.synchronize()
 with Census() as cs:
     tr.train_step(batch)
     torch.cuda.synchronize()
-for (name, where), n in sorted(cs.c.items(), key=lambda kv: (kv[0][1], -kv[1])):
-    print(f"{n:4d}  {name:34s} {where}")
+for (name, where, big), n in sorted(cs.c.items(), key=lambda kv: (kv[0][1], -kv[1])):
+    print(f"{n:4d}  {name:34s} {where:24s} largest operand {big / 1e6:8.3f} MB")
