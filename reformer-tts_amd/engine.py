@@ -589,8 +589,10 @@ class FusedStackFn(torch.autograd.Function):
         b, t, d = x.shape
         prog = seq._program
         with torch.no_grad():
-            s1 = x.detach().reshape(b * t, d).clone()
-            s2 = s1.clone()
+            # both streams start as x: one broadcast copy into a (2, B*T, d) buffer (x is read once, one launch)
+            both = torch.empty(2, b * t, d, dtype=x.dtype, device=x.device)
+            both.copy_(x.detach().reshape(1, b * t, d).expand(2, -1, -1))
+            s1, s2 = both[0], both[1]
             extra = {}
             if context is not None:
                 kpm = next((k.get("key_padding_mask") for k in kwargs_list if "key" in k), None)
@@ -618,8 +620,9 @@ class FusedStackFn(torch.autograd.Function):
         s1, s2, steps, extra, b, t, d, has_ctx, seq = ctx.state
         ctx.state = None
         with torch.no_grad():
-            g1 = dout.detach().reshape(b * t, d).to(torch.float32).clone()
-            g2 = g1.clone()
+            gboth = torch.empty(2, b * t, d, dtype=torch.float32, device=dout.device)
+            gboth.copy_(dout.detach().reshape(1, b * t, d).expand(2, -1, -1))
+            g1, g2 = gboth[0], gboth[1]
             dkeys = None
             if has_ctx:
                 dkeys = torch.zeros(extra["keys_bf16"].shape, dtype=torch.float32, device=dout.device)

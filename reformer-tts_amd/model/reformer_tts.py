@@ -59,6 +59,8 @@ def pad_to_multiple(tensor, pad_base):
     """Right zero-pad (batch, seq_len, channels) to a multiple of ``pad_base`` on the tensor's own
     device (``reformer_tts.py:224-232`` relies on a process-wide default CUDA tensor type)."""
     new_len = ((tensor.shape[1] - 1) // pad_base + 1) * pad_base
+    if new_len == tensor.shape[1]:
+        return tensor          # already a multiple (every synthetic batch; most LJSpeech batches are not): no copy
     return F.pad(tensor, (0, 0, 0, new_len - tensor.shape[1]))
 
 
