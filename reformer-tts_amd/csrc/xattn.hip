@@ -28,6 +28,18 @@ __device__ __forceinline__ bf16x8 xa_tr_frag(const unsigned char* p0, const unsi
 }
 
 // ------------------------------------------------------------------------------ forward
+// LDS images of the backward (and the forward's V image) (same layouts as lsh_attn_bwd.hip, where the bank arithmetic is written out): rows of 128 B
+// without padding, 16-byte pieces XOR-swizzled by the row so that ds_read_b128 of one piece from 16 rows and
+// ds_read_b64_tr_b16 of 4 consecutive rows x 64 B are both conflict free; the dS^T image [key][128 queries] swizzles its
+// 8-byte granules by the key (conflict-free 8-byte stores of 16 consecutive keys and transposed reads of 4 keys x 64 B;
+// the padded 272-byte rows were 4-way conflicted on the read side).
+__device__ __forceinline__ int xa_sw(int row) { return ((row >> 1) & 3) | ((((row >> 3) ^ (row >> 1)) & 1) << 2); }
+__device__ __forceinline__ int xa_off(int row, int piece) { return row * 128 + ((piece ^ xa_sw(row)) << 4); }
+__device__ __forceinline__ int xa_ds_off(int key, int gran) {
+    const int k0 = key & 1, k1 = (key >> 1) & 1, k2 = (key >> 2) & 1, k3 = (key >> 3) & 1;
+    return key * 256 + ((gran ^ ((k1 << 4) | (k0 << 3) | (k1 << 2) | (k2 << 1) | k3)) << 3);
+}
+
 template <int TK>
 __global__ __launch_bounds__(256) void xattn_fwd_kernel(const bf16_t* __restrict__ q, int64_t ld_q, const bf16_t* __restrict__ kv,
                                                         int64_t ld_kv, const uint8_t* __restrict__ kvalid, int H, int Tq,
@@ -68,7 +80,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const bf16_t* __restrict
     for (int it = 0; it < ITERS; ++it) {
         const int row = (it * 256 + tid) >> 3, piece = tid & 7;
         *reinterpret_cast<uint4*>(Ks + row * XA_ROWB + piece * 16) = kreg[it];
-        *reinterpret_cast<uint4*>(Vs + row * XA_ROWB + piece * 16) = vreg[it];
+        *reinterpret_cast<uint4*>(Vs + xa_off(row, piece)) = vreg[it];       // V: unpadded rows, swizzled (transposed reads)
     }
     for (int j = tid; j < TK; j += 256) kval[j] = kvalid ? (int)kvalid[(size_t)b * TK + j] : 1;
     __syncthreads();
@@ -132,9 +144,10 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const bf16_t* __restrict
                                          s[kt][o8 + 6], s[kt][o8 + 7]);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                const int keyb = kt * 32 + 16 * s2 + 4 * hh + trq;
-                const int col = (dt * 32 + 16 * trc + 4 * trp) * 2;
-                const bf16x8 vf = xa_tr_frag(Vs + keyb * XA_ROWB + col, Vs + (keyb + 8) * XA_ROWB + col);
+                const int blk = (kt * 32 + 16 * s2) * 128;
+                const int t0 = xa_off(4 * hh + trq, dt * 4 + 2 * trc + (trp >> 1)) + 8 * (trp & 1);
+                const int t1 = xa_off(4 * hh + trq, (dt ^ 1) * 4 + 2 * trc + (trp >> 1)) + 8 * (trp & 1);   // row + 8: sw flips bit 2
+                const bf16x8 vf = xa_tr_frag(Vs + blk + t0, Vs + blk + 8 * 128 + t1);
                 oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
             }
         }
@@ -162,12 +175,12 @@ __global__ __launch_bounds__(TK) void xattn_bwd_kernel(const bf16_t* __restrict_
                                                        const uint32_t* __restrict__ seed_dev, uint32_t thresh, float dscale) {
     constexpr int NTHR = TK;                 // one wave per 64 keys
     if (thresh && seed_dev) seed += seed_dev[0];
-    constexpr int DSROW = XA_QB * 2 + 16;
+    constexpr int DSROW = XA_QB * 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* Ks = smem;                        // [TK][144]
-    unsigned char* Qs = Ks + TK * XA_ROWB;           // [128][144]
-    unsigned char* Os = Qs + XA_QB * XA_ROWB;        // [128][144]
-    unsigned char* Ds = Os + XA_QB * XA_ROWB;        // [TK][DSROW]  dS^T (already * scale)
+    unsigned char* Ks = smem;                        // [TK][128]   swizzled
+    unsigned char* Qs = Ks + TK * 128;               // [128][128]  swizzled
+    unsigned char* Os = Qs + XA_QB * 128;            // [128][128]  swizzled
+    unsigned char* Ds = Os + XA_QB * 128;            // [TK][256]   dS^T (already * scale), swizzled
     float* qlse = reinterpret_cast<float*>(Ds + TK * DSROW);
     float* qdel = qlse + XA_QB;
 
@@ -186,14 +199,14 @@ __global__ __launch_bounds__(TK) void xattn_bwd_kernel(const bf16_t* __restrict_
 
     for (int idx = tid; idx < TK * 8; idx += NTHR) {
         const int row = idx >> 3, piece = idx & 7;
-        *reinterpret_cast<uint4*>(Ks + row * XA_ROWB + piece * 16) =
+        *reinterpret_cast<uint4*>(Ks + xa_off(row, piece)) =
             *reinterpret_cast<const uint4*>(kbase + (size_t)row * ld_kv + piece * 8);
     }
     for (int idx = tid; idx < XA_QB * 8; idx += NTHR) {
         const int row = idx >> 3, piece = idx & 7;
-        *reinterpret_cast<uint4*>(Qs + row * XA_ROWB + piece * 16) =
+        *reinterpret_cast<uint4*>(Qs + xa_off(row, piece)) =
             *reinterpret_cast<const uint4*>(qbase + (size_t)row * ld_q + piece * 8);
-        *reinterpret_cast<uint4*>(Os + row * XA_ROWB + piece * 16) =
+        *reinterpret_cast<uint4*>(Os + xa_off(row, piece)) =
             *reinterpret_cast<const uint4*>(dobase + (size_t)row * ld_do + piece * 8);
     }
     for (int j = tid; j < XA_QB; j += NTHR) {
@@ -223,24 +236,33 @@ __global__ __launch_bounds__(TK) void xattn_bwd_kernel(const bf16_t* __restrict_
             gacc[a][c2] = (f32x16){0};
         }
     const int trq = (lane & 15) >> 2, trp = lane & 3, trc = (lane >> 4) & 1;
+    int fro[4], tro[2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fro[ks] = xa_off(r, ks * 2 + hh);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) tro[dt] = xa_off(4 * hh + trq, dt * 4 + 2 * trc + (trp >> 1)) + 8 * (trp & 1);
+    int dso[2][4];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dso[k2][g] = xa_ds_off(wave * 64 + 32 * k2 + r, 2 * g + hh);
 
 #pragma unroll 1
     for (int qt = 0; qt < XA_QB / 32; ++qt) {
         bf16x8 qf[4], dof[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            qf[ks] = *reinterpret_cast<const bf16x8*>(Qs + (qt * 32 + r) * XA_ROWB + (ks * 16 + 8 * hh) * 2);
-            dof[ks] = *reinterpret_cast<const bf16x8*>(Os + (qt * 32 + r) * XA_ROWB + (ks * 16 + 8 * hh) * 2);
+            qf[ks] = *reinterpret_cast<const bf16x8*>(Qs + qt * (32 * 128) + fro[ks]);
+            dof[ks] = *reinterpret_cast<const bf16x8*>(Os + qt * (32 * 128) + fro[ks]);
         }
         bf16x8 qtf[2][2], dotf[2][2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                const int qrow = qt * 32 + 16 * s2 + 4 * hh + trq;
-                const int col = (dt * 32 + 16 * trc + 4 * trp) * 2;
-                qtf[s2][dt] = xa_tr_frag(Qs + qrow * XA_ROWB + col, Qs + (qrow + 8) * XA_ROWB + col);
-                dotf[s2][dt] = xa_tr_frag(Os + qrow * XA_ROWB + col, Os + (qrow + 8) * XA_ROWB + col);
+                const int blk = (qt * 32 + 16 * s2) * 128;     // second read: 8 rows on, where sw flips the piece bit dt toggles
+                qtf[s2][dt] = xa_tr_frag(Qs + blk + tro[dt], Qs + blk + 8 * 128 + tro[dt ^ 1]);
+                dotf[s2][dt] = xa_tr_frag(Os + blk + tro[dt], Os + blk + 8 * 128 + tro[dt ^ 1]);
             }
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
@@ -286,7 +308,7 @@ __global__ __launch_bounds__(TK) void xattn_bwd_kernel(const bf16_t* __restrict_
                 uint2 pk;
                 pk.x = pack_bf16x2(ds[4 * g], ds[4 * g + 1]);
                 pk.y = pack_bf16x2(ds[4 * g + 2], ds[4 * g + 3]);
-                *reinterpret_cast<uint2*>(Ds + myrow[k2] * DSROW + (qt * 32 + 8 * g + 4 * hh) * 2) = pk;
+                *reinterpret_cast<uint2*>(Ds + (dso[k2][g] ^ (qt << 6))) = pk;
             }
         }
     }
@@ -315,15 +337,22 @@ __global__ __launch_bounds__(TK) void xattn_bwd_kernel(const bf16_t* __restrict_
     // dQ^T[dh][q] = K^T dS^T: the TK/64 waves split the 4 query tiles
     for (int qt = wave; qt < XA_QB / 32; qt += TK / 64) {
         f32x16 dqa[2] = {{0}, {0}};
-#pragma unroll 4
+        const int rl = 8 * hh + trq;                       // key row inside a 16-key step (second read: +4)
+        const int gq = qt * 8 + 4 * trc + trp;             // 8-byte granule of the dS^T row
+        const int do0 = xa_ds_off(rl, gq), do1 = xa_ds_off(rl + 4, gq);
+        int ko0[2], ko1[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const int kpc = dt * 4 + 2 * trc + (trp >> 1);
+            ko0[dt] = xa_off(rl, kpc) + 8 * (trp & 1);
+            ko1[dt] = xa_off(rl + 4, kpc) + 8 * (trp & 1);
+        }
+#pragma unroll
         for (int kb = 0; kb < TK; kb += 16) {
-            const int keyr = kb + 8 * hh + trq;
-            const int qcol = (qt * 32 + 16 * trc + 4 * trp) * 2;
-            const bf16x8 bfrag = xa_tr_frag(Ds + keyr * DSROW + qcol, Ds + (keyr + 4) * DSROW + qcol);
+            const bf16x8 bfrag = xa_tr_frag(Ds + kb * DSROW + do0, Ds + kb * DSROW + do1);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                const int col = (dt * 32 + 16 * trc + 4 * trp) * 2;
-                const bf16x8 afrag = xa_tr_frag(Ks + keyr * XA_ROWB + col, Ks + (keyr + 4) * XA_ROWB + col);
+                const bf16x8 afrag = xa_tr_frag(Ks + kb * 128 + ko0[dt], Ks + kb * 128 + ko1[dt]);
                 dqa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, dqa[dt], 0, 0, 0);
             }
         }
@@ -409,7 +438,7 @@ extern "C" int rtts_xattn_bwd(const void* q, int64_t ld_q, const void* kv, int64
     RTTS_REQUIRE((((uintptr_t)q | (uintptr_t)kv | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dkv_part) & 15) == 0,
                  "rtts_xattn_bwd: buffers must be 16-byte aligned");
     const dim3 grid(B * H * (Tq / XA_QB));
-    const size_t lds = (size_t)Tk * XA_ROWB + 2 * (size_t)XA_QB * XA_ROWB + (size_t)Tk * (XA_QB * 2 + 16) + XA_QB * 8;
+    const size_t lds = (size_t)Tk * 128 + 2 * (size_t)XA_QB * 128 + (size_t)Tk * (XA_QB * 2) + XA_QB * 8;
 #define GO(TK_)                                                                                                           \
     do {                                                                                                                  \
         auto kern = xattn_bwd_kernel<TK_>;                                                                                \
