@@ -199,6 +199,187 @@ __global__ __launch_bounds__(64 * WN * WK) void gemm_tn_kernel(const GtGroup grp
         }
 }
 
+// ---- ring variant of the 256 x 256 kernel: operands by LDS-DMA into a 4-deep ring of 32-row stages -----------------
+// The register double buffer above has ONE 64-row stage (64 KB) in flight against a load latency that, with every CU
+// streaming, is longer than the stage's MFMA time, so each stage ends in a stall.  Here global_load_lds_dwordx4 writes the
+// stages straight into LDS (no staging registers, no ds_write pass); three stages (96 KB) are in flight while one is
+// consumed, a wave waits with a COUNTED s_waitcnt vmcnt(N) for its own pieces of the oldest stage and a raw s_barrier (no
+// vmcnt(0) drain) publishes it.  The images are unpadded (a DMA instruction writes 1 KB = 2 rows contiguously), the 64-byte
+// chunks of a row XOR-swizzled with (row & 3) on the SOURCE side so that the transposed fragment reads (4 consecutive rows
+// x 64 B) stay bank-conflict free.
+#define GT_RS 32       // rows per ring stage
+#ifndef GT_NST
+#define GT_NST 4       // ring depth
+#endif
+
+template <int WN, int WK, int TN, int TK>
+__global__ __launch_bounds__(64 * WN * WK) void gemm_tn_ring_kernel(const GtGroup grp) {
+    constexpr int BN = 32 * TN * WN, BK = 32 * TK * WK, NTHR = 64 * WN * WK, NWAVE = WN * WK;
+    static_assert(BN == 256 && BK == 256 && NWAVE == 8, "ring variant: 256 x 256 tile, 8 waves");
+    constexpr int ROWB = 512;                                  // bytes per LDS row of either operand
+    constexpr int STAGE = GT_RS * ROWB;                        // 16 KB per operand and stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* As = smem;                                  // [GT_NST][32][512]
+    unsigned char* Bs = smem + GT_NST * STAGE;
+
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < RTTS_GEMM_TN_MAX_GROUP; ++i)
+        if (i < grp.n && (int)blockIdx.x >= grp.p[i].wg_start) pi = i;
+    const GtProb& P = grp.p[pi];
+    const bf16_t* __restrict__ a = P.a;
+    const bf16_t* __restrict__ b = P.b;
+    float* __restrict__ out = P.out;
+    const int64_t lda = P.lda, ldb = P.ldb, ldo = P.ldo;
+    const int M = P.M, K = P.K, split = P.split, accumulate = P.accumulate;
+    const size_t slab_stride = P.slab_stride;
+    const int blk = (int)blockIdx.x - P.wg_start;
+    const int tiles_k = K / BK;
+    const int tile = blk / split, sp = blk % split;
+    const int n0 = (tile / tiles_k) * BN, k0 = (tile % tiles_k) * BK;
+    const int rows_per = M / split;                    // multiple of 64 (checked on the host)
+    const int m_begin = sp * rows_per, nstage = rows_per / GT_RS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave / WK, wk = wave % WK;
+    const int hh = lane >> 5;
+    const int trq = (lane & 15) >> 2, trp = lane & 3, trc = (lane >> 4) & 1;
+
+    // DMA map: a wave-instruction fills 2 rows; wave w owns rows 4w .. 4w+3 of a stage (2 instructions per operand).
+    // Lane l lands on physical 16-byte piece l & 31 of row (l >> 5): it fetches the logical chunk ((l & 31) >> 2) ^ (row & 3).
+    const bf16_t* srcA[2];
+    const bf16_t* srcB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 4 * wave + 2 * i + (lane >> 5);
+        const int pp = lane & 31;
+        const int col = ((((pp >> 2) ^ (row & 3)) << 6) + ((pp & 3) << 4)) >> 1;     // bf16 elements
+        srcA[i] = a + ((size_t)m_begin + row) * lda + n0 + col;
+        srcB[i] = b + ((size_t)m_begin + row) * ldb + k0 + col;
+    }
+#define GT_ISSUE(stage_)                                                                                              \
+    do {                                                                                                              \
+        const int buf_ = (stage_) % GT_NST;                                                                           \
+        const size_t mo_ = (size_t)(stage_) * GT_RS;                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                               \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + mo_ * lda),    \
+                                             (RTTS_LDS void*)(As + buf_ * STAGE + (4 * wave + 2 * i) * ROWB), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + mo_ * ldb),    \
+                                             (RTTS_LDS void*)(Bs + buf_ * STAGE + (4 * wave + 2 * i) * ROWB), 16, 0, 0); \
+        }                                                                                                             \
+    } while (0)
+
+    f32x16 acc[TN][TK];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j) acc[i][j] = (f32x16){0};
+
+    // fragment offsets inside a stage: row 16*ks + 8*hh + trq (second read: +4), byte column (tile column + 16*trc + 4*trp) * 2;
+    // (row & 3) = trq for both reads (16*ks + 8*hh and +4 do not touch the low two bits)
+    int offA[TN], offB[TK];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int cb = (wn * 32 * TN + t * 32 + 16 * trc + 4 * trp) * 2;
+        offA[t] = (8 * hh + trq) * ROWB + ((((cb >> 6) ^ trq) << 6) | (cb & 63));
+    }
+#pragma unroll
+    for (int t = 0; t < TK; ++t) {
+        const int cb = (wk * 32 * TK + t * 32 + 16 * trc + 4 * trp) * 2;
+        offB[t] = (8 * hh + trq) * ROWB + ((((cb >> 6) ^ trq) << 6) | (cb & 63));
+    }
+
+    constexpr int AHEAD = GT_NST - 1;                // stages in flight beyond the one being consumed
+    static_assert(AHEAD >= 2 && AHEAD <= 4, "ring depth 3..5");
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i)
+        if (i < nstage) GT_ISSUE(i);
+    for (int s = 0; s < nstage; ++s) {
+        // this wave's pieces of stage s have landed once at most the later stages' instructions (4 each) are outstanding
+        const int later = min(AHEAD - 1, nstage - 1 - s);
+        if (later >= 3) __builtin_amdgcn_s_waitcnt(0x0F7C);              // vmcnt(12)
+        else if (later == 2) __builtin_amdgcn_s_waitcnt(0x0F78);         // vmcnt(8)
+        else if (later == 1) __builtin_amdgcn_s_waitcnt(0x0F74);         // vmcnt(4)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0)
+        asm volatile("s_barrier" ::: "memory");      // everybody's pieces of stage s are in LDS; everybody is done reading stage s-1
+        if (s + AHEAD < nstage) GT_ISSUE(s + AHEAD); // into the buffer stage s-1 occupied
+        const unsigned char* Ab = As + (s % GT_NST) * STAGE;
+        const unsigned char* Bb = Bs + (s % GT_NST) * STAGE;
+        // The fragment reads are issued as inline assembly: the compiler cannot prove that an LDS read does not alias the
+        // LDS-DMA writes still in flight and would drain them all (s_waitcnt vmcnt(0)) in front of the first read, which
+        // is exactly the pipelining this kernel exists for.  Which stage is complete is known here (counted wait + barrier
+        // above), so the reads wait only on lgkmcnt; the wait statement takes every fragment as an in/out operand, which
+        // keeps the MFMAs behind it.
+        const uint32_t abase = (uint32_t)(uintptr_t)(RTTS_LDS unsigned char*)Ab;
+        const uint32_t bbase = (uint32_t)(uintptr_t)(RTTS_LDS unsigned char*)Bb;
+        short4v al[2][TN], ah[2][TN], bl[2][TK], bh[2][TK];
+#define GT_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const uint32_t ad = abase + offA[t];
+            GT_TR(al[0][t], ad, 0);
+            GT_TR(ah[0][t], ad, 4 * ROWB);
+            GT_TR(al[1][t], ad, 16 * ROWB);
+            GT_TR(ah[1][t], ad, 20 * ROWB);
+        }
+#pragma unroll
+        for (int t = 0; t < TK; ++t) {
+            const uint32_t ad = bbase + offB[t];
+            GT_TR(bl[0][t], ad, 0);
+            GT_TR(bh[0][t], ad, 4 * ROWB);
+            GT_TR(bl[1][t], ad, 16 * ROWB);
+            GT_TR(bh[1][t], ad, 20 * ROWB);
+        }
+#undef GT_TR
+        static_assert(TN == 2 && TK == 4, "operand list of the wait below");
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(al[0][0]), "+v"(ah[0][0]), "+v"(al[1][0]), "+v"(ah[1][0]), "+v"(al[0][1]), "+v"(ah[0][1]), "+v"(al[1][1]),
+                       "+v"(ah[1][1]), "+v"(bl[0][0]), "+v"(bh[0][0]), "+v"(bl[1][0]), "+v"(bh[1][0]), "+v"(bl[0][1]), "+v"(bh[0][1]),
+                       "+v"(bl[1][1]), "+v"(bh[1][1]), "+v"(bl[0][2]), "+v"(bh[0][2]), "+v"(bl[1][2]), "+v"(bh[1][2]), "+v"(bl[0][3]),
+                       "+v"(bh[0][3]), "+v"(bl[1][3]), "+v"(bh[1][3]));
+        bf16x8 af0[TN], bf0[TK], af1[TN], bf1[TK];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const gt_short8 f0 = {al[0][t][0], al[0][t][1], al[0][t][2], al[0][t][3], ah[0][t][0], ah[0][t][1], ah[0][t][2], ah[0][t][3]};
+            const gt_short8 f1 = {al[1][t][0], al[1][t][1], al[1][t][2], al[1][t][3], ah[1][t][0], ah[1][t][1], ah[1][t][2], ah[1][t][3]};
+            af0[t] = __builtin_bit_cast(bf16x8, f0);
+            af1[t] = __builtin_bit_cast(bf16x8, f1);
+        }
+#pragma unroll
+        for (int t = 0; t < TK; ++t) {
+            const gt_short8 f0 = {bl[0][t][0], bl[0][t][1], bl[0][t][2], bl[0][t][3], bh[0][t][0], bh[0][t][1], bh[0][t][2], bh[0][t][3]};
+            const gt_short8 f1 = {bl[1][t][0], bl[1][t][1], bl[1][t][2], bl[1][t][3], bh[1][t][0], bh[1][t][1], bh[1][t][2], bh[1][t][3]};
+            bf0[t] = __builtin_bit_cast(bf16x8, f0);
+            bf1[t] = __builtin_bit_cast(bf16x8, f1);
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af0[i], bf0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af1[i], bf1[j], acc[i][j], 0, 0, 0);
+    }
+#undef GT_ISSUE
+
+    // epilogue: C tile rows n = (i&3) + 8*(i>>2) + 4*hh, cols k = lane&31
+    float* dst = out + (split > 1 ? (size_t)sp * slab_stride : 0);
+    const bool add = (split == 1) && accumulate;
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j) {
+            const int nb = n0 + wn * 32 * TN + i * 32 + 4 * hh;
+            const int kc = k0 + wk * 32 * TK + j * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float* p = dst + (size_t)(nb + (e & 3) + 8 * (e >> 2)) * ldo + kc;
+                *p = add ? *p + acc[i][j][e] : acc[i][j][e];
+            }
+        }
+}
+
 // c[n][k] (+)= sum over slabs, fixed order; 4 floats per thread; one launch for every split problem of the group
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const GtGroup grp) {
     int pi = 0;
@@ -298,7 +479,17 @@ extern "C" int rtts_gemm_tn_grouped(const rtts_gemm_tn_problem* problems, int n,
         }
     }
     hipStream_t s = (hipStream_t)stream;
-    if (big) gt_launch<4, 2, 2, 4>(grp, wg, s); else gt_launch<2, 2, 2, 2>(grp, wg, s);
+    static const bool ring = getenv("RTTS_GEMM_TN_NO_RING") == nullptr;
+    if (big && ring) {
+        const size_t lds = 2 * GT_NST * GT_RS * 512;
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_ring_kernel<4, 2, 2, 4>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 2, 2, 4>), dim3(wg), dim3(512), lds, s, grp);
+    } else if (big) gt_launch<4, 2, 2, 4>(grp, wg, s); else gt_launch<2, 2, 2, 2>(grp, wg, s);
     if (any_split) hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(256), 0, s, grp);
     RTTS_LAUNCH_CHECK("rtts_gemm_tn");
     return 0;
