@@ -36,13 +36,16 @@ def build_hip(force: bool = False, verbose: bool = True) -> str:
     flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-ffp-contract=on",
              # no SLP packing of adjacent f32 ops into v_pk_*_f32: beside MFMAs a packed op costs several times two plain ones
              "-fno-slp-vectorize"]
+    # per-file extras, measured A/B on one box (scripts/ab_attn.py): the ILP-first machine scheduler buys the LSH backward
+    # 2-7 % (its tile loop alternates MFMA bursts and softmax arithmetic of two waves per SIMD); neutral on the forward
+    extra = {"lsh_attn_bwd.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}
     objs, procs = [], []
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s) + ".o")
         objs.append(o)
         if not force and _newer(o, [s] + [d for d in deps if d.endswith(".h")]):
             continue
-        cmd = [hipcc, *flags, "-x", "hip", "-c", s, "-o", o]
+        cmd = [hipcc, *flags, *extra.get(os.path.basename(s), []), "-x", "hip", "-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd)))

@@ -25,7 +25,7 @@ def lib_path(flags):
 
 def build(flags):
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-ffp-contract=on",
-           "-fno-slp-vectorize", *flags.split(), "-shared", "-x", "hip", os.path.join(CSRC, f"lsh_attn_{KERNEL}.hip"),
+           "-fno-slp-vectorize", *(["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"] if KERNEL == "bwd" and "sched-strategy" not in flags else []), *flags.split(), "-shared", "-x", "hip", os.path.join(CSRC, f"lsh_attn_{KERNEL}.hip"),
            os.path.join(CSRC, "rtts_api.cpp"), "-o", lib_path(flags)]
     print(" ".join(cmd[-8:]), flush=True)
     subprocess.check_call(cmd)

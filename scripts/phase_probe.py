@@ -21,7 +21,7 @@ PROBE = os.path.join(ROOT, "reformer-tts_amd", "lib", f"librtts_probe_u{UNROLL}.
 
 def build():
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-ffp-contract=on",
-           "-fno-slp-vectorize", "-DAB_PHASE_TIMING", f"-DAB_UNROLL={UNROLL}", "-shared", "-x", "hip", os.path.join(CSRC, "lsh_attn_bwd.hip"), os.path.join(CSRC, "rtts_api.cpp"),
+           "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-DAB_PHASE_TIMING", f"-DAB_UNROLL={UNROLL}", "-shared", "-x", "hip", os.path.join(CSRC, "lsh_attn_bwd.hip"), os.path.join(CSRC, "rtts_api.cpp"),
            "-o", PROBE]
     print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
