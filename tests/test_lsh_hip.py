@@ -40,6 +40,7 @@ def _flat_perm(st_cpu):
 @pytest.mark.parametrize("b,h,t,bs,nh,per_head", [
     (2, 2, 128, 64, 4, False), (2, 3, 256, 64, 8, True), (2, 8, 1024, 128, 8, False),
     (1, 2, 1024, 64, 8, False), (1, 2, 4096, 64, 8, False), (1, 1, 2048, 128, 3, True),
+    (1, 2, 3072, 64, 4, True),      # 48 buckets: the f32-MFMA projection path with zero-padded rotation columns
 ])
 def test_hash_sort_bit_exact(ops, b, h, t, bs, nh, per_head):
     dh = 64
