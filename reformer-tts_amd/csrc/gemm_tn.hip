@@ -440,7 +440,8 @@ extern "C" int rtts_gemm_tn_grouped(const rtts_gemm_tn_problem* problems, int n,
     // small groups cannot fill 256 CUs with 256 x 256 tiles without splitting the token range very finely
     // (measured: one 25.8 GFLOP problem 45 us with 128-tiles / 50 us with 256-tiles; the 87 GFLOP group of a decoder
     // layer 143 us / 127 us)
-    if (flops < 40000000000LL) big = false;
+    static const long long big_min = [] { const char* e = getenv("RTTS_GEMM_TN_BIG_MIN_GFLOP"); return (e ? atoll(e) : 40LL) * 1000000000LL; }();
+    if (flops < big_min) big = false;
     const int bt = big ? 256 : 128;
     int total_tiles = 0;
     for (int i = 0; i < n; ++i) total_tiles += (problems[i].N / bt) * (problems[i].K / bt);
