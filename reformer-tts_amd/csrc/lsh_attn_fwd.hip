@@ -33,7 +33,7 @@ typedef __attribute__((ext_vector_type(8))) short af_short8;
 // key-tile loop unroll: 2 for bucket size 64 (4-wave workgroups, registers to spare: -4 %), 1 for 128 (unrolling costs the
 // second workgroup per CU: +35 %); scripts/ab_attn.py --fwd measures others
 #ifndef AF_UNROLL
-#define AF_UNROLL (BS == 64 ? 2 : 1)
+#define AF_UNROLL BS == 64 ? 2 : 1
 #endif
 // V image: [row][128 B] without padding, the eight 16-byte pieces of a row XOR-swizzled (same function as the backward's
 // images, lsh_attn_bwd.hip) so that the transposed reads (4 consecutive rows x 64 B) are bank-conflict free; it is filled by
