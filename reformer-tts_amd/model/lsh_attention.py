@@ -78,6 +78,8 @@ class LSHSelfAttention(nn.Module):
         self.forced_rotations: Optional[torch.Tensor] = None  # tests: use these instead of sampling
         self.last_st: Optional[torch.Tensor] = None
 
+    rotation_pool = None       # (flat fp32 normal samples, [next offset]) while a graph-mode training forward runs, else None
+
     def _rotations(self, x, n_buckets):
         if self.forced_rotations is not None and hasattr(self.forced_rotations, "__next__"):
             return next(self.forced_rotations).to(device=x.device, dtype=torch.float32).contiguous()   # tests: one per call
@@ -88,6 +90,12 @@ class LSHSelfAttention(nn.Module):
         rows = x.shape[0] * self.heads if self.random_rotations_per_head else 1
         shape = (rows, self.dim // self.heads, self.n_hashes, n_buckets // 2)
         if getattr(self, "use_default_generator", False):     # hipGraph capture: the default generator is graph-safe
+            pool = LSHSelfAttention.rotation_pool             # one randn per training step for all layers (trainer.forward_loss)
+            n = rows * shape[1] * shape[2] * shape[3]
+            if pool is not None and pool[0].device == x.device and pool[1][0] + n <= pool[0].numel():
+                off = pool[1][0]
+                pool[1][0] = off + n
+                return pool[0][off:off + n].view(shape)
             return torch.randn(shape, device=x.device, dtype=torch.float32)
         if self._gen is None or self._gen.device != x.device:
             self._gen = torch.Generator(device=x.device)

@@ -159,6 +159,18 @@ class Trainer:
     def forward_loss(self, batch, split: bool = False):
         """``wrappers.py:53-72``: input frames [0, L-1), targets [1, L), mask = loss_mask.mean(-1)."""
         spec = batch["spectrogram"]
+        from ..model.lsh_attention import LSHSelfAttention
+        if getattr(self, "_graph_rotations", False):
+            # graph mode: the hash rotations of every LSH layer of this forward are slices of ONE sample (one launch, not one
+            # per layer); 256 K values cover 6 + 6 layers at 64 buckets (a layer that does not fit draws its own)
+            LSHSelfAttention.rotation_pool = (torch.randn(1 << 18, device=spec.device, dtype=torch.float32), [0])
+        try:
+            return self._forward_loss(batch, split)
+        finally:
+            LSHSelfAttention.rotation_pool = None
+
+    def _forward_loss(self, batch, split: bool = False):
+        spec = batch["spectrogram"]
         if self._fused_edges_ok(batch):
             from ..edges import PostnetLoss
             if getattr(self, "_postnet_loss", None) is None:
@@ -355,6 +367,7 @@ class Trainer:
         for m in self.model.modules():
             if isinstance(m, LSHSelfAttention):
                 m.use_default_generator = True
+        self._graph_rotations = True
         self._bulk_allreduce = bool(segmented)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
