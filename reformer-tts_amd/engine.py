@@ -565,7 +565,8 @@ def _mask_u8(m, cache):
     if m is None:
         return None
     if id(m) not in cache:
-        cache[id(m)] = m.to(torch.uint8).contiguous()
+        # a bool tensor already is one byte of 0/1 per element: reinterpret instead of converting (no launch)
+        cache[id(m)] = m.contiguous().view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8).contiguous()
     return cache[id(m)]
 
 
@@ -597,7 +598,8 @@ class FusedStackFn(torch.autograd.Function):
             if context is not None:
                 kpm = next((k.get("key_padding_mask") for k in kwargs_list if "key" in k), None)
                 extra = dict(keys_bf16=context.detach().reshape(-1, d).to(torch.bfloat16),
-                             kvalid=None if kpm is None else (~kpm).to(torch.uint8).contiguous())
+                             kvalid=None if kpm is None else ((~kpm).contiguous().view(torch.uint8) if kpm.dtype == torch.bool
+                                                              else (~kpm).to(torch.uint8).contiguous()))
             steps, mask_cache = [], {}
             for (kind, f, g), kwargs in zip(prog, kwargs_list):
                 kw, kwg = _step_kwargs(kind, kwargs, extra, mask_cache)
