@@ -91,3 +91,26 @@ def test_padded_layouts_were_conflicted():
     rows144 = [(trq) * 144 + (4 * trc + trp) * 8 for trq, trc, trp in itertools.product(range(4), range(2), range(4))]
     rows272 = [(trq) * 272 + (4 * trc + trp) * 8 for trq, trc, trp in itertools.product(range(4), range(2), range(4))]
     assert not conflict_free(rows144, 8, 64) and not conflict_free(rows272, 8, 64)
+
+
+@pytest.mark.parametrize("ks,tcol,second", itertools.product(range(2), range(0, 256, 32), range(2)))
+def test_gemm_tn_ring_stage_reads(ks, tcol, second):
+    """csrc/gemm_tn.hip, ring kernel: 512-byte rows, 64-byte chunks XOR-swizzled with (row & 3) on the DMA's source side;
+    lane -> row 16*ks + 8*hh + trq (+4), byte column (tcol + 16*trc + 4*trp) * 2."""
+    for hh in range(2):
+        addrs = []
+        for trq, trc, trp in itertools.product(range(4), range(2), range(4)):
+            row = 16 * ks + 8 * hh + trq + 4 * second
+            cb = (tcol + 16 * trc + 4 * trp) * 2
+            addrs.append(row * 512 + ((((cb >> 6) ^ (row & 3)) << 6) | (cb & 63)))
+        assert conflict_free(addrs, 8, 64)
+
+
+def test_gemm_tn_ring_dma_fill_is_a_permutation_of_the_row():
+    """A DMA instruction writes 2 rows in lane order: lane l lands on physical 16-byte piece l & 31 of row l >> 5 and fetches
+    logical chunk ((l & 31) >> 2) ^ (row & 3); every logical piece of a row must be fetched exactly once."""
+    for rowbase in range(0, 32, 2):
+        for sub in range(2):
+            row = rowbase + sub
+            logical = sorted((((pp >> 2) ^ (row & 3)) << 2) | (pp & 3) for pp in range(32))
+            assert logical == list(range(32))
