@@ -30,6 +30,17 @@
 
 typedef __attribute__((ext_vector_type(8))) short af_short8;
 
+// Phase probe (scripts/phase_probe.py --fwd builds a private copy with -DAF_PHASE_TIMING): waves 0 and NQT (the two key
+// halves of query tile 0) stamp the shader clock at the phase boundaries.  Never defined in the product build.
+#ifdef AF_PHASE_TIMING
+__device__ unsigned long long g_af_phase[16 * 8192];
+#define AF_STAMP(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 8192 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == BS / 32)) \
+        g_af_phase[blockIdx.x * 16 + ((threadIdx.x >> 6) ? 8 : 0) + (i)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int rtts_debug_af_phases(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_af_phase), sizeof(g_af_phase)); }
+#else
+#define AF_STAMP(i) do { } while (0)
+#endif
+
 // key-tile loop unroll: 2 for bucket size 64 (4-wave workgroups, registers to spare: -4 %), 1 for 128 (unrolling costs the
 // second workgroup per CU: +35 %); scripts/ab_attn.py --fwd measures others
 #ifndef AF_UNROLL
@@ -69,6 +80,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
     const bf16_t* qbase = qk + (size_t)b * T * ld + (size_t)h * AF_DH;
     const bf16_t* vbase = v + (size_t)b * T * ld + (size_t)h * AF_DH;
 
+    AF_STAMP(0);
     // ---- 1. gather -------------------------------------------------------------------
     constexpr int ITERS = NK * 8 / NTHR;   // = 4
     {
@@ -116,7 +128,9 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
             if (piece < 3) *reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(ksc) + cbase + row * 4) = w;
         }
     }
+    AF_STAMP(1);
     __syncthreads();
+    AF_STAMP(2);
 
     // ---- 2. per-wave online softmax over key tiles ---------------------------------------
     const int r = lane & 31, hh = lane >> 5;
@@ -222,7 +236,9 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
 
     // ---- merge the two key halves of a query tile through LDS (aliases the K image) ----------
     float* part = reinterpret_cast<float*>(Ks) + (size_t)qt * 34 * 64;   // [34][64]: 32 x O, m, l per lane
+    AF_STAMP(3);
     __syncthreads();                       // every wave is done reading K
+    AF_STAMP(4);
     if (kh == 1) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -276,6 +292,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(o + (obase + rpos[i]) * AF_DH + spiece * 8) = rowv[i];
+    AF_STAMP(5);
 }
 
 static bool g_fwd_attr_set[2][4];

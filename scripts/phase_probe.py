@@ -27,7 +27,63 @@ def build():
     subprocess.check_call(cmd)
 
 
+def build_fwd():
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-ffp-contract=on",
+           "-fno-slp-vectorize", "-DAF_PHASE_TIMING", "-shared", "-x", "hip", os.path.join(CSRC, "lsh_attn_fwd.hip"),
+           os.path.join(CSRC, "rtts_api.cpp"), "-o", PROBE.replace("probe_u", "probe_fwd_u")]
+    print(" ".join(cmd[-6:]), flush=True)
+    subprocess.check_call(cmd)
+
+
+def main_fwd():
+    import numpy as np
+    import torch
+    from reformer_tts_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    lib = C.CDLL(PROBE.replace("probe_u", "probe_fwd_u"))
+    lib.rtts_lsh_attn_fwd.argtypes = _lib.SIGNATURES["rtts_lsh_attn_fwd"]
+    lib.rtts_debug_af_phases.argtypes = [C.c_void_p]
+    b, h, t, bs, nh, causal, dh = 12, 8, 1024, 128, 8, True, 64
+    g = torch.Generator().manual_seed(0)
+    qkv = torch.randn(b, t, 2 * h * dh, generator=g).bfloat16().to(dev)
+    qk, v = qkv[..., :h * dh], qkv[..., h * dh:]
+    rot = torch.randn(1, dh, nh, t // bs // 2, generator=g).to(dev)
+    mask = torch.ones(b, t, dtype=torch.uint8, device=dev)
+    mask[0, t - t // 4:] = 0
+    st, _, _ = ops.lsh_hash_sort(qk, rot, h, bs)
+    o = torch.empty(b * h, nh, t, dh, dtype=torch.bfloat16, device=dev)
+    lse = torch.empty(b * h, nh, t, dtype=torch.float32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    for _ in range(5):
+        rc = lib.rtts_lsh_attn_fwd(qk.data_ptr(), v.data_ptr(), qkv.stride(1), st.data_ptr(), mask.data_ptr(), b, h, t, dh, nh, bs,
+                                   int(causal), o.data_ptr(), lse.data_ptr(), s)
+        assert rc == 0
+    torch.cuda.synchronize()
+    buf = np.zeros(16 * 8192, dtype=np.uint64)
+    assert lib.rtts_debug_af_phases(buf.ctypes.data) == 0
+    allp = buf.reshape(8192, 16)[: b * h * nh * (t // bs)].astype(np.int64)
+    names = ["gather (positions -> rows -> LDS image)", "wait barrier 1", "Q fragments + 4 key tiles (online softmax)",
+             "wait merge barrier", "merge + stage + row stores issued"]
+    for half, off in (("own keys (wave 0)", 0), ("looked-back keys (wave NQT)", 8)):
+        ph = allp[:, off:off + 6]
+        ph = ph[ph[:, 3] > 0]
+        d = np.diff(ph, axis=1)
+        print(f"{half}: workgroups {len(ph)}")
+        for i, nm in enumerate(names):
+            if off and i == 4:
+                break           # the second half returns after handing its partial results over
+            print(f"  {nm:44s} median {np.median(d[:, i]):8.0f}  p10 {np.percentile(d[:, i], 10):8.0f}  p90 {np.percentile(d[:, i], 90):8.0f}")
+        if not off:
+            print(f"  total                                        median {np.median(ph[:, 5] - ph[:, 0]):8.0f}")
+
+
 def main():
+    if "--fwd" in sys.argv:
+        if "--build" in sys.argv:
+            build_fwd()
+        else:
+            main_fwd()
+        return
     if "--build" in sys.argv:
         build()
         return
