@@ -281,6 +281,7 @@ class LSHExec:
         self.stash = None     # (out, lse_tot) of the forward when STASH_ATTENTION: the recompute skips the attention forward
         self.g_stash = None   # f(x) of the forward when STASH_BLOCK_OUTPUT
         self.drop = None      # (p, seed) of the forward's post-attention dropout
+        self._wqkv_t = None   # transposed QKV weight of the forward, kept for the recompute only (never across steps)
 
     @staticmethod
     def supported(withnorm) -> bool:
@@ -307,7 +308,15 @@ class LSHExec:
             raise NotImplementedError("full-attention shortcut (T <= full_attn_thres) is outside the HIP path")
         xn, mean, rstd = pre if pre is not None else ln_fwd(inp, self.norm)
         wqkv = self._wqkv()
-        qkv = torch.mm(xn, wqkv.t()).view(b, t, 2 * e)
+        if xn.shape[0] >= 8192:
+            # (12288 x 512) x (512 x 1024): the library's heuristic picks a poor kernel for the NT form (26.9 us) and a good
+            # one for NN (19.9 us, scripts/gemm_probe.py), so the decoder-sized projection runs on a transposed copy of the
+            # weight made once per step (1 MB, one launch) and kept for the recompute
+            if self._wqkv_t is None:
+                self._wqkv_t = wqkv.t().contiguous()
+            qkv = torch.mm(xn, self._wqkv_t).view(b, t, 2 * e)
+        else:
+            qkv = torch.mm(xn, wqkv.t()).view(b, t, 2 * e)
         if st is None:
             rot = lyr._rotations(qkv, t // lyr.bucket_size)
             st, _, _ = ops.lsh_hash_sort(qkv[..., :e], rot, lyr.heads, lyr.bucket_size)
@@ -322,6 +331,7 @@ class LSHExec:
         return xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g
 
     def forward(self, acc, inp, b, t, mask=None, pre=None, next_norm=None, **_):
+        self._wqkv_t = None                    # every forward transposes the CURRENT weight; only its own backward re-uses it
         *_, st, out, lse_tot, g = self._internals(inp, b, t, mask, None, pre=pre)
         self.st = st
         self.stash = (out, lse_tot) if STASH_ATTENTION else None
@@ -334,7 +344,7 @@ class LSHExec:
         lyr = self.layer
         e = lyr.dim
         xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g = self._internals(inp, b, t, mask, self.st, self.stash, self.g_stash, pre)
-        self.st = self.stash = self.g_stash = None
+        self.st = self.stash = self.g_stash = self._wqkv_t = None
         drop, self.drop = self.drop, None
         post = residual(acc, g, lyr.to_out.bias, -1.0, next_norm, drop)       # reconstruct the stream (same dropout mask)
         dyb = _out_grad(d_acc, _grad(lyr.to_out.bias), drop, pre_cast)
