@@ -24,7 +24,9 @@ def t(fn, n=50):
     return a.elapsed_time(b) / 100 * 1e3
 
 
-for m, n, k in [(12288, 512, 512), (12288, 1024, 512), (12288, 2048, 512), (12288, 512, 2048), (12288, 512, 1024), (3072, 1024, 512), (3072, 2048, 512)]:
+for m, n, k in [(12288, 512, 512), (12288, 1024, 512), (12288, 2048, 512), (12288, 512, 2048), (12288, 512, 1024), (3072, 1024, 512), (3072, 2048, 512),
+                (12288, 512, 2560), (12288, 2560, 512), (12288, 512, 640), (12288, 128, 2560), (12288, 128, 512), (12288, 512, 128),
+                (3072, 512, 2560), (3072, 2560, 512), (3072, 512, 512), (3072, 512, 2048)]:
     x = torch.randn(m, k, device=dev).bfloat16()
     w = torch.randn(n, k, device=dev).bfloat16()       # Linear weight (out, in)
     wt = w.t().contiguous()                            # (in, out)
