@@ -264,6 +264,19 @@ def wgrad(grad_view: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, accumulate
         ws = _slab_ws(dy.device)
         _lib.call("rtts_gemm_tn", dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), m, n, k, grad_view.data_ptr(),
                   grad_view.stride(0), int(accumulate), ws.data_ptr(), ws.numel(), _s())
+    elif n % 128 == 0 and m % 64 == 0 and m >= 4096 and k < 128 and dy.stride(1) == 1:
+        # a narrow input (the decoder prenet's 80 mel channels): the library's TN kernel for a (N x 80) output over 12288 rows
+        # is 8 workgroups walking the whole token range (82 us); zero-padded to 128 columns the split-K kernel takes it
+        xp = torch.zeros(m, 128, dtype=x.dtype, device=x.device)
+        xp[:, :k].copy_(x)
+        tmp = torch.empty(n, 128, dtype=torch.float32, device=x.device)
+        ws = _slab_ws(dy.device)
+        _lib.call("rtts_gemm_tn", dy.data_ptr(), dy.stride(0), xp.data_ptr(), 128, m, n, 128, tmp.data_ptr(), 128, 0, ws.data_ptr(),
+                  ws.numel(), _s())
+        if accumulate:
+            grad_view.add_(tmp[:, :k])
+        else:
+            grad_view.copy_(tmp[:, :k])
     elif accumulate:
         grad_view.add_(torch.mm(dy.t(), x, out_dtype=torch.float32))
     else:
