@@ -26,7 +26,7 @@ def t(fn, n=50):
 
 for m, n, k in [(12288, 512, 512), (12288, 1024, 512), (12288, 2048, 512), (12288, 512, 2048), (12288, 512, 1024), (3072, 1024, 512), (3072, 2048, 512),
                 (12288, 512, 2560), (12288, 2560, 512), (12288, 512, 640), (12288, 128, 2560), (12288, 128, 512), (12288, 512, 128),
-                (3072, 512, 2560), (3072, 2560, 512), (3072, 512, 512), (3072, 512, 2048)]:
+                (3072, 512, 2560), (3072, 2560, 512), (3072, 512, 512), (3072, 512, 2048)][:int(__import__('os').environ.get('GEMM_PROBE_SHAPES', '99'))]:
     x = torch.randn(m, k, device=dev).bfloat16()
     w = torch.randn(n, k, device=dev).bfloat16()       # Linear weight (out, in)
     wt = w.t().contiguous()                            # (in, out)
@@ -37,5 +37,8 @@ for m, n, k in [(12288, 512, 512), (12288, 1024, 512), (12288, 2048, 512), (1228
     r["mm(x, wt)"] = t(lambda: torch.mm(x, wt))
     r["mm out="] = t(lambda: torch.mm(x, w.t(), out=out))
     r["addmm"] = t(lambda: torch.addmm(bias, x, w.t()))
+    r["addmm+relu NT"] = t(lambda: torch._addmm_activation(bias, x, w.t(), use_gelu=False))
+    r["addmm+relu NN"] = t(lambda: torch._addmm_activation(bias, x, wt, use_gelu=False))
+    r["transpose"] = t(lambda: w.t().contiguous())
     fl = 2.0 * m * n * k
     print(f"M={m} N={n} K={k}: " + "  ".join(f"{kk} {v:6.1f} us ({fl / v / 1e6:5.0f} TF/s)" for kk, v in r.items()), flush=True)
