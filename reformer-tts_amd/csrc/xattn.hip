@@ -17,6 +17,9 @@
 #define XA_DH 64
 #define XA_ROWB 144
 #define XA_QB 128     // queries per workgroup
+#ifndef XA_UNROLL
+#define XA_UNROLL 1   // query-tile loop of the backward
+#endif
 
 typedef __attribute__((ext_vector_type(8))) short xa_short8;
 
@@ -166,15 +169,22 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const bf16_t* __restrict
 }
 
 // ------------------------------------------------------------------------------ backward
-template <int TK>
-__global__ __launch_bounds__(TK) void xattn_bwd_kernel(const bf16_t* __restrict__ q, int64_t ld_q, const bf16_t* __restrict__ kv,
+// XA_KT2 = 32-key tiles per wave: 2 = one wave per 64 keys (one wave per SIMD at TK = 256), 1 = one wave per 32 keys (two per SIMD,
+// the decomposition of lsh_attn_bwd.hip, which runs the same 128 x 256 tile in under half the cycles)
+#ifndef XA_KT2
+#define XA_KT2 1
+#endif
+template <int TK, bool DROP>
+__global__ __launch_bounds__(TK * 2 / XA_KT2) void xattn_bwd_kernel(const bf16_t* __restrict__ q, int64_t ld_q, const bf16_t* __restrict__ kv,
                                                        int64_t ld_kv, const uint8_t* __restrict__ kvalid,
                                                        const bf16_t* __restrict__ dout, int64_t ld_do, const float* __restrict__ lse,
                                                        const float* __restrict__ delta, int H, int Tq, bf16_t* __restrict__ dq,
                                                        int64_t ld_dq, bf16_t* __restrict__ dkv_part, int B, uint32_t seed,
                                                        const uint32_t* __restrict__ seed_dev, uint32_t thresh, float dscale) {
-    constexpr int NTHR = TK;                 // one wave per 64 keys
-    if (thresh && seed_dev) seed += seed_dev[0];
+    constexpr int KT2 = XA_KT2;
+    constexpr int NTHR = TK * 2 / KT2;       // one wave per 32 * KT2 keys
+    constexpr int NW = NTHR / 64;
+    if (DROP && seed_dev) seed += seed_dev[0];
     constexpr int DSROW = XA_QB * 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Ks = smem;                        // [TK][128]   swizzled
@@ -210,14 +220,16 @@ __global__ __launch_bounds__(TK) void xattn_bwd_kernel(const bf16_t* __restrict_
             *reinterpret_cast<const uint4*>(dobase + (size_t)row * ld_do + piece * 8);
     }
     for (int j = tid; j < XA_QB; j += NTHR) {
-        qlse[j] = lse[(size_t)bh * Tq + qb * XA_QB + j];
+        qlse[j] = lse[(size_t)bh * Tq + qb * XA_QB + j] * 1.4426950408889634f;   // base-2 softmax: exp2(s * c - lse * log2 e)
         qdel[j] = delta[(size_t)bh * Tq + qb * XA_QB + j];
     }
-    const int myrow[2] = {wave * 64 + r, wave * 64 + 32 + r};
-    bf16x8 vf[2][4], kf[2][4];
-    int kvl[2];
+    int myrow[KT2];
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) {
+    for (int k2 = 0; k2 < KT2; ++k2) myrow[k2] = (wave * KT2 + k2) * 32 + r;
+    bf16x8 vf[KT2][4], kf[KT2][4];
+    int kvl[KT2];
+#pragma unroll
+    for (int k2 = 0; k2 < KT2; ++k2) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             vf[k2][ks] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)myrow[k2] * ld_kv + ks * 16 + 8 * hh);
@@ -227,9 +239,9 @@ __global__ __launch_bounds__(TK) void xattn_bwd_kernel(const bf16_t* __restrict_
     }
     __syncthreads();
 
-    f32x16 dvacc[2][2], gacc[2][2];
+    f32x16 dvacc[KT2][2], gacc[KT2][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < KT2; ++a)
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) {
             dvacc[a][c2] = (f32x16){0};
@@ -241,13 +253,13 @@ __global__ __launch_bounds__(TK) void xattn_bwd_kernel(const bf16_t* __restrict_
     for (int ks = 0; ks < 4; ++ks) fro[ks] = xa_off(r, ks * 2 + hh);
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) tro[dt] = xa_off(4 * hh + trq, dt * 4 + 2 * trc + (trp >> 1)) + 8 * (trp & 1);
-    int dso[2][4];
+    int dso[KT2][4];
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2)
+    for (int k2 = 0; k2 < KT2; ++k2)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) dso[k2][g] = xa_ds_off(wave * 64 + 32 * k2 + r, 2 * g + hh);
+        for (int g = 0; g < 4; ++g) dso[k2][g] = xa_ds_off((wave * KT2 + k2) * 32 + r, 2 * g + hh);
 
-#pragma unroll 1
+#pragma unroll XA_UNROLL
     for (int qt = 0; qt < XA_QB / 32; ++qt) {
         bf16x8 qf[4], dof[4];
 #pragma unroll
@@ -265,7 +277,7 @@ __global__ __launch_bounds__(TK) void xattn_bwd_kernel(const bf16_t* __restrict_
                 dotf[s2][dt] = xa_tr_frag(Os + blk + tro[dt], Os + blk + 8 * 128 + tro[dt ^ 1]);
             }
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
+        for (int k2 = 0; k2 < KT2; ++k2) {
             f32x16 sacc = {0}, pacc = {0};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -282,9 +294,10 @@ __global__ __launch_bounds__(TK) void xattn_bwd_kernel(const bf16_t* __restrict_
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int i = 4 * g + j;
-                    const float p = kvl[k2] ? __expf(sacc[i] * 0.125f - lv[j]) : 0.f;
-                    // dropout on P: O = (D*P) V  =>  dV += (D*P)^T dO,  dS = P * (D*dP - delta)   (delta = O.dO as ever)
-                    const float keep = thresh ? rtts_drop_keep(seed, ((uint32_t)bh * (uint32_t)Tq + (uint32_t)(qb * XA_QB + q0 + j)) *
+                    const float p = kvl[k2] ? __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[i], 0.125f * 1.4426950408889634f, -lv[j])) : 0.f;
+                    // dropout on P: O = (D*P) V  =>  dV += (D*P)^T dO,  dS = P * (D*dP - delta)   (delta = O.dO as ever);
+                    // DROP is a template parameter: nn.MultiheadAttention's dropout is 0 in config/baseline.yml
+                    const float keep = DROP ? rtts_drop_keep(seed, ((uint32_t)bh * (uint32_t)Tq + (uint32_t)(qb * XA_QB + q0 + j)) *
                                                                          (uint32_t)TK + (uint32_t)myrow[k2], thresh, dscale)
                                               : 1.f;
                     pp[i] = p * keep;
@@ -316,7 +329,7 @@ __global__ __launch_bounds__(TK) void xattn_bwd_kernel(const bf16_t* __restrict_
     // dK | dV partial slab of this query block: layout (nqb, B, TK, 2d)
     bf16_t* slab = dkv_part + (((size_t)qb * B + b) * TK) * (size_t)(2 * d) + (size_t)h * XA_DH;
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) {
+    for (int k2 = 0; k2 < KT2; ++k2) {
         bf16_t* dkp = slab + (size_t)myrow[k2] * (2 * d);
         bf16_t* dvp = dkp + d;
 #pragma unroll
@@ -334,38 +347,30 @@ __global__ __launch_bounds__(TK) void xattn_bwd_kernel(const bf16_t* __restrict_
     }
     __syncthreads();
 
-    // dQ^T[dh][q] = K^T dS^T: the TK/64 waves split the 4 query tiles
-    for (int qt = wave; qt < XA_QB / 32; qt += TK / 64) {
-        f32x16 dqa[2] = {{0}, {0}};
+    // dQ^T[dh][q] = K^T dS^T: the 8 (query tile, dh half) outputs are dealt over the waves
+    constexpr int NOUT = (XA_QB / 32) * 2;
+    for (int oi = wave; oi < NOUT; oi += NW) {
+        const int qt = oi >> 1, dt = oi & 1;
+        f32x16 dqa = {0};
         const int rl = 8 * hh + trq;                       // key row inside a 16-key step (second read: +4)
         const int gq = qt * 8 + 4 * trc + trp;             // 8-byte granule of the dS^T row
         const int do0 = xa_ds_off(rl, gq), do1 = xa_ds_off(rl + 4, gq);
-        int ko0[2], ko1[2];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            const int kpc = dt * 4 + 2 * trc + (trp >> 1);
-            ko0[dt] = xa_off(rl, kpc) + 8 * (trp & 1);
-            ko1[dt] = xa_off(rl + 4, kpc) + 8 * (trp & 1);
-        }
+        const int kpc = dt * 4 + 2 * trc + (trp >> 1);
+        const int ko0 = xa_off(rl, kpc) + 8 * (trp & 1), ko1 = xa_off(rl + 4, kpc) + 8 * (trp & 1);
 #pragma unroll
         for (int kb = 0; kb < TK; kb += 16) {
             const bf16x8 bfrag = xa_tr_frag(Ds + kb * DSROW + do0, Ds + kb * DSROW + do1);
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const bf16x8 afrag = xa_tr_frag(Ks + kb * 128 + ko0[dt], Ks + kb * 128 + ko1[dt]);
-                dqa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, dqa[dt], 0, 0, 0);
-            }
+            const bf16x8 afrag = xa_tr_frag(Ks + kb * 128 + ko0, Ks + kb * 128 + ko1);
+            dqa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, dqa, 0, 0, 0);
         }
         bf16_t* dqp = dq + ((size_t)b * Tq + (size_t)qb * XA_QB + qt * 32 + r) * ld_dq + (size_t)h * XA_DH;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 pk;
-                pk.x = pack_bf16x2(dqa[dt][4 * g], dqa[dt][4 * g + 1]);
-                pk.y = pack_bf16x2(dqa[dt][4 * g + 2], dqa[dt][4 * g + 3]);
-                *reinterpret_cast<uint2*>(dqp + dt * 32 + 8 * g + 4 * hh) = pk;
-            }
+        for (int g = 0; g < 4; ++g) {
+            uint2 pk;
+            pk.x = pack_bf16x2(dqa[4 * g], dqa[4 * g + 1]);
+            pk.y = pack_bf16x2(dqa[4 * g + 2], dqa[4 * g + 3]);
+            *reinterpret_cast<uint2*>(dqp + dt * 32 + 8 * g + 4 * hh) = pk;
+        }
     }
 }
 
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const bf16_t* __restrict
     }
 }
 
-static bool g_xa_attr[2][2];
+static bool g_xa_attr[3][2];
 
 static int xa_check(const char* fn, int B, int H, int Tq, int Tk, int dh, int64_t ld_q, int64_t ld_kv) {
     RTTS_REQUIRE(dh == XA_DH, "%s: dh=%d unsupported (this build: 64)", fn, dh);
@@ -441,12 +446,12 @@ extern "C" int rtts_xattn_bwd(const void* q, int64_t ld_q, const void* kv, int64
     const size_t lds = (size_t)Tk * 128 + 2 * (size_t)XA_QB * 128 + (size_t)Tk * (XA_QB * 2) + XA_QB * 8;
 #define GO(TK_)                                                                                                           \
     do {                                                                                                                  \
-        auto kern = xattn_bwd_kernel<TK_>;                                                                                \
-        if (!g_xa_attr[1][TK_ == 256]) {                                                                                  \
+        auto kern = drop_p > 0.f ? xattn_bwd_kernel<TK_, true> : xattn_bwd_kernel<TK_, false>;                            \
+        if (!g_xa_attr[1 + (drop_p > 0.f)][TK_ == 256]) {                                                                                  \
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            g_xa_attr[1][TK_ == 256] = true;                                                                              \
+            g_xa_attr[1 + (drop_p > 0.f)][TK_ == 256] = true;                                                                              \
         }                                                                                                                 \
-        hipLaunchKernelGGL(kern, grid, dim3(TK_), lds, (hipStream_t)stream, (const bf16_t*)q, ld_q, (const bf16_t*)kv, ld_kv, \
+        hipLaunchKernelGGL(kern, grid, dim3(TK_ * 2 / XA_KT2), lds, (hipStream_t)stream, (const bf16_t*)q, ld_q, (const bf16_t*)kv, ld_kv, \
                            kvalid, (const bf16_t*)dout, ld_dout, lse, delta, H, Tq, (bf16_t*)dq, ld_dq, (bf16_t*)dkv_part, B,    \
                            seed, seed_dev, rtts_drop_thresh(drop_p), 1.f / (1.f - drop_p));                               \
     } while (0)
