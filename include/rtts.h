@@ -211,6 +211,15 @@ int rtts_im2col_k5(const void* x, int64_t ldx, int B, int L, int C, int CP, void
 int rtts_col2im_k5(const void* dcols, int B, int L, int C, int CP, void* dx, int64_t lddx, int out_f32, void* stream);
 int rtts_conv_w_perm(const float* w, int Co, int Ci, int CP, void* wp, void* stream);
 int rtts_conv_dw_unperm(const float* dwp, int Co, int Ci, int CP, float* dw, void* stream);
+/* All convolution weights of a step re-laid-out in ONE launch (they only change in the optimizer step, and a launch costs
+ * ~5 us whatever its size): jobs[i] is one rtts_conv_w_perm problem. */
+#define RTTS_CONV_PERM_MAX_GROUP 8
+typedef struct {
+    const float* w;    /* (Co, Ci, 5) fp32 master */
+    void* wp;          /* (>= Co, 5*CP) bf16 */
+    int32_t Co, Ci, CP, reserved;
+} rtts_conv_perm_job;
+int rtts_conv_w_perm_grouped(const rtts_conv_perm_job* jobs, int n, void* stream);
 int rtts_bn_stats(const float* y, int M, int C, float* mean, float* rstd, float* run_mean, float* run_var,
                   const float* mean_shift, int64_t* num_batches, float* partial_ws, void* stream);
 int rtts_bn_act_fwd(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,

@@ -29,6 +29,14 @@ class ColsumJob(C.Structure):
 
 COLSUM_MAX_GROUP = 48
 
+
+class ConvPermJob(C.Structure):
+    """rtts_conv_perm_job of include/rtts.h."""
+    _fields_ = [("w", _vp), ("wp", _vp), ("Co", C.c_int32), ("Ci", C.c_int32), ("CP", C.c_int32), ("reserved", C.c_int32)]
+
+
+CONV_PERM_MAX_GROUP = 8
+
 # name -> argtypes, exactly the prototypes of include/rtts.h
 SIGNATURES = {
     "rtts_lsh_hash_sort": [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
@@ -57,6 +65,7 @@ SIGNATURES = {
     "rtts_col2im_k5": [_vp, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _vp],
     "rtts_conv_w_perm": [_vp, _i32, _i32, _i32, _vp, _vp],
     "rtts_conv_dw_unperm": [_vp, _i32, _i32, _i32, _vp, _vp],
+    "rtts_conv_w_perm_grouped": [C.POINTER(ConvPermJob), _i32, _vp],
     "rtts_bn_stats": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "rtts_bn_act_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _u32, _vp, _i32, _i32, _vp, _vp],
     "rtts_bn_act_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _u32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp],

@@ -42,6 +42,8 @@ def _pad128(c: int) -> int:
 class ConvK5:
     """One Conv1d(kernel 5, padding 2) as im2col + GEMM; keeps what its backward needs."""
 
+    instances = None      # weakref.WeakSet of every executor: refresh_all() re-lays-out all their weights in one launch
+
     def __init__(self, conv: torch.nn.Conv1d):
         self.conv = conv
         self.co, self.ci = conv.out_channels, conv.in_channels
@@ -49,6 +51,30 @@ class ConvK5:
         self.cop = _pad128(self.co)         # output channels padded likewise (zero rows)
         self._wp = None
         self._wp_version = None
+        if ConvK5.instances is None:
+            import weakref
+            ConvK5.instances = weakref.WeakSet()
+        ConvK5.instances.add(self)
+
+    def _version(self):
+        w = self.conv.weight
+        return (w._version, WEIGHT_EPOCH[0], w.data_ptr())
+
+    @staticmethod
+    def refresh_all(device) -> None:
+        """Re-layout the weights of every live executor on ``device`` whose cached copy is stale: one grouped launch at the
+        start of a step (the weights only change in the optimizer step) instead of one launch per convolution."""
+        stale = [c for c in (ConvK5.instances or ()) if c.conv.weight.device == device and c._wp_version != c._version()]
+        for i in range(0, len(stale), _lib.CONV_PERM_MAX_GROUP):
+            chunk = stale[i:i + _lib.CONV_PERM_MAX_GROUP]
+            jobs = (_lib.ConvPermJob * len(chunk))()
+            for j, c in zip(jobs, chunk):
+                if c._wp is None or c._wp.device != device:
+                    c._wp = torch.zeros(c.cop, 5 * c.cp, dtype=torch.bfloat16, device=device)
+                j.w, j.wp, j.Co, j.Ci, j.CP = c.conv.weight.data_ptr(), c._wp.data_ptr(), c.co, c.ci, c.cp
+            _lib.call("rtts_conv_w_perm_grouped", jobs, len(chunk), _s())
+            for c in chunk:
+                c._wp_version = c._version()
 
     def weight_perm(self) -> torch.Tensor:
         """(Cout_pad, 5*Cin_pad) bf16 with wp[co][k][ci] = w[co][ci][k]; rebuilt when the master changed."""

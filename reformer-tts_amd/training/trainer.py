@@ -164,6 +164,9 @@ class Trainer:
             # graph mode: the hash rotations of every LSH layer of this forward are slices of ONE sample (one launch, not one
             # per layer); 256 K values cover 6 + 6 layers at 64 buckets (a layer that does not fit draws its own)
             LSHSelfAttention.rotation_pool = (torch.randn(1 << 18, device=spec.device, dtype=torch.float32), [0])
+        if spec.device.type == "cuda":
+            from ..edges import ConvK5
+            ConvK5.refresh_all(spec.device)          # every convolution's GEMM-layout weight copy, one launch
         try:
             return self._forward_loss(batch, split)
         finally:
