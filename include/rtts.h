@@ -220,6 +220,9 @@ typedef struct {
     int32_t Co, Ci, CP, reserved;
 } rtts_conv_perm_job;
 int rtts_conv_w_perm_grouped(const rtts_conv_perm_job* jobs, int n, void* stream);
+/* The adjoint for the gradients, likewise grouped: jobs[i].w = dwp (Co_pad, 5*CP) fp32, jobs[i].wp = dw (Co, Ci, 5) fp32,
+ * dw[co][ci][k] += dwp[co][k][ci]. */
+int rtts_conv_dw_unperm_grouped(const rtts_conv_perm_job* jobs, int n, void* stream);
 int rtts_bn_stats(const float* y, int M, int C, float* mean, float* rstd, float* run_mean, float* run_var,
                   const float* mean_shift, int64_t* num_batches, float* partial_ws, void* stream);
 int rtts_bn_act_fwd(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,

@@ -66,6 +66,7 @@ SIGNATURES = {
     "rtts_conv_w_perm": [_vp, _i32, _i32, _i32, _vp, _vp],
     "rtts_conv_dw_unperm": [_vp, _i32, _i32, _i32, _vp, _vp],
     "rtts_conv_w_perm_grouped": [C.POINTER(ConvPermJob), _i32, _vp],
+    "rtts_conv_dw_unperm_grouped": [C.POINTER(ConvPermJob), _i32, _vp],
     "rtts_bn_stats": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "rtts_bn_act_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _u32, _vp, _i32, _i32, _vp, _vp],
     "rtts_bn_act_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _u32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp],

@@ -105,6 +105,22 @@ __global__ __launch_bounds__(ED_THREADS) void conv_w_perm_grouped_kernel(const C
         wp[i] = ci < Ci ? f32_to_bf16(w[((size_t)co * Ci + ci) * 5 + k]) : (bf16_t)0;
     }
 }
+__global__ __launch_bounds__(ED_THREADS) void conv_dw_unperm_grouped_kernel(const CwGroup g) {
+    int ji = 0;
+#pragma unroll
+    for (int i = 1; i < RTTS_CONV_PERM_MAX_GROUP; ++i)
+        if (i < g.n && (int)blockIdx.x >= g.blk_start[i]) ji = i;
+    const rtts_conv_perm_job& J = g.j[ji];
+    const int Co = J.Co, Ci = J.Ci, CP = J.CP;
+    const float* __restrict__ dwp = J.w;
+    float* __restrict__ dw = (float*)J.wp;
+    const size_t total = (size_t)Co * Ci * 5;
+    const size_t nthr = (size_t)(g.blk_start[ji + 1] - g.blk_start[ji]) * blockDim.x;
+    for (size_t i = (size_t)((int)blockIdx.x - g.blk_start[ji]) * blockDim.x + threadIdx.x; i < total; i += nthr) {
+        const int k = (int)(i % 5), ci = (int)((i / 5) % Ci), co = (int)(i / ((size_t)Ci * 5));
+        dw[i] += dwp[((size_t)co * 5 + k) * CP + ci];
+    }
+}
 // dw[co][ci][k] += dwp[co][k][ci]
 __global__ __launch_bounds__(ED_THREADS) void conv_dw_unperm_kernel(const float* __restrict__ dwp, int Co, int Ci, int CP, float* __restrict__ dw) {
     const size_t total = (size_t)Co * Ci * 5;
@@ -535,6 +551,23 @@ extern "C" int rtts_conv_w_perm_grouped(const rtts_conv_perm_job* jobs, int n, v
     for (int i = n; i <= RTTS_CONV_PERM_MAX_GROUP; ++i) g.blk_start[i] = blk;
     hipLaunchKernelGGL(conv_w_perm_grouped_kernel, dim3(blk), dim3(ED_THREADS), 0, (hipStream_t)stream, g);
     RTTS_LAUNCH_CHECK("rtts_conv_w_perm_grouped");
+    return 0;
+}
+
+extern "C" int rtts_conv_dw_unperm_grouped(const rtts_conv_perm_job* jobs, int n, void* stream) {
+    RTTS_REQUIRE(jobs && n > 0 && n <= RTTS_CONV_PERM_MAX_GROUP, "rtts_conv_dw_unperm_grouped: 1..%d jobs", RTTS_CONV_PERM_MAX_GROUP);
+    CwGroup g;
+    g.n = n;
+    int blk = 0;
+    for (int i = 0; i < n; ++i) {
+        RTTS_REQUIRE(jobs[i].w && jobs[i].wp && jobs[i].Co > 0 && jobs[i].Ci > 0 && jobs[i].CP >= jobs[i].Ci, "rtts_conv_dw_unperm_grouped: bad job %d", i);
+        g.j[i] = jobs[i];
+        g.blk_start[i] = blk;
+        blk += (int)ed_grid((size_t)jobs[i].Co * jobs[i].Ci * 5);
+    }
+    for (int i = n; i <= RTTS_CONV_PERM_MAX_GROUP; ++i) g.blk_start[i] = blk;
+    hipLaunchKernelGGL(conv_dw_unperm_grouped_kernel, dim3(blk), dim3(ED_THREADS), 0, (hipStream_t)stream, g);
+    RTTS_LAUNCH_CHECK("rtts_conv_dw_unperm_grouped");
     return 0;
 }
 

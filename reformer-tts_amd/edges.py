@@ -19,6 +19,7 @@ from typing import List
 import torch
 
 from . import _lib
+from . import engine as _engine
 from .engine import WEIGHT_EPOCH, _WS, _bf16, _grad, cast_colsum, wgrad
 
 from ._seeds import _seed_counter, seed_base  # noqa: E402,F401  (shared with engine.py)
@@ -37,6 +38,20 @@ def _ws(device, c: int) -> torch.Tensor:
 
 def _pad128(c: int) -> int:
     return -(-c // 128) * 128
+
+
+_PENDING_DW = []
+
+
+def flush_conv_dw() -> None:
+    """dw[co][ci][k] += dwp[co][k][ci] for every convolution whose backward has run since the last flush (one launch)."""
+    while _PENDING_DW:
+        chunk = _PENDING_DW[:_lib.CONV_PERM_MAX_GROUP]
+        del _PENDING_DW[:len(chunk)]
+        jobs = (_lib.ConvPermJob * len(chunk))()
+        for j, (dwp, co, ci, cp, gw) in zip(jobs, chunk):
+            j.w, j.wp, j.Co, j.Ci, j.CP = dwp.data_ptr(), gw.data_ptr(), co, ci, cp
+        _lib.call("rtts_conv_dw_unperm_grouped", jobs, len(chunk), _s())
 
 
 class ConvK5:
@@ -103,7 +118,14 @@ class ConvK5:
         """dy bf16 (M, cop) -> accumulates dW, returns dx (M, ci rounded up to 8) bf16/fp32."""
         dwp = torch.empty(self.cop, 5 * self.cp, dtype=torch.float32, device=dy.device)
         wgrad(dwp, dy, cols, accumulate=False)
-        _lib.call("rtts_conv_dw_unperm", dwp.data_ptr(), self.co, self.ci, self.cp, _grad(self.conv.weight).data_ptr(), _s())
+        # dW goes back to nn.Conv1d's (Co, Ci, 5) layout with the other deferred gradient work of the backward: one grouped
+        # launch for all convolutions (engine.flush_wgrad runs the hook before anything reads the gradients)
+        _PENDING_DW.append((dwp, self.co, self.ci, self.cp, _grad(self.conv.weight)))
+        if len(_PENDING_DW) >= _lib.CONV_PERM_MAX_GROUP:
+            flush_conv_dw()
+        else:
+            from .engine import _queue_final_flush
+            _queue_final_flush()
         if not need_dx:
             return None
         dcols = torch.mm(dy, self.weight_perm())
@@ -365,3 +387,6 @@ def decoder_prenet_pe(prenet, pe, spec):
     h = _ReluDropLinearFn.apply(x, lyr.fc1, lyr.dropout1.p if training else 0.0, lyr.fc1.weight)
     h = _ReluDropLinearFn.apply(h, lyr.fc2, lyr.dropout2.p if training else 0.0, lyr.fc2.weight)
     return proj_pe(h.view(b, l, -1), lyr.projection, pe)
+
+
+_engine.FLUSH_HOOKS.append(flush_conv_dw)

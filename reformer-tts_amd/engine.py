@@ -244,6 +244,11 @@ def flush_wgrad():
             q.M, q.N, q.K, q.accumulate = dy.shape[0], dy.shape[1], x.shape[1], 1
         ws = _slab_ws(group[0][1].device)
         _lib.call("rtts_gemm_tn_grouped", arr, len(group), ws.data_ptr(), ws.numel(), _s())
+    for hook in FLUSH_HOOKS:           # other deferred gradient work (edges.py: the convolutions' dW re-layout)
+        hook()
+
+
+FLUSH_HOOKS = []
 
 
 def pending_wgrads() -> int:
