@@ -240,8 +240,7 @@ class _PostnetLossFn(torch.autograd.Function):
         yb = y_dec.detach().reshape(m, d).to(torch.bfloat16)
         wh, bh = ex._heads_weight()
         heads = torch.mm(yb, wh.t(), out_dtype=torch.float32) + bh          # (M,128): [mel(80) | stop | 0...]
-        x0 = torch.zeros(m, 128, dtype=torch.bfloat16, device=dev)
-        x0[:, :nm] = heads[:, :nm]
+        x0 = heads.to(torch.bfloat16)               # the first convolution reads channels < nm only; columns >= nm stay unread
         saved, cur = [], x0
         for layer in ex.layers:
             cur, s = layer.forward(cur, b, lp)
@@ -251,30 +250,33 @@ class _PostnetLossFn(torch.autograd.Function):
         post = heads[:, :128] + res                                           # cols >= nm are junk and never read
         lm = ex.loss_mod
         losses = torch.empty(4, dtype=torch.float32, device=dev)
-        d_raw = torch.empty(m, 128, dtype=torch.float32, device=dev)       # 128-wide rows; the kernel zeroes the pad columns
-        d_post = torch.empty(m, 128, dtype=torch.float32, device=dev)
-        g_stop = torch.empty(m, dtype=torch.float32, device=dev)
+        # the three stored gradients share one buffer so that the backward scales them with one launch
+        gbuf = torch.empty(m * 257, dtype=torch.float32, device=dev)
+        d_raw = gbuf[:m * 128].view(m, 128)                                # 128-wide rows; the kernel zeroes the pad columns
+        d_post = gbuf[m * 128:m * 256].view(m, 128)
+        g_stop = gbuf[m * 256:]
         kind = 0 if isinstance(lm.spectrogram_loss, torch.nn.MSELoss) else 1
         pw = torch.empty(512 * 3, dtype=torch.float32, device=dev)
         _lib.call("rtts_tts_loss", heads.data_ptr(), post.data_ptr(), 128, true_mel.contiguous().data_ptr(), true_mask.contiguous().data_ptr(),
                   heads[:, nm:].data_ptr(), 128, true_stop.contiguous().data_ptr(), m, nm, kind, ex.pos_weight,
                   float(lm.raw_pred_loss_weight), float(lm.post_pred_loss_weight), float(lm.stop_loss_weight), d_raw.data_ptr(),
                   d_post.data_ptr(), 128, g_stop.data_ptr(), losses.data_ptr(), pw.data_ptr(), lp, l, _s())
-        ctx.ex, ctx.state = ex, (yb, wh, saved, cur, cols_end, d_raw, d_post, g_stop, b, lp, d)
+        ctx.ex, ctx.state = ex, (yb, wh, saved, cur, cols_end, gbuf, b, lp, d)
         return losses
 
     @staticmethod
     def backward(ctx, dlosses):
         ex = ctx.ex
-        yb, wh, saved, z_last, cols_end, d_raw, d_post, g_stop, b, lp, d = ctx.state
+        yb, wh, saved, z_last, cols_end, gbuf, b, lp, d = ctx.state
         ctx.state = None
         nm, dev = ex.nm, yb.device
         m = b * lp
         # the stored gradients are those of losses[0]; scale them by its upstream weight (1 in the trainer)
-        scale = dlosses[0]
-        d_raw, d_post, g_stop = d_raw * scale, d_post * scale, g_stop * scale
+        gbuf = gbuf * dlosses[0]
+        d_raw, d_post, g_stop = gbuf[:m * 128].view(m, 128), gbuf[m * 128:m * 256].view(m, 128), gbuf[m * 256:]
         # convend: res = conv(z_last) + bias;  d_res = d_post
-        dbias_pad = torch.zeros(128, dtype=torch.float32, device=dev)
+        zpad = torch.zeros(256, dtype=torch.float32, device=dev)
+        dbias_pad, bsum = zpad[:128], zpad[128:]
         dresb = cast_colsum(d_post, dbias_pad, defer=False)                 # deterministic column sums (no ATen reduction)
         _grad(ex.convend.conv.bias).add_(dbias_pad[:nm])
         dz = ex.convend.backward(dresb, cols_end, b, lp)
@@ -284,7 +286,6 @@ class _PostnetLossFn(torch.autograd.Function):
         dheads = d_raw + d_post
         dheads[:, :nm] += dx0[:, :nm]
         dheads[:, nm] = g_stop
-        bsum = torch.zeros(128, dtype=torch.float32, device=dev)
         dhb = cast_colsum(dheads, bsum, defer=False)      # read two lines below
         mel, stop = ex.model.dec.mel_linear, ex.model.dec.stop_linear
         _grad(mel.bias).add_(bsum[:nm])
@@ -298,9 +299,11 @@ class _PostnetLossFn(torch.autograd.Function):
 
 
 def _pad_bias(c: ConvK5, dev):
-    bias = torch.zeros(c.cop, dtype=torch.float32, device=dev)
-    bias[:c.co] = c.conv.bias.detach()
-    return bias
+    """The convolution's bias in a persistent zero-padded (cop) buffer: one copy per call, no fill."""
+    if getattr(c, "_bias_pad", None) is None or c._bias_pad.device != dev:
+        c._bias_pad = torch.zeros(c.cop, dtype=torch.float32, device=dev)
+    c._bias_pad[:c.co].copy_(c.conv.bias.detach())
+    return c._bias_pad
 
 
 # ------------------------------------------------------------------------------------------------------------------
