@@ -269,6 +269,23 @@ typedef struct {
 } rtts_gemm_tn_problem;
 int rtts_gemm_tn_grouped(const rtts_gemm_tn_problem* problems, int n, float* slab_ws, int64_t slab_ws_floats, void* stream);
 
+/* ---- forward / input-gradient GEMM of the stacks' Linear layers ---------------------------------
+ * c[M][N] (bf16, stride ldc) = epilogue( a[M][K] (bf16, stride lda) x W ), fp32 accumulation:
+ *   w_is_kn = 0: W = w[N][K] (stride ldw)  -> y = x W^T, the forward of nn.Linear: toqk / tov / to_out of the LSH layer
+ *                (reformer.py:198-217 via reformer_pytorch), in_proj / out_proj of nn.MultiheadAttention
+ *                (reformer.py:161-186), FeedForward net.0 / net.3 (modules.py:195-207)
+ *   w_is_kn = 1: W = w[K][N] (stride ldw)  -> dx = dy W, the input gradient autograd derives for the same lines
+ * epilogue: 0 none; 1 + bias[N] (fp32); 2 relu(+ bias) (FeedForward's Linear -> ReLU, modules.py:200-201);
+ *           3 ReLU gate: c = acc * (gate[M][N] > 0) (bf16, stride ldg) -- the backward of that ReLU -- and, if
+ *             colsum_partial != NULL, fp32 partial column sums of c: rtts_gemm_nt_partial_rows(M, N) rows of N floats
+ *             (the hidden bias gradient; sum them with rtts_colsum_final_grouped).
+ * K % 64 == 0; (M, N) must tile by one of 192x128, 256x128, 96x64, 128x64; a, w 16-byte aligned, lda, ldw % 8 == 0.
+ * Replaces the reference's ATen/cuBLAS calls for these layers; parity vs oracle/model_ref.py in tests/test_gemm_hip.py. */
+int rtts_gemm_nt(const void* a, int64_t lda, const void* w, int64_t ldw, int w_is_kn, int M, int N, int K, void* c,
+                 int64_t ldc, const float* bias, int epilogue, const void* gate, int64_t ldg, float* colsum_partial,
+                 void* stream);
+int rtts_gemm_nt_partial_rows(int M, int N);
+
 /* ---- SqueezeWave vocoder, inference -----------------------------------
  * Activations are channels-last rows; the 1x1 convolutions are GEMMs outside.  Replaces, per WN layer
  * (reference reformer_tts/squeeze_wave/modules.py):

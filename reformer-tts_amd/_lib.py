@@ -77,6 +77,8 @@ SIGNATURES = {
     "rtts_embedding_bwd": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],
     "rtts_gemm_tn": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _i32, _vp, _i64, _vp],
     "rtts_gemm_tn_grouped": [C.POINTER(GemmTnProblem), _i32, _vp, _i64, _vp],
+    "rtts_gemm_nt": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _vp],
+    "rtts_gemm_nt_partial_rows": [_i32, _i32],
     "rtts_sw_depthwise_k3": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "rtts_sw_gate": [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "rtts_sw_coupling_inv": [_vp, _i64, _vp, _i64, _i32, _vp],

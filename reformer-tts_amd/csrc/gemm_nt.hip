@@ -1,0 +1,374 @@
+// Forward / input-gradient GEMM of the Linear layers of the reversible stacks:
+//     C[M][N] (bf16) = epilogue( A[M][K] (bf16) x W )        fp32 accumulation on v_mfma_f32_16x16x32_bf16
+//   W_KN = 0:  W stored [N][K]  (y = x W^T, the forward of nn.Linear:   toqk/tov/to_out, in_proj/out_proj, FeedForward net.0/net.3;
+//              /root/reference/reformer_tts/model/modules.py:195-207, reformer.py:161-217)
+//   W_KN = 1:  W stored [K][N]  (dx = dy W, the input gradient of the same layers: the autograd backward of the lines above)
+// Epilogues (fused into the store of the accumulators, nothing is re-read):
+//   0 plain   1 + bias   2 relu(+ bias)   3 ReLU gate: C = acc * (gate > 0) with the column sums of C over the workgroup's
+//   rows written as fp32 partial rows (the bias gradient of the first FeedForward layer; summed by rtts_colsum_final_grouped)
+//
+// Shape of the problem on MI355X: M = B*T = 12288 tokens, N and K only 512..2048 -- a few hundred output tiles and 8..32
+// K-steps, so the kernel is sized for launch ramp and operand ingest, not for a long steady state:
+//   * tile BM x BN = 192 x 128 (256 x 128 when 192 does not divide M): (M/192) x (N/128) = 256, 512, 1024 workgroups for
+//     N = 512, 1024, 2048 = whole waves of one 8-wave workgroup per CU; small problems (the encoder, M = 3072) use 96 x 64;
+//   * both operands arrive by LDS-DMA (global_load_lds_dwordx4) into a 3-deep ring of 64-deep K stages: two stages in
+//     flight while one is consumed, a counted s_waitcnt vmcnt(N) + ONE raw s_barrier per stage;
+//   * LDS images are unpadded 128-byte rows ([row][64 k]) whose 16-byte chunks are XOR-swizzled with (row >> 1) & 7 on the
+//     SOURCE side of the DMA, so every ds_read_b128 fragment read (16 rows x 4 chunks) touches 16 distinct 16-byte slots;
+//     the [K][N] weight image keeps k rows and is read with ds_read_b64_tr_b16 (32-byte chunks XOR-swizzled by the k row);
+//   * the product is computed transposed (D^T = W-fragment x A-fragment) so that a lane ends up with 4 CONSECUTIVE output
+//     columns of one row: the epilogue stores 8 bytes per lane straight from the accumulators, bias / gate are 16 / 8-byte loads;
+//   * XCD-aware tile order: the N/BN tiles that share an A row panel run on one XCD back to back (one fetch of the panel
+//     from HBM / Infinity Cache per XCD, the weight stays resident in every L2).
+#include "rtts_common.h"
+
+typedef __attribute__((ext_vector_type(4))) int gn_v4i;
+typedef __attribute__((ext_vector_type(2))) int gn_v2i;
+
+
+#include <type_traits>
+template <int I, int N, typename F>
+__device__ __forceinline__ void gn_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        gn_static_for<I + 1, N>(f);
+    }
+}
+// LDS reads as inline assembly with immediate offsets (an "n" operand must be a template constant, not a loop variable)
+template <int OFF>
+__device__ __forceinline__ void gn_rd128(gn_v4i& dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void gn_rdtr(gn_v2i& dst, uint32_t addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void gn_wait_lgkm() {
+    static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+
+#define GN_BK 64
+#define GN_NST 3
+
+struct GnArgs {
+    const bf16_t* a;
+    const bf16_t* w;
+    bf16_t* c;
+    const float* bias;
+    const bf16_t* gate;
+    float* colsum;       // [(M / BM) * WM][N] partial rows (epilogue 3), may be null
+    int64_t lda, ldw, ldc, ldg;
+    int M, N, K, epi;
+};
+
+// swizzle of the [K][N] weight image: XOR applied to the index of a 32-byte chunk (16 columns) of k row `k`
+template <int RP>
+__device__ __forceinline__ int gn_kn_swz(int k) {
+    if constexpr (RP == 128) return ((k >> 1) & 1) | (((k >> 3) & 1) << 1);
+    else return (k & 3) | (((k >> 3) & 1) << 2);
+}
+
+template <int BM, int BN, int WM, int WN, bool W_KN, int EPI>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;          // 16 x 16 MFMA tiles per wave
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
+    constexpr int PA = BM / 8 / NW, PW = BN / 8 / NW, PER = PA + PW;   // 1-KB DMA pieces per wave and stage
+    constexpr int RP = 2 * BN;                                    // row pitch of the [K][N] image (bytes)
+    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "DMA pieces must divide over the waves");
+    static_assert(BM % (16 * WM) == 0 && BN % (16 * WN) == 0, "wave tiles");
+    static_assert(!W_KN || RP == 128 || RP == 256 || RP == 512, "[K][N] image: BN in {64, 128, 256}");
+    static_assert(!W_KN || ((BN / WN) % 64 == 0) || TN <= 2, "[K][N] image: wave column base");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntn = P.N / BN;
+    const uint32_t logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (int)(logical / ntn) * BM, n0 = (int)(logical % ntn) * BN;
+    const int nk = P.K / GN_BK;
+    const int64_t lda = P.lda, ldw = P.ldw;
+
+    // ---- DMA sources (per lane), stage 0; a stage advances A by 64 columns, W by 64 columns ([N][K]) or 64 rows ([K][N])
+    const bf16_t* srcA[PA];
+    const bf16_t* srcW[PW];
+#pragma unroll
+    for (int t = 0; t < PA; ++t) {
+        const int p = wave + NW * t, row = 8 * p + (lane >> 3);
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        srcA[t] = P.a + (size_t)(m0 + row) * lda + lc * 8;
+    }
+#pragma unroll
+    for (int t = 0; t < PW; ++t) {
+        const int p = wave + NW * t;
+        if constexpr (!W_KN) {
+            const int row = 8 * p + (lane >> 3);
+            const int lc = (lane & 7) ^ ((row >> 1) & 7);
+            srcW[t] = P.w + (size_t)(n0 + row) * ldw + lc * 8;
+        } else {
+            constexpr int UPR = RP / 16;                          // 16-byte units per k row
+            const int row = (1024 / RP) * p + lane / UPR, u = lane % UPR;
+            const int lchunk = (u >> 1) ^ gn_kn_swz<RP>(row);
+            srcW[t] = P.w + (size_t)row * ldw + n0 + lchunk * 16 + (u & 1) * 8;
+        }
+    }
+    const size_t wstep = W_KN ? (size_t)GN_BK * ldw : (size_t)GN_BK;
+#define GN_ISSUE(stage_, buf_)                                                                                          \
+    do {                                                                                                                \
+        unsigned char* sb_ = smem + (buf_) * STAGE;                                                                     \
+        const size_t ka_ = (size_t)(stage_) * GN_BK, kw_ = (size_t)(stage_) * wstep;                                    \
+        _Pragma("unroll") for (int t = 0; t < PA; ++t)                                                                  \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[t] + ka_),           \
+                                             (RTTS_LDS void*)(sb_ + (wave + NW * t) * 1024), 16, 0, 0);                 \
+        _Pragma("unroll") for (int t = 0; t < PW; ++t)                                                                  \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[t] + kw_),           \
+                                             (RTTS_LDS void*)(sb_ + A_BYTES + (wave + NW * t) * 1024), 16, 0, 0);       \
+    } while (0)
+
+    // ---- fragment read offsets inside a stage
+    const int r = lane & 15, g = lane >> 4;
+    // [row][64 k] images: 16 rows x 4 chunks per fragment; k32-step 1 flips bit 2 of the chunk index (address ^ 64)
+    const uint32_t offA0 = (uint32_t)(wm * (BM / WM) * 128 + r * 128 + ((g ^ ((r >> 1) & 7)) << 4));
+    const uint32_t offA1 = offA0 ^ 64u;
+    uint32_t offW[W_KN ? TN : 2];
+    if constexpr (!W_KN) {
+        offW[0] = (uint32_t)(A_BYTES + wn * (BN / WN) * 128 + r * 128 + ((g ^ ((r >> 1) & 7)) << 4));
+        offW[1] = offW[0] ^ 64u;
+    } else {
+        // transposed read: lane 4q+p of 16-lane group g supplies k row 8g + q (second read: + 4), columns 4p .. 4p+3 of tile j
+        const int q = r >> 2, p = r & 3;
+        const int fl = gn_kn_swz<RP>(8 * g + q);                   // does not depend on the k32-step or the half
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int jj = wn * (BN / WN) / 16 + j;
+            offW[j] = (uint32_t)(A_BYTES + (8 * g + q) * RP + ((jj ^ fl) << 5) + 8 * p);
+        }
+    }
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int i = 0; i < GN_NST - 1; ++i)
+        if (i < nk) GN_ISSUE(i, i);
+
+    int buf = 0;
+    for (int s = 0; s < nk; ++s) {
+        // stage s has landed (this wave's pieces) once at most the later stages' instructions are outstanding
+        if (nk - 1 - s >= 1) {
+            static_assert(GN_NST == 3, "one later stage in flight");
+            if constexpr (PER == 5) __builtin_amdgcn_s_waitcnt(0x0F75);          // vmcnt(5)
+            else if constexpr (PER == 6) __builtin_amdgcn_s_waitcnt(0x0F76);
+            else if constexpr (PER == 4) __builtin_amdgcn_s_waitcnt(0x0F74);
+            else if constexpr (PER == 3) __builtin_amdgcn_s_waitcnt(0x0F73);
+            else if constexpr (PER == 8) __builtin_amdgcn_s_waitcnt(0x0F78);
+            else if constexpr (PER == 10) __builtin_amdgcn_s_waitcnt(0x0F7A);
+            else __builtin_amdgcn_s_waitcnt(0x0F70);
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);                                   // vmcnt(0)
+        }
+        asm volatile("s_barrier" ::: "memory");      // stage s complete in LDS; everybody is done reading stage s-1
+        if (s + GN_NST - 1 < nk) {
+            int nb = buf + GN_NST - 1;
+            if (nb >= GN_NST) nb -= GN_NST;
+            GN_ISSUE(s + GN_NST - 1, nb);            // into the buffer stage s-1 occupied
+        }
+        const uint32_t sb = (uint32_t)(uintptr_t)(RTTS_LDS unsigned char*)(smem + buf * STAGE);
+        // Fragment reads as inline assembly: the compiler cannot prove that an LDS read does not alias the LDS-DMA writes
+        // still in flight and would drain them (vmcnt(0)) in front of the first read.  Which stage is complete is known
+        // here (counted wait + barrier above); the reads are ordered by lgkmcnt only.
+        gn_v4i af[2][TM], wf[2][TN];
+        gn_v2i wl[2][TN], wh[2][TN];
+        (void)wf; (void)wl; (void)wh;
+        gn_static_for<0, 2>([&](auto ksc) {
+            constexpr int ks = decltype(ksc)::value;
+            if constexpr (!W_KN) {
+                const uint32_t aw = sb + offW[ks];
+                gn_static_for<0, TN>([&](auto jc) { constexpr int j = decltype(jc)::value; gn_rd128<j * 2048>(wf[ks][j], aw); });
+            } else {
+                gn_static_for<0, TN>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    const uint32_t aw = sb + offW[j];
+                    gn_rdtr<(32 * ks) * RP>(wl[ks][j], aw);
+                    gn_rdtr<(32 * ks + 4) * RP>(wh[ks][j], aw);
+                });
+            }
+            const uint32_t aa = sb + (ks ? offA1 : offA0);
+            gn_static_for<0, TM>([&](auto ic) { constexpr int i = decltype(ic)::value; gn_rd128<i * 2048>(af[ks][i], aa); });
+        });
+        constexpr int RD_PER_KS = (W_KN ? 2 * TN : TN) + TM;
+        // k32-step 0's fragments are back once at most step 1's reads are outstanding (LDS returns in order)
+        gn_wait_lgkm<RD_PER_KS>();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks == 1) {
+                __builtin_amdgcn_sched_barrier(0);   // (keeps the second wait behind step 0's MFMAs)
+                gn_wait_lgkm<0>();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            bf16x8 wfr[TN], afr[TM];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (!W_KN) wfr[j] = __builtin_bit_cast(bf16x8, wf[ks][j]);
+                else {
+                    const gn_v4i both = {wl[ks][j][0], wl[ks][j][1], wh[ks][j][0], wh[ks][j][1]};
+                    wfr[j] = __builtin_bit_cast(bf16x8, both);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) afr[i] = __builtin_bit_cast(bf16x8, af[ks][i]);
+            // D^T tile: rows = output columns n (weight fragment as the A operand), columns = output rows m
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[j], afr[i], acc[i][j], 0, 0, 0);
+        }
+        buf = buf + 1 == GN_NST ? 0 : buf + 1;
+    }
+#undef GN_ISSUE
+
+    // ---- epilogue: lane holds C[m][n .. n+3], m = m0 + wave rows + 16 i + (lane & 15), n = n0 + wave cols + 16 j + 4 (lane >> 4)
+    constexpr int epi = EPI;
+    const int mrow = m0 + wm * (BM / WM) + r;
+    const int ncol = n0 + wn * (BN / WN) + 4 * g;
+    f32x4 cs[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) cs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = ncol + 16 * j;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (epi == 1 || epi == 2) bv = *reinterpret_cast<const f32x4*>(P.bias + n);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const size_t m = (size_t)(mrow + 16 * i);
+            f32x4 v = acc[i][j] + bv;
+            if constexpr (epi == 2) {
+                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+            } else if constexpr (epi == 3) {
+                const uint2 hv = *reinterpret_cast<const uint2*>(P.gate + m * P.ldg + n);
+                // bf16 h > 0  <=>  sign bit clear and magnitude non-zero
+                v[0] = ((hv.x & 0x8000u) == 0 && (hv.x & 0x7FFFu) != 0) ? v[0] : 0.f;
+                v[1] = ((hv.x & 0x80000000u) == 0 && (hv.x & 0x7FFF0000u) != 0) ? v[1] : 0.f;
+                v[2] = ((hv.y & 0x8000u) == 0 && (hv.y & 0x7FFFu) != 0) ? v[2] : 0.f;
+                v[3] = ((hv.y & 0x80000000u) == 0 && (hv.y & 0x7FFF0000u) != 0) ? v[3] : 0.f;
+                cs[j] += v;
+            }
+            uint2 o;
+            o.x = pack_bf16x2(v[0], v[1]);
+            o.y = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(P.c + m * P.ldc + n) = o;
+        }
+    }
+    if constexpr (epi == 3) if (P.colsum != nullptr) {
+        // sum over the wave's rows: the 16 lanes of a group hold 16 different rows of the same 4 columns
+        float* dst = P.colsum + ((size_t)(m0 / BM) * WM + wm) * P.N;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            f32x4 v = cs[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = v[e];
+                x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));     // lane ^ 1
+                x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));     // lane ^ 2
+                x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true));    // row_half_mirror
+                x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xF, 0xF, true));    // row_mirror
+                v[e] = x;
+            }
+            if (r == 0) *reinterpret_cast<f32x4*>(dst + ncol + 16 * j) = v;
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool W_KN, int EPI>
+static int gn_launch2(const GnArgs& P, hipStream_t s) {
+    constexpr size_t lds = (size_t)GN_NST * (BM + BN) * 128;
+    static bool attr[64] = {};                   // per device: the dynamic-LDS limit is an attribute of the loaded function
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<BM, BN, WM, WN, W_KN, EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        RTTS_REQUIRE(e == hipSuccess, "rtts_gemm_nt: cannot raise the dynamic LDS limit to %zu bytes", lds);
+        attr[dev] = true;
+    }
+    const int grid = (P.M / BM) * (P.N / BN);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, W_KN, EPI>), dim3(grid), dim3(64 * WM * WN), lds, s, P);
+    return 0;
+}
+
+template <int BM, int BN, int WM, int WN>
+static int gn_launch(const GnArgs& P, int w_kn, hipStream_t s) {
+    if (w_kn) {                       // input gradients: plain store or the ReLU gate of the FeedForward hidden layer
+        if (P.epi == 3) return gn_launch2<BM, BN, WM, WN, true, 3>(P, s);
+        if (P.epi == 0) return gn_launch2<BM, BN, WM, WN, true, 0>(P, s);
+        rtts_set_error("rtts_gemm_nt: a [K][N] weight (input gradient) takes epilogue 0 or 3, got %d", P.epi);
+        return -1;
+    }
+    switch (P.epi) {
+        case 0: return gn_launch2<BM, BN, WM, WN, false, 0>(P, s);
+        case 1: return gn_launch2<BM, BN, WM, WN, false, 1>(P, s);
+        case 2: return gn_launch2<BM, BN, WM, WN, false, 2>(P, s);
+        default: return gn_launch2<BM, BN, WM, WN, false, 3>(P, s);
+    }
+}
+
+// tile choice: the largest tile that still gives the chip >= ~0.75 workgroups per CU
+static int gn_pick(int M, int N) {
+    const int cand[4][2] = {{192, 128}, {256, 128}, {96, 64}, {128, 64}};
+    int best = -1;
+    for (int i = 0; i < 4; ++i) {
+        if (M % cand[i][0] || N % cand[i][1]) continue;
+        if (best < 0) best = i;                   // fallback: the first that tiles
+        if ((M / cand[i][0]) * (N / cand[i][1]) >= 192) return i;
+    }
+    // nothing reaches 192 workgroups: take the smallest tile that fits (most workgroups)
+    for (int i = 3; i >= 2; --i)
+        if (M % cand[i][0] == 0 && N % cand[i][1] == 0) return i;
+    return best;
+}
+
+extern "C" int rtts_gemm_nt_partial_rows(int M, int N) {
+    const int cand[4][2] = {{192, 128}, {256, 128}, {96, 64}, {128, 64}};
+    const int wm[4] = {4, 4, 2, 2};
+    const int i = gn_pick(M, N);
+    return i < 0 ? -1 : (M / cand[i][0]) * wm[i];
+}
+
+extern "C" int rtts_gemm_nt(const void* a, int64_t lda, const void* w, int64_t ldw, int w_is_kn, int M, int N, int K, void* c,
+                            int64_t ldc, const float* bias, int epilogue, const void* gate, int64_t ldg, float* colsum_partial,
+                            void* stream) {
+    RTTS_REQUIRE(a && w && c, "rtts_gemm_nt: null pointer");
+    RTTS_REQUIRE(M > 0 && N > 0 && K > 0 && K % GN_BK == 0, "rtts_gemm_nt: K must be a positive multiple of 64 (got M=%d N=%d K=%d)", M, N, K);
+    RTTS_REQUIRE(epilogue >= 0 && epilogue <= 3, "rtts_gemm_nt: epilogue 0..3");
+    RTTS_REQUIRE(!(epilogue == 1 || epilogue == 2) || bias, "rtts_gemm_nt: epilogue %d needs a bias", epilogue);
+    RTTS_REQUIRE(epilogue != 3 || (gate && ldg >= N && ldg % 4 == 0), "rtts_gemm_nt: epilogue 3 needs a gate (M, N) with ldg %% 4 == 0");
+    RTTS_REQUIRE(lda >= K && lda % 8 == 0 && ldc >= N && ldc % 4 == 0, "rtts_gemm_nt: bad leading dimensions (lda=%lld ldc=%lld)",
+                 (long long)lda, (long long)ldc);
+    RTTS_REQUIRE(ldw % 8 == 0 && ldw >= (w_is_kn ? N : K), "rtts_gemm_nt: bad ldw=%lld", (long long)ldw);
+    RTTS_REQUIRE((((uintptr_t)a | (uintptr_t)w) & 15) == 0 && (((uintptr_t)c | (uintptr_t)gate) & 7) == 0 &&
+                 (((uintptr_t)bias | (uintptr_t)colsum_partial) & 15) == 0, "rtts_gemm_nt: misaligned buffer");
+    const int pick = gn_pick(M, N);
+    RTTS_REQUIRE(pick >= 0, "rtts_gemm_nt: M x N = %d x %d tiles by none of 192x128, 256x128, 96x64, 128x64", M, N);
+    GnArgs P;
+    P.a = (const bf16_t*)a; P.w = (const bf16_t*)w; P.c = (bf16_t*)c; P.bias = bias; P.gate = (const bf16_t*)gate;
+    P.colsum = colsum_partial; P.lda = lda; P.ldw = ldw; P.ldc = ldc; P.ldg = ldg; P.M = M; P.N = N; P.K = K; P.epi = epilogue;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = 0;
+    switch (pick) {
+        case 0: rc = gn_launch<192, 128, 4, 2>(P, w_is_kn, s); break;
+        case 1: rc = gn_launch<256, 128, 4, 2>(P, w_is_kn, s); break;
+        case 2: rc = gn_launch<96, 64, 2, 2>(P, w_is_kn, s); break;
+        default: rc = gn_launch<128, 64, 2, 2>(P, w_is_kn, s); break;
+    }
+    if (rc) return rc;
+    RTTS_LAUNCH_CHECK("rtts_gemm_nt");
+    return 0;
+}
