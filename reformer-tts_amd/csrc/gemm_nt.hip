@@ -11,8 +11,10 @@
 // K-steps, so the kernel is sized for launch ramp and operand ingest, not for a long steady state:
 //   * tile BM x BN = 192 x 128 (256 x 128 when 192 does not divide M): (M/192) x (N/128) = 256, 512, 1024 workgroups for
 //     N = 512, 1024, 2048 = whole waves of one 8-wave workgroup per CU; small problems (the encoder, M = 3072) use 96 x 64;
-//   * both operands arrive by LDS-DMA (global_load_lds_dwordx4) into a 3-deep ring of 64-deep K stages: two stages in
-//     flight while one is consumed, a counted s_waitcnt vmcnt(N) + ONE raw s_barrier per stage;
+//   * both operands arrive by LDS-DMA (global_load_lds_dwordx4) into a ring of 64-deep K stages as deep as LDS allows
+//     (4 x 40 KB for the 192 x 128 tile): NST-1 stages in flight while one is consumed, a counted s_waitcnt vmcnt(N) +
+//     ONE raw s_barrier per stage; the loop is software-pipelined over half stages so that every fragment read from LDS
+//     is issued under the MFMAs of the previous half stage;
 //   * LDS images are unpadded 128-byte rows ([row][64 k]) whose 16-byte chunks are XOR-swizzled with (row >> 1) & 7 on the
 //     SOURCE side of the DMA, so every ds_read_b128 fragment read (16 rows x 4 chunks) touches 16 distinct 16-byte slots;
 //     the [K][N] weight image keeps k rows and is read with ds_read_b64_tr_b16 (32-byte chunks XOR-swizzled by the k row);
@@ -21,6 +23,7 @@
 //   * XCD-aware tile order: the N/BN tiles that share an A row panel run on one XCD back to back (one fetch of the panel
 //     from HBM / Infinity Cache per XCD, the weight stays resident in every L2).
 #include "rtts_common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) int gn_v4i;
 typedef __attribute__((ext_vector_type(2))) int gn_v2i;
@@ -44,13 +47,17 @@ __device__ __forceinline__ void gn_rdtr(gn_v2i& dst, uint32_t addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
 }
 template <int N>
+__device__ __forceinline__ void gn_wait_vm() {
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int N>
 __device__ __forceinline__ void gn_wait_lgkm() {
     static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 }
 
 #define GN_BK 64
-#define GN_NST 3
 
 struct GnArgs {
     const bf16_t* a;
@@ -70,7 +77,7 @@ __device__ __forceinline__ int gn_kn_swz(int k) {
     else return (k & 3) | (((k >> 3) & 1) << 2);
 }
 
-template <int BM, int BN, int WM, int WN, bool W_KN, int EPI>
+template <int BM, int BN, int WM, int WN, bool W_KN, int EPI, int NST>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;          // 16 x 16 MFMA tiles per wave
@@ -82,6 +89,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
     static_assert(!W_KN || RP == 128 || RP == 256 || RP == 512, "[K][N] image: BN in {64, 128, 256}");
     static_assert(!W_KN || ((BN / WN) % 64 == 0) || TN <= 2, "[K][N] image: wave column base");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef GN_STAMPS
+    // diagnostic build (scripts/gemm_nt_stamps.py): wave 0 stamps the phase boundaries with the shader clock and the 100 MHz
+    // real-time clock into a buffer of its own (passed in the colsum slot of a plain-epilogue call); never in the product build
+    unsigned long long st_c[5], st_r[5];
+#define GN_STAMP(i_)                                                                                     \
+    do {                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c[i_]), "=s"(st_r[i_])::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+    } while (0)
+#else
+#define GN_STAMP(i_)
+#endif
+    GN_STAMP(0);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -153,85 +174,144 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll
-    for (int i = 0; i < GN_NST - 1; ++i)
-        if (i < nk) GN_ISSUE(i, i);
+    // ---- main loop, software-pipelined over half stages (k32-steps):
+    //   F0 = fragments of (stage s, step 0) are in registers at the top of iteration s;
+    //   read F1 = (s, 1)  | MFMA(F0) | F1 back | stage s+1 landed (counted vmcnt) + ONE barrier: every wave is also done
+    //   reading stage s | DMA of stage s+NST into the buffer of stage s | read F0 = (s+1, 0) | MFMA(F1)
+    // so every LDS fragment read runs under 12..16 MFMAs of the same wave, and NST-1 stages are in flight during them.
+    gn_v4i a0[TM], a1[TM], w0[TN], w1[TN];
+    gn_v2i wl0[TN], wh0[TN], wl1[TN], wh1[TN];
+    (void)w0; (void)w1; (void)wl0; (void)wh0; (void)wl1; (void)wh1;
+    constexpr int RD_PER_KS = (W_KN ? 2 * TN : TN) + TM;
+#define GN_READ(AF, WF, WL, WH, sb_, KS)                                                                                   \
+    do {                                                                                                                   \
+        if constexpr (!W_KN) {                                                                                             \
+            const uint32_t aw_ = (sb_) + offW[KS];                                                                         \
+            gn_static_for<0, TN>([&](auto jc) { constexpr int j = decltype(jc)::value; gn_rd128<j * 2048>(WF[j], aw_); }); \
+        } else {                                                                                                           \
+            gn_static_for<0, TN>([&](auto jc) {                                                                            \
+                constexpr int j = decltype(jc)::value;                                                                     \
+                const uint32_t aw_ = (sb_) + offW[j];                                                                      \
+                gn_rdtr<(32 * KS) * RP>(WL[j], aw_);                                                                       \
+                gn_rdtr<(32 * KS + 4) * RP>(WH[j], aw_);                                                                   \
+            });                                                                                                            \
+        }                                                                                                                  \
+        const uint32_t aa_ = (sb_) + (KS ? offA1 : offA0);                                                                 \
+        gn_static_for<0, TM>([&](auto ic) { constexpr int i = decltype(ic)::value; gn_rd128<i * 2048>(AF[i], aa_); });     \
+    } while (0)
+    // One burst = the TM x TN MFMAs of a half stage.  The DMA pieces of the stage being prefetched are issued INSIDE the bursts,
+    // one piece every GAP MFMAs (pieces [Q0, Q1) of stage ST_ into buffer BUF_ when COND_): a global_load_lds issued into a
+    // busy texture-address queue blocks its wave for 60..200 cycles (MI355X_MICROARCH.md, LDS-DMA piece issue cost), and
+    // with all eight waves issuing their pieces back to back behind the barrier the matrix pipes idled ~475 cycles per stage
+    // (scripts/gemm_nt_stamps.py ablations, profiles/r02_gemm_nt_ablation.log); spread out, a blocked wave's SIMD partner keeps
+    // the pipe busy.
+    constexpr int SPB = (PER + 1) / 2;                     // pieces issued per burst
+    constexpr int GAP = (TM * TN) / SPB > 0 ? (TM * TN) / SPB : 1;
+    auto issue_piece = [&](auto qc, int stage_, int bufi_) {
+        constexpr int q = decltype(qc)::value;
+        unsigned char* sb_ = smem + bufi_ * STAGE;
+        if constexpr (q < PA)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[q] + (size_t)stage_ * GN_BK),
+                                             (RTTS_LDS void*)(sb_ + (wave + NW * q) * 1024), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[q - PA] + (size_t)stage_ * wstep),
+                                             (RTTS_LDS void*)(sb_ + A_BYTES + (wave + NW * (q - PA)) * 1024), 16, 0, 0);
+    };
+#define GN_MFMA(AF, WF, WL, WH, COND_, ST_, BUF_, Q0, Q1)                                                                  \
+    do {                                                                                                                   \
+        bf16x8 wfr_[TN], afr_[TM];                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                                   \
+            if constexpr (!W_KN) wfr_[j] = __builtin_bit_cast(bf16x8, WF[j]);                                              \
+            else {                                                                                                         \
+                const gn_v4i both_ = {WL[j][0], WL[j][1], WH[j][0], WH[j][1]};                                             \
+                wfr_[j] = __builtin_bit_cast(bf16x8, both_);                                                               \
+            }                                                                                                              \
+        }                                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) afr_[i] = __builtin_bit_cast(bf16x8, AF[i]);                        \
+        const bool cond_ = (COND_);                                                                                        \
+        /* D^T tile: rows = output columns n (weight fragment as the A operand), columns = output rows m */               \
+        gn_static_for<0, TM * TN>([&](auto xc) {                                                                           \
+            constexpr int x = decltype(xc)::value, i = x / TN, j = x % TN;                                                 \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr_[j], afr_[i], acc[i][j], 0, 0, 0);                     \
+            if constexpr (x % GAP == GAP - 1 && (Q0) + x / GAP < (Q1)) {                                                   \
+                __builtin_amdgcn_sched_barrier(0);                                                                         \
+                if (cond_) issue_piece(std::integral_constant<int, (Q0) + x / GAP>{}, (ST_), (BUF_));                      \
+                __builtin_amdgcn_sched_barrier(0);                                                                         \
+            }                                                                                                              \
+        });                                                                                                                \
+    } while (0)
+    // this wave's pieces of a stage have landed once at most `later` younger stages (PER instructions each) are outstanding
+#define GN_WAIT_STAGE(later_)                                                                                              \
+    do {                                                                                                                   \
+        const int l_ = (later_);                                                                                           \
+        if (l_ <= 0) gn_wait_vm<0>();                                                                                      \
+        else if (l_ == 1) gn_wait_vm<PER>();                                                                               \
+        else if (l_ == 2) gn_wait_vm<2 * PER>();                                                                           \
+        else gn_wait_vm<3 * PER>();                                                                                        \
+    } while (0)
+    static_assert(NST >= 2 && NST <= 4 && 3 * PER <= 63, "ring depth");
 
+#pragma unroll
+    for (int i = 0; i < NST; ++i)
+        if (i < nk) GN_ISSUE(i, i);
+    GN_WAIT_STAGE(min(NST - 1, nk - 1));
+    asm volatile("s_barrier" ::: "memory");
+    GN_STAMP(1);
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(RTTS_LDS unsigned char*)smem;
+    GN_READ(a0, w0, wl0, wh0, smem_base, 0);
     int buf = 0;
+#ifdef GN_ABL_NOLDS          // timing-only builds (scripts/gemm_nt_stamps.py): results are wrong by construction
+#undef GN_READ
+#define GN_READ(AF, WF, WL, WH, sb_, KS) do { } while (0)
+    gn_static_for<0, TM>([&](auto ic) { constexpr int i = decltype(ic)::value; a0[i] = a1[i] = (gn_v4i){lane, i, 3, 4}; });
+    gn_static_for<0, TN>([&](auto jc) { constexpr int j = decltype(jc)::value; w0[j] = w1[j] = (gn_v4i){j, lane, 5, 6};
+                                        wl0[j] = wl1[j] = wh0[j] = wh1[j] = (gn_v2i){lane, j}; });
+#endif
+#ifdef GN_ABL_NOMFMA
+#undef GN_MFMA
+#define GN_MFMA(AF, WF, WL, WH, COND_, ST_, BUF_, Q0, Q1)                                         \
+    do {                                                                                          \
+        if (COND_) gn_static_for<(Q0), (Q1)>([&](auto qc) { issue_piece(qc, (ST_), (BUF_)); });   \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(AF[i]));             \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                          \
+            if constexpr (!W_KN) asm volatile("" ::"v"(WF[j]));                                   \
+            else asm volatile("" ::"v"(WL[j]), "v"(WH[j]));                                       \
+        }                                                                                         \
+    } while (0)
+#endif
+    int pbuf = 0;                                    // buffer of stage s-1: the second half of stage s-1+NST's pieces goes there
     for (int s = 0; s < nk; ++s) {
-        // stage s has landed (this wave's pieces) once at most the later stages' instructions are outstanding
-        if (nk - 1 - s >= 1) {
-            static_assert(GN_NST == 3, "one later stage in flight");
-            if constexpr (PER == 5) __builtin_amdgcn_s_waitcnt(0x0F75);          // vmcnt(5)
-            else if constexpr (PER == 6) __builtin_amdgcn_s_waitcnt(0x0F76);
-            else if constexpr (PER == 4) __builtin_amdgcn_s_waitcnt(0x0F74);
-            else if constexpr (PER == 3) __builtin_amdgcn_s_waitcnt(0x0F73);
-            else if constexpr (PER == 8) __builtin_amdgcn_s_waitcnt(0x0F78);
-            else if constexpr (PER == 10) __builtin_amdgcn_s_waitcnt(0x0F7A);
-            else __builtin_amdgcn_s_waitcnt(0x0F70);
-        } else {
-            __builtin_amdgcn_s_waitcnt(0x0F70);                                   // vmcnt(0)
-        }
-        asm volatile("s_barrier" ::: "memory");      // stage s complete in LDS; everybody is done reading stage s-1
-        if (s + GN_NST - 1 < nk) {
-            int nb = buf + GN_NST - 1;
-            if (nb >= GN_NST) nb -= GN_NST;
-            GN_ISSUE(s + GN_NST - 1, nb);            // into the buffer stage s-1 occupied
-        }
-        const uint32_t sb = (uint32_t)(uintptr_t)(RTTS_LDS unsigned char*)(smem + buf * STAGE);
-        // Fragment reads as inline assembly: the compiler cannot prove that an LDS read does not alias the LDS-DMA writes
-        // still in flight and would drain them (vmcnt(0)) in front of the first read.  Which stage is complete is known
-        // here (counted wait + barrier above); the reads are ordered by lgkmcnt only.
-        gn_v4i af[2][TM], wf[2][TN];
-        gn_v2i wl[2][TN], wh[2][TN];
-        (void)wf; (void)wl; (void)wh;
-        gn_static_for<0, 2>([&](auto ksc) {
-            constexpr int ks = decltype(ksc)::value;
-            if constexpr (!W_KN) {
-                const uint32_t aw = sb + offW[ks];
-                gn_static_for<0, TN>([&](auto jc) { constexpr int j = decltype(jc)::value; gn_rd128<j * 2048>(wf[ks][j], aw); });
-            } else {
-                gn_static_for<0, TN>([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    const uint32_t aw = sb + offW[j];
-                    gn_rdtr<(32 * ks) * RP>(wl[ks][j], aw);
-                    gn_rdtr<(32 * ks + 4) * RP>(wh[ks][j], aw);
-                });
-            }
-            const uint32_t aa = sb + (ks ? offA1 : offA0);
-            gn_static_for<0, TM>([&](auto ic) { constexpr int i = decltype(ic)::value; gn_rd128<i * 2048>(af[ks][i], aa); });
-        });
-        constexpr int RD_PER_KS = (W_KN ? 2 * TN : TN) + TM;
-        // k32-step 0's fragments are back once at most step 1's reads are outstanding (LDS returns in order)
-        gn_wait_lgkm<RD_PER_KS>();
+        const uint32_t sb = smem_base + buf * STAGE;
+        int nb = buf + 1 == NST ? 0 : buf + 1;
+        GN_READ(a1, w1, wl1, wh1, sb, 1);
+        gn_wait_lgkm<RD_PER_KS>();                   // F0 is back (LDS returns in order; only F1's reads may be outstanding)
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            if (ks == 1) {
-                __builtin_amdgcn_sched_barrier(0);   // (keeps the second wait behind step 0's MFMAs)
-                gn_wait_lgkm<0>();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            bf16x8 wfr[TN], afr[TM];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if constexpr (!W_KN) wfr[j] = __builtin_bit_cast(bf16x8, wf[ks][j]);
-                else {
-                    const gn_v4i both = {wl[ks][j][0], wl[ks][j][1], wh[ks][j][0], wh[ks][j][1]};
-                    wfr[j] = __builtin_bit_cast(bf16x8, both);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) afr[i] = __builtin_bit_cast(bf16x8, af[ks][i]);
-            // D^T tile: rows = output columns n (weight fragment as the A operand), columns = output rows m
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[j], afr[i], acc[i][j], 0, 0, 0);
+#ifndef GN_ABL_NODMA
+        GN_MFMA(a0, w0, wl0, wh0, s >= 1 && s - 1 + NST < nk, s - 1 + NST, pbuf, SPB, PER);
+#else
+        GN_MFMA(a0, w0, wl0, wh0, false, 0, 0, 0, 0);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        gn_wait_lgkm<0>();                           // F1 is back: this wave has no read of stage s left
+        if (s + 1 < nk) {
+            GN_WAIT_STAGE(min(NST - 2, nk - 2 - s));
+            asm volatile("s_barrier" ::: "memory");  // stage s+1 complete in LDS; everybody is done reading stage s
+            GN_READ(a0, w0, wl0, wh0, smem_base + nb * STAGE, 0);
         }
-        buf = buf + 1 == GN_NST ? 0 : buf + 1;
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef GN_ABL_NODMA
+        GN_MFMA(a1, w1, wl1, wh1, s + NST < nk, s + NST, buf, 0, SPB);    // (s + NST < nk implies s + 1 < nk: behind the barrier)
+#else
+        GN_MFMA(a1, w1, wl1, wh1, false, 0, 0, 0, 0);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        pbuf = buf;
+        buf = nb;
     }
+#undef GN_READ
+#undef GN_MFMA
+#undef GN_WAIT_STAGE
+    GN_STAMP(2);
 #undef GN_ISSUE
 
     // ---- epilogue: lane holds C[m][n .. n+3], m = m0 + wave rows + 16 i + (lane & 15), n = n0 + wave cols + 16 j + 4 (lane >> 4)
@@ -264,7 +344,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
             uint2 o;
             o.x = pack_bf16x2(v[0], v[1]);
             o.y = pack_bf16x2(v[2], v[3]);
+#ifdef GN_NT_STORE
+            __builtin_nontemporal_store(o.x, reinterpret_cast<uint32_t*>(P.c + m * P.ldc + n));
+            __builtin_nontemporal_store(o.y, reinterpret_cast<uint32_t*>(P.c + m * P.ldc + n) + 1);
+#else
             *reinterpret_cast<uint2*>(P.c + m * P.ldc + n) = o;
+#endif
         }
     }
     if constexpr (epi == 3) if (P.colsum != nullptr) {
@@ -285,23 +370,59 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
             if (r == 0) *reinterpret_cast<f32x4*>(dst + ncol + 16 * j) = v;
         }
     }
+#ifdef GN_STAMPS
+    if constexpr (EPI == 0) {
+        GN_STAMP(3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GN_STAMP(4);
+        if (P.colsum != nullptr && tid == 0) {
+            unsigned long long* d = reinterpret_cast<unsigned long long*>(P.colsum) + (size_t)blockIdx.x * 12;
+            for (int i = 0; i < 5; ++i) { d[i] = st_c[i]; d[5 + i] = st_r[i]; }
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            d[10] = xcc; d[11] = logical;
+        }
+    }
+#endif
 }
 
-template <int BM, int BN, int WM, int WN, bool W_KN, int EPI>
-static int gn_launch2(const GnArgs& P, hipStream_t s) {
-    constexpr size_t lds = (size_t)GN_NST * (BM + BN) * 128;
+// ring depth: as deep as 160 KB of LDS allow, at most 4 stages
+template <int BM, int BN>
+constexpr int gn_nst() { return (4 * (BM + BN) * 128 <= 160 * 1024) ? 4 : 3; }
+
+template <int BM, int BN, int WM, int WN, bool W_KN, int EPI, int NST>
+static int gn_launch3(const GnArgs& P, hipStream_t s) {
+    constexpr size_t lds = (size_t)NST * (BM + BN) * 128;
     static bool attr[64] = {};                   // per device: the dynamic-LDS limit is an attribute of the loaded function
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<BM, BN, WM, WN, W_KN, EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<BM, BN, WM, WN, W_KN, EPI, NST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         RTTS_REQUIRE(e == hipSuccess, "rtts_gemm_nt: cannot raise the dynamic LDS limit to %zu bytes", lds);
         attr[dev] = true;
     }
     const int grid = (P.M / BM) * (P.N / BN);
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, W_KN, EPI>), dim3(grid), dim3(64 * WM * WN), lds, s, P);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, W_KN, EPI, NST>), dim3(grid), dim3(64 * WM * WN), lds, s, P);
     return 0;
+}
+
+template <int BM, int BN, int WM, int WN, bool W_KN, int EPI>
+static int gn_launch2(const GnArgs& P, hipStream_t s) {
+    constexpr int NST = gn_nst<BM, BN>();
+#ifdef RTTS_GEMM_NT_AB
+    static const int want = [] { const char* e = getenv("RTTS_GEMM_NT_NST"); return e ? atoi(e) : 0; }();   // kernel A/B runs
+    if (want == 4) return gn_launch3<BM, BN, WM, WN, W_KN, EPI, NST>(P, s);
+    if (want == 3) return gn_launch3<BM, BN, WM, WN, W_KN, EPI, 3>(P, s);
+    if (want == 2) return gn_launch3<BM, BN, WM, WN, W_KN, EPI, 2>(P, s);
+#endif
+    // A grid of one workgroup per CU wants the deepest ring; a grid of several waves of workgroups runs faster with TWO
+    // workgroups per CU on a 2-deep ring (80 KB each): they are not barrier-coupled, so one's prologue, epilogue and
+    // barrier stalls fill with the other's MFMAs (N = 2048, K = 512: 37.4 vs 45.5 us; profiles/r02_gemm_nt_probe.log)
+    if constexpr (BM == 192 && BN == 128) {
+        if ((P.M / BM) * (P.N / BN) >= 512) return gn_launch3<BM, BN, WM, WN, W_KN, EPI, 2>(P, s);
+    }
+    return gn_launch3<BM, BN, WM, WN, W_KN, EPI, NST>(P, s);
 }
 
 template <int BM, int BN, int WM, int WN>

@@ -2,8 +2,8 @@
 
 The reference runs every block under nested ``torch.autograd.backward`` calls
 (``/root/reference/reformer_tts/model/reversible.py:62-98,148-170``) over eager ATen graphs; here
-each block is a short, fixed sequence of launches -- library GEMMs (hipBLASLt through
-``torch.mm``) and the hand-written kernels of librtts_hip.so -- for the forward, for the
+each block is a short, fixed sequence of launches of the hand-written kernels of librtts_hip.so
+(the projections and feed-forward layers included: ``gemm`` -> csrc/gemm_nt.hip) -- for the forward, for the
 reconstruction ``x = y - f(.)`` and for the backward, with parameter gradients accumulated
 straight into the flat gradient buffer.  The two residual streams and their gradients are four
 fp32 buffers updated IN PLACE; a swap exchanges two Python references.
@@ -195,6 +195,35 @@ def residual(acc, g, bias, sign: float, next_norm=None, drop=None):
     return xn, mean, rstd
 
 
+def gemm(a: torch.Tensor, w: torch.Tensor, kn: bool = False, bias: Optional[torch.Tensor] = None, relu: bool = False,
+         gate: Optional[torch.Tensor] = None, gate_bias_grad: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C (M, N) bf16 = epilogue(a (M, K) @ W), csrc/gemm_nt.hip (hand-written MFMA kernel; no library GEMM on the stack path).
+    ``kn=False``: w is (N, K) -- y = x W^T, the forward of nn.Linear; ``kn=True``: w is (K, N) -- dx = dy W, its input gradient.
+    ``bias`` (fp32, N) [+ ``relu``] ride in the epilogue; ``gate`` (M, N) bf16: C = acc * (gate > 0), the backward of ReLU,
+    with ``gate_bias_grad`` += column sums of C (queued with the other deferred column sums)."""
+    m, k = a.shape
+    n = w.shape[1] if kn else w.shape[0]
+    if (w.shape[0] if kn else w.shape[1]) != k or a.stride(1) != 1 or w.stride(1) != 1:
+        raise ValueError(f"gemm: operand shapes {tuple(a.shape)} x {tuple(w.shape)} (kn={kn}) do not match")
+    c = torch.empty(m, n, dtype=torch.bfloat16, device=a.device)
+    epi, cs = 0, None
+    if gate is not None:
+        epi = 3
+        if gate_bias_grad is not None:
+            rows = _lib.load().rtts_gemm_nt_partial_rows(m, n)
+            if rows <= 0:
+                raise _lib.RttsError(f"rtts_gemm_nt: no tile shape for M x N = {m} x {n}")
+            cs = torch.empty(rows, n, dtype=torch.float32, device=a.device)
+    elif bias is not None:
+        epi = 2 if relu else 1
+    _lib.call("rtts_gemm_nt", a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), int(kn), m, n, k, c.data_ptr(), n,
+              None if bias is None else bias.data_ptr(), epi, None if gate is None else gate.data_ptr(),
+              0 if gate is None else gate.stride(0), None if cs is None else cs.data_ptr(), _s())
+    if cs is not None:
+        _queue_colsum(cs, 0, cs.shape[0], n, gate_bias_grad)
+    return c
+
+
 _SLAB_FLOATS = 16 * 1024 * 1024   # 64 MB: 16 splits of a 2048 x 512 gradient
 
 # Weight gradients are leaves of the backward's dependency graph: nothing reads them before the block's all-reduce /
@@ -299,7 +328,6 @@ class LSHExec:
         self.stash = None     # (out, lse_tot) of the forward when STASH_ATTENTION: the recompute skips the attention forward
         self.g_stash = None   # f(x) of the forward when STASH_BLOCK_OUTPUT
         self.drop = None      # (p, seed) of the forward's post-attention dropout
-        self._wqkv_t = None   # transposed QKV weight of the forward, kept for the recompute only (never across steps)
 
     @staticmethod
     def supported(withnorm) -> bool:
@@ -326,15 +354,7 @@ class LSHExec:
             raise NotImplementedError("full-attention shortcut (T <= full_attn_thres) is outside the HIP path")
         xn, mean, rstd = pre if pre is not None else ln_fwd(inp, self.norm)
         wqkv = self._wqkv()
-        if xn.shape[0] >= 8192:
-            # (12288 x 512) x (512 x 1024): the library's heuristic picks a poor kernel for the NT form (26.9 us) and a good
-            # one for NN (19.9 us, scripts/gemm_probe.py), so the decoder-sized projection runs on a transposed copy of the
-            # weight made once per step (1 MB, one launch) and kept for the recompute
-            if self._wqkv_t is None:
-                self._wqkv_t = wqkv.t().contiguous()
-            qkv = torch.mm(xn, self._wqkv_t).view(b, t, 2 * e)
-        else:
-            qkv = torch.mm(xn, wqkv.t()).view(b, t, 2 * e)
+        qkv = gemm(xn, wqkv).view(b, t, 2 * e)
         if st is None:
             rot = lyr._rotations(qkv, t // lyr.bucket_size)
             st, _, _ = ops.lsh_hash_sort(qkv[..., :e], rot, lyr.heads, lyr.bucket_size)
@@ -345,11 +365,10 @@ class LSHExec:
             o, lse = ops.lsh_attn_fwd(qkv[..., :e], qkv[..., e:], st, lyr.heads, lyr.bucket_size, lyr.causal, mask)
             out, lse_tot = ops.lsh_combine_fwd(o, lse, b, lyr.heads)
         if g is None:
-            g = torch.mm(out.view(b * t, e), _bf16(lyr.to_out.weight).t())
+            g = gemm(out.view(b * t, e), _bf16(lyr.to_out.weight))
         return xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g
 
     def forward(self, acc, inp, b, t, mask=None, pre=None, next_norm=None, **_):
-        self._wqkv_t = None                    # every forward transposes the CURRENT weight; only its own backward re-uses it
         *_, st, out, lse_tot, g = self._internals(inp, b, t, mask, None, pre=pre)
         self.st = st
         self.stash = (out, lse_tot) if STASH_ATTENTION else None
@@ -362,13 +381,13 @@ class LSHExec:
         lyr = self.layer
         e = lyr.dim
         xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g = self._internals(inp, b, t, mask, self.st, self.stash, self.g_stash, pre)
-        self.st = self.stash = self.g_stash = self._wqkv_t = None
+        self.st = self.stash = self.g_stash = None
         drop, self.drop = self.drop, None
         post = residual(acc, g, lyr.to_out.bias, -1.0, next_norm, drop)       # reconstruct the stream (same dropout mask)
         dyb = _out_grad(d_acc, _grad(lyr.to_out.bias), drop, pre_cast)
         out2 = out.view(b * t, e)
         wgrad(_grad(lyr.to_out.weight), dyb, out2)
-        dout = torch.mm(dyb, _bf16(lyr.to_out.weight)).view(b, t, e)
+        dout = gemm(dyb, _bf16(lyr.to_out.weight), kn=True).view(b, t, e)
         dqkv = torch.empty_like(qkv)
         ops.lsh_attn_bwd(qkv[..., :e], qkv[..., e:], st, out, dout, lse_tot, lyr.heads, lyr.bucket_size, lyr.causal, mask,
                          dqkv=(dqkv[..., :e], dqkv[..., e:]))
@@ -380,7 +399,7 @@ class LSHExec:
             full = torch.mm(dqkv2.t(), xn, out_dtype=torch.float32)
             pair[0].add_(full[:e])
             pair[1].add_(full[e:])
-        dxn = torch.mm(dqkv2, wqkv)
+        dxn = gemm(dqkv2, wqkv, kn=True)
         return post, ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp, next_cast)
 
 
@@ -400,10 +419,10 @@ class FFNExec:
 
     def _internals(self, inp, g=None, pre=None):
         xn, mean, rstd = pre if pre is not None else ln_fwd(inp, self.norm)
-        # bias + ReLU ride in the library GEMM's epilogue (fp32 accumulate, one rounding to bf16)
-        h = torch._addmm_activation(_bf16(self.l1.bias), xn, _bf16(self.l1.weight).t(), use_gelu=False)
+        # bias + ReLU ride in the GEMM's epilogue (fp32 accumulate and fp32 bias, one rounding to bf16)
+        h = gemm(xn, _bf16(self.l1.weight), bias=self.l1.bias, relu=True)
         if g is None:
-            g = torch.mm(h, _bf16(self.l2.weight).t())
+            g = gemm(h, _bf16(self.l2.weight))
         return xn, mean, rstd, h, g
 
     def forward(self, acc, inp, b, t, pre=None, next_norm=None, **_):
@@ -417,10 +436,10 @@ class FFNExec:
         post = residual(acc, g, self.l2.bias, -1.0, next_norm)
         dyb = _out_grad(d_acc, _grad(self.l2.bias), None, pre_cast)
         wgrad(_grad(self.l2.weight), dyb, h)
-        dh = torch.mm(dyb, _bf16(self.l2.weight))
-        colsum_bf16(dh, _grad(self.l1.bias), h)                                # relu gate in place + db1
+        # the ReLU gate and the partial column sums of db1 ride in the epilogue of the dgrad GEMM
+        dh = gemm(dyb, _bf16(self.l2.weight), kn=True, gate=h, gate_bias_grad=_grad(self.l1.bias))
         wgrad(_grad(self.l1.weight), dh, xn)
-        dxn = torch.mm(dh, _bf16(self.l1.weight))
+        dxn = gemm(dh, _bf16(self.l1.weight), kn=True)
         return post, ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp, next_cast)
 
 
@@ -443,10 +462,10 @@ class XAttnExec:
         m = self.mha
         e, h = m.embed_dim, m.num_heads
         tk = keys_bf16.shape[0] // b
-        w, bias = _bf16(m.in_proj_weight), _bf16(m.in_proj_bias)
+        w, bias = _bf16(m.in_proj_weight), m.in_proj_bias
         xn, mean, rstd = pre if pre is not None else ln_fwd(inp, self.norm)
-        q = torch.addmm(bias[:e], xn, w[:e].t())
-        kv = torch.addmm(bias[e:], keys_bf16, w[e:].t())
+        q = gemm(xn, w[:e], bias=bias[:e])
+        kv = gemm(keys_bf16, w[e:], bias=bias[e:])
         if stash is not None:
             o, lse = stash
         else:
@@ -456,7 +475,7 @@ class XAttnExec:
             _lib.call("rtts_xattn_fwd", q.data_ptr(), e, kv.data_ptr(), 2 * e, None if kvalid is None else kvalid.data_ptr(), b, h, t,
                       tk, e // h, o.data_ptr(), e, lse.data_ptr(), float(p), seed, seed_base(inp.device).data_ptr(), _s())
         if g is None:
-            g = torch.mm(o, _bf16(m.out_proj.weight).t())
+            g = gemm(o, _bf16(m.out_proj.weight))
         return xn, mean, rstd, w, q, kv, o, lse, g, tk
 
     def forward(self, acc, inp, b, t, keys_bf16=None, kvalid=None, pre=None, next_norm=None, **_):
@@ -477,7 +496,7 @@ class XAttnExec:
         post = residual(acc, g, m.out_proj.bias, -1.0, next_norm)
         dyb = _out_grad(d_acc, _grad(m.out_proj.bias), None, pre_cast)
         wgrad(_grad(m.out_proj.weight), dyb, o)
-        do = torch.mm(dyb, _bf16(m.out_proj.weight))
+        do = gemm(dyb, _bf16(m.out_proj.weight), kn=True)
         dev = inp.device
         delta = torch.empty(b * h, t, dtype=torch.float32, device=dev)
         _lib.call("rtts_lsh_bwd_delta", o.data_ptr(), e, do.data_ptr(), e, b, h, t, e // h, delta.data_ptr(), _s())
@@ -495,9 +514,9 @@ class XAttnExec:
         colsum_bf16(dkv, gb[e:])
         wgrad(gw[:e], dq, xn)
         wgrad(gw[e:], dkv, keys_bf16)
-        dxn = torch.mm(dq, w[:e])
+        dxn = gemm(dq, w[:e], kn=True)
         nxt = ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp, next_cast)
-        residual(dkeys, torch.mm(dkv, w[e:]), None, 1.0)                      # dkeys (fp32) += dkv W_kv
+        residual(dkeys, gemm(dkv, w[e:], kn=True), None, 1.0)                 # dkeys (fp32) += dkv W_kv
         return post, nxt
 
 

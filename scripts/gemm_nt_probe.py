@@ -85,7 +85,17 @@ def main():
     if not ok:
         print("CORRECTNESS FAILED", flush=True)
         sys.exit(1)
+    quick = os.environ.get("GEMM_PROBE_QUICK") == "1"       # only the hand-written kernel's plain forms (A/B of build variants)
     for m, n, k in shapes:
+        if quick:
+            x = torch.randn(m, k, device=dev).bfloat16()
+            w = torch.randn(n, k, device=dev).bfloat16()
+            wkn = w.t().contiguous()
+            out = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
+            r = {"rtts nt": t(lambda: gemm_nt(x, w, out=out)), "rtts kn": t(lambda: gemm_nt(x, wkn, kn=True, out=out))}
+            fl = 2.0 * m * n * k
+            print(f"M={m} N={n} K={k}: " + "  ".join(f"{kk} {v:6.1f} us ({fl / v / 1e6:5.0f} TF)" for kk, v in r.items()), flush=True)
+            continue
         x = torch.randn(m, k, device=dev).bfloat16()
         w = torch.randn(n, k, device=dev).bfloat16()
         wkn = w.t().contiguous()
