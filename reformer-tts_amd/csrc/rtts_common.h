@@ -88,9 +88,14 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t id, uint32_t n) {
 // Counter-based dropout: element idx of a tensor is kept iff hash(seed, idx) >= thresh, thresh = p * 2^32; the same
 // (seed, idx) gives the same decision in the forward, in the reversible reconstruction and in the backward, so no
 // mask is ever stored.  seed = host constant + a device word the trainer rewrites per step (graph replays draw fresh masks).
+// The seed passes through a finalizer of its own and enters the index hash TWICE (added in front, xor-ed in the middle):
+// the host's per-site seeds are multiples of the index multiplier, and with a single additive entry the masks of two
+// sites were shifted copies of one sequence (mask_{k+1}[i] == mask_k[i+1]); a keyed double entry has no such alias.
 __device__ __forceinline__ uint32_t rtts_drop_hash(uint32_t seed, uint32_t idx) {
-    uint32_t x = idx * 0x9E3779B1u + seed;
-    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    uint32_t s = seed;
+    s ^= s >> 16; s *= 0x85ebca6bu; s ^= s >> 13; s *= 0xc2b2ae35u; s ^= s >> 16;
+    uint32_t x = idx * 0x9E3779B1u + s;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= (s << 13) | (s >> 19); x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
 // keep-scale of element idx: 0 (dropped) or 1/(1-p)

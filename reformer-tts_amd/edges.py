@@ -255,7 +255,7 @@ class _PostnetLossFn(torch.autograd.Function):
         d_raw = gbuf[:m * 128].view(m, 128)                                # 128-wide rows; the kernel zeroes the pad columns
         d_post = gbuf[m * 128:m * 256].view(m, 128)
         g_stop = gbuf[m * 256:]
-        kind = 0 if isinstance(lm.spectrogram_loss, torch.nn.MSELoss) else 1
+        kind = lm.kind
         pw = torch.empty(512 * 3, dtype=torch.float32, device=dev)
         _lib.call("rtts_tts_loss", heads.data_ptr(), post.data_ptr(), 128, true_mel.contiguous().data_ptr(), true_mask.contiguous().data_ptr(),
                   heads[:, nm:].data_ptr(), 128, true_stop.contiguous().data_ptr(), m, nm, kind, ex.pos_weight,

@@ -26,8 +26,10 @@ from .model.lsh_attention import LSHSelfAttention
 
 # Reversible recompute with a selective stash: the attention cores' outputs (bf16 (B,T,d) + one fp32 logsumexp per
 # token.head, ~13 MB per decoder layer at the baseline shape) are kept from the forward, so the backward's recompute of
-# f(x) = to_out(attention(LN x)) re-runs only LayerNorm and the projections, not the attention forward.  Bitwise the same
-# result (the kernels are deterministic); HBM capacity traded for time.  False = the reference's pure recompute.
+# f(x) = to_out(attention(LN x)) re-runs only LayerNorm and the projections, not the attention forward.  The same function
+# (deterministic kernels), but NOT bitwise: the pure recompute sees the reconstructed stream, whose last bits differ from
+# the forward's (tests/test_model_hip.py::test_attention_stash_matches_pure_recompute).  HBM capacity traded for time.
+# False = the reference's pure recompute.
 STASH_ATTENTION = True
 # The same trade one step further: keep f(x) itself (bf16 (B*T, d), 12.6 MB per decoder block at the baseline shape,
 # ~130 MB for the whole model) so that the reconstruction x = y - f(.) subtracts exactly what the forward added and
@@ -85,7 +87,19 @@ def ln_fwd(x, norm):
 # producing kernels only write their per-workgroup partial rows (into a buffer of their own, held until the flush) and ONE
 # grouped launch per layer adds them into the gradients -- a decoder layer otherwise pays fifteen 5-us launches for it.
 DEFER_COLSUM = True
-_PENDING_CS = []      # (partial buffer [kept alive], byte offset of the block, rows, d, out tensor)
+
+
+class _Queues(__import__("threading").local):
+    """Deferred gradient work of the backward pass running on THIS thread (autograd runs one backward per thread at a time and
+    the queues are drained before it returns, so two models -- or two threads -- never see each other's entries)."""
+
+    def __init__(self):
+        self.colsums = []          # (partial buffer [kept alive], float offset of the block, rows, d, out tensor)
+        self.wgrads = []           # (grad_view, dy, x)
+        self.flush_queued = False
+
+
+_Q = _Queues()
 
 
 def _partial_rows(m: int) -> int:
@@ -93,14 +107,15 @@ def _partial_rows(m: int) -> int:
 
 
 def _queue_colsum(partial: torch.Tensor, offset_floats: int, rows: int, d: int, out: torch.Tensor):
-    _PENDING_CS.append((partial, offset_floats, rows, d, out))
+    _Q.colsums.append((partial, offset_floats, rows, d, out))
     _queue_final_flush()
 
 
 def flush_colsum():
-    while _PENDING_CS:
-        group = _PENDING_CS[:_lib.COLSUM_MAX_GROUP]
-        del _PENDING_CS[:len(group)]
+    pending = _Q.colsums
+    while pending:
+        group = pending[:_lib.COLSUM_MAX_GROUP]
+        del pending[:len(group)]
         arr = (_lib.ColsumJob * len(group))()
         for j, (partial, off, rows, d, out) in zip(arr, group):
             j.partial, j.out, j.nrows, j.n = partial.data_ptr() + 4 * off, out.data_ptr(), rows, d
@@ -234,39 +249,39 @@ DEFER_WGRAD = True
 # (A second HIP stream for the weight gradients, forked/joined by events = parallel branches of the captured hipGraph,
 #  was measured SLOWER on MI355X in round 1: 9.35 vs 8.94 ms/step; the cross-branch dependencies of the replayed graph
 #  cost more than the overlapped tails recover.  Removed.)
-_PENDING = []      # (grad_view, dy, x)
-_FINAL_FLUSH_QUEUED = [False]
 
 
 def _final_flush():
-    _FINAL_FLUSH_QUEUED[0] = False
+    _Q.flush_queued = False
     flush_wgrad()
 
 
 def _slab_ws(device):
-    key = ("slab", device)
+    key = ("slab", device, torch.cuda.current_stream(device).cuda_stream)     # launches on one stream are ordered; two streams
+    # (two trainers, a side stream) must not share partial-tile scratch
     if key not in _WS._cache:
         _WS._cache[key] = torch.empty(_SLAB_FLOATS, dtype=torch.float32, device=device)
     return _WS._cache[key]
 
 
 def _queue_final_flush():
-    if not _FINAL_FLUSH_QUEUED[0]:
+    if not _Q.flush_queued:
         # whatever is still queued when the running autograd pass ends is launched by the engine's callback
         try:
             torch.autograd.Variable._execution_engine.queue_callback(_final_flush)
-            _FINAL_FLUSH_QUEUED[0] = True
+            _Q.flush_queued = True
         except RuntimeError:          # not inside a backward pass: the caller flushes
             pass
 
 
 def flush_wgrad():
     """Launch every queued weight gradient and column-sum finalisation (grouped), release the held operands."""
-    _FINAL_FLUSH_QUEUED[0] = False     # the next deferral queues a fresh end-of-backward callback (extra ones are no-ops);
+    _Q.flush_queued = False            # the next deferral queues a fresh end-of-backward callback (extra ones are no-ops);
     flush_colsum()                     # a backward that died half-way therefore cannot leave the flag stuck
-    while _PENDING:
-        group = _PENDING[:_lib.GEMM_TN_MAX_GROUP]
-        del _PENDING[:len(group)]
+    pending = _Q.wgrads
+    while pending:
+        group = pending[:_lib.GEMM_TN_MAX_GROUP]
+        del pending[:len(group)]
         arr = (_lib.GemmTnProblem * len(group))()
         for q, (gv, dy, x) in zip(arr, group):
             q.a, q.lda, q.b, q.ldb, q.c, q.ldc = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), gv.data_ptr(), gv.stride(0)
@@ -281,7 +296,7 @@ FLUSH_HOOKS = []
 
 
 def pending_wgrads() -> int:
-    return len(_PENDING)
+    return len(_Q.wgrads)
 
 
 def wgrad(grad_view: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, accumulate: bool = True):
@@ -292,7 +307,7 @@ def wgrad(grad_view: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, accumulate
     k = x.shape[1]
     if n % 128 == 0 and k % 128 == 0 and m % 64 == 0 and dy.stride(1) == 1 and x.stride(1) == 1 and grad_view.stride(1) == 1:
         if DEFER_WGRAD and accumulate:
-            _PENDING.append((grad_view, dy, x))
+            _Q.wgrads.append((grad_view, dy, x))
             _queue_final_flush()
             return
         ws = _slab_ws(dy.device)
@@ -324,10 +339,12 @@ class LSHExec:
     def __init__(self, withnorm):
         self.norm = withnorm.norm
         self.layer: LSHSelfAttention = withnorm.fn.layer
-        self.st = None
-        self.stash = None     # (out, lse_tot) of the forward when STASH_ATTENTION: the recompute skips the attention forward
-        self.g_stash = None   # f(x) of the forward when STASH_BLOCK_OUTPUT
-        self.drop = None      # (p, seed) of the forward's post-attention dropout
+        # What a forward leaves for ITS backward lives in a per-call slot (a dict owned by FusedStackFn's ctx), never on the
+        # executor: a second forward before the first backward (two losses, an eval forward in between, two models sharing
+        # layers) must not hand the first backward the second forward's permutation / stash / dropout seed.  Keys:
+        #   st (sort permutation), stash ((out, lse_tot) when STASH_ATTENTION), g (f(x) when STASH_BLOCK_OUTPUT),
+        #   drop ((p, seed) of the post-attention dropout)
+        self._own_slot = {}   # direct use of one executor outside a stack (tests)
 
     @staticmethod
     def supported(withnorm) -> bool:
@@ -368,21 +385,24 @@ class LSHExec:
             g = gemm(out.view(b * t, e), _bf16(lyr.to_out.weight))
         return xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g
 
-    def forward(self, acc, inp, b, t, mask=None, pre=None, next_norm=None, **_):
+    def forward(self, acc, inp, b, t, mask=None, pre=None, next_norm=None, slot=None, **_):
+        slot = self._own_slot if slot is None else slot
         *_, st, out, lse_tot, g = self._internals(inp, b, t, mask, None, pre=pre)
-        self.st = st
-        self.stash = (out, lse_tot) if STASH_ATTENTION else None
-        self.g_stash = g if STASH_BLOCK_OUTPUT else None
         p = self.layer.post_attn_dropout.p if self.layer.training else 0.0
-        self.drop = (p, next_seed()) if p > 0.0 else None
-        return residual(acc, g, self.layer.to_out.bias, 1.0, next_norm, self.drop)
+        slot.clear()
+        slot.update(st=st, stash=(out, lse_tot) if STASH_ATTENTION else None, g=g if STASH_BLOCK_OUTPUT else None,
+                    drop=(p, next_seed()) if p > 0.0 else None)
+        return residual(acc, g, self.layer.to_out.bias, 1.0, next_norm, slot["drop"])
 
-    def backward(self, acc, inp, d_acc, d_inp, b, t, mask=None, pre=None, next_norm=None, pre_cast=None, next_cast=None, **_):
+    def backward(self, acc, inp, d_acc, d_inp, b, t, mask=None, pre=None, next_norm=None, pre_cast=None, next_cast=None, slot=None, **_):
+        slot = self._own_slot if slot is None else slot
+        if "st" not in slot:
+            raise RuntimeError("LSHExec.backward: no forward state for this call (backward run twice, or without its forward)")
         lyr = self.layer
         e = lyr.dim
-        xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g = self._internals(inp, b, t, mask, self.st, self.stash, self.g_stash, pre)
-        self.st = self.stash = self.g_stash = None
-        drop, self.drop = self.drop, None
+        xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g = self._internals(inp, b, t, mask, slot["st"], slot["stash"], slot["g"], pre)
+        drop = slot["drop"]
+        slot.clear()
         post = residual(acc, g, lyr.to_out.bias, -1.0, next_norm, drop)       # reconstruct the stream (same dropout mask)
         dyb = _out_grad(d_acc, _grad(lyr.to_out.bias), drop, pre_cast)
         out2 = out.view(b * t, e)
@@ -410,7 +430,7 @@ class FFNExec:
         wn = mod.fn if hasattr(mod, "chunks") else mod
         self.norm = wn.norm
         self.l1, self.l2 = wn.fn.net[0], wn.fn.net[3]
-        self.g_stash = None
+        self._own_slot = {}
 
     @staticmethod
     def supported(mod) -> bool:
@@ -425,14 +445,19 @@ class FFNExec:
             g = gemm(h, _bf16(self.l2.weight))
         return xn, mean, rstd, h, g
 
-    def forward(self, acc, inp, b, t, pre=None, next_norm=None, **_):
+    def forward(self, acc, inp, b, t, pre=None, next_norm=None, slot=None, **_):
+        slot = self._own_slot if slot is None else slot
         *_, g = self._internals(inp, pre=pre)
-        self.g_stash = g if STASH_BLOCK_OUTPUT else None
+        slot.clear()
+        slot.update(g=g if STASH_BLOCK_OUTPUT else None)
         return residual(acc, g, self.l2.bias, 1.0, next_norm)
 
-    def backward(self, acc, inp, d_acc, d_inp, b, t, pre=None, next_norm=None, pre_cast=None, next_cast=None, **_):
-        xn, mean, rstd, h, g = self._internals(inp, self.g_stash, pre)
-        self.g_stash = None
+    def backward(self, acc, inp, d_acc, d_inp, b, t, pre=None, next_norm=None, pre_cast=None, next_cast=None, slot=None, **_):
+        slot = self._own_slot if slot is None else slot
+        if "g" not in slot:
+            raise RuntimeError("FFNExec.backward: no forward state for this call (backward run twice, or without its forward)")
+        xn, mean, rstd, h, g = self._internals(inp, slot["g"], pre)
+        slot.clear()
         post = residual(acc, g, self.l2.bias, -1.0, next_norm)
         dyb = _out_grad(d_acc, _grad(self.l2.bias), None, pre_cast)
         wgrad(_grad(self.l2.weight), dyb, h)
@@ -449,9 +474,8 @@ class XAttnExec:
     def __init__(self, withnorm):
         self.norm = withnorm.norm
         self.mha = withnorm.fn.layer
-        self.stash = None
-        self.g_stash = None
-        self.pdrop = None     # (p, seed) of the dropout on the attention probabilities (NOT an output dropout)
+        self._own_slot = {}   # per-call keys: stash ((o, lse)), g (f(x)), pdrop ((p, seed) of the dropout on the attention
+        #                       probabilities -- NOT an output dropout)
 
     @staticmethod
     def supported(withnorm) -> bool:
@@ -478,21 +502,25 @@ class XAttnExec:
             g = gemm(o, _bf16(m.out_proj.weight))
         return xn, mean, rstd, w, q, kv, o, lse, g, tk
 
-    def forward(self, acc, inp, b, t, keys_bf16=None, kvalid=None, pre=None, next_norm=None, **_):
+    def forward(self, acc, inp, b, t, keys_bf16=None, kvalid=None, pre=None, next_norm=None, slot=None, **_):
+        slot = self._own_slot if slot is None else slot
         p = self.mha.dropout if self.mha.training else 0.0
-        self.pdrop = (p, next_seed()) if p > 0.0 else None
-        *_, o, lse, g, _ = self._internals(inp, b, t, keys_bf16, kvalid, pre=pre, drop=self.pdrop)
-        self.stash = (o, lse) if STASH_ATTENTION else None
-        self.g_stash = g if STASH_BLOCK_OUTPUT else None
+        pdrop = (p, next_seed()) if p > 0.0 else None
+        *_, o, lse, g, _ = self._internals(inp, b, t, keys_bf16, kvalid, pre=pre, drop=pdrop)
+        slot.clear()
+        slot.update(stash=(o, lse) if STASH_ATTENTION else None, g=g if STASH_BLOCK_OUTPUT else None, pdrop=pdrop)
         return residual(acc, g, self.mha.out_proj.bias, 1.0, next_norm)
 
     def backward(self, acc, inp, d_acc, d_inp, b, t, keys_bf16=None, kvalid=None, dkeys=None, pre=None, next_norm=None,
-                 pre_cast=None, next_cast=None, **_):
+                 pre_cast=None, next_cast=None, slot=None, **_):
+        slot = self._own_slot if slot is None else slot
+        if "pdrop" not in slot:
+            raise RuntimeError("XAttnExec.backward: no forward state for this call (backward run twice, or without its forward)")
         m = self.mha
         e, h = m.embed_dim, m.num_heads
-        drop, self.pdrop = self.pdrop, None
-        xn, mean, rstd, w, q, kv, o, lse, g, tk = self._internals(inp, b, t, keys_bf16, kvalid, self.stash, self.g_stash, pre, drop)
-        self.stash = self.g_stash = None
+        drop = slot["pdrop"]
+        xn, mean, rstd, w, q, kv, o, lse, g, tk = self._internals(inp, b, t, keys_bf16, kvalid, slot["stash"], slot["g"], pre, drop)
+        slot.clear()
         post = residual(acc, g, m.out_proj.bias, -1.0, next_norm)
         dyb = _out_grad(d_acc, _grad(m.out_proj.bias), None, pre_cast)
         wgrad(_grad(m.out_proj.weight), dyb, o)
@@ -542,12 +570,13 @@ def _flat_calls(steps):
 class _Chain:
     """Carries LayerNorm(acc) from the executor that wrote ``acc`` to the one that reads it next."""
 
-    def __init__(self, calls, reverse: bool):
+    def __init__(self, calls, reverse: bool, slots=None):
         order = list(reversed(calls)) if reverse else calls
-        self.next_norm, self.next_exec = {}, {}
-        for (ex, i, w), (nxt, _, _) in zip(order, order[1:]):
+        self.next_norm, self.next_exec, self.next_slot = {}, {}, {}
+        for (ex, i, w), (nxt, ni, nw) in zip(order, order[1:]):
             self.next_norm[(i, w)] = nxt.norm
             self.next_exec[(i, w)] = nxt
+            self.next_slot[(i, w)] = slots[(ni, nw)] if slots is not None else {}
         self.pre, self.ptr = None, None
         self.cast, self.cast_ptr = None, None
 
@@ -563,8 +592,8 @@ class _Chain:
     def grad_args(self, i, which, d_acc):
         pre_cast = self.cast if (self.cast is not None and self.cast_ptr == d_acc.data_ptr()) else None
         nxt = self.next_exec.get((i, which)) if FUSE_RESIDUAL_LN else None
-        # .drop = an executor's dropout on its OUTPUT (the LSH layers' post_attn_dropout); only that one masks d_acc
-        return dict(pre_cast=pre_cast, next_cast=None if nxt is None else (getattr(nxt, "drop", None),))
+        # "drop" = an executor's dropout on its OUTPUT (the LSH layers' post_attn_dropout); only that one masks d_acc
+        return dict(pre_cast=pre_cast, next_cast=None if nxt is None else (self.next_slot[(i, which)].get("drop"),))
 
     def grad_done(self, nxt, d_inp):
         self.cast, self.cast_ptr = nxt, (d_inp.data_ptr() if nxt is not None else None)
@@ -652,21 +681,25 @@ class FusedStackFn(torch.autograd.Function):
                 kw, kwg = _step_kwargs(kind, kwargs, extra, mask_cache)
                 steps.append((kind, f, g, kw))
             chain = _Chain(_flat_calls(steps), reverse=False)
+            slots = {(i, w): {} for (_, i, w) in _flat_calls(steps)}      # forward -> backward state of THIS call, one per executor
             for i, (kind, f, g, kw) in enumerate(steps):
                 if kind == "swap":
                     s1, s2 = s2, s1
                 elif kind == "half":
-                    chain.done(f.forward(s1, s2, b, t, **kw, **chain.args(i, "f", s2)), s1)
+                    chain.done(f.forward(s1, s2, b, t, slot=slots[(i, "f")], **kw, **chain.args(i, "f", s2)), s1)
                 else:
-                    chain.done(f.forward(s1, s2, b, t, **kw, **chain.args(i, "f", s2)), s1)
-                    chain.done(g.forward(s2, s1, b, t, **chain.args(i, "g", s1)), s2)
+                    chain.done(f.forward(s1, s2, b, t, slot=slots[(i, "f")], **kw, **chain.args(i, "f", s2)), s1)
+                    chain.done(g.forward(s2, s1, b, t, slot=slots[(i, "g")], **chain.args(i, "g", s1)), s2)
             out = (s1 + s2).view(b, t, d)
-        ctx.state = (s1, s2, steps, extra, b, t, d, context is not None, seq)
+        ctx.state = (s1, s2, steps, extra, b, t, d, context is not None, seq, slots)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        s1, s2, steps, extra, b, t, d, has_ctx, seq = ctx.state
+        if ctx.state is None:
+            raise RuntimeError("FusedStackFn.backward: this forward's state was already consumed (the streams are rebuilt in "
+                               "place; a second backward through the same stack call is not possible)")
+        s1, s2, steps, extra, b, t, d, has_ctx, seq, slots = ctx.state
         ctx.state = None
         with torch.no_grad():
             gboth = torch.empty(2, b * t, d, dtype=torch.float32, device=dout.device)
@@ -677,7 +710,7 @@ class FusedStackFn(torch.autograd.Function):
                 dkeys = torch.zeros(extra["keys_bf16"].shape, dtype=torch.float32, device=dout.device)
                 extra = dict(extra, dkeys=dkeys)
             done = []
-            chain = _Chain(_flat_calls(steps), reverse=True)
+            chain = _Chain(_flat_calls(steps), reverse=True, slots=slots)
             for i in range(len(steps) - 1, -1, -1):
                 kind, f, g, kw = steps[i]
                 if kind == "swap":
@@ -685,14 +718,17 @@ class FusedStackFn(torch.autograd.Function):
                 elif kind == "half":
                     if "keys_bf16" in kw:
                         kw = dict(kw, dkeys=dkeys)
-                    post, nxt = f.backward(s1, s2, g1, g2, b, t, **kw, **chain.args(i, "f", s2), **chain.grad_args(i, "f", g1))
+                    post, nxt = f.backward(s1, s2, g1, g2, b, t, slot=slots[(i, "f")], **kw, **chain.args(i, "f", s2),
+                                           **chain.grad_args(i, "f", g1))
                     chain.done(post, s1)
                     chain.grad_done(nxt, g2)
                 else:
-                    post, nxt = g.backward(s2, s1, g2, g1, b, t, **chain.args(i, "g", s1), **chain.grad_args(i, "g", g2))
+                    post, nxt = g.backward(s2, s1, g2, g1, b, t, slot=slots[(i, "g")], **chain.args(i, "g", s1),
+                                           **chain.grad_args(i, "g", g2))
                     chain.done(post, s2)
                     chain.grad_done(nxt, g1)
-                    post, nxt = f.backward(s1, s2, g1, g2, b, t, **kw, **chain.args(i, "f", s2), **chain.grad_args(i, "f", g1))
+                    post, nxt = f.backward(s1, s2, g1, g2, b, t, slot=slots[(i, "f")], **kw, **chain.args(i, "f", s2),
+                                           **chain.grad_args(i, "f", g1))
                     chain.done(post, s1)
                     chain.grad_done(nxt, g2)
                 done.append(i)

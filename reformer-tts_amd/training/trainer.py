@@ -56,10 +56,30 @@ class Trainer:
                             cfg.post_pred_loss_weight, cfg.stop_loss_weight, cfg.spectrogram_loss)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank = dist.get_rank(process_group) if self.world > 1 else 0
         self.global_step = 0
+        self._decorrelate_replicas()
         self._flatten()
         self._make_buckets()
         self._pending: List = []
+
+    def _decorrelate_replicas(self):
+        """Data-parallel replicas hold identical parameters but must draw their own randomness (seed + rank):
+        the LSH layers' rotation generators, the default device generator (rotations in graph mode) and the per-step dropout
+        seed word (``step_seed``) all depend on the rank.  Rank 0 of any world keeps the single-GPU streams."""
+        if self.rank == 0:
+            return
+        from ..model.lsh_attention import LSHSelfAttention
+        for m in self.model.modules():
+            if isinstance(m, LSHSelfAttention):
+                m.seed = int(m.seed) + 1000003 * self.rank
+                m._gen = None
+        if self.device.type == "cuda":
+            torch.cuda.manual_seed(torch.initial_seed() + 1000003 * self.rank)
+
+    def step_seed(self, step_index: int) -> int:
+        """Dropout seed word of optimizer step ``step_index`` on this rank (added to every site's constant in the kernels)."""
+        return (step_index * 2246822519 + 3266489917 + self.rank * 2654435769) % (1 << 31)
 
     # ------------------------------------------------------------------ flat storage
     def _flatten(self):
@@ -91,8 +111,12 @@ class Trainer:
             self.ws_partial = torch.zeros(2048, dtype=torch.float32, device=dev)
             self.ws_scale = torch.zeros(2, dtype=torch.float32, device=dev)
             self.hyper = torch.zeros(2, dtype=torch.float32, device=dev)        # {lr, bias-corrected step size} of the step
-            self.hyper_host = torch.zeros(2, dtype=torch.float32).pin_memory()
-            self._seed_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            # pinned staging of the per-step words {lr, step size | dropout seed}: a RING of slots, each guarded by an event
+            # recorded behind its copies -- the host runs several steps ahead of the stream (nothing in replay/train_step
+            # synchronises), so a single slot would be overwritten before the copy queued for an earlier step has read it
+            self._hyper_ring = [dict(hyper=torch.zeros(2, dtype=torch.float32).pin_memory(),
+                                     seed=torch.zeros(1, dtype=torch.int32).pin_memory(), ev=None) for _ in range(8)]
+            self._ring_next = 0
             # bf16 mirror of every parameter, refreshed by ONE cast launch per optimizer step; modules see views
             self.flat_pb = torch.zeros(total + pad, dtype=torch.bfloat16, device=dev)
             for n, p in named:
@@ -214,12 +238,18 @@ class Trainer:
         """Host -> device copy of this step's {lr, lr*sqrt(1-b2^t)/(1-b1^t)} (t = step_index + 1); outside any graph."""
         lr = self.lr_now_for(step_index)
         t = step_index + 1
-        self.hyper_host[0] = lr
-        self.hyper_host[1] = lr * math.sqrt(1.0 - 0.999 ** t) / (1.0 - 0.9 ** t)
-        self.hyper.copy_(self.hyper_host, non_blocking=True)
+        slot = self._hyper_ring[self._ring_next % len(self._hyper_ring)]
+        self._ring_next += 1
+        if slot["ev"] is not None:
+            slot["ev"].synchronize()                 # the copies that last read this slot have run (8 steps ago: no stall)
+        slot["hyper"][0] = lr
+        slot["hyper"][1] = lr * math.sqrt(1.0 - 0.999 ** t) / (1.0 - 0.9 ** t)
+        self.hyper.copy_(slot["hyper"], non_blocking=True)
         from .._seeds import seed_base
-        self._seed_host[0] = (step_index * 2246822519 + 3266489917) % (1 << 31)     # fresh dropout masks every step
-        seed_base(self.device).copy_(self._seed_host, non_blocking=True)
+        slot["seed"][0] = self.step_seed(step_index)                                # fresh dropout masks every step, per rank
+        seed_base(self.device).copy_(slot["seed"], non_blocking=True)
+        slot["ev"] = torch.cuda.Event()
+        slot["ev"].record(torch.cuda.current_stream())
 
     def optimizer_step(self, update_hyper: bool = True):
         """Clip by global norm (after the all-reduce, on averaged gradients) + HF-AdamW."""

@@ -50,6 +50,14 @@ def _worker(rank, world, port, q):
         both = [torch.zeros_like(chk) for _ in range(world)]
         dist.all_gather(both, chk)
         assert all(torch.equal(both[0], b) for b in both)
+        # ... but their own randomness (seed + rank): LSH rotation seeds and the per-step dropout seed word
+        from reformer_tts_amd.model.lsh_attention import LSHSelfAttention
+        mine = torch.tensor([float(tr.step_seed(5))] + [float(m.seed) for m in model.modules() if isinstance(m, LSHSelfAttention)],
+                            dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        assert all(bool((every[0] != e).all()) for e in every[1:]), every
+        assert tr.rank == rank
         q.put((rank, "ok"))
     except Exception as exc:  # noqa: BLE001
         q.put((rank, repr(exc)))

@@ -621,6 +621,126 @@ def test_post_attention_dropout_kernels_agree(gpu):
     torch.testing.assert_close(dbias, (dy * keep).sum(0), rtol=1e-4, atol=1e-3)
 
 
+def test_two_forwards_before_the_first_backward_keep_their_own_state(gpu):
+    """What a stack forward leaves for its backward (sort permutations, stashes, dropout seeds) lives in that call's autograd
+    context: a second forward (another batch, an eval pass) between a forward and its backward must not change the first
+    call's gradients."""
+    from reformer_tts_amd.model.config import model_config_from_dict
+    from reformer_tts_amd.training import build_model, synthetic_batch
+    from reformer_tts_amd.model.loss import TTSLoss
+    cfg = model_ref.small_cfg()
+    cfg["enc_reformer_kwargs"]["attn_kwargs"]["implementation"] = "hip"
+    cfg["dec_reformer_kwargs"]["self_attn_kwargs"]["implementation"] = "hip"
+    torch.manual_seed(3)
+    model = build_model(model_config_from_dict(cfg), gpu).train()
+    b1 = synthetic_batch(2, 100, 256, seed=1, device=gpu)
+    b2 = synthetic_batch(2, 120, 256, seed=2, device=gpu)
+    loss_fn = TTSLoss(torch.tensor(5.0, device=gpu))
+
+    def run(batch):
+        out = model(batch["phonemes"], batch["spectrogram"][:, :-1])
+        return loss_fn(out[0].clone(), out[1].clone(), out[2], batch["spectrogram"][:, 1:], batch["stop_tokens"].unsqueeze(-1),
+                       batch["loss_mask"])[0]
+
+    def grads():
+        return torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None]).clone()
+
+    from reformer_tts_amd import _seeds
+    from reformer_tts_amd.model.lsh_attention import LSHSelfAttention
+
+    def restart_randomness():
+        _seeds.reset(0)                      # dropout site seeds
+        torch.manual_seed(11)                # torch-side dropout (positional encodings)
+        for mm in model.modules():           # per-layer rotation generators
+            if isinstance(mm, LSHSelfAttention):
+                mm._gen = None
+        model.zero_grad(set_to_none=True)
+
+    # reference: forward(b1), backward
+    restart_randomness()
+    run(b1).backward()
+    want = grads()
+    # interleaved: forward(b1), forward(b2) (its own graph, dropped), eval forward, THEN backward of the first
+    restart_randomness()
+    l1 = run(b1)
+    l2 = run(b2)
+    with torch.no_grad():
+        model.eval()
+        model(b2["phonemes"], b2["spectrogram"][:, :-1])
+        model.train()
+    l1.backward()
+    got = grads()
+    del l2
+    rel = float((got - want).norm() / want.norm())
+    print(f"\n[interleaved forwards] rel-L2 difference of the first call's gradients {rel:.3e} (tol 1e-6)")
+    assert rel <= 1e-6
+
+
+def test_dropout_masks_of_neighbouring_sites_and_ranks_are_unrelated(gpu):
+    """Per-site seeds are consecutive multiples of 2654435761 (= the hash's index multiplier) and per-rank step seeds
+    differ by a constant: neither may turn one site's (rank's) mask into a shifted copy of another's.  Independent masks
+    with keep probability q agree on a fraction q^2 + (1-q)^2 of the elements."""
+    m, d, p = 256, 512, 0.3
+    sd = torch.tensor([12345], dtype=torch.int32, device=gpu)
+    q = 1 - p
+    indep = q * q + p * p
+    masks = [(_drop_mask_rows(gpu, m, d, p, k * 2654435761 % (1 << 32), sd) > 0).flatten() for k in (7, 8, 9)]
+    worst = 0.0
+    for a, b in ((0, 1), (1, 2), (0, 2)):
+        for shift in (0, 1, 2, -1, d, -d):
+            x, y = masks[a], torch.roll(masks[b], shift)
+            agree = float((x == y).float().mean())
+            worst = max(worst, abs(agree - indep))
+            assert abs(agree - indep) < 1e-2, (a, b, shift, agree, indep)
+    # two data-parallel ranks at the same step and site
+    from reformer_tts_amd.training import Trainer
+    seeds = []
+    for rank in (0, 1):
+        tr = Trainer.__new__(Trainer)
+        tr.rank = rank
+        seeds.append(tr.step_seed(17))
+    assert seeds[0] != seeds[1]
+    ra = (_drop_mask_rows(gpu, m, d, p, 4242, torch.tensor([seeds[0]], dtype=torch.int32, device=gpu)) > 0).flatten()
+    rb = (_drop_mask_rows(gpu, m, d, p, 4242, torch.tensor([seeds[1]], dtype=torch.int32, device=gpu)) > 0).flatten()
+    for shift in (0, 1, -1):
+        agree = float((ra == torch.roll(rb, shift)).float().mean())
+        worst = max(worst, abs(agree - indep))
+        assert abs(agree - indep) < 1e-2, ("ranks", shift, agree, indep)
+    print(f"\n[dropout masks] largest deviation of the agreement rate from independence {worst:.2e} (tol 1e-2)")
+
+
+def test_unsynchronised_replays_match_synchronised_steps(gpu):
+    """The host runs ahead of the stream when steps are replayed without synchronisation; every queued step must still see
+    ITS learning rate, Adam step size and dropout seed (pinned staging ring in Trainer.set_step_hyper)."""
+    from reformer_tts_amd.model.config import TTSTrainingConfig, model_config_from_dict
+    from reformer_tts_amd.model.lsh_attention import LSHSelfAttention
+    from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
+    cfg = model_ref.small_cfg()
+    cfg["enc_reformer_kwargs"]["attn_kwargs"]["implementation"] = "hip"
+    cfg["dec_reformer_kwargs"]["self_attn_kwargs"]["implementation"] = "hip"
+    batch = synthetic_batch(2, 100, 256, device=gpu)
+    finals = []
+    for sync in (True, False):
+        torch.manual_seed(1)
+        model = build_model(model_config_from_dict(cfg), gpu)
+        for mm in model.modules():
+            if isinstance(mm, LSHSelfAttention):
+                mm.forced_rotations = torch.randn(1, 64, 4, (128 if not mm.causal else 256) // 64 // 2,
+                                                  generator=torch.Generator().manual_seed(5))
+        tr = Trainer(model, TTSTrainingConfig(batch_size=2, learning_rate=1e-3, warmup_steps=40, gradient_clip_val=1.0), gpu)
+        tr.capture(batch)
+        torch.cuda.synchronize()
+        for _ in range(24):                          # three times round the staging ring, inside the warm-up ramp
+            tr.replay()
+            if sync:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        finals.append(tr.flat_p.clone())
+    diff = float((finals[0] - finals[1]).abs().max())
+    print(f"\n[unsynchronised replays] max parameter difference after 24 steps {diff:.3e} (must be 0)")
+    assert diff == 0.0
+
+
 def test_cross_attention_dropout_vs_autograd(gpu):
     """rtts_xattn_fwd / rtts_xattn_bwd with dropout on the probabilities against torch autograd using the mask the kernel
     drew (read back with Q = K = 0, i.e. uniform probabilities, and V = one 64-key block of the identity at a time)."""
