@@ -187,28 +187,47 @@ int rtts_xattn_bwd(const void* q, int64_t ld_q, const void* kv, int64_t ld_kv, c
 int rtts_sum_slabs(const void* part, int nslabs, int64_t n, void* out, void* stream);
 
 /* ---- convolutional edges (prenet / postnet) and the loss ------------------------------------------
- * Conv1d(k=5, pad=2) on channels-last rows = rtts_im2col_k5 + a library GEMM over (B*L, 5*CP); the
- * kernels below are everything else (reference reformer_tts/model/modules.py:8-61,103-169; loss.py:28-53).
- *   rtts_im2col_k5      cols[(b,l)][k*CP + c] = x[b][l+k-2][c] (zero padded; bf16; C, CP multiples of 8)
- *   rtts_col2im_k5      adjoint: dx[b][l][c] = sum_k dcols[(b,l-k+2)][k*CP + c]   (bf16 or fp32 out)
+ * Reference reformer_tts/model/modules.py:8-61 (EncoderPreNet), :103-169 (PostConvNet); loss.py:28-53.
+ * HALO ROWS.  The activations of a convolution stack are channels-last rows (B, L + 2*halo, C), halo = 2, with `halo` zero
+ * rows in front of and behind every sequence; a halo array may have a lead-in of `lead` rows before halo row 0 and any
+ * number of rows behind row B*(L+2*halo) - 1 -- all zero.  Row m (counted from halo row 0) belongs to sequence m / (L+4)
+ * at position m % (L+4) - 2.  A Conv1d(k=5, pad=2) is then the IMPLICIT GEMM rtts_conv1d_k5: tap k reads the same rows
+ * shifted by k - 2, the halo supplies the zero padding, nothing like an im2col matrix is written; the transposed product
+ * (input gradient) reads the output gradient shifted by 2 - k, and the weight gradient is five rtts_gemm_tn problems on
+ * row-shifted views.  halo = 0 everywhere below means plain (B*L) rows.
+ *   rtts_conv1d_k5      y (M, C_out) = conv(x) on halo rows: M rows starting at halo row 0 (any multiple of the GEMM's row
+ *                       tile; x must be readable 2 rows before and after).  transposed = 0: wp (C_out, 5*C_in) bf16 from
+ *                       rtts_conv_w_perm; transposed = 1: dx = conv^T(dy), wp (C_in, 5*C_out) is the SAME array seen as
+ *                       [channel of dy][tap][channel of dx].  out_f32: unrounded fp32 result (+ optional bias), else bf16.
+ *                       C_in % 64 == 0, (M, C_out) must tile like rtts_gemm_nt.
+ *   rtts_to_halo        dst (bf16, `rows` rows, halo row 0 at row `lead`) = src (plain (B*L, ld_src) rows, fp32 or bf16),
+ *                       zero everywhere outside the valid set
  *   rtts_conv_w_perm    wp[co][k][ci] (bf16, ci < CP zero padded) = w[co][ci][k] (fp32 master layout of nn.Conv1d)
  *   rtts_conv_dw_unperm dw[co][ci][k] += dwp[co][k][ci]
- *   rtts_bn_stats       per-channel batch mean / rstd (eps 1e-5) of y (M,C) fp32; optional running-stat update
- *                       (momentum 0.1, unbiased variance; mean_shift[c], may be NULL, is added to the batch mean
- *                       first: the conv bias that the fused path leaves out of y; *num_batches += 1 if given)
- *   rtts_bn_act_fwd     z(bf16) = dropout_p(act(gamma*(y-mean)*rstd + beta)); act 1 = ReLU, 2 = tanh;
- *                       the dropout mask is a hash of (seed + *seed_dev, element index), reproduced by the backward;
- *                       seed_dev (device u32, may be NULL) lets a captured hipGraph draw fresh masks every replay
- *   rtts_bn_act_bwd     dy(bf16) = BatchNorm(train) backward through act and dropout; dgamma, dbeta accumulate
+ *   rtts_bn_stats       per-channel batch mean / rstd (eps 1e-5) over the B*L valid rows of y (fp32; halo or plain rows);
+ *                       optional running-stat update (momentum 0.1, unbiased variance; mean_shift = the conv bias that was
+ *                       left out of y)
+ *   rtts_bn_act_fwd     z(bf16) = dropout_p(act(gamma*(y-mean)*rstd + beta)); act 1 = ReLU, 2 = tanh; z_halo = 1: z is a halo
+ *                       array (z_rows rows, lead-in z_lead), zero outside the valid set; z_halo = 0: B*L plain rows
+ *   rtts_bn_act_bwd     dy(bf16, y's layout: dy_rows rows, lead-in dy_lead, zero outside the valid set) = BatchNorm(train)
+ *                       backward through act and dropout; dz in halo rows (dz_halo = 1, no lead-in) or plain rows;
+ *                       dgamma, dbeta accumulate
  *   rtts_tts_loss       losses[4] = {total, raw, post, stop} and d_raw, d_post (rows, NM; row stride ld_grad >= NM,
  *                       the pad columns are written as zero), d_stop (rows):
  *                       masked MSE (kind 0) / L1 (kind 1) means over ALL elements + BCE-with-logits(pos_weight);
  *                       predictions / gradients have rows = batch * padded_len (the decoder's length, a multiple of
  *                       pad_base), targets batch * valid_len rows (reformer_tts.py:141-143 crops the predictions): rows
- *                       t >= valid_len get zero gradient and do not count
+ *                       t >= valid_len get zero gradient and do not count.  res != NULL: the postnet prediction is
+ *                       raw + res (reformer_tts.py:139-140) with res fp32 in halo rows (no lead-in, stride ld_res), `post`
+ *                       is ignored and d_post is written in halo rows (dpost_rows rows, lead-in dpost_lead, zero outside
+ *                       the valid set); res == NULL: halo = dpost_lead = 0, d_post in plain rows
+ *   rtts_heads_grad     dheads (B*L, width) fp32 = d_raw + d_post (halo rows, lead-in dpost_lead) + dx0 (halo rows, no
+ *                       lead-in; columns < n_mels), column n_mels = d_stop: the gradient of the [mel | stop] heads
  * partial_ws: >= (2*256 + 2)*C floats (bn) / 1536 floats (loss). */
-int rtts_im2col_k5(const void* x, int64_t ldx, int B, int L, int C, int CP, void* cols, void* stream);
-int rtts_col2im_k5(const void* dcols, int B, int L, int C, int CP, void* dx, int64_t lddx, int out_f32, void* stream);
+int rtts_conv1d_k5(const void* x, int64_t ldx, const void* wp, int64_t ldw, int transposed, int M, int C_out, int C_in,
+                   void* y, int64_t ldy, const float* bias, int out_f32, void* stream);
+int rtts_to_halo(const void* src, int64_t ld_src, int src_f32, int B, int L, int halo, int C, void* dst, int lead,
+                 int64_t rows, void* stream);
 int rtts_conv_w_perm(const float* w, int Co, int Ci, int CP, void* wp, void* stream);
 int rtts_conv_dw_unperm(const float* dwp, int Co, int Ci, int CP, float* dw, void* stream);
 /* All convolution weights of a step re-laid-out in ONE launch (they only change in the optimizer step, and a launch costs
@@ -223,17 +242,21 @@ int rtts_conv_w_perm_grouped(const rtts_conv_perm_job* jobs, int n, void* stream
 /* The adjoint for the gradients, likewise grouped: jobs[i].w = dwp (Co_pad, 5*CP) fp32, jobs[i].wp = dw (Co, Ci, 5) fp32,
  * dw[co][ci][k] += dwp[co][k][ci]. */
 int rtts_conv_dw_unperm_grouped(const rtts_conv_perm_job* jobs, int n, void* stream);
-int rtts_bn_stats(const float* y, int M, int C, float* mean, float* rstd, float* run_mean, float* run_var,
+int rtts_bn_stats(const float* y, int B, int L, int halo, int C, float* mean, float* rstd, float* run_mean, float* run_var,
                   const float* mean_shift, int64_t* num_batches, float* partial_ws, void* stream);
 int rtts_bn_act_fwd(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
-                    float drop_p, uint32_t seed, const uint32_t* seed_dev, int M, int C, void* z, void* stream);
-int rtts_bn_act_bwd(const float* y, const void* dz, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                    int act, float drop_p, uint32_t seed, const uint32_t* seed_dev, int M, int C, void* dy, float* dgamma,
-                    float* dbeta, float* partial_ws, void* stream);
+                    float drop_p, uint32_t seed, const uint32_t* seed_dev, int B, int L, int halo, int C, void* z, int z_halo,
+                    int z_lead, int64_t z_rows, void* stream);
+int rtts_bn_act_bwd(const float* y, const void* dz, int dz_halo, const float* mean, const float* rstd, const float* gamma,
+                    const float* beta, int act, float drop_p, uint32_t seed, const uint32_t* seed_dev, int B, int L, int halo, int C,
+                    void* dy, int dy_lead, int64_t dy_rows, float* dgamma, float* dbeta, float* partial_ws, void* stream);
 int rtts_tts_loss(const float* raw, const float* post, int64_t ld_mel, const float* tgt, const float* mask, const float* stop,
                   int64_t ld_stop, const float* tstop, int rows, int NM, int kind, float pos_weight, float w_raw, float w_post,
                   float w_stop, float* d_raw, float* d_post, int64_t ld_grad, float* d_stop, float* losses, float* partial_ws,
-                  int padded_len, int valid_len, void* stream);
+                  int padded_len, int valid_len, const float* res, int64_t ld_res, int halo, int dpost_lead, int64_t dpost_rows,
+                  void* stream);
+int rtts_heads_grad(const float* d_raw, const float* d_post, int dpost_lead, const float* dx0, int64_t ld_dx0, const float* d_stop,
+                    int B, int L, int halo, int n_mels, int width, float* dheads, void* stream);
 
 /* Scaled positional encoding (reference modules.py:172-192): out = y + alpha * dropout_p(table[t]), the mask shared over the
  * batch; dalpha += sum dy * dropout_p(table).  relu_drop: h = dropout_p(relu(h)) in place (decoder prenet, modules.py:82-100). */

@@ -61,16 +61,18 @@ SIGNATURES = {
     "rtts_xattn_fwd": [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _f32, _u32, _vp, _vp],
     "rtts_xattn_bwd": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _f32, _u32, _vp, _vp],
     "rtts_sum_slabs": [_vp, _i32, _i64, _vp, _vp],
-    "rtts_im2col_k5": [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp],
-    "rtts_col2im_k5": [_vp, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _vp],
+    "rtts_conv1d_k5": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _vp],
+    "rtts_to_halo": [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i64, _vp],
+    "rtts_heads_grad": [_vp, _vp, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "rtts_conv_w_perm": [_vp, _i32, _i32, _i32, _vp, _vp],
     "rtts_conv_dw_unperm": [_vp, _i32, _i32, _i32, _vp, _vp],
     "rtts_conv_w_perm_grouped": [C.POINTER(ConvPermJob), _i32, _vp],
     "rtts_conv_dw_unperm_grouped": [C.POINTER(ConvPermJob), _i32, _vp],
-    "rtts_bn_stats": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "rtts_bn_act_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _u32, _vp, _i32, _i32, _vp, _vp],
-    "rtts_bn_act_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _u32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
-    "rtts_tts_loss": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp],
+    "rtts_bn_stats": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "rtts_bn_act_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _u32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i64, _vp],
+    "rtts_bn_act_bwd": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _u32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i64, _vp, _vp, _vp, _vp],
+    "rtts_tts_loss": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32,
+                      _vp, _i64, _i32, _i32, _i64, _vp],
     "rtts_pe_add": [_vp, _vp, _vp, _f32, _u32, _vp, _i32, _i64, _i32, _vp, _vp],
     "rtts_pe_dalpha": [_vp, _vp, _f32, _u32, _vp, _i32, _i64, _i32, _vp, _vp, _vp],
     "rtts_relu_drop": [_vp, _f32, _u32, _vp, _i64, _vp],

@@ -1,9 +1,11 @@
 // Kernels of the convolutional "edges" of the model: encoder prenet convolutions and the mel postnet
 // (/root/reference/reformer_tts/model/modules.py:8-61,103-169) and the loss (model/loss.py:28-53).
 //
-// A Conv1d(k=5, pad=2) on channels-last rows is im2col (here) + ONE library GEMM over the
-// (B*L, 5*C) window matrix; everything around the GEMM is fused here:
-//   im2col_k5 / col2im_k5          window matrix and its adjoint (bf16, 16-byte pieces, coalesced)
+// A Conv1d(k=5, pad=2) on channels-last rows is an IMPLICIT GEMM (rtts_conv1d_k5, csrc/gemm_nt.hip): the activations of a
+// convolution stack live in "halo rows" -- (B, L + 4, C) with two zero rows in front of and behind every sequence -- so the
+// five taps are five row-shifted reads of the same array (forward, input gradient and weight gradient alike) and no window
+// matrix is ever written.  Everything around the GEMMs is here and knows the halo:
+//   to_halo                        plain rows (fp32 | bf16) -> bf16 halo rows (the stack's input)
 //   conv weight permute + cast     (Cout,Cin,5) fp32 master -> (Cout,5,Cin_pad) bf16, and the adjoint for dW
 //   col_stats                      per-channel batch mean / rstd (+ running-stat update), two-stage, deterministic
 //   bn_act_fwd                     z = dropout(act(gamma * (y-mean)*rstd + beta))  -> bf16
@@ -20,57 +22,44 @@
 // keep-scale of element idx: 0 (dropped) or 1/(1-p)   (rtts_common.h)
 #define ed_drop rtts_drop_keep
 
-// ------------------------------------------------------------------ im2col / col2im (k=5, pad=2)
-// cols[(b*L + l)][k*CP + c] = x[b][l + k - 2][c] (zero outside [0,L) and for c >= C); 8 channels per thread
-__global__ __launch_bounds__(ED_THREADS) void im2col_k5_kernel(const bf16_t* __restrict__ x, int64_t ldx, int B, int L, int C, int CP,
-                                                               bf16_t* __restrict__ cols) {
-    const int pieces = CP / 8;
-    const size_t total = (size_t)B * L * 5 * pieces;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int pc = (int)(i % pieces);
-        const int k = (int)((i / pieces) % 5);
-        const size_t row = i / ((size_t)pieces * 5);
-        const int l = (int)(row % L);
-        const int ls = l + k - 2;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (ls >= 0 && ls < L && pc * 8 < C) v = *reinterpret_cast<const uint4*>(x + (row + k - 2) * ldx + pc * 8);
-        *reinterpret_cast<uint4*>(cols + row * (size_t)(5 * CP) + (size_t)k * CP + pc * 8) = v;
-    }
+// ------------------------------------------------------------------ halo rows
+// Row m of a halo array belongs to sequence b = m / P (P = L + 2H) at position t = m % P - H; it carries data iff b < B and
+// 0 <= t < L, and is zero otherwise.  A plain array is the case H = 0, P = L.
+struct EdHalo {
+    int B, L, P, H;
+};
+__device__ __forceinline__ bool ed_valid(const EdHalo& g, long long m, int& b, int& t) {
+    if (m < 0 || m >= (long long)g.B * g.P) return false;
+    b = (int)(m / g.P);
+    t = (int)(m - (long long)b * g.P) - g.H;
+    return (unsigned)t < (unsigned)g.L;
 }
+static inline EdHalo ed_halo(int B, int L, int halo) { return EdHalo{B, L, L + 2 * halo, halo}; }
 
-// dx[b][l][c] = sum_k dcols[(b, l - k + 2)][k*CP + c]
-template <bool OUT_F32>
-__global__ __launch_bounds__(ED_THREADS) void col2im_k5_kernel(const bf16_t* __restrict__ dcols, int B, int L, int C, int CP,
-                                                               void* __restrict__ dx, int64_t lddx) {
+// dst (bf16 halo rows: `rows` rows of C channels, halo row 0 at row `lead`) = src (plain (B*L, ld_src) rows, fp32 or bf16);
+// every row outside the valid set is written as zero.  8 channels per thread.
+template <bool SRC_F32>
+__global__ __launch_bounds__(ED_THREADS) void to_halo_kernel(const void* __restrict__ src, int64_t ld_src, EdHalo g, int C, int lead,
+                                                             long long rows, bf16_t* __restrict__ dst) {
     const int pieces = C / 8;
-    const size_t total = (size_t)B * L * pieces;
+    const size_t total = (size_t)rows * pieces;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int pc = (int)(i % pieces);
-        const size_t row = i / pieces;
-        const int l = (int)(row % L);
-        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int ls = l - k + 2;
-            if (ls < 0 || ls >= L) continue;
-            const uint4 t = *reinterpret_cast<const uint4*>(dcols + (row - k + 2) * (size_t)(5 * CP) + (size_t)k * CP + pc * 8);
-            const uint32_t u[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[2 * j] += __uint_as_float(u[j] << 16);
-                acc[2 * j + 1] += __uint_as_float(u[j] & 0xffff0000u);
+        const long long r = (long long)(i / pieces);
+        int b, t;
+        uint4 o = make_uint4(0, 0, 0, 0);
+        if (ed_valid(g, r - lead, b, t)) {
+            const size_t srow = (size_t)b * g.L + t;
+            if (SRC_F32) {
+                const float* p = reinterpret_cast<const float*>(src) + srow * ld_src + pc * 8;
+                const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + 4);
+                o.x = pack_bf16x2(v0.x, v0.y); o.y = pack_bf16x2(v0.z, v0.w);
+                o.z = pack_bf16x2(v1.x, v1.y); o.w = pack_bf16x2(v1.z, v1.w);
+            } else {
+                o = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(src) + srow * ld_src + pc * 8);
             }
         }
-        if (OUT_F32) {
-            float* p = reinterpret_cast<float*>(dx) + row * lddx + pc * 8;
-            *reinterpret_cast<float4*>(p) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            *reinterpret_cast<float4*>(p + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
-        } else {
-            uint4 o;
-            o.x = pack_bf16x2(acc[0], acc[1]); o.y = pack_bf16x2(acc[2], acc[3]);
-            o.z = pack_bf16x2(acc[4], acc[5]); o.w = pack_bf16x2(acc[6], acc[7]);
-            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(dx) + row * lddx + pc * 8) = o;
-        }
+        *reinterpret_cast<uint4*>(dst + (size_t)r * C + pc * 8) = o;
     }
 }
 
@@ -136,9 +125,10 @@ template <int MODE>   // 0: (y, y*y)   1: (g, g*yhat) with g = dz * act'(.) * dr
 __global__ __launch_bounds__(ED_THREADS) void col_partial_kernel(const float* __restrict__ y, const bf16_t* __restrict__ dz,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta, int act,
-                                                                 uint32_t seed, const uint32_t* __restrict__ seed_dev, uint32_t thresh, float dscale, int M, int C,
-                                                                 float* __restrict__ partial) {
+                                                                 uint32_t seed, const uint32_t* __restrict__ seed_dev, uint32_t thresh, float dscale, EdHalo g,
+                                                                 int dz_halo, int C, float* __restrict__ partial) {
     if (seed_dev) seed += seed_dev[0];
+    const int M = g.B * g.P;               // rows of y that can carry data (halo rows among them are skipped)
     // block = 64 channel-quads x 4 row-lanes; grid.x = row slabs, grid.y = channel groups of 256
     const int cq = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.y * 256 + cq * 4;
@@ -151,13 +141,16 @@ __global__ __launch_bounds__(ED_THREADS) void col_partial_kernel(const float* __
             for (int j = 0; j < 4; ++j) { mu[j] = mean[c + j]; rs[j] = rstd[c + j]; ga[j] = gamma[c + j]; be[j] = beta[c + j]; }
         }
         for (int row = blockIdx.x * 4 + rl; row < M; row += gridDim.x * 4) {
+            int sb_, st_;
+            if (!ed_valid(g, row, sb_, st_)) continue;
             const float4 yv = *reinterpret_cast<const float4*>(y + (size_t)row * C + c);
             const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
             if (MODE == 0) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { sa[j] += yy[j]; sb[j] = __builtin_fmaf(yy[j], yy[j], sb[j]); }
             } else {
-                const uint2 dv = *reinterpret_cast<const uint2*>(dz + (size_t)row * C + c);
+                const size_t drow = dz_halo ? (size_t)row : (size_t)sb_ * g.L + st_;
+                const uint2 dv = *reinterpret_cast<const uint2*>(dz + drow * C + c);
                 const float dd[4] = {__uint_as_float(dv.x << 16), __uint_as_float(dv.x & 0xffff0000u), __uint_as_float(dv.y << 16),
                                      __uint_as_float(dv.y & 0xffff0000u)};
 #pragma unroll
@@ -241,63 +234,87 @@ __global__ __launch_bounds__(ED_THREADS) void bn_finalize_bwd_kernel(const float
     dgamma[c] += q;
 }
 
-// z = dropout(act(gamma*(y-mean)*rstd + beta)) as bf16; 4 channels per thread
+// z = dropout(act(gamma*(y-mean)*rstd + beta)) as bf16; 4 channels per thread.  y: halo (or plain) rows described by g;
+// z_halo: z is a halo array of z_rows rows whose row z_lead is halo row 0 (everything outside the valid set is written as
+// zero: the next convolution's taps read it); else z has B*L plain rows.  The dropout counter is the element index in y.
 __global__ __launch_bounds__(ED_THREADS) void bn_act_fwd_kernel(const float* __restrict__ y, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, int act, uint32_t seed, const uint32_t* __restrict__ seed_dev,
-                                                                uint32_t thresh, float dscale, size_t n4, int C, bf16_t* __restrict__ z) {
+                                                                uint32_t thresh, float dscale, EdHalo g, int z_halo, int z_lead, size_t n4, int C,
+                                                                bf16_t* __restrict__ z) {
     if (seed_dev) seed += seed_dev[0];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t e = i * 4;
-        const int c = (int)(e % C);
-        const float4 yv = reinterpret_cast<const float4*>(y)[i];
-        const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
-        float o[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float pre = __builtin_fmaf((yy[j] - mean[c + j]) * rstd[c + j], gamma[c + j], beta[c + j]);
-            float a = act == 1 ? fmaxf(pre, 0.f) : tanhf(pre);
-            if (thresh) a *= ed_drop(seed, (uint32_t)(e + j), thresh, dscale);
-            o[j] = a;
+        const size_t ze = i * 4;
+        const int c = (int)(ze % C);
+        const long long zr = (long long)(ze / C);
+        long long ym;
+        bool ok = true;
+        if (z_halo) {
+            int b, t;
+            ym = zr - z_lead;
+            ok = ed_valid(g, ym, b, t);
+        } else {
+            const long long b = zr / g.L;
+            ym = b * g.P + g.H + (zr - b * g.L);
         }
-        uint2 pk;
-        pk.x = pack_bf16x2(o[0], o[1]);
-        pk.y = pack_bf16x2(o[2], o[3]);
+        uint2 pk = make_uint2(0u, 0u);
+        if (ok) {
+            const size_t e = (size_t)ym * C + c;
+            const float4 yv = *reinterpret_cast<const float4*>(y + e);
+            const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float pre = __builtin_fmaf((yy[j] - mean[c + j]) * rstd[c + j], gamma[c + j], beta[c + j]);
+                float a = act == 1 ? fmaxf(pre, 0.f) : tanhf(pre);
+                if (thresh) a *= ed_drop(seed, (uint32_t)(e + j), thresh, dscale);
+                o[j] = a;
+            }
+            pk.x = pack_bf16x2(o[0], o[1]);
+            pk.y = pack_bf16x2(o[2], o[3]);
+        }
         reinterpret_cast<uint2*>(z)[i] = pk;
     }
 }
 
-// dy = gamma*rstd * (g - mean(g) - yhat*mean(g*yhat))  as bf16
+// dy = gamma*rstd * (g - mean(g) - yhat*mean(g*yhat))  as bf16, in y's layout (dy_rows rows, halo row 0 at row dy_lead, zero
+// outside the valid set: the transposed convolution and the weight gradient read it with shifted rows); dz halo or plain
 __global__ __launch_bounds__(ED_THREADS) void bn_act_bwd_apply_kernel(const float* __restrict__ y, const bf16_t* __restrict__ dz,
                                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int act,
                                                                       uint32_t seed, const uint32_t* __restrict__ seed_dev, uint32_t thresh, float dscale,
-                                                                      const float* __restrict__ sums, float inv_m, size_t n4, int C,
-                                                                      bf16_t* __restrict__ dy) {
+                                                                      const float* __restrict__ sums, float inv_m, EdHalo g, int dz_halo, int dy_lead,
+                                                                      size_t n4, int C, bf16_t* __restrict__ dy) {
     if (seed_dev) seed += seed_dev[0];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t e = i * 4;
-        const int c = (int)(e % C);
-        const float4 yv = reinterpret_cast<const float4*>(y)[i];
-        const uint2 dv = reinterpret_cast<const uint2*>(dz)[i];
-        const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
-        const float dd[4] = {__uint_as_float(dv.x << 16), __uint_as_float(dv.x & 0xffff0000u), __uint_as_float(dv.y << 16),
-                             __uint_as_float(dv.y & 0xffff0000u)};
-        float o[4];
+        const size_t de = i * 4;
+        const int c = (int)(de % C);
+        const long long ym = (long long)(de / C) - dy_lead;
+        int b, t;
+        uint2 pk = make_uint2(0u, 0u);
+        if (ed_valid(g, ym, b, t)) {
+            const size_t e = (size_t)ym * C + c;
+            const float4 yv = *reinterpret_cast<const float4*>(y + e);
+            const size_t drow = dz_halo ? (size_t)ym : (size_t)b * g.L + t;
+            const uint2 dv = *reinterpret_cast<const uint2*>(dz + drow * C + c);
+            const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+            const float dd[4] = {__uint_as_float(dv.x << 16), __uint_as_float(dv.x & 0xffff0000u), __uint_as_float(dv.y << 16),
+                                 __uint_as_float(dv.y & 0xffff0000u)};
+            float o[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float rs = rstd[c + j], ga = gamma[c + j];
-            const float yh = (yy[j] - mean[c + j]) * rs;
-            const float pre = __builtin_fmaf(yh, ga, beta[c + j]);
-            float da;
-            if (act == 1) da = pre > 0.f ? 1.f : 0.f;
-            else { const float th = tanhf(pre); da = 1.f - th * th; }
-            const float g = dd[j] * da * (thresh ? ed_drop(seed, (uint32_t)(e + j), thresh, dscale) : 1.f);
-            o[j] = ga * rs * (g - sums[c + j] * inv_m - yh * sums[C + c + j] * inv_m);
+            for (int j = 0; j < 4; ++j) {
+                const float rs = rstd[c + j], ga = gamma[c + j];
+                const float yh = (yy[j] - mean[c + j]) * rs;
+                const float pre = __builtin_fmaf(yh, ga, beta[c + j]);
+                float da;
+                if (act == 1) da = pre > 0.f ? 1.f : 0.f;
+                else { const float th = tanhf(pre); da = 1.f - th * th; }
+                const float gg = dd[j] * da * (thresh ? ed_drop(seed, (uint32_t)(e + j), thresh, dscale) : 1.f);
+                o[j] = ga * rs * (gg - sums[c + j] * inv_m - yh * sums[C + c + j] * inv_m);
+            }
+            pk.x = pack_bf16x2(o[0], o[1]);
+            pk.y = pack_bf16x2(o[2], o[3]);
         }
-        uint2 pk;
-        pk.x = pack_bf16x2(o[0], o[1]);
-        pk.y = pack_bf16x2(o[2], o[3]);
         reinterpret_cast<uint2*>(dy)[i] = pk;
     }
 }
@@ -312,7 +329,12 @@ __global__ __launch_bounds__(ED_THREADS) void tts_loss_kernel(const float* __res
                                                               int rows, int NM, int kind, float pos_weight, float w_raw, float w_post,
                                                               float w_stop, float* __restrict__ d_raw, float* __restrict__ d_post,
                                                               int64_t ld_grad, float* __restrict__ d_stop, float* __restrict__ partial,
-                                                              int Lp, int Lv) {
+                                                              int Lp, int Lv, const float* __restrict__ res, int64_t ld_res, int hp, int dp_lead,
+                                                              long long dp_rows) {
+    // res != NULL: the postnet prediction is raw + res, res in halo rows (halo hp) -- the residual add of
+    // reformer_tts.py:139-140 happens here; d_post is then written in the same halo rows (dp_rows rows, halo row 0 at row
+    // dp_lead, zero outside the valid set): it is the output gradient of the last convolution.
+    const int PH = Lp + 2 * hp;
     // predictions / gradients: rows = B*Lp (the decoder's padded length); targets: B*Lv rows (the batch's own length,
     // reformer_tts.py:141-143 crops the predictions to it).  Rows t >= Lv of a sample get zero gradient and no loss.
     float s_raw = 0.f, s_post = 0.f, s_stop = 0.f;
@@ -323,24 +345,28 @@ __global__ __launch_bounds__(ED_THREADS) void tts_loss_kernel(const float* __res
         const size_t row = i / NM;
         const int c = (int)(i % NM);
         const int t = (int)(row % Lp);
+        const size_t hrow = (row / Lp) * PH + hp + t;             // the same row in halo coordinates (== row when hp == 0)
+        const size_t prow = (size_t)dp_lead + hrow;
         if (t >= Lv) {
             d_raw[row * ld_grad + c] = 0.f;
-            d_post[row * ld_grad + c] = 0.f;
+            d_post[prow * ld_grad + c] = 0.f;
             continue;
         }
         const size_t ti = ((row / Lp) * Lv + t) * NM + c;
         const float mk = mask[ti], tg = tgt[ti];
-        const float r = raw[row * ld_mel + c] * mk - tg, p = post[row * ld_mel + c] * mk - tg;
+        const float rv = raw[row * ld_mel + c];
+        const float pv = res ? rv + res[hrow * ld_res + c] : post[row * ld_mel + c];
+        const float r = rv * mk - tg, p = pv * mk - tg;
         if (kind == 0) {
             s_raw = __builtin_fmaf(r, r, s_raw);
             s_post = __builtin_fmaf(p, p, s_post);
             d_raw[row * ld_grad + c] = w_raw * 2.f * r * mk * inv_el;
-            d_post[row * ld_grad + c] = w_post * 2.f * p * mk * inv_el;
+            d_post[prow * ld_grad + c] = w_post * 2.f * p * mk * inv_el;
         } else {
             s_raw += fabsf(r);
             s_post += fabsf(p);
             d_raw[row * ld_grad + c] = w_raw * (r > 0.f ? 1.f : (r < 0.f ? -1.f : 0.f)) * mk * inv_el;
-            d_post[row * ld_grad + c] = w_post * (p > 0.f ? 1.f : (p < 0.f ? -1.f : 0.f)) * mk * inv_el;
+            d_post[prow * ld_grad + c] = w_post * (p > 0.f ? 1.f : (p < 0.f ? -1.f : 0.f)) * mk * inv_el;
         }
     }
     // columns NM .. ld_grad of the gradient rows (padding of a 128-wide layout) are zeroed here
@@ -349,7 +375,14 @@ __global__ __launch_bounds__(ED_THREADS) void tts_loss_kernel(const float* __res
         const size_t row = i / npad;
         const int c = NM + (int)(i % npad);
         d_raw[row * ld_grad + c] = 0.f;
-        d_post[row * ld_grad + c] = 0.f;
+        d_post[((size_t)dp_lead + (row / Lp) * PH + hp + row % Lp) * ld_grad + c] = 0.f;
+    }
+    if (hp > 0) {       // halo rows, lead-in and tail of d_post
+        const EdHalo g{rows / Lp, Lp, PH, hp};
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)dp_rows * ld_grad; i += (size_t)gridDim.x * blockDim.x) {
+            int b, t;
+            if (!ed_valid(g, (long long)(i / ld_grad) - dp_lead, b, t)) d_post[i] = 0.f;
+        }
     }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)rows; i += (size_t)gridDim.x * blockDim.x) {
         const int tt = (int)(i % Lp);
@@ -397,6 +430,29 @@ __global__ void tts_loss_finalize_kernel(const float* __restrict__ partial, int 
     a *= inv_el; b *= inv_el; c *= inv_rows;
     losses[0] = w_raw * a + w_post * b + w_stop * c;
     losses[1] = a; losses[2] = b; losses[3] = c;
+}
+
+// ------------------------------------------------------------------ gradient of the [mel | stop] heads
+// dheads (M, W) fp32 = d_raw (plain rows) + d_post (halo rows) + dx0 (halo rows; columns < NM only: the gradient that came back
+// through the postnet's first convolution), column NM = d_stop  (reformer_tts.py:65-66,139-140 backward).  W = 128.
+__global__ __launch_bounds__(ED_THREADS) void heads_grad_kernel(const float* __restrict__ d_raw, const float* __restrict__ d_post, int dp_lead,
+                                                                const float* __restrict__ dx0, int64_t ld_dx0, const float* __restrict__ d_stop,
+                                                                EdHalo g, int NM, int W, float* __restrict__ out) {
+    const size_t total = (size_t)g.B * g.L * (W / 4);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % (W / 4)) * 4;
+        const size_t row = i / (W / 4);
+        const size_t hrow = (row / g.L) * g.P + g.H + row % g.L;
+        const float4 a = *reinterpret_cast<const float4*>(d_raw + row * W + c);
+        const float4 b = *reinterpret_cast<const float4*>(d_post + ((size_t)dp_lead + hrow) * W + c);
+        float o[4] = {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (c + j < NM) o[j] += dx0[hrow * ld_dx0 + c + j];
+            else if (c + j == NM) o[j] = d_stop[row];
+        }
+        *reinterpret_cast<float4*>(out + row * W + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
 }
 
 // ------------------------------------------------------------------ embedding backward (padding_idx rows get no gradient)
@@ -511,22 +567,30 @@ static inline unsigned ed_grid(size_t items) {
 }
 static inline uint32_t ed_thresh(float p) { return p <= 0.f ? 0u : (uint32_t)((double)p * 4294967296.0); }
 
-extern "C" int rtts_im2col_k5(const void* x, int64_t ldx, int B, int L, int C, int CP, void* cols, void* stream) {
-    RTTS_REQUIRE(x && cols && B > 0 && L > 0 && C > 0 && C % 8 == 0 && CP % 8 == 0 && CP >= C && ldx % 8 == 0, "rtts_im2col_k5: bad arguments");
-    hipLaunchKernelGGL(im2col_k5_kernel, dim3(ed_grid((size_t)B * L * 5 * (CP / 8))), dim3(ED_THREADS), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, ldx, B, L, C, CP, (bf16_t*)cols);
-    RTTS_LAUNCH_CHECK("rtts_im2col_k5");
+extern "C" int rtts_to_halo(const void* src, int64_t ld_src, int src_f32, int B, int L, int halo, int C, void* dst, int lead,
+                            int64_t rows, void* stream) {
+    RTTS_REQUIRE(src && dst && B > 0 && L > 0 && halo >= 0 && C > 0 && C % 8 == 0 && ld_src >= C && ld_src % (src_f32 ? 4 : 8) == 0,
+                 "rtts_to_halo: bad arguments");
+    RTTS_REQUIRE(lead >= 0 && rows >= lead + (int64_t)B * (L + 2 * halo), "rtts_to_halo: dst has %lld rows, needs %lld", (long long)rows,
+                 (long long)(lead + (int64_t)B * (L + 2 * halo)));
+    const dim3 grid(ed_grid((size_t)rows * (C / 8)));
+    if (src_f32)
+        hipLaunchKernelGGL(to_halo_kernel<true>, grid, dim3(ED_THREADS), 0, (hipStream_t)stream, src, ld_src, ed_halo(B, L, halo), C, lead,
+                           (long long)rows, (bf16_t*)dst);
+    else
+        hipLaunchKernelGGL(to_halo_kernel<false>, grid, dim3(ED_THREADS), 0, (hipStream_t)stream, src, ld_src, ed_halo(B, L, halo), C, lead,
+                           (long long)rows, (bf16_t*)dst);
+    RTTS_LAUNCH_CHECK("rtts_to_halo");
     return 0;
 }
 
-extern "C" int rtts_col2im_k5(const void* dcols, int B, int L, int C, int CP, void* dx, int64_t lddx, int out_f32, void* stream) {
-    RTTS_REQUIRE(dcols && dx && B > 0 && L > 0 && C > 0 && C % 8 == 0 && CP % 8 == 0 && CP >= C, "rtts_col2im_k5: bad arguments");
-    const dim3 grid(ed_grid((size_t)B * L * (C / 8)));
-    if (out_f32)
-        hipLaunchKernelGGL(col2im_k5_kernel<true>, grid, dim3(ED_THREADS), 0, (hipStream_t)stream, (const bf16_t*)dcols, B, L, C, CP, dx, lddx);
-    else
-        hipLaunchKernelGGL(col2im_k5_kernel<false>, grid, dim3(ED_THREADS), 0, (hipStream_t)stream, (const bf16_t*)dcols, B, L, C, CP, dx, lddx);
-    RTTS_LAUNCH_CHECK("rtts_col2im_k5");
+extern "C" int rtts_heads_grad(const float* d_raw, const float* d_post, int dpost_lead, const float* dx0, int64_t ld_dx0, const float* d_stop,
+                               int B, int L, int halo, int n_mels, int width, float* dheads, void* stream) {
+    RTTS_REQUIRE(d_raw && d_post && dx0 && d_stop && dheads && B > 0 && L > 0 && halo >= 0 && width % 4 == 0 && n_mels < width && dpost_lead >= 0,
+                 "rtts_heads_grad: bad arguments");
+    hipLaunchKernelGGL(heads_grad_kernel, dim3(ed_grid((size_t)B * L * (width / 4))), dim3(ED_THREADS), 0, (hipStream_t)stream, d_raw, d_post,
+                       dpost_lead, dx0, ld_dx0, d_stop, ed_halo(B, L, halo), n_mels, width, dheads);
+    RTTS_LAUNCH_CHECK("rtts_heads_grad");
     return 0;
 }
 
@@ -584,45 +648,55 @@ static inline dim3 ed_col_grid(int M, int C) {
     return dim3(slabs, (C + 255) / 256);
 }
 
-extern "C" int rtts_bn_stats(const float* y, int M, int C, float* mean, float* rstd, float* run_mean, float* run_var,
+extern "C" int rtts_bn_stats(const float* y, int B, int L, int halo, int C, float* mean, float* rstd, float* run_mean, float* run_var,
                              const float* mean_shift, int64_t* num_batches, float* partial_ws, void* stream) {
-    RTTS_REQUIRE(y && mean && rstd && partial_ws && M > 0 && C > 0 && C % 4 == 0, "rtts_bn_stats: bad arguments");
-    const dim3 grid = ed_col_grid(M, C);
+    RTTS_REQUIRE(y && mean && rstd && partial_ws && B > 0 && L > 0 && halo >= 0 && C > 0 && C % 4 == 0, "rtts_bn_stats: bad arguments");
+    const EdHalo g = ed_halo(B, L, halo);
+    const dim3 grid = ed_col_grid(B * g.P, C);
     hipLaunchKernelGGL((col_partial_kernel<0>), grid, dim3(ED_THREADS), 0, (hipStream_t)stream, y, (const bf16_t*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0u, (const uint32_t*)nullptr, 0u, 1.f, M, C, partial_ws);
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0u, (const uint32_t*)nullptr, 0u, 1.f, g, 1, C,
+                       partial_ws);
     hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((C + 63) / 64), dim3(ED_THREADS), 0, (hipStream_t)stream, partial_ws,
-                       (int)grid.x, M, C, mean, rstd, run_mean, run_var, mean_shift, (long long*)num_batches);
+                       (int)grid.x, B * L, C, mean, rstd, run_mean, run_var, mean_shift, (long long*)num_batches);
     RTTS_LAUNCH_CHECK("rtts_bn_stats");
     return 0;
 }
 
 extern "C" int rtts_bn_act_fwd(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
-                               float drop_p, uint32_t seed, const uint32_t* seed_dev, int M, int C, void* z, void* stream) {
-    RTTS_REQUIRE(y && mean && rstd && gamma && beta && z && M > 0 && C % 4 == 0 && (act == 1 || act == 2) && drop_p >= 0.f && drop_p < 1.f,
-                 "rtts_bn_act_fwd: bad arguments");
-    const size_t n4 = (size_t)M * C / 4;
+                               float drop_p, uint32_t seed, const uint32_t* seed_dev, int B, int L, int halo, int C, void* z, int z_halo,
+                               int z_lead, int64_t z_rows, void* stream) {
+    RTTS_REQUIRE(y && mean && rstd && gamma && beta && z && B > 0 && L > 0 && halo >= 0 && C % 4 == 0 && (act == 1 || act == 2) && drop_p >= 0.f &&
+                     drop_p < 1.f, "rtts_bn_act_fwd: bad arguments");
+    const EdHalo g = ed_halo(B, L, halo);
+    RTTS_REQUIRE(z_halo ? (halo > 0 && z_lead >= 0 && z_rows >= z_lead + (int64_t)B * g.P) : (z_rows == (int64_t)B * L && z_lead == 0),
+                 "rtts_bn_act_fwd: z must be a halo array with room for B*(L+2*halo) rows behind its lead-in, or B*L plain rows");
+    const size_t n4 = (size_t)z_rows * C / 4;
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ed_grid(n4)), dim3(ED_THREADS), 0, (hipStream_t)stream, y, mean, rstd, gamma, beta, act, seed, seed_dev,
-                       ed_thresh(drop_p), 1.f / (1.f - drop_p), n4, C, (bf16_t*)z);
+                       ed_thresh(drop_p), 1.f / (1.f - drop_p), g, z_halo, z_lead, n4, C, (bf16_t*)z);
     RTTS_LAUNCH_CHECK("rtts_bn_act_fwd");
     return 0;
 }
 
-extern "C" int rtts_bn_act_bwd(const float* y, const void* dz, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                               int act, float drop_p, uint32_t seed, const uint32_t* seed_dev, int M, int C, void* dy, float* dgamma, float* dbeta,
-                               float* partial_ws, void* stream) {
-    RTTS_REQUIRE(y && dz && mean && rstd && gamma && beta && dy && dgamma && dbeta && partial_ws && M > 0 && C % 4 == 0 && (act == 1 || act == 2),
-                 "rtts_bn_act_bwd: bad arguments");
-    const dim3 grid = ed_col_grid(M, C);
+extern "C" int rtts_bn_act_bwd(const float* y, const void* dz, int dz_halo, const float* mean, const float* rstd, const float* gamma,
+                               const float* beta, int act, float drop_p, uint32_t seed, const uint32_t* seed_dev, int B, int L, int halo, int C,
+                               void* dy, int dy_lead, int64_t dy_rows, float* dgamma, float* dbeta, float* partial_ws, void* stream) {
+    RTTS_REQUIRE(y && dz && mean && rstd && gamma && beta && dy && dgamma && dbeta && partial_ws && B > 0 && L > 0 && halo >= 0 && C % 4 == 0 &&
+                     (act == 1 || act == 2), "rtts_bn_act_bwd: bad arguments");
+    const EdHalo g = ed_halo(B, L, halo);
+    RTTS_REQUIRE(dy_lead >= 0 && dy_rows >= dy_lead + (int64_t)B * g.P && (halo > 0 || dz_halo == 0 || true),
+                 "rtts_bn_act_bwd: dy needs room for B*(L+2*halo) rows behind its lead-in");
+    const dim3 grid = ed_col_grid(B * g.P, C);
     const uint32_t th = ed_thresh(drop_p);
     const float ds = 1.f / (1.f - drop_p);
     float* sums = partial_ws + (size_t)ED_PBLOCKS * 2 * C;
+    const int dzh = (halo > 0 && dz_halo) ? 1 : 0;
     hipLaunchKernelGGL((col_partial_kernel<1>), grid, dim3(ED_THREADS), 0, (hipStream_t)stream, y, (const bf16_t*)dz, mean, rstd, gamma, beta, act,
-                       seed, seed_dev, th, ds, M, C, partial_ws);
+                       seed, seed_dev, th, ds, g, dzh, C, partial_ws);
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 63) / 64), dim3(ED_THREADS), 0, (hipStream_t)stream, partial_ws,
                        (int)grid.x, C, sums, dgamma, dbeta);
-    const size_t n4 = (size_t)M * C / 4;
+    const size_t n4 = (size_t)dy_rows * C / 4;
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ed_grid(n4)), dim3(ED_THREADS), 0, (hipStream_t)stream, y, (const bf16_t*)dz, mean, rstd,
-                       gamma, beta, act, seed, seed_dev, th, ds, sums, 1.f / (float)M, n4, C, (bf16_t*)dy);
+                       gamma, beta, act, seed, seed_dev, th, ds, sums, 1.f / (float)((size_t)B * L), g, dzh, dy_lead, n4, C, (bf16_t*)dy);
     RTTS_LAUNCH_CHECK("rtts_bn_act_bwd");
     return 0;
 }
@@ -630,16 +704,21 @@ extern "C" int rtts_bn_act_bwd(const float* y, const void* dz, const float* mean
 extern "C" int rtts_tts_loss(const float* raw, const float* post, int64_t ld_mel, const float* tgt, const float* mask, const float* stop,
                              int64_t ld_stop, const float* tstop, int rows, int NM, int kind, float pos_weight, float w_raw, float w_post,
                              float w_stop, float* d_raw, float* d_post, int64_t ld_grad, float* d_stop, float* losses, float* partial_ws,
-                             int padded_len, int valid_len, void* stream) {
-    RTTS_REQUIRE(raw && post && tgt && mask && stop && tstop && d_raw && d_post && d_stop && losses && partial_ws && rows > 0 && NM > 0 &&
+                             int padded_len, int valid_len, const float* res, int64_t ld_res, int halo, int dpost_lead, int64_t dpost_rows,
+                             void* stream) {
+    RTTS_REQUIRE(raw && (post || res) && tgt && mask && stop && tstop && d_raw && d_post && d_stop && losses && partial_ws && rows > 0 && NM > 0 &&
                      ld_grad >= NM, "rtts_tts_loss: bad arguments");
     RTTS_REQUIRE(padded_len > 0 && valid_len > 0 && valid_len <= padded_len && rows % padded_len == 0,
                  "rtts_tts_loss: rows must be batch * padded_len and 0 < valid_len <= padded_len");
     RTTS_REQUIRE(kind == 0 || kind == 1, "rtts_tts_loss: Unsupported loss type: %d", kind);
+    RTTS_REQUIRE(res ? (halo > 0 && ld_res >= NM && dpost_lead >= 0 &&
+                        dpost_rows >= dpost_lead + (int64_t)(rows / padded_len) * (padded_len + 2 * halo))
+                     : (halo == 0 && dpost_lead == 0),
+                 "rtts_tts_loss: res / d_post in halo rows need halo > 0 and room for B*(L+2*halo) rows; without res: halo = lead = 0");
     const int blocks = 512;
     hipLaunchKernelGGL(tts_loss_kernel, dim3(blocks), dim3(ED_THREADS), 0, (hipStream_t)stream, raw, post, ld_mel, tgt, mask, stop, ld_stop,
                        tstop, rows, NM, kind, pos_weight, w_raw, w_post, w_stop, d_raw, d_post, ld_grad, d_stop, partial_ws, padded_len,
-                       valid_len);
+                       valid_len, res, ld_res, halo, dpost_lead, (long long)dpost_rows);
     const float vrows = (float)(rows / padded_len) * (float)valid_len;
     hipLaunchKernelGGL(tts_loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_ws, blocks, 1.f / (vrows * NM),
                        1.f / vrows, w_raw, w_post, w_stop, losses);

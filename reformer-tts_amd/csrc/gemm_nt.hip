@@ -68,6 +68,11 @@ struct GnArgs {
     float* colsum;       // [(M / BM) * WM][N] partial rows (epilogue 3), may be null
     int64_t lda, ldw, ldc, ldg;
     int M, N, K, epi;
+    // implicit-GEMM Conv1d(k = 5): conv_cpt = 64-deep channel blocks per tap (0 = plain GEMM).  K stage s is tap s / conv_cpt,
+    // channel block s % conv_cpt: the A rows are shifted by conv_sign * (tap - 2) (the caller's rows carry a zero halo), and a
+    // [K][N] weight (input gradient) is addressed as row = channel, column offset tap * conv_wtap.
+    int conv_cpt, conv_sign;
+    int64_t conv_wtap;
 };
 
 // swizzle of the [K][N] weight image: XOR applied to the index of a 32-byte chunk (16 columns) of k row `k`
@@ -136,10 +141,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
         }
     }
     const size_t wstep = W_KN ? (size_t)GN_BK * ldw : (size_t)GN_BK;
+    const int conv_cpt = P.conv_cpt;
+    // element offsets of K stage `st` into the A rows / the weight (wave-uniform scalar arithmetic)
+    auto a_off = [&](int st) -> int64_t {
+        if (conv_cpt == 0) return (int64_t)st * GN_BK;
+        const int tap = st / conv_cpt, cb = st - tap * conv_cpt;
+        return (int64_t)(P.conv_sign * (tap - 2)) * lda + (int64_t)cb * GN_BK;
+    };
+    auto w_off = [&](int st) -> int64_t {
+        if (!W_KN || conv_cpt == 0) return (int64_t)st * (int64_t)wstep;
+        const int tap = st / conv_cpt, cb = st - tap * conv_cpt;
+        return (int64_t)cb * GN_BK * ldw + (int64_t)tap * P.conv_wtap;
+    };
 #define GN_ISSUE(stage_, buf_)                                                                                          \
     do {                                                                                                                \
         unsigned char* sb_ = smem + (buf_) * STAGE;                                                                     \
-        const size_t ka_ = (size_t)(stage_) * GN_BK, kw_ = (size_t)(stage_) * wstep;                                    \
+        const int64_t ka_ = a_off(stage_), kw_ = w_off(stage_);                                                         \
         _Pragma("unroll") for (int t = 0; t < PA; ++t)                                                                  \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[t] + ka_),           \
                                              (RTTS_LDS void*)(sb_ + (wave + NW * t) * 1024), 16, 0, 0);                 \
@@ -211,10 +228,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
         constexpr int q = decltype(qc)::value;
         unsigned char* sb_ = smem + bufi_ * STAGE;
         if constexpr (q < PA)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[q] + (size_t)stage_ * GN_BK),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[q] + a_off(stage_)),
                                              (RTTS_LDS void*)(sb_ + (wave + NW * q) * 1024), 16, 0, 0);
         else
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[q - PA] + (size_t)stage_ * wstep),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[q - PA] + w_off(stage_)),
                                              (RTTS_LDS void*)(sb_ + A_BYTES + (wave + NW * (q - PA)) * 1024), 16, 0, 0);
     };
 #define GN_MFMA(AF, WF, WL, WH, COND_, ST_, BUF_, Q0, Q1)                                                                  \
@@ -326,6 +343,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
         const int n = ncol + 16 * j;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if constexpr (epi == 1 || epi == 2) bv = *reinterpret_cast<const f32x4*>(P.bias + n);
+        if constexpr (epi == 4) if (P.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(P.bias + n);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const size_t m = (size_t)(mrow + 16 * i);
@@ -340,6 +358,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
                 v[2] = ((hv.y & 0x8000u) == 0 && (hv.y & 0x7FFFu) != 0) ? v[2] : 0.f;
                 v[3] = ((hv.y & 0x80000000u) == 0 && (hv.y & 0x7FFF0000u) != 0) ? v[3] : 0.f;
                 cs[j] += v;
+            }
+            if constexpr (epi == 4) {          // unrounded fp32 result (rows of ldc floats): in front of a BatchNorm / the loss
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(P.c) + m * P.ldc + n) = v;
+                continue;
             }
             uint2 o;
             o.x = pack_bf16x2(v[0], v[1]);
@@ -427,17 +449,19 @@ static int gn_launch2(const GnArgs& P, hipStream_t s) {
 
 template <int BM, int BN, int WM, int WN>
 static int gn_launch(const GnArgs& P, int w_kn, hipStream_t s) {
-    if (w_kn) {                       // input gradients: plain store or the ReLU gate of the FeedForward hidden layer
+    if (w_kn) {                       // input gradients: plain / fp32 store or the ReLU gate of the FeedForward hidden layer
         if (P.epi == 3) return gn_launch2<BM, BN, WM, WN, true, 3>(P, s);
         if (P.epi == 0) return gn_launch2<BM, BN, WM, WN, true, 0>(P, s);
-        rtts_set_error("rtts_gemm_nt: a [K][N] weight (input gradient) takes epilogue 0 or 3, got %d", P.epi);
+        if (P.epi == 4) return gn_launch2<BM, BN, WM, WN, true, 4>(P, s);
+        rtts_set_error("rtts_gemm_nt: a [K][N] weight (input gradient) takes epilogue 0, 3 or 4, got %d", P.epi);
         return -1;
     }
     switch (P.epi) {
         case 0: return gn_launch2<BM, BN, WM, WN, false, 0>(P, s);
         case 1: return gn_launch2<BM, BN, WM, WN, false, 1>(P, s);
         case 2: return gn_launch2<BM, BN, WM, WN, false, 2>(P, s);
-        default: return gn_launch2<BM, BN, WM, WN, false, 3>(P, s);
+        case 3: return gn_launch2<BM, BN, WM, WN, false, 3>(P, s);
+        default: return gn_launch2<BM, BN, WM, WN, false, 4>(P, s);
     }
 }
 
@@ -463,24 +487,25 @@ extern "C" int rtts_gemm_nt_partial_rows(int M, int N) {
     return i < 0 ? -1 : (M / cand[i][0]) * wm[i];
 }
 
-extern "C" int rtts_gemm_nt(const void* a, int64_t lda, const void* w, int64_t ldw, int w_is_kn, int M, int N, int K, void* c,
-                            int64_t ldc, const float* bias, int epilogue, const void* gate, int64_t ldg, float* colsum_partial,
-                            void* stream) {
+static int gn_run(const void* a, int64_t lda, const void* w, int64_t ldw, int w_is_kn, int M, int N, int K, void* c, int64_t ldc,
+                  const float* bias, int epilogue, const void* gate, int64_t ldg, float* colsum_partial, int conv_cpt, int conv_sign,
+                  int64_t conv_wtap, void* stream) {
     RTTS_REQUIRE(a && w && c, "rtts_gemm_nt: null pointer");
     RTTS_REQUIRE(M > 0 && N > 0 && K > 0 && K % GN_BK == 0, "rtts_gemm_nt: K must be a positive multiple of 64 (got M=%d N=%d K=%d)", M, N, K);
-    RTTS_REQUIRE(epilogue >= 0 && epilogue <= 3, "rtts_gemm_nt: epilogue 0..3");
+    RTTS_REQUIRE(epilogue >= 0 && epilogue <= 4, "rtts_gemm_nt: epilogue 0..4");
     RTTS_REQUIRE(!(epilogue == 1 || epilogue == 2) || bias, "rtts_gemm_nt: epilogue %d needs a bias", epilogue);
     RTTS_REQUIRE(epilogue != 3 || (gate && ldg >= N && ldg % 4 == 0), "rtts_gemm_nt: epilogue 3 needs a gate (M, N) with ldg %% 4 == 0");
-    RTTS_REQUIRE(lda >= K && lda % 8 == 0 && ldc >= N && ldc % 4 == 0, "rtts_gemm_nt: bad leading dimensions (lda=%lld ldc=%lld)",
+    RTTS_REQUIRE(lda % 8 == 0 && (conv_cpt || lda >= K) && ldc >= N && ldc % 4 == 0, "rtts_gemm_nt: bad leading dimensions (lda=%lld ldc=%lld)",
                  (long long)lda, (long long)ldc);
-    RTTS_REQUIRE(ldw % 8 == 0 && ldw >= (w_is_kn ? N : K), "rtts_gemm_nt: bad ldw=%lld", (long long)ldw);
-    RTTS_REQUIRE((((uintptr_t)a | (uintptr_t)w) & 15) == 0 && (((uintptr_t)c | (uintptr_t)gate) & 7) == 0 &&
+    RTTS_REQUIRE(ldw % 8 == 0 && (conv_cpt || ldw >= (w_is_kn ? N : K)), "rtts_gemm_nt: bad ldw=%lld", (long long)ldw);
+    RTTS_REQUIRE((((uintptr_t)a | (uintptr_t)w) & 15) == 0 && (((uintptr_t)c | (uintptr_t)gate) & (epilogue == 4 ? 15 : 7)) == 0 &&
                  (((uintptr_t)bias | (uintptr_t)colsum_partial) & 15) == 0, "rtts_gemm_nt: misaligned buffer");
     const int pick = gn_pick(M, N);
     RTTS_REQUIRE(pick >= 0, "rtts_gemm_nt: M x N = %d x %d tiles by none of 192x128, 256x128, 96x64, 128x64", M, N);
     GnArgs P;
     P.a = (const bf16_t*)a; P.w = (const bf16_t*)w; P.c = (bf16_t*)c; P.bias = bias; P.gate = (const bf16_t*)gate;
     P.colsum = colsum_partial; P.lda = lda; P.ldw = ldw; P.ldc = ldc; P.ldg = ldg; P.M = M; P.N = N; P.K = K; P.epi = epilogue;
+    P.conv_cpt = conv_cpt; P.conv_sign = conv_sign; P.conv_wtap = conv_wtap;
     hipStream_t s = (hipStream_t)stream;
     int rc = 0;
     switch (pick) {
@@ -492,4 +517,20 @@ extern "C" int rtts_gemm_nt(const void* a, int64_t lda, const void* w, int64_t l
     if (rc) return rc;
     RTTS_LAUNCH_CHECK("rtts_gemm_nt");
     return 0;
+}
+
+extern "C" int rtts_gemm_nt(const void* a, int64_t lda, const void* w, int64_t ldw, int w_is_kn, int M, int N, int K, void* c,
+                            int64_t ldc, const float* bias, int epilogue, const void* gate, int64_t ldg, float* colsum_partial,
+                            void* stream) {
+    return gn_run(a, lda, w, ldw, w_is_kn, M, N, K, c, ldc, bias, epilogue, gate, ldg, colsum_partial, 0, 0, 0, stream);
+}
+
+extern "C" int rtts_conv1d_k5(const void* x, int64_t ldx, const void* wp, int64_t ldw, int transposed, int M, int C_out, int C_in,
+                              void* y, int64_t ldy, const float* bias, int out_f32, void* stream) {
+    RTTS_REQUIRE(C_in > 0 && C_in % GN_BK == 0 && C_out > 0, "rtts_conv1d_k5: channel counts must be multiples of 64 (got %d -> %d)", C_in, C_out);
+    RTTS_REQUIRE(!bias || out_f32, "rtts_conv1d_k5: a bias rides in the fp32 epilogue only");
+    // forward:    y[m][co] = sum_{tap, ci} x[m + tap - 2][ci] * wp[co][tap * C_in + ci]              (wp (C_out, 5 C_in), NT)
+    // transposed: y[m][co] = sum_{tap, ci} x[m - tap + 2][ci] * wp[ci][tap * C_out + co]             (wp (C_in, 5 C_out), [K][N])
+    return gn_run(x, ldx, wp, ldw, transposed ? 1 : 0, M, C_out, 5 * C_in, y, ldy, bias, out_f32 ? 4 : 0, nullptr, 0, nullptr,
+                  C_in / GN_BK, transposed ? -1 : 1, transposed ? (int64_t)C_out : 0, stream);
 }

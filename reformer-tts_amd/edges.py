@@ -6,21 +6,24 @@
                     residual (``modules.py:146-169``, ``reformer_tts.py:139-143``) -> TTSLoss
                     (``model/loss.py:28-53``), forward values and the gradient w.r.t. the decoder output
 
-A convolution is im2col + one library GEMM (hipBLASLt via ``torch.mm``); im2col/col2im, BatchNorm
-statistics / normalisation / backward, activations, dropout masks, weight re-layouts, weight gradients
-(split-K ``rtts_gemm_tn``) and the loss are kernels of ``csrc/edges.hip`` / ``gemm_tn.hip``.
-The conv bias in front of a BatchNorm only shifts the batch mean: it is folded into the running mean
+A convolution is an IMPLICIT GEMM on the hand-written MFMA kernel (``rtts_conv1d_k5``, csrc/gemm_nt.hip): the activations of
+a stack live in halo rows -- (B, L + 4, C) with two zero rows around every sequence, see ``Halo`` -- so the five taps of the
+forward, of the input gradient and of the weight gradient are row-shifted reads of one array; no window (im2col) matrix
+exists.  BatchNorm statistics / normalisation / backward, activations, dropout masks, weight re-layouts, weight gradients
+(split-K ``rtts_gemm_tn`` on shifted views), the heads and the loss are kernels of ``csrc/edges.hip`` / ``gemm_tn.hip`` /
+``gemm_nt.hip``.  The conv bias in front of a BatchNorm only shifts the batch mean: it is folded into the running mean
 and its (exactly zero) gradient is not computed.
 """
 from __future__ import annotations
 
+import threading
 from typing import List
 
 import torch
 
 from . import _lib
 from . import engine as _engine
-from .engine import WEIGHT_EPOCH, _WS, _bf16, _grad, cast_colsum, wgrad
+from .engine import WEIGHT_EPOCH, _WS, _bf16, _grad, cast_colsum, gemm, wgrad
 
 from ._seeds import _seed_counter, seed_base  # noqa: E402,F401  (shared with engine.py)
 
@@ -30,7 +33,7 @@ def _s() -> int:
 
 
 def _ws(device, c: int) -> torch.Tensor:
-    key = ("edge", device, c)
+    key = ("edge", device, c, torch.cuda.current_stream(device).cuda_stream)
     if key not in _WS._cache:
         _WS._cache[key] = torch.empty((2 * 256 + 2) * c, dtype=torch.float32, device=device)
     return _WS._cache[key]
@@ -40,14 +43,47 @@ def _pad128(c: int) -> int:
     return -(-c // 128) * 128
 
 
-_PENDING_DW = []
+class Halo:
+    """Halo rows of one (B, L) batch: rows m = b * (L + 4) + 2 + t carry sequence b, position t; the two rows in front of
+    and behind every sequence, the ``LEAD`` rows before row 0 and everything behind row B * (L + 4) - 1 are zero.  ``mp`` =
+    the row count the GEMMs run over (a multiple of their 192-row tile); a buffer has ``alloc`` = mp + 2 * LEAD rows so that
+    the taps' shifted reads (+-2 rows) stay inside it.  Every kernel that produces a halo array writes ALL its rows (zeros
+    outside the valid set), so buffers come from ``torch.empty`` and carry no state from call to call."""
+    H, LEAD, TILE = 2, 8, 192
+
+    def __init__(self, b: int, l: int):
+        self.b, self.l = b, l
+        self.p = l + 2 * self.H
+        self.rows = b * self.p
+        self.mp = -(-self.rows // self.TILE) * self.TILE
+        self.alloc = self.mp + 2 * self.LEAD
+
+    def new(self, c: int, device, dtype=torch.bfloat16) -> torch.Tensor:
+        return torch.empty(self.alloc, c, dtype=dtype, device=device)
+
+    def body(self, buf: torch.Tensor, shift: int = 0) -> torch.Tensor:
+        """(mp, C) view starting ``shift`` rows from halo row 0."""
+        return buf[self.LEAD + shift:self.LEAD + shift + self.mp]
+
+    def valid(self, body: torch.Tensor) -> torch.Tensor:
+        """(B, L, C) strided view of the rows that carry data, of an array whose row 0 is halo row 0."""
+        return body[:self.rows].view(self.b, self.p, -1)[:, self.H:self.H + self.l]
+
+
+class _DwQueue(threading.local):
+    def __init__(self):
+        self.items = []
+
+
+_DW = _DwQueue()
 
 
 def flush_conv_dw() -> None:
     """dw[co][ci][k] += dwp[co][k][ci] for every convolution whose backward has run since the last flush (one launch)."""
-    while _PENDING_DW:
-        chunk = _PENDING_DW[:_lib.CONV_PERM_MAX_GROUP]
-        del _PENDING_DW[:len(chunk)]
+    pending = _DW.items
+    while pending:
+        chunk = pending[:_lib.CONV_PERM_MAX_GROUP]
+        del pending[:len(chunk)]
         jobs = (_lib.ConvPermJob * len(chunk))()
         for j, (dwp, co, ci, cp, gw) in zip(jobs, chunk):
             j.w, j.wp, j.Co, j.Ci, j.CP = dwp.data_ptr(), gw.data_ptr(), co, ci, cp
@@ -55,14 +91,14 @@ def flush_conv_dw() -> None:
 
 
 class ConvK5:
-    """One Conv1d(kernel 5, padding 2) as im2col + GEMM; keeps what its backward needs."""
+    """One Conv1d(kernel 5, padding 2) on halo rows (implicit GEMM); forward, input gradient, weight gradient."""
 
     instances = None      # weakref.WeakSet of every executor: refresh_all() re-lays-out all their weights in one launch
 
     def __init__(self, conv: torch.nn.Conv1d):
         self.conv = conv
         self.co, self.ci = conv.out_channels, conv.in_channels
-        self.cp = _pad128(self.ci)          # input channels padded (zero weights) so that K = 5*cp tiles
+        self.cp = _pad128(self.ci)          # input channels padded (zero weights): the channel count of the input rows
         self.cop = _pad128(self.co)         # output channels padded likewise (zero rows)
         self._wp = None
         self._wp_version = None
@@ -102,97 +138,120 @@ class ConvK5:
             self._wp_version = ver
         return self._wp
 
-    def im2col(self, x: torch.Tensor, b: int, l: int) -> torch.Tensor:
-        """x bf16 (B*L, C_stride) with C = ci valid channels -> (B*L, 5*cp)."""
-        cols = torch.empty(b * l, 5 * self.cp, dtype=torch.bfloat16, device=x.device)
-        cin = -(-self.ci // 8) * 8
-        _lib.call("rtts_im2col_k5", x.data_ptr(), x.stride(0), b, l, cin, self.cp, cols.data_ptr(), _s())
-        return cols
+    def forward(self, xh: torch.Tensor, g: Halo, bias=None) -> torch.Tensor:
+        """xh: halo buffer (alloc, cp) bf16 -> y (mp, cop) fp32 (unrounded: a BatchNorm or the loss reads it)."""
+        y = torch.empty(g.mp, self.cop, dtype=torch.float32, device=xh.device)
+        wp = self.weight_perm()
+        _lib.call("rtts_conv1d_k5", g.body(xh).data_ptr(), self.cp, wp.data_ptr(), 5 * self.cp, 0, g.mp, self.cop, self.cp, y.data_ptr(),
+                  self.cop, None if bias is None else bias.data_ptr(), 1, _s())
+        return y
 
-    def forward(self, x, b, l):
-        cols = self.im2col(x, b, l)
-        y = torch.mm(cols, self.weight_perm().t(), out_dtype=torch.float32)      # (M, cop) fp32, bias not added
-        return cols, y
-
-    def backward(self, dy: torch.Tensor, cols: torch.Tensor, b: int, l: int, need_dx: bool = True, dx_f32: bool = False):
-        """dy bf16 (M, cop) -> accumulates dW, returns dx (M, ci rounded up to 8) bf16/fp32."""
-        dwp = torch.empty(self.cop, 5 * self.cp, dtype=torch.float32, device=dy.device)
-        wgrad(dwp, dy, cols, accumulate=False)
+    def backward(self, dyh: torch.Tensor, xh: torch.Tensor, g: Halo, need_dx: bool = True, dx_f32: bool = False):
+        """dyh: halo buffer (alloc, cop) bf16, zero outside the valid set -> accumulates dW; returns dx (mp, cp) bf16 / fp32
+        in halo rows (row 0 = halo row 0; rows outside the valid set hold no meaning)."""
+        dev = dyh.device
+        dwp = torch.empty(self.cop, 5 * self.cp, dtype=torch.float32, device=dev)
+        # weight gradient of tap k = (dy)^T (x shifted by k - 2): five problems of one grouped split-K launch
+        arr = (_lib.GemmTnProblem * 5)()
+        dyb = g.body(dyh)
+        for k, q in enumerate(arr):
+            xs, ck = g.body(xh, k - 2), dwp[:, k * self.cp:(k + 1) * self.cp]
+            q.a, q.lda, q.b, q.ldb, q.c, q.ldc = dyb.data_ptr(), self.cop, xs.data_ptr(), self.cp, ck.data_ptr(), 5 * self.cp
+            q.M, q.N, q.K, q.accumulate = g.mp, self.cop, self.cp, 0
+        ws = _engine._slab_ws(dev)
+        _lib.call("rtts_gemm_tn_grouped", arr, 5, ws.data_ptr(), ws.numel(), _s())
         # dW goes back to nn.Conv1d's (Co, Ci, 5) layout with the other deferred gradient work of the backward: one grouped
         # launch for all convolutions (engine.flush_wgrad runs the hook before anything reads the gradients)
-        _PENDING_DW.append((dwp, self.co, self.ci, self.cp, _grad(self.conv.weight)))
-        if len(_PENDING_DW) >= _lib.CONV_PERM_MAX_GROUP:
+        _DW.items.append((dwp, self.co, self.ci, self.cp, _grad(self.conv.weight)))
+        if len(_DW.items) >= _lib.CONV_PERM_MAX_GROUP:
             flush_conv_dw()
         else:
             from .engine import _queue_final_flush
             _queue_final_flush()
         if not need_dx:
             return None
-        dcols = torch.mm(dy, self.weight_perm())
-        cin = -(-self.ci // 8) * 8
-        dx = torch.empty(b * l, cin, dtype=torch.float32 if dx_f32 else torch.bfloat16, device=dy.device)
-        _lib.call("rtts_col2im_k5", dcols.data_ptr(), b, l, cin, self.cp, dx.data_ptr(), dx.stride(0), int(dx_f32), _s())
+        dx = torch.empty(g.mp, self.cp, dtype=torch.float32 if dx_f32 else torch.bfloat16, device=dev)
+        _lib.call("rtts_conv1d_k5", dyb.data_ptr(), self.cop, self.weight_perm().data_ptr(), 5 * self.cp, 1, g.mp, self.cp, self.cop,
+                  dx.data_ptr(), self.cp, None, int(dx_f32), _s())
         return dx
 
 
 class ConvBNAct:
-    """Conv1d(k5) -> BatchNorm1d (batch statistics) -> act (1 relu / 2 tanh) -> Dropout(p)."""
+    """Conv1d(k5) -> BatchNorm1d (batch statistics) -> act (1 relu / 2 tanh) -> Dropout(p), on halo rows."""
 
     def __init__(self, conv, bn, act: int, p: float):
         self.c = ConvK5(conv)
         self.bn, self.act, self.p = bn, act, float(p)
 
-    def forward(self, x, b, l):
-        cols, y = self.c.forward(x, b, l)
-        m, c = y.shape
+    def forward(self, xh, g: Halo, plain_out: bool = False):
+        """-> z (halo buffer (alloc, C) bf16, or (B*L, C) plain rows for the last layer of a stack), saved state."""
+        y = self.c.forward(xh, g)
+        c = y.shape[1]
         dev = y.device
         mean = torch.empty(c, dtype=torch.float32, device=dev)
         rstd = torch.empty(c, dtype=torch.float32, device=dev)
         bn = self.bn
         # running_mean tracks the mean of (y + conv bias): the bias is left out of y (BatchNorm cancels it) and shifts
         # only the running mean; num_batches_tracked is bumped by the same launch
-        _lib.call("rtts_bn_stats", y.data_ptr(), m, c, mean.data_ptr(), rstd.data_ptr(), bn.running_mean.data_ptr(),
+        _lib.call("rtts_bn_stats", y.data_ptr(), g.b, g.l, g.H, c, mean.data_ptr(), rstd.data_ptr(), bn.running_mean.data_ptr(),
                   bn.running_var.data_ptr(), self.c.conv.bias.data_ptr(), bn.num_batches_tracked.data_ptr(), _ws(dev, c).data_ptr(), _s())
         seed = next(_seed_counter) * 2654435761 % (1 << 32)
-        z = torch.empty(m, c, dtype=torch.bfloat16, device=dev)
+        if plain_out:
+            z = torch.empty(g.b * g.l, c, dtype=torch.bfloat16, device=dev)
+            zargs = (0, 0, g.b * g.l)
+        else:
+            z = g.new(c, dev)
+            zargs = (1, g.LEAD, g.alloc)
         _lib.call("rtts_bn_act_fwd", y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), self.act,
-                  self.p, seed, seed_base(dev).data_ptr(), m, c, z.data_ptr(), _s())
-        return z, (cols, y, mean, rstd, seed)
+                  self.p, seed, seed_base(dev).data_ptr(), g.b, g.l, g.H, c, z.data_ptr(), *zargs, _s())
+        return z, (xh, y, mean, rstd, seed)
 
-    def backward(self, dz, saved, b, l, need_dx=True, dx_f32=False):
-        cols, y, mean, rstd, seed = saved
-        m, c = y.shape
+    def backward(self, dz, dz_halo: bool, saved, g: Halo, need_dx=True, dx_f32=False):
+        """dz: (mp, C) halo rows (row 0 = halo row 0) or (B*L, C) plain rows, bf16."""
+        xh, y, mean, rstd, seed = saved
+        c = y.shape[1]
         bn = self.bn
-        dy = torch.empty(m, c, dtype=torch.bfloat16, device=y.device)
-        _lib.call("rtts_bn_act_bwd", y.data_ptr(), dz.data_ptr(), mean.data_ptr(), rstd.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
-                  self.act, self.p, seed, seed_base(y.device).data_ptr(), m, c, dy.data_ptr(), _grad(bn.weight).data_ptr(), _grad(bn.bias).data_ptr(),
-                  _ws(y.device, c).data_ptr(), _s())
+        dy = g.new(c, y.device)
+        _lib.call("rtts_bn_act_bwd", y.data_ptr(), dz.data_ptr(), int(dz_halo), mean.data_ptr(), rstd.data_ptr(), bn.weight.data_ptr(),
+                  bn.bias.data_ptr(), self.act, self.p, seed, seed_base(y.device).data_ptr(), g.b, g.l, g.H, c, dy.data_ptr(), g.LEAD, g.alloc,
+                  _grad(bn.weight).data_ptr(), _grad(bn.bias).data_ptr(), _ws(y.device, c).data_ptr(), _s())
         _grad(self.c.conv.bias)       # exists (stays zero: the true gradient of a bias in front of BatchNorm is zero)
-        return self.c.backward(dy, cols, b, l, need_dx, dx_f32)
+        return self.c.backward(dy, xh, g, need_dx, dx_f32)
 
 
 class ConvStackFn(torch.autograd.Function):
-    """x (B, L, C) bf16 -> z (B, L, C) bf16 through a list of ConvBNAct."""
+    """x (B, L, C) fp32 | bf16 -> z (B, L, C) bf16 through a list of ConvBNAct."""
 
     @staticmethod
     def forward(ctx, x, stack: List[ConvBNAct], training: bool):
         b, l, c = x.shape
-        cur = x.reshape(b * l, c)
+        g = Halo(b, l)
+        x2 = x.detach().reshape(b * l, c)
+        if x2.dtype not in (torch.float32, torch.bfloat16) or x2.stride(1) != 1:
+            x2 = x2.float().contiguous()
+        cur = g.new(c, x.device)
+        _lib.call("rtts_to_halo", x2.data_ptr(), x2.stride(0), int(x2.dtype == torch.float32), b, l, g.H, c, cur.data_ptr(), g.LEAD, g.alloc, _s())
         saved = []
-        for layer in stack:
-            cur, s = layer.forward(cur, b, l)
+        for i, layer in enumerate(stack):
+            cur, s = layer.forward(cur, g, plain_out=(i == len(stack) - 1))
             saved.append(s)
-        ctx.stack, ctx.saved_state, ctx.shape = stack, saved, (b, l, c)
+        ctx.stack, ctx.saved_state, ctx.geom, ctx.in_dtype = stack, saved, g, x.dtype
         return cur.view(b, l, -1)
 
     @staticmethod
     def backward(ctx, dz):
-        b, l, c = ctx.shape
-        cur = dz.reshape(b * l, -1).to(torch.bfloat16).contiguous()
-        for layer, s in zip(reversed(ctx.stack), reversed(ctx.saved_state)):
-            cur = layer.backward(cur, s, b, l)
+        g = ctx.geom
+        if ctx.saved_state is None:
+            raise RuntimeError("ConvStackFn.backward: state already consumed")
+        cur = dz.reshape(g.b * g.l, -1).to(torch.bfloat16).contiguous()
+        halo = False
+        n = len(ctx.stack)
+        for i in range(n - 1, -1, -1):
+            cur = ctx.stack[i].backward(cur, halo, ctx.saved_state[i], g, need_dx=True, dx_f32=(i == 0))
+            halo = True
         ctx.saved_state = None
-        return cur.view(b, l, c), None, None
+        dx = g.valid(cur)                     # (B, L, C) fp32 view of the halo rows that carry data
+        return (dx if ctx.in_dtype == torch.float32 else dx.to(ctx.in_dtype)), None, None
 
 
 def encoder_prenet_stack(prenet) -> List[ConvBNAct]:
@@ -237,55 +296,59 @@ class _PostnetLossFn(torch.autograd.Function):
         l = true_mel.shape[1]                       # loss length (cutoff)
         nm, dev = ex.nm, y_dec.device
         m = b * lp
+        g = Halo(b, lp)
         yb = y_dec.detach().reshape(m, d).to(torch.bfloat16)
         wh, bh = ex._heads_weight()
-        heads = torch.mm(yb, wh.t(), out_dtype=torch.float32) + bh          # (M,128): [mel(80) | stop | 0...]
-        x0 = heads.to(torch.bfloat16)               # the first convolution reads channels < nm only; columns >= nm stay unread
+        heads = gemm(yb, wh, bias=bh, out_f32=True)                         # (M,128) fp32: [mel(80) | stop | 0...]
+        x0 = g.new(128, dev)                        # the first convolution's weights are zero for channels >= nm
+        _lib.call("rtts_to_halo", heads.data_ptr(), 128, 1, b, lp, g.H, 128, x0.data_ptr(), g.LEAD, g.alloc, _s())
         saved, cur = [], x0
         for layer in ex.layers:
-            cur, s = layer.forward(cur, b, lp)
+            cur, s = layer.forward(cur, g)
             saved.append(s)
-        cols_end = ex.convend.im2col(cur, b, lp)
-        res = torch.mm(cols_end, ex.convend.weight_perm().t(), out_dtype=torch.float32) + _pad_bias(ex.convend, dev)
-        post = heads[:, :128] + res                                           # cols >= nm are junk and never read
+        res = ex.convend.forward(cur, g, bias=_pad_bias(ex.convend, dev))    # (mp, 128) fp32 halo rows; cols >= nm never read
         lm = ex.loss_mod
         losses = torch.empty(4, dtype=torch.float32, device=dev)
-        # the three stored gradients share one buffer so that the backward scales them with one launch
-        gbuf = torch.empty(m * 257, dtype=torch.float32, device=dev)
-        d_raw = gbuf[:m * 128].view(m, 128)                                # 128-wide rows; the kernel zeroes the pad columns
-        d_post = gbuf[m * 128:m * 256].view(m, 128)
-        g_stop = gbuf[m * 256:]
-        kind = lm.kind
+        # the three stored gradients share one buffer so that the backward scales them with one launch; d_post is the output
+        # gradient of the last convolution and is written in halo rows (the residual add post = raw + res happens in the kernel)
+        n_raw, n_post = m * 128, g.alloc * 128
+        gbuf = torch.empty(n_raw + n_post + m, dtype=torch.float32, device=dev)
+        d_raw, d_post, g_stop = gbuf[:n_raw].view(m, 128), gbuf[n_raw:n_raw + n_post].view(g.alloc, 128), gbuf[n_raw + n_post:]
         pw = torch.empty(512 * 3, dtype=torch.float32, device=dev)
-        _lib.call("rtts_tts_loss", heads.data_ptr(), post.data_ptr(), 128, true_mel.contiguous().data_ptr(), true_mask.contiguous().data_ptr(),
-                  heads[:, nm:].data_ptr(), 128, true_stop.contiguous().data_ptr(), m, nm, kind, ex.pos_weight,
+        _lib.call("rtts_tts_loss", heads.data_ptr(), None, 128, true_mel.contiguous().data_ptr(), true_mask.contiguous().data_ptr(),
+                  heads[:, nm:].data_ptr(), 128, true_stop.contiguous().data_ptr(), m, nm, lm.kind, ex.pos_weight,
                   float(lm.raw_pred_loss_weight), float(lm.post_pred_loss_weight), float(lm.stop_loss_weight), d_raw.data_ptr(),
-                  d_post.data_ptr(), 128, g_stop.data_ptr(), losses.data_ptr(), pw.data_ptr(), lp, l, _s())
-        ctx.ex, ctx.state = ex, (yb, wh, saved, cur, cols_end, gbuf, b, lp, d)
+                  d_post.data_ptr(), 128, g_stop.data_ptr(), losses.data_ptr(), pw.data_ptr(), lp, l, res.data_ptr(), 128, g.H, g.LEAD,
+                  g.alloc, _s())
+        ctx.ex, ctx.state = ex, (yb, wh, saved, cur, gbuf, g, d)
         return losses
 
     @staticmethod
     def backward(ctx, dlosses):
         ex = ctx.ex
-        yb, wh, saved, z_last, cols_end, gbuf, b, lp, d = ctx.state
+        if ctx.state is None:
+            raise RuntimeError("PostnetLoss.backward: state already consumed")
+        yb, wh, saved, z_last, gbuf, g, d = ctx.state
         ctx.state = None
         nm, dev = ex.nm, yb.device
+        b, lp = g.b, g.l
         m = b * lp
         # the stored gradients are those of losses[0]; scale them by its upstream weight (1 in the trainer)
         gbuf = gbuf * dlosses[0]
-        d_raw, d_post, g_stop = gbuf[:m * 128].view(m, 128), gbuf[m * 128:m * 256].view(m, 128), gbuf[m * 256:]
+        n_raw, n_post = m * 128, g.alloc * 128
+        d_raw, d_post, g_stop = gbuf[:n_raw].view(m, 128), gbuf[n_raw:n_raw + n_post].view(g.alloc, 128), gbuf[n_raw + n_post:]
         # convend: res = conv(z_last) + bias;  d_res = d_post
         zpad = torch.zeros(256, dtype=torch.float32, device=dev)
         dbias_pad, bsum = zpad[:128], zpad[128:]
         dresb = cast_colsum(d_post, dbias_pad, defer=False)                 # deterministic column sums (no ATen reduction)
         _grad(ex.convend.conv.bias).add_(dbias_pad[:nm])
-        dz = ex.convend.backward(dresb, cols_end, b, lp)
+        dz = ex.convend.backward(dresb, z_last, g)
         for layer, s in zip(reversed(ex.layers[1:]), reversed(saved[1:])):
-            dz = layer.backward(dz, s, b, lp)
-        dx0 = ex.layers[0].backward(dz, saved[0], b, lp, need_dx=True, dx_f32=True)        # (M, 80) fp32
-        dheads = d_raw + d_post
-        dheads[:, :nm] += dx0[:, :nm]
-        dheads[:, nm] = g_stop
+            dz = layer.backward(dz, True, s, g)
+        dx0 = ex.layers[0].backward(dz, True, saved[0], g, need_dx=True, dx_f32=True)        # (mp, 128) fp32 halo rows
+        dheads = torch.empty(m, 128, dtype=torch.float32, device=dev)
+        _lib.call("rtts_heads_grad", d_raw.data_ptr(), d_post.data_ptr(), g.LEAD, dx0.data_ptr(), 128, g_stop.data_ptr(), b, lp, g.H, nm, 128,
+                  dheads.data_ptr(), _s())
         dhb = cast_colsum(dheads, bsum, defer=False)      # read two lines below
         mel, stop = ex.model.dec.mel_linear, ex.model.dec.stop_linear
         _grad(mel.bias).add_(bsum[:nm])
@@ -294,7 +357,7 @@ class _PostnetLossFn(torch.autograd.Function):
         wgrad(dwh, dhb, yb, accumulate=False)
         _grad(mel.weight).add_(dwh[:nm])
         _grad(stop.weight).add_(dwh[nm:nm + 1])
-        dy = torch.mm(dhb, wh).float().view(b, lp, d)
+        dy = gemm(dhb, wh, kn=True).float().view(b, lp, d)
         return dy, None, None, None, None
 
 

@@ -211,18 +211,23 @@ def residual(acc, g, bias, sign: float, next_norm=None, drop=None):
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, kn: bool = False, bias: Optional[torch.Tensor] = None, relu: bool = False,
-         gate: Optional[torch.Tensor] = None, gate_bias_grad: Optional[torch.Tensor] = None) -> torch.Tensor:
+         gate: Optional[torch.Tensor] = None, gate_bias_grad: Optional[torch.Tensor] = None, out_f32: bool = False) -> torch.Tensor:
     """C (M, N) bf16 = epilogue(a (M, K) @ W), csrc/gemm_nt.hip (hand-written MFMA kernel; no library GEMM on the stack path).
     ``kn=False``: w is (N, K) -- y = x W^T, the forward of nn.Linear; ``kn=True``: w is (K, N) -- dx = dy W, its input gradient.
     ``bias`` (fp32, N) [+ ``relu``] ride in the epilogue; ``gate`` (M, N) bf16: C = acc * (gate > 0), the backward of ReLU,
-    with ``gate_bias_grad`` += column sums of C (queued with the other deferred column sums)."""
+    with ``gate_bias_grad`` += column sums of C (queued with the other deferred column sums).  ``out_f32``: the unrounded fp32
+    result (+ bias) instead of bf16."""
     m, k = a.shape
     n = w.shape[1] if kn else w.shape[0]
     if (w.shape[0] if kn else w.shape[1]) != k or a.stride(1) != 1 or w.stride(1) != 1:
         raise ValueError(f"gemm: operand shapes {tuple(a.shape)} x {tuple(w.shape)} (kn={kn}) do not match")
-    c = torch.empty(m, n, dtype=torch.bfloat16, device=a.device)
+    c = torch.empty(m, n, dtype=torch.float32 if out_f32 else torch.bfloat16, device=a.device)
     epi, cs = 0, None
-    if gate is not None:
+    if out_f32:
+        if gate is not None or relu:
+            raise ValueError("gemm: out_f32 takes a plain or bias epilogue")
+        epi = 4
+    elif gate is not None:
         epi = 3
         if gate_bias_grad is not None:
             rows = _lib.load().rtts_gemm_nt_partial_rows(m, n)

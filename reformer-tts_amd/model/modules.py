@@ -1,7 +1,7 @@
 """Prenets, postnet, positional encoding and position-wise FFN with the reference's module and
-parameter names (``/root/reference/reformer_tts/model/modules.py``).  Convolutions / BatchNorm /
-small linears still run on ATen GEMMs (hipBLASLt) in this round; see DESIGN.md for which rows
-of SURVEY.md section 8a are hand-written HIP."""
+parameter names (``/root/reference/reformer_tts/model/modules.py``).  On the GPU training path the
+convolutions, BatchNorm and projections run on the kernels of librtts_hip.so (``edges.py``); the
+eager bodies below are the general path (eval, exotic shapes) and say so when taken."""
 from __future__ import annotations
 
 from collections import OrderedDict
@@ -111,7 +111,7 @@ class EncoderPreNet(nn.Module):
             from ..edges import ConvStackFn, encoder_prenet_stack
             if getattr(self, "_stack", None) is None:
                 self._stack = encoder_prenet_stack(self)
-            z = ConvStackFn.apply(x.to(torch.bfloat16), self._stack, True)
+            z = ConvStackFn.apply(x, self._stack, True)            # the cast to bf16 rides in the stack's first kernel
             if pe is not None:
                 from ..edges import proj_pe
                 return proj_pe(z, self.projection, pe)               # projection + positional encoding fused

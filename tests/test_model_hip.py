@@ -387,14 +387,40 @@ def layer_buckets(layer, model, batch):
     return t // layer.bucket_size
 
 
-@pytest.mark.parametrize("act,p", [(1, 0.0), (2, 0.3), (1, 0.1)])
-def test_bn_act_dropout_kernels_vs_autograd(gpu, act, p):
+@pytest.mark.parametrize("act,p,halo", [(1, 0.0, 0), (2, 0.3, 0), (1, 0.1, 0), (2, 0.3, 2), (1, 0.1, 2)])
+def test_bn_act_dropout_kernels_vs_autograd(gpu, act, p, halo):
     """rtts_bn_stats / rtts_bn_act_fwd / rtts_bn_act_bwd against torch autograd, with the dropout mask the
-    forward kernel actually drew (recovered from its output) held fixed in the reference."""
+    forward kernel actually drew (recovered from its output) held fixed in the reference.  halo = 2: the same data in halo rows
+    (two rows around every sequence, a lead-in and a tail, all filled with junk in y): statistics and gradients must ignore
+    them and every produced halo array must be zero there."""
     from reformer_tts_amd import _lib
     g = torch.Generator().manual_seed(act * 10 + int(p * 10))
-    m, c = 768, 256
+    b, l, c = 3, 256, 256
+    m = b * l
+    P, lead = l + 2 * halo, (8 if halo else 0)
+    rows = (lead + b * P + 11) if halo else m              # an arbitrary tail behind the last sequence
+
+    def to_h(x, junk=0.0):
+        """plain (m, c) -> the kernels' layout for this case (halo rows with lead-in, or plain)."""
+        if not halo:
+            return x.contiguous()
+        out = torch.full((rows, c), junk, dtype=x.dtype, device=x.device)
+        out[lead:lead + b * P].view(b, P, c)[:, halo:halo + l] = x.view(b, l, c)
+        return out
+
+    def from_h(xh):
+        return xh[lead:lead + b * P].view(b, P, c)[:, halo:halo + l].reshape(m, c) if halo else xh
+
+    def outside_is_zero(xh):
+        if not halo:
+            return True
+        mask = torch.ones(rows, dtype=torch.bool, device=xh.device)
+        mask[lead:lead + b * P].view(b, P)[:, halo:halo + l] = False
+        return bool((xh[mask].float() == 0).all())
+
     y = (torch.randn(m, c, generator=g) * 1.5 + 0.3).to(gpu)
+    yh = to_h(y, junk=1e3)[lead:] if halo else y          # y itself has no lead-in (row 0 = halo row 0)
+    yh = yh.contiguous()
     gamma = (1 + 0.1 * torch.randn(c, generator=g)).to(gpu)
     beta = (0.1 * torch.randn(c, generator=g)).to(gpu)
     dz = torch.randn(m, c, generator=g).bfloat16().to(gpu)
@@ -403,27 +429,42 @@ def test_bn_act_dropout_kernels_vs_autograd(gpu, act, p):
     ws = torch.empty((2 * 256 + 2) * c, device=gpu)
     s = torch.cuda.current_stream().cuda_stream
     seed = 12345
-    _lib.call("rtts_bn_stats", y.data_ptr(), m, c, mean.data_ptr(), rstd.data_ptr(), rm.data_ptr(), rv.data_ptr(), None, None, ws.data_ptr(), s)
-    z = torch.empty(m, c, dtype=torch.bfloat16, device=gpu)
+    _lib.call("rtts_bn_stats", yh.data_ptr(), b, l, halo, c, mean.data_ptr(), rstd.data_ptr(), rm.data_ptr(), rv.data_ptr(), None, None, ws.data_ptr(), s)
+    zh = torch.full((rows, c), 7.0, dtype=torch.bfloat16, device=gpu)
     sd = torch.tensor([77], dtype=torch.int32, device=gpu)      # device part of the seed (what a graph replay refreshes)
-    _lib.call("rtts_bn_act_fwd", y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act, p, seed,
-              sd.data_ptr(), m, c, z.data_ptr(), s)
-    dy = torch.empty(m, c, dtype=torch.bfloat16, device=gpu)
+    zargs = (1, lead, rows) if halo else (0, 0, m)
+    _lib.call("rtts_bn_act_fwd", yh.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act, p, seed,
+              sd.data_ptr(), b, l, halo, c, zh.data_ptr(), *zargs, s)
+    dyh = torch.full((rows, c), 7.0, dtype=torch.bfloat16, device=gpu)
     dgam, dbet = torch.zeros(c, device=gpu), torch.zeros(c, device=gpu)
-    _lib.call("rtts_bn_act_bwd", y.data_ptr(), dz.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act, p,
-              seed, sd.data_ptr(), m, c, dy.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), ws.data_ptr(), s)
+    # dz once in halo rows (no lead-in), once in plain rows (the last layer of a stack)
+    dzh = (to_h(dz, junk=50.0)[lead:].contiguous() if halo else dz)
+    _lib.call("rtts_bn_act_bwd", yh.data_ptr(), dzh.data_ptr(), 1 if halo else 0, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+              act, p, seed, sd.data_ptr(), b, l, halo, c, dyh.data_ptr(), lead, rows, dgam.data_ptr(), dbet.data_ptr(), ws.data_ptr(), s)
     torch.cuda.synchronize()
+    z, dy = from_h(zh), from_h(dyh)
+    assert outside_is_zero(zh) and outside_is_zero(dyh)
+    if halo:
+        dy2 = torch.full((rows, c), 7.0, dtype=torch.bfloat16, device=gpu)
+        g2, b2 = torch.zeros(c, device=gpu), torch.zeros(c, device=gpu)
+        _lib.call("rtts_bn_act_bwd", yh.data_ptr(), dz.data_ptr(), 0, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                  act, p, seed, sd.data_ptr(), b, l, halo, c, dy2.data_ptr(), lead, rows, g2.data_ptr(), b2.data_ptr(), ws.data_ptr(), s)
+        assert torch.equal(dy2, dyh) and torch.equal(g2, dgam) and torch.equal(b2, dbet)
+        zp = torch.empty(m, c, dtype=torch.bfloat16, device=gpu)          # plain-row output from halo-row input
+        _lib.call("rtts_bn_act_fwd", yh.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act, p, seed,
+                  sd.data_ptr(), b, l, halo, c, zp.data_ptr(), 0, 0, m, s)
+        assert torch.equal(zp, z)
     yr = y.clone().requires_grad_()
     gr, br = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
     pre = torch.nn.functional.batch_norm(yr, None, None, gr, br, True, 0.1, 1e-5)
     a = torch.relu(pre) if act == 1 else torch.tanh(pre)
     if p > 0:
         # the mask itself: same seed and shape on a constant pre-activation of 1 (gamma = 0, beta = 1, ReLU)
-        ones = torch.empty(m, c, dtype=torch.bfloat16, device=gpu)
+        ones = torch.empty(rows, c, dtype=torch.bfloat16, device=gpu)
         g0, b1 = torch.zeros(c, device=gpu), torch.ones(c, device=gpu)
-        _lib.call("rtts_bn_act_fwd", y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g0.data_ptr(), b1.data_ptr(), 1, p, seed,
-                  sd.data_ptr(), m, c, ones.data_ptr(), s)
-        keep = ones.float() != 0
+        _lib.call("rtts_bn_act_fwd", yh.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g0.data_ptr(), b1.data_ptr(), 1, p, seed,
+                  sd.data_ptr(), b, l, halo, c, ones.data_ptr(), *zargs, s)
+        keep = from_h(ones).float() != 0
         assert abs(keep.float().mean().item() - (1 - p)) < 0.01
         a = a * keep / (1 - p)
     torch.testing.assert_close(z.float(), a.detach(), rtol=1e-2, atol=1e-2)
@@ -434,7 +475,7 @@ def test_bn_act_dropout_kernels_vs_autograd(gpu, act, p):
     # the fused path keeps the conv bias out of y: it shifts the running mean only, and the launch counts the batch
     shift, nbt = torch.randn(c, generator=g).to(gpu), torch.tensor(4, dtype=torch.int64, device=gpu)
     rm2, rv2 = torch.zeros(c, device=gpu), torch.ones(c, device=gpu)
-    _lib.call("rtts_bn_stats", y.data_ptr(), m, c, mean.data_ptr(), rstd.data_ptr(), rm2.data_ptr(), rv2.data_ptr(), shift.data_ptr(),
+    _lib.call("rtts_bn_stats", yh.data_ptr(), b, l, halo, c, mean.data_ptr(), rstd.data_ptr(), rm2.data_ptr(), rv2.data_ptr(), shift.data_ptr(),
               nbt.data_ptr(), ws.data_ptr(), s)
     bn = torch.nn.BatchNorm1d(c).to(gpu).train()
     bn(y + shift)
@@ -444,6 +485,45 @@ def test_bn_act_dropout_kernels_vs_autograd(gpu, act, p):
     torch.testing.assert_close(dy.float(), yr.grad, rtol=2e-2, atol=2e-2)
     torch.testing.assert_close(dgam, gr.grad, rtol=1e-3, atol=1e-2)
     torch.testing.assert_close(dbet, br.grad, rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize("b,l,ci,co", [(12, 256, 512, 512), (3, 1024, 80, 512), (2, 768, 512, 80), (1, 256, 128, 128)])
+def test_conv1d_k5_implicit_gemm_vs_float64(gpu, b, l, ci, co):
+    """edges.ConvK5 on halo rows -- forward, transposed (input gradient) and weight gradient, all implicit GEMMs on shifted
+    rows -- against float64 F.conv1d autograd on the SAME bf16-rounded operands (reference modules.py:19-54,146-169: every
+    Conv1d(k=5, padding=2) of the prenet / postnet).  What is left is fp32 accumulation + one rounding where the kernel rounds."""
+    import torch.nn.functional as F
+    from reformer_tts_amd import _lib, edges, engine
+    torch.manual_seed(b * 1000 + l + ci)
+    conv = torch.nn.Conv1d(ci, co, 5, padding=2).to(gpu)
+    ex = edges.ConvK5(conv)
+    g = edges.Halo(b, l)
+    x = torch.randn(b, l, ci, device=gpu).bfloat16()
+    dy = (torch.randn(b, l, co, device=gpu) / 8).bfloat16()
+    xh = torch.zeros(g.alloc, ex.cp, dtype=torch.bfloat16, device=gpu)
+    g.valid(g.body(xh))[..., :ci] = x
+    dyh = torch.zeros(g.alloc, ex.cop, dtype=torch.bfloat16, device=gpu)
+    g.valid(g.body(dyh))[..., :co] = dy
+    y = ex.forward(xh, g)                                   # (mp, cop) fp32, bias not added
+    conv.weight.grad = None
+    dx = ex.backward(dyh, xh, g, need_dx=True, dx_f32=True)
+    engine.flush_wgrad()
+    torch.cuda.synchronize()
+    w64 = conv.weight.detach().bfloat16().double().cpu().requires_grad_(True)
+    x64 = x.double().cpu().transpose(1, 2).requires_grad_(True)
+    y64 = F.conv1d(x64, w64, None, padding=2)
+    y64.backward(dy.double().cpu().transpose(1, 2))
+
+    def rel(a, ref):
+        return float((a.double().cpu() - ref).norm() / ref.norm())
+    e_y = rel(g.valid(y)[..., :co], y64.detach().transpose(1, 2))
+    e_dx = rel(g.valid(dx)[..., :ci], x64.grad.transpose(1, 2))
+    e_dw = rel(conv.weight.grad, w64.grad)
+    print(f"\n[conv1d_k5 B={b} L={l} {ci}->{co}] rel-L2 vs float64 on the same bf16 operands: y {e_y:.2e}, dx {e_dx:.2e}, dW {e_dw:.2e} "
+          f"(tol 1e-5: fp32 accumulation only, nothing is rounded to bf16)")
+    assert e_y <= 1e-5 and e_dx <= 1e-5 and e_dw <= 1e-5
+    if ex.cop > co:
+        assert float(y[:, co:].abs().max()) == 0.0          # padded output channels: zero weight rows
 
 
 def test_attention_stash_matches_pure_recompute(gpu):
