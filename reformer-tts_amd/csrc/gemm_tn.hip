@@ -86,8 +86,11 @@ __global__ __launch_bounds__(64 * WN * WK) void gemm_tn_kernel(const GtGroup grp
     const int tiles_k = K / BK;
     const int tile = blk / split, sp = blk % split;
     const int n0 = (tile / tiles_k) * BN, k0 = (tile % tiles_k) * BK;
-    const int rows_per = M / split;                    // multiple of 64 (checked on the host)
-    const int m_begin = sp * rows_per, nstage = rows_per / GT_BM;
+    // the token range is cut into `split` runs of whole stages, the first (stages % split) one stage longer: any split
+    // factor works, not only divisors of the stage count (M = 12544 halo rows = 196 stages)
+    const int st_all = M / GT_BM, st_base = st_all / split, st_rem = st_all % split;
+    const int nstage = st_base + (sp < st_rem ? 1 : 0);
+    const int m_begin = (sp * st_base + min(sp, st_rem)) * GT_BM;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave / WK, wk = wave % WK;
@@ -237,8 +240,9 @@ __global__ __launch_bounds__(64 * WN * WK) void gemm_tn_ring_kernel(const GtGrou
     const int tiles_k = K / BK;
     const int tile = blk / split, sp = blk % split;
     const int n0 = (tile / tiles_k) * BN, k0 = (tile % tiles_k) * BK;
-    const int rows_per = M / split;                    // multiple of 64 (checked on the host)
-    const int m_begin = sp * rows_per, nstage = rows_per / GT_RS;
+    const int st_all = M / GT_RS, st_base = st_all / split, st_rem = st_all % split;      // (see gemm_tn_kernel)
+    const int nstage = st_base + (sp < st_rem ? 1 : 0);
+    const int m_begin = (sp * st_base + min(sp, st_rem)) * GT_RS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave / WK, wk = wave % WK;
@@ -459,7 +463,7 @@ extern "C" int rtts_gemm_tn_grouped(const rtts_gemm_tn_problem* problems, int n,
         const int tiles = (q.N / bt) * (q.K / bt), stages = q.M / GT_BM;
         const size_t slab = (size_t)q.N * q.K;
         int split = 1;
-        while (split < want && split * 2 <= stages / 4 && stages % (split * 2) == 0) split *= 2;
+        while (split < want && split * 2 <= stages / 4) split *= 2;
         while (split > 1 && (!slab_ws || slab_used + slab * split > (size_t)slab_ws_floats)) split /= 2;
         P.a = (const bf16_t*)q.a; P.b = (const bf16_t*)q.b; P.c = q.c;
         P.lda = q.lda; P.ldb = q.ldb; P.ldc = q.ldc;

@@ -46,10 +46,12 @@ def _pad128(c: int) -> int:
 class Halo:
     """Halo rows of one (B, L) batch: rows m = b * (L + 4) + 2 + t carry sequence b, position t; the two rows in front of
     and behind every sequence, the ``LEAD`` rows before row 0 and everything behind row B * (L + 4) - 1 are zero.  ``mp`` =
-    the row count the GEMMs run over (a multiple of their 192-row tile); a buffer has ``alloc`` = mp + 2 * LEAD rows so that
+    the row count the GEMMs run over (a multiple of 256: the 256 x 128 and 128 x 64 tiles of rtts_gemm_nt -- B*L itself is a
+    multiple of 192 x 64 at the baseline shape, so the halo rows would spill a 192-row tiling into a second, almost empty
+    wave of workgroups -- and of the weight gradient's 64-row stages); a buffer has ``alloc`` = mp + 2 * LEAD rows so that
     the taps' shifted reads (+-2 rows) stay inside it.  Every kernel that produces a halo array writes ALL its rows (zeros
     outside the valid set), so buffers come from ``torch.empty`` and carry no state from call to call."""
-    H, LEAD, TILE = 2, 8, 192
+    H, LEAD, TILE = 2, 8, 256
 
     def __init__(self, b: int, l: int):
         self.b, self.l = b, l
