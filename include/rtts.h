@@ -200,8 +200,9 @@ int rtts_sum_slabs(const void* part, int nslabs, int64_t n, void* out, void* str
  *                       rtts_conv_w_perm; transposed = 1: dx = conv^T(dy), wp (C_in, 5*C_out) is the SAME array seen as
  *                       [channel of dy][tap][channel of dx].  out_f32: unrounded fp32 result (+ optional bias), else bf16.
  *                       C_in % 64 == 0, (M, C_out) must tile like rtts_gemm_nt.
- *   rtts_to_halo        dst (bf16, `rows` rows, halo row 0 at row `lead`) = src (plain (B*L, ld_src) rows, fp32 or bf16),
- *                       zero everywhere outside the valid set
+ *   rtts_to_halo        dst (bf16, `rows` rows of C channels, halo row 0 at row `lead`) = the first C_src channels of src
+ *                       (plain (B*L, ld_src) rows, fp32 or bf16); zero in channels >= C_src and everywhere outside the valid
+ *                       set (halo = 0: a cast of plain rows with the channels zero-padded to the GEMM's K granule)
  *   rtts_conv_w_perm    wp[co][k][ci] (bf16, ci < CP zero padded) = w[co][ci][k] (fp32 master layout of nn.Conv1d)
  *   rtts_conv_dw_unperm dw[co][ci][k] += dwp[co][k][ci]
  *   rtts_bn_stats       per-channel batch mean / rstd (eps 1e-5) over the B*L valid rows of y (fp32; halo or plain rows);
@@ -226,7 +227,7 @@ int rtts_sum_slabs(const void* part, int nslabs, int64_t n, void* out, void* str
  * partial_ws: >= (2*256 + 2)*C floats (bn) / 1536 floats (loss). */
 int rtts_conv1d_k5(const void* x, int64_t ldx, const void* wp, int64_t ldw, int transposed, int M, int C_out, int C_in,
                    void* y, int64_t ldy, const float* bias, int out_f32, void* stream);
-int rtts_to_halo(const void* src, int64_t ld_src, int src_f32, int B, int L, int halo, int C, void* dst, int lead,
+int rtts_to_halo(const void* src, int64_t ld_src, int C_src, int src_f32, int B, int L, int halo, int C, void* dst, int lead,
                  int64_t rows, void* stream);
 int rtts_conv_w_perm(const float* w, int Co, int Ci, int CP, void* wp, void* stream);
 int rtts_conv_dw_unperm(const float* dwp, int Co, int Ci, int CP, float* dw, void* stream);

@@ -62,7 +62,7 @@ SIGNATURES = {
     "rtts_xattn_bwd": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _f32, _u32, _vp, _vp],
     "rtts_sum_slabs": [_vp, _i32, _i64, _vp, _vp],
     "rtts_conv1d_k5": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _vp],
-    "rtts_to_halo": [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i64, _vp],
+    "rtts_to_halo": [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i64, _vp],
     "rtts_heads_grad": [_vp, _vp, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "rtts_conv_w_perm": [_vp, _i32, _i32, _i32, _vp, _vp],
     "rtts_conv_dw_unperm": [_vp, _i32, _i32, _i32, _vp, _vp],
@@ -92,6 +92,22 @@ _lib = None
 
 class RttsError(RuntimeError):
     pass
+
+
+_NOTED = set()
+PATHS_LEFT = []        # (where, reason) of every distinct departure from the explicit executors, in order (tests read this)
+
+
+def note_general_path(where: str, reason: str) -> None:
+    """Say ONCE per (where, reason) that a stack / edge / loss runs on the general eager path instead of the explicit HIP
+    executors: a user can tell which path produced a number (logger ``reformer_tts_amd``, level WARNING)."""
+    key = (where, reason)
+    if key in _NOTED:
+        return
+    _NOTED.add(key)
+    PATHS_LEFT.append(key)
+    import logging
+    logging.getLogger("reformer_tts_amd").warning("%s: general (eager) path instead of the explicit HIP executor -- %s", where, reason)
 
 
 def load() -> C.CDLL:

@@ -39,7 +39,7 @@ static inline EdHalo ed_halo(int B, int L, int halo) { return EdHalo{B, L, L + 2
 // dst (bf16 halo rows: `rows` rows of C channels, halo row 0 at row `lead`) = src (plain (B*L, ld_src) rows, fp32 or bf16);
 // every row outside the valid set is written as zero.  8 channels per thread.
 template <bool SRC_F32>
-__global__ __launch_bounds__(ED_THREADS) void to_halo_kernel(const void* __restrict__ src, int64_t ld_src, EdHalo g, int C, int lead,
+__global__ __launch_bounds__(ED_THREADS) void to_halo_kernel(const void* __restrict__ src, int64_t ld_src, int C_src, EdHalo g, int C, int lead,
                                                              long long rows, bf16_t* __restrict__ dst) {
     const int pieces = C / 8;
     const size_t total = (size_t)rows * pieces;
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(ED_THREADS) void to_halo_kernel(const void* __restr
         const long long r = (long long)(i / pieces);
         int b, t;
         uint4 o = make_uint4(0, 0, 0, 0);
-        if (ed_valid(g, r - lead, b, t)) {
+        if (pc * 8 < C_src && ed_valid(g, r - lead, b, t)) {        // channels >= C_src: zero padding up to the GEMM's K granule
             const size_t srow = (size_t)b * g.L + t;
             if (SRC_F32) {
                 const float* p = reinterpret_cast<const float*>(src) + srow * ld_src + pc * 8;
@@ -567,18 +567,18 @@ static inline unsigned ed_grid(size_t items) {
 }
 static inline uint32_t ed_thresh(float p) { return p <= 0.f ? 0u : (uint32_t)((double)p * 4294967296.0); }
 
-extern "C" int rtts_to_halo(const void* src, int64_t ld_src, int src_f32, int B, int L, int halo, int C, void* dst, int lead,
+extern "C" int rtts_to_halo(const void* src, int64_t ld_src, int C_src, int src_f32, int B, int L, int halo, int C, void* dst, int lead,
                             int64_t rows, void* stream) {
-    RTTS_REQUIRE(src && dst && B > 0 && L > 0 && halo >= 0 && C > 0 && C % 8 == 0 && ld_src >= C && ld_src % (src_f32 ? 4 : 8) == 0,
-                 "rtts_to_halo: bad arguments");
+    RTTS_REQUIRE(src && dst && B > 0 && L > 0 && halo >= 0 && C > 0 && C % 8 == 0 && C_src > 0 && C_src % 8 == 0 && C_src <= C && ld_src >= C_src &&
+                     ld_src % (src_f32 ? 4 : 8) == 0, "rtts_to_halo: bad arguments");
     RTTS_REQUIRE(lead >= 0 && rows >= lead + (int64_t)B * (L + 2 * halo), "rtts_to_halo: dst has %lld rows, needs %lld", (long long)rows,
                  (long long)(lead + (int64_t)B * (L + 2 * halo)));
     const dim3 grid(ed_grid((size_t)rows * (C / 8)));
     if (src_f32)
-        hipLaunchKernelGGL(to_halo_kernel<true>, grid, dim3(ED_THREADS), 0, (hipStream_t)stream, src, ld_src, ed_halo(B, L, halo), C, lead,
+        hipLaunchKernelGGL(to_halo_kernel<true>, grid, dim3(ED_THREADS), 0, (hipStream_t)stream, src, ld_src, C_src, ed_halo(B, L, halo), C, lead,
                            (long long)rows, (bf16_t*)dst);
     else
-        hipLaunchKernelGGL(to_halo_kernel<false>, grid, dim3(ED_THREADS), 0, (hipStream_t)stream, src, ld_src, ed_halo(B, L, halo), C, lead,
+        hipLaunchKernelGGL(to_halo_kernel<false>, grid, dim3(ED_THREADS), 0, (hipStream_t)stream, src, ld_src, C_src, ed_halo(B, L, halo), C, lead,
                            (long long)rows, (bf16_t*)dst);
     RTTS_LAUNCH_CHECK("rtts_to_halo");
     return 0;

@@ -232,7 +232,7 @@ class ConvStackFn(torch.autograd.Function):
         if x2.dtype not in (torch.float32, torch.bfloat16) or x2.stride(1) != 1:
             x2 = x2.float().contiguous()
         cur = g.new(c, x.device)
-        _lib.call("rtts_to_halo", x2.data_ptr(), x2.stride(0), int(x2.dtype == torch.float32), b, l, g.H, c, cur.data_ptr(), g.LEAD, g.alloc, _s())
+        _lib.call("rtts_to_halo", x2.data_ptr(), x2.stride(0), c, int(x2.dtype == torch.float32), b, l, g.H, c, cur.data_ptr(), g.LEAD, g.alloc, _s())
         saved = []
         for i, layer in enumerate(stack):
             cur, s = layer.forward(cur, g, plain_out=(i == len(stack) - 1))
@@ -303,7 +303,7 @@ class _PostnetLossFn(torch.autograd.Function):
         wh, bh = ex._heads_weight()
         heads = gemm(yb, wh, bias=bh, out_f32=True)                         # (M,128) fp32: [mel(80) | stop | 0...]
         x0 = g.new(128, dev)                        # the first convolution's weights are zero for channels >= nm
-        _lib.call("rtts_to_halo", heads.data_ptr(), 128, 1, b, lp, g.H, 128, x0.data_ptr(), g.LEAD, g.alloc, _s())
+        _lib.call("rtts_to_halo", heads.data_ptr(), 128, 128, 1, b, lp, g.H, 128, x0.data_ptr(), g.LEAD, g.alloc, _s())
         saved, cur = [], x0
         for layer in ex.layers:
             cur, s = layer.forward(cur, g)
@@ -397,7 +397,7 @@ class _ProjPEFn(torch.autograd.Function):
         b, l, k = z.shape
         d = lin.out_features
         z2 = z.reshape(b * l, k)
-        y = torch.addmm(_bf16(lin.bias), z2, _bf16(lin.weight).t())
+        y = gemm(z2, _bf16(lin.weight), bias=lin.bias)
         table = pe.table(l, z.device).contiguous()
         out = torch.empty(b * l, d, dtype=torch.float32, device=z.device)
         p = pe.dropout.p if pe.training else 0.0
@@ -416,7 +416,7 @@ class _ProjPEFn(torch.autograd.Function):
                   _pe_ws(dy.device).data_ptr(), _s())
         dyb = cast_colsum(dy, _grad(lin.bias))
         wgrad(_grad(lin.weight), dyb, z2)
-        dz = torch.mm(dyb, _bf16(lin.weight))
+        dz = gemm(dyb, _bf16(lin.weight), kn=True)
         return dz.view(b, l, k), None, None, None
 
 
@@ -424,36 +424,68 @@ def proj_pe(z, lin, pe):
     return _ProjPEFn.apply(z, lin, pe, lin.weight)
 
 
+def _k_padded_weight(lin) -> torch.Tensor:
+    """bf16 copy of a Linear weight whose input width is not a multiple of the GEMM's 64-deep K stage (the decoder prenet's
+    80 mel channels), zero-padded to 128 columns; refreshed when the master changed (one small copy per optimizer step)."""
+    w = lin.weight
+    ver = (w._version, WEIGHT_EPOCH[0], w.data_ptr())
+    cache = getattr(lin, "_rtts_kpad", None)
+    if cache is None or cache[0] != ver or cache[1].device != w.device:
+        buf = cache[1] if cache is not None and cache[1].device == w.device else torch.zeros(w.shape[0], 128, dtype=torch.bfloat16, device=w.device)
+        buf[:, :w.shape[1]].copy_(_bf16(w))
+        lin._rtts_kpad = cache = (ver, buf)
+    return cache[1]
+
+
 class _ReluDropLinearFn(torch.autograd.Function):
-    """x (M,K) bf16 -> dropout_p(relu(x W^T + b)) bf16 (decoder prenet stages fc1/fc2, ``modules.py:82-94``)."""
+    """x (M,K) bf16 -> dropout_p(relu(x W^T + b)) bf16 (decoder prenet stages fc1/fc2, ``modules.py:82-94``); bias and ReLU in
+    the GEMM's epilogue.  ``kpad``: x arrives zero-padded to 128 columns (K = 80 mel channels) and the weight is padded to match."""
 
     @staticmethod
-    def forward(ctx, x, lin, p, _track):
-        h = torch.addmm(_bf16(lin.bias), x, _bf16(lin.weight).t())
+    def forward(ctx, x, lin, p, kpad, _track):
+        h = gemm(x, _k_padded_weight(lin) if kpad else _bf16(lin.weight), bias=lin.bias, relu=True)
         seed = _seed()
-        _lib.call("rtts_relu_drop", h.data_ptr(), float(p), seed, seed_base(h.device).data_ptr(), h.numel(), _s())
-        ctx.lin, ctx.state = lin, (x, h, p)
+        if p > 0.0:
+            _lib.call("rtts_relu_drop", h.data_ptr(), float(p), seed, seed_base(h.device).data_ptr(), h.numel(), _s())
+        ctx.lin, ctx.state = lin, (x, h, p, kpad)
         return h
 
     @staticmethod
     def backward(ctx, dh):
         from .engine import colsum_bf16
         lin = ctx.lin
-        x, h, p = ctx.state
+        x, h, p, kpad = ctx.state
         dh = dh.to(torch.bfloat16).contiguous().clone() if dh.dtype != torch.bfloat16 or not dh.is_contiguous() else dh.clone()
         colsum_bf16(dh, _grad(lin.bias), h, 1.0 / (1.0 - p))        # gate (h > 0) * 1/(1-p) in place + bias gradient
+        if kpad:
+            k = lin.weight.shape[1]
+            tmp = torch.empty(lin.weight.shape[0], 128, dtype=torch.float32, device=dh.device)
+            wgrad(tmp, dh, x, accumulate=False)
+            _grad(lin.weight).add_(tmp[:, :k])
+            return None, None, None, None, None                      # the padded input is data (the mel frames): no gradient
         wgrad(_grad(lin.weight), dh, x)
-        return (torch.mm(dh, _bf16(lin.weight)) if ctx.needs_input_grad[0] else None), None, None, None
+        return (gemm(dh, _bf16(lin.weight), kn=True) if ctx.needs_input_grad[0] else None), None, None, None, None
 
 
 def decoder_prenet_pe(prenet, pe, spec):
     """DecoderPreNet + ScaledPositionalEncoding on (B, L, n_mels) fp32 -> (B, L, d) fp32."""
     b, l, nm = spec.shape
     lyr = prenet.layer
-    x = spec.reshape(b * l, nm).to(torch.bfloat16)
     training = prenet.training
-    h = _ReluDropLinearFn.apply(x, lyr.fc1, lyr.dropout1.p if training else 0.0, lyr.fc1.weight)
-    h = _ReluDropLinearFn.apply(h, lyr.fc2, lyr.dropout2.p if training else 0.0, lyr.fc2.weight)
+    m = b * l
+    s2 = spec.reshape(m, nm)
+    if s2.dtype != torch.float32 or s2.stride(1) != 1:
+        s2 = s2.float().contiguous()
+    kpad = nm % 64 != 0
+    if kpad:
+        if nm % 8 != 0 or nm > 128:
+            raise NotImplementedError(f"decoder prenet: {nm} mel channels (supported: multiples of 8 up to 128, or multiples of 64)")
+        x = torch.empty(m, 128, dtype=torch.bfloat16, device=spec.device)     # cast + zero padding of the channels in one launch
+        _lib.call("rtts_to_halo", s2.data_ptr(), s2.stride(0), nm, 1, b, l, 0, 128, x.data_ptr(), 0, m, _s())
+    else:
+        x = s2.to(torch.bfloat16)
+    h = _ReluDropLinearFn.apply(x, lyr.fc1, lyr.dropout1.p if training else 0.0, kpad, lyr.fc1.weight)
+    h = _ReluDropLinearFn.apply(h, lyr.fc2, lyr.dropout2.p if training else 0.0, False, lyr.fc2.weight)
     return proj_pe(h.view(b, l, -1), lyr.projection, pe)
 
 

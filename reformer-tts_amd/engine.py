@@ -331,10 +331,12 @@ def wgrad(grad_view: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, accumulate
             grad_view.add_(tmp[:, :k])
         else:
             grad_view.copy_(tmp[:, :k])
-    elif accumulate:
-        grad_view.add_(torch.mm(dy.t(), x, out_dtype=torch.float32))
     else:
-        grad_view.copy_(torch.mm(dy.t(), x, out_dtype=torch.float32))
+        _lib.note_general_path("weight gradient", f"dW {n} x {k} over {m} rows does not tile (N, K % 128, M % 64): library GEMM")
+        if accumulate:
+            grad_view.add_(torch.mm(dy.t(), x, out_dtype=torch.float32))
+        else:
+            grad_view.copy_(torch.mm(dy.t(), x, out_dtype=torch.float32))
 
 
 # ------------------------------------------------------------------------------------------ blocks
@@ -421,6 +423,7 @@ class LSHExec:
         if gview is not None:
             wgrad(gview, dqkv2, xn)
         else:
+            _lib.note_general_path("weight gradient", "toqk / tov gradients are not neighbours in one buffer: library GEMM")
             full = torch.mm(dqkv2.t(), xn, out_dtype=torch.float32)
             pair[0].add_(full[:e])
             pair[1].add_(full[e:])

@@ -116,6 +116,11 @@ class EncoderPreNet(nn.Module):
                 from ..edges import proj_pe
                 return proj_pe(z, self.projection, pe)               # projection + positional encoding fused
             return _bf16_linear(z, self.projection).float()
+        if self.training and x.is_cuda:
+            from .._lib import note_general_path
+            note_general_path("encoder prenet", "use_fused is off" if not self.use_fused else
+                              f"width {self.embedding_dim} / {x.shape[0] * x.shape[1]} rows outside the executor's envelope "
+                              "(width % 128 == 0, rows % 64 == 0)")
         for conv, bn, drop in ((c.conv1, c.bn1, c.dropout1), (c.conv2, c.bn2, c.dropout2), (c.conv3, c.bn3, c.dropout3)):
             x = drop(F.relu(batch_norm_rows(conv1d_k5_rows(x, conv), bn)))
         y = _bf16_linear(x, self.projection).float()

@@ -200,6 +200,11 @@ class ReversibleSequence(nn.Module):
             if self._program is not None:
                 from ..engine import FusedStackFn
                 return FusedStackFn.apply(x, context, self, kwargs_list)
+            from .._lib import note_general_path
+            note_general_path("reversible stack", "a block is outside the executors' envelope (e.g. feed-forward dropout > 0)")
+        elif self.use_fused and x.is_cuda and not keys_ok:
+            from .._lib import note_general_path
+            note_general_path("decoder stack", f"{context.shape[1]} encoder keys: the on-chip cross-attention holds 128 or 256")
         y1, y2 = self.forward_halves(x, x, kwargs_list, context)
         return y1 + y2
 

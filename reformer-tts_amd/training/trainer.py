@@ -166,7 +166,10 @@ class Trainer:
         spec = batch["spectrogram"]
         lm = spec.shape[1] - 1
         lp = -(-lm // self.model.pad_base) * self.model.pad_base      # the decoder runs on the padded length
-        return self.use_fused_edges and self.device.type == "cuda" and self.model.training and (spec.shape[0] * lp) % 64 == 0
+        ok = self.use_fused_edges and self.device.type == "cuda" and self.model.training and (spec.shape[0] * lp) % 64 == 0
+        if not ok and self.use_fused_edges and self.device.type == "cuda" and self.model.training:
+            _lib.note_general_path("heads / postnet / loss", f"batch x padded length = {spec.shape[0]} x {lp} is not a multiple of 64")
+        return ok
 
     def _cut_at_encoder(self, keys):
         """keys_hook of the split step: the decoder reads a detached copy, the encoder's backward is run later from its grad."""
