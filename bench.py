@@ -7,11 +7,15 @@ backward + gradient all-reduce + clip + AdamW) on synthetic LJSpeech-shaped batc
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement): whole-job mel-frames/s, plus
-  roofline      the dominant kernel (LSH chunk-attention backward, MFMA-bound): algorithmic FLOP per
-                launch / its average duration measured with HIP events on the launch stream
-  cpu_baseline  the CPU oracle (eager fp32 PyTorch restatement of the reference's step) timed on
-                this host's cores on a bounded sample of the same workload (rank 0, N=1 only)
+Prints ONE JSON line on rank 0 (contract in the task statement): whole-job mel-frames/s of the default (``stash``) mode, plus
+  config.full_recompute_ms   the same step with the reference's pure recompute (``reversible_recompute: full``), same run
+  roofline        the dominant kernel (LSH chunk-attention backward, MFMA-bound): algorithmic FLOP per launch / its average
+                  duration measured with HIP events on the launch stream
+  rooflines       that entry plus lsh_hash_sort (HBM-bound, SURVEY.md 8(d) bytes) and rtts_gemm_nt (every projection /
+                  feed-forward / convolution GEMM of the step, MFMA-bound), each against the spec peak AND the peak measured
+                  on this box by a stream copy / an MFMA loop (``peak_measured``)
+  cpu_baseline    the CPU oracle (eager fp32 PyTorch restatement of the reference's step) timed on this host's cores on a
+                  bounded sample of the same workload: one warm-up pass, then up to 3 timed passes (rank 0, N=1 only)
 """
 from __future__ import annotations
 
@@ -27,8 +31,8 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
-HBM_PEAK_GBS = 8000.0
+BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA (spec)
+HBM_PEAK_GBS = 8000.0             # 8 TB/s HBM3E (spec)
 
 
 def parse():
@@ -36,23 +40,31 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=12, help="per-GPU batch (baseline.yml: 12)")
-    ap.add_argument("--mel-len", type=int, default=1024)
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (baseline.yml: 12; long: 4)")
+    ap.add_argument("--mel-len", type=int, default=None)
     ap.add_argument("--text-len", type=int, default=200)
-    ap.add_argument("--config", default="baseline", choices=["baseline", "long"])
+    ap.add_argument("--config", default="baseline", choices=["baseline", "long"],
+                    help="baseline = config/baseline.yml (BASELINE.json configs[1]); long = config/bucket-size-64-18-06.yml at "
+                         "mel 4096 (configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the full-recompute leg and the peak probes")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     ap.add_argument("--recompute", default="stash", choices=["stash", "attention-stash", "full"],
                     help="what the reversible backward recomputes: 'full' = everything, as the reference does; "
                          "'attention-stash' = attention outputs kept; 'stash' (default) = attention outputs and block outputs "
                          "f(x) kept, LayerNorm and the input projections recomputed, streams reconstructed by subtraction")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 12 if args.config == "baseline" else 4
+    if args.mel_len is None:
+        args.mel_len = 1024 if args.config == "baseline" else 4096
+    return args
 
 
 def cpu_baseline(model_cfg, mel_len, text_len, budget_s):
-    """Oracle forward + loss + backward on the host cores, bounded sample: B=1 at the bench's
-    sequence lengths (frames/s is size-normalised), 1 warm-up-free pass repeated while time remains."""
+    """Oracle forward + loss + backward on the host cores, bounded sample: B=1 at the bench's sequence lengths (frames/s is
+    size-normalised); ONE warm-up pass, then timed passes while the budget lasts (at most 3)."""
     from oracle import model_ref, synth
     from reformer_tts_amd.model.config import as_kwargs
     cores = min(len(os.sched_getaffinity(0)), 16)      # the GPU box grants 16 host cores per GPU
@@ -65,21 +77,55 @@ def cpu_baseline(model_cfg, mel_len, text_len, budget_s):
     batch = model_ref.synthetic_batch(1, text_len, mel_len, seed=42)
     g = torch.Generator().manual_seed(1)
     rots = [torch.randn(s, generator=g) for s in model_ref.rotation_shapes(cfg, text_len, mel_len)]
-    times = []
-    t_end = time.perf_counter() + budget_s
-    while True:
+
+    def one_pass():
         t0 = time.perf_counter()
         loss = model_ref.training_forward(sd, cfg, batch, rots)[0]
         loss.backward()
-        times.append(time.perf_counter() - t0)
+        dt = time.perf_counter() - t0
         for v in sd.values():
             v.grad = None
-        if time.perf_counter() + times[-1] > t_end or len(times) >= 3:
-            break
-    best = min(times)
-    return dict(value=round(mel_len / best, 2), unit="mel-frames/s", cores=cores, kind="port",
-                sample=f"B=1, text {text_len}, mel {mel_len}: forward+loss+backward of oracle/model_ref.py "
-                       f"(fp32 eager, {len(times)} pass(es), best {best:.2f} s; no optimizer step)")
+        return dt
+
+    warm = one_pass()
+    times = []
+    t_end = time.perf_counter() + max(budget_s - warm, 0.0)
+    while len(times) < 3 and (not times or time.perf_counter() + times[-1] <= t_end):
+        times.append(one_pass())
+    mean = sum(times) / len(times)
+    return dict(value=round(mel_len / mean, 2), unit="mel-frames/s", cores=cores, kind="port",
+                sample=f"B=1, text {text_len}, mel {mel_len}: forward+loss+backward of oracle/model_ref.py (fp32 eager; 1 warm-up "
+                       f"pass of {warm:.2f} s, then {len(times)} timed pass(es), mean {mean:.2f} s, best {min(times):.2f} s; no "
+                       f"optimizer step)")
+
+
+def measure_peaks(dev):
+    """Stream-copy GB/s and bf16 MFMA TFLOP/s this box reaches (HIP events on the current stream)."""
+    from reformer_tts_amd import _lib
+    s = torch.cuda.current_stream().cuda_stream
+    n = 1 << 30
+    src = torch.empty(n, dtype=torch.uint8, device=dev)
+    dst = torch.empty(n, dtype=torch.uint8, device=dev)
+    src.zero_()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(2):
+        _lib.call("rtts_peak_copy", src.data_ptr(), dst.data_ptr(), n, s)
+    a.record()
+    for _ in range(5):
+        _lib.call("rtts_peak_copy", src.data_ptr(), dst.data_ptr(), n, s)
+    b.record()
+    torch.cuda.synchronize()
+    copy_gbs = 5 * 2 * n / (a.elapsed_time(b) * 1e-3) / 1e9
+    del src, dst
+    sink = torch.zeros(64, dtype=torch.float32, device=dev)
+    wgs, iters = 256, 20000                        # one 8-wave workgroup per CU = two waves per SIMD
+    _lib.call("rtts_peak_mfma", sink.data_ptr(), wgs, 2000, s)
+    a.record()
+    _lib.call("rtts_peak_mfma", sink.data_ptr(), wgs, iters, s)
+    b.record()
+    torch.cuda.synchronize()
+    mfma_tf = wgs * 8 * iters * 8 * 16384.0 / (a.elapsed_time(b) * 1e-3) / 1e12
+    return round(copy_gbs, 1), round(mfma_tf, 1)
 
 
 def main():
@@ -109,8 +155,8 @@ def main():
     model_cfg = baseline_model_config() if args.config == "baseline" else long_sequence_model_config()
     tcfg = baseline_training_config()
     tcfg.batch_size = args.batch
-    model = build_model(model_cfg, dev, seed=42)          # identical init on every rank
-    trainer = Trainer(model, tcfg, dev)
+    model = build_model(model_cfg, dev, seed=42)          # identical init on every rank ...
+    trainer = Trainer(model, tcfg, dev)                   # ... rank-dependent rotations and dropout (Trainer._decorrelate_replicas)
     batch = synthetic_batch(args.batch, args.text_len, args.mel_len, seed=42 + rank, device=dev)
 
     def note(msg):
@@ -118,16 +164,16 @@ def main():
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
     dec_bucket = int(model_cfg.dec_reformer_kwargs.self_attn_kwargs.bucket_size)
-    tkey = f"rtts_lsh_attn_bwd/bs{dec_bucket}"        # the decoder's LSH backward: the dominant kernel of the step
+    t_dec = -(-args.mel_len // 256) * 256
+    tags = dict(bwd=f"rtts_lsh_attn_bwd/bs{dec_bucket}", hash=f"rtts_lsh_hash_sort/nb{t_dec // dec_bucket}", gemm="rtts_gemm_nt")
     note(f"model built ({trainer.n_params} parameters), warming up")
     # N == 1: the whole step is one hipGraph.  N > 1: four graphs (fwd + decoder-side bwd | encoder stack bwd | encoder
     # prenet bwd | clip+AdamW) around three eager all-reduces of parts of the flat gradient buffer, so no collective is
-    # ever captured;
-    # RTTS_GRAPH_DP=1 opts into a single graph with the per-block RCCL all-reduces captured inside (overlapped with the
-    # backward; not exercisable on a 1-GPU box).
+    # ever captured.
     use_graph = not args.no_graph
-    one_graph = world == 1 or (os.environ.get("RTTS_GRAPH_DP") == "1" and backend == "nccl")
-    if use_graph:
+    one_graph = world == 1
+
+    def capture():
         ok = 1
         try:
             trainer.capture(batch, segmented=not one_graph)
@@ -139,7 +185,28 @@ def main():
             flag = torch.tensor([ok], device=dev, dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = int(flag.item())
-        use_graph = bool(ok)
+        return bool(ok)
+
+    def timed(step_fn, steps):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = step_fn()[0]
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, last
+
+    if use_graph:
+        use_graph = capture()
     if use_graph:
         step_fn = trainer.replay
         note("step captured into " + ("one hipGraph" if one_graph else "four hipGraphs around the three gradient all-reduces"))
@@ -150,63 +217,105 @@ def main():
         step_fn()
         torch.cuda.synchronize()
         note(f"warm-up step {i} done")
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    if not use_graph:
-        ops.TIMING.enable(tkey)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step_fn()[0]
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, loss = timed(step_fn, args.steps)
     note(f"timed region done: {1e3 * elapsed / args.steps:.2f} ms/step")
-    if use_graph:
-        # HIP events cannot be read back from inside a replayed graph: time the dominant kernel on the same stream over
-        # the same number of eager steps of the same workload, directly after the timed region
-        ops.TIMING.enable(tkey)
-        for _ in range(args.steps):
-            trainer.train_step(batch)
-        torch.cuda.synchronize()
-    avg_ms, launches, flops_per_launch = ops.TIMING.summary(tkey)
-    ops.TIMING.disable()
 
+    # HIP events cannot be read back from inside a replayed graph: time the roofline kernels on the same stream over eager
+    # steps of the same workload, directly after the timed region
+    n_eager = min(args.steps, 10)
+    ops.TIMING.enable(*tags.values())
+    for _ in range(n_eager):
+        trainer.train_step(batch)
+    torch.cuda.synchronize()
+    timing = {k: ops.TIMING.summary(t) for k, t in tags.items()}
+    gemm_shapes = {k.split("/")[1]: ops.TIMING.summary(k) for k in ops.TIMING.records if k.startswith("rtts_gemm_nt/")}
+    ops.TIMING.disable()
     if not (float(loss) == float(loss)):
         raise RuntimeError("training loss is not finite")
+
+    # the same step with the reference's pure recompute, in the same run (a second capture on the same trainer)
+    full_ms = None
+    if not args.no_extra and args.recompute != "full":
+        engine.STASH_ATTENTION = engine.STASH_BLOCK_OUTPUT = False
+        ok = capture() if use_graph else True
+        fn = trainer.replay if (use_graph and ok) else (lambda: trainer.train_step(batch))
+        for _ in range(2):
+            fn()
+        k = max(3, min(args.steps, 10))
+        dt, _ = timed(fn, k)
+        full_ms = round(1e3 * dt / k, 3)
+        engine.STASH_ATTENTION = args.recompute != "full"
+        engine.STASH_BLOCK_OUTPUT = args.recompute == "stash"
+        note(f"pure recompute (reference's mode): {full_ms} ms/step")
+    peaks = (None, None)
+    if rank == 0 and not args.no_extra:
+        peaks = measure_peaks(dev)
+        note(f"measured on this box: stream copy {peaks[0]} GB/s, bf16 MFMA loop {peaks[1]} TFLOP/s")
+
     if rank == 0:
         frames = world * args.batch * args.mel_len * args.steps
+        n_par = trainer.n_params
+        launch = ("hipGraph replay" if one_graph else
+                  "hipGraph replay (fwd+dec bwd | all-reduce | enc stack bwd | all-reduce | enc prenet bwd | all-reduce | optimizer)") \
+            if use_graph else "eager"
+        workload = (f"config/baseline.yml full Reformer-TTS training step (enc 3 / dec 3 layers, d=512, LSH 8 rounds, buckets 64/128), "
+                    f"per-GPU batch {args.batch}, text {args.text_len}->256, mel {args.mel_len}x80" if args.config == "baseline" else
+                    f"config/bucket-size-64-18-06.yml full Reformer-TTS training step (enc 6 / dec 6 layers, d=512, LSH 8 rounds, "
+                    f"buckets 64/64, dropouts 0.15), per-GPU batch {args.batch}, text {args.text_len}->256, mel {args.mel_len}x80")
         out = {
             "metric": "mel-frames/sec training step, LJSpeech-shape batch",
             "value": round(frames / elapsed, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"config/baseline.yml full Reformer-TTS training step (enc 3 / dec 3 layers, d=512, "
-                                   f"LSH 8 rounds, buckets 64/128), per-GPU batch {args.batch}, text {args.text_len}->256, "
-                                   f"mel {args.mel_len}x80" if args.config == "baseline" else
-                                   f"config/bucket-size-64-18-06.yml, per-GPU batch {args.batch}, mel {args.mel_len}",
-                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(float(loss), 4), "reversible_recompute": args.recompute,
-                       "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2),
-                       "launch": ("hipGraph replay" if one_graph else "hipGraph replay (fwd+dec bwd | all-reduce | enc stack bwd | all-reduce | enc prenet bwd | all-reduce | optimizer)")
-                       if use_graph else "eager"},
+            "config": {"workload": workload, "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                       "final_loss": round(float(loss), 4), "reversible_recompute": args.recompute, "full_recompute_ms": full_ms,
+                       "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2), "launch": launch,
+                       # what a multi-GPU record can be checked against
+                       "dist": {"world_size": world, "backend": (dist.get_backend() if world > 1 else None),
+                                "backend_ranks": (dist.get_world_size() if world > 1 else 1),
+                                "allreduce_bytes_per_step": (4 * n_par if world > 1 else 0),
+                                "collectives_per_step": (3 if (world > 1 and use_graph) else (0 if world == 1 else "per block")),
+                                "rank_seeds": "rotations and dropout seeded with seed + rank"}},
         }
+        rooflines = []
+        avg_ms, launches, flops = timing["bwd"]
         if launches:
             traffic = None      # HBM bytes per launch from the committed rocprofv3 PMC passes (collected outside this process)
             try:
-                with open(os.path.join(ROOT, "profiles", "r01k_pmc_lsh_attn_bwd.json")) as fh:
+                with open(os.path.join(ROOT, "profiles", "r02_pmc_lsh_attn_bwd.json")) as fh:
                     traffic = json.load(fh)["traffic_bytes"] if (args.batch, args.mel_len, args.config) == (12, 1024, "baseline") else None
             except OSError:
                 pass
-            ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "lsh_attn_bwd_kernel", "bound": "mfma", "achieved": round(ach, 2),
-                               "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
-                               "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches}
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            entry = {"kernel": "lsh_attn_bwd_kernel", "bound": "mfma", "achieved": round(ach, 2), "peak": BF16_DENSE_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
+                     "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches, "peak_measured": peaks[1],
+                     "frac_of_measured": (round(ach / peaks[1], 4) if peaks[1] else None)}
+            out["roofline"] = entry
+            rooflines.append(entry)
+        avg_ms, launches, nbytes = timing["hash"]
+        if launches:
+            ach = nbytes / (avg_ms * 1e-3) / 1e9
+            rooflines.append({"kernel": "lsh_hash_sort_kernel", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                              "launches_timed": launches, "peak_measured": peaks[0],
+                              "frac_of_measured": (round(ach / peaks[0], 4) if peaks[0] else None),
+                              "algorithmic_bytes_per_launch": int(nbytes),
+                              "note": "SURVEY.md 8(d): 224 B per token and head (hash 128 + 32, sort 64); decoder-shape launches"})
+        avg_ms, launches, flops = timing["gemm"]
+        if launches:
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            big = max(gemm_shapes.items(), key=lambda kv: kv[1][2]) if gemm_shapes else None
+            e = {"kernel": "gemm_nt_kernel (all shapes of the step)", "bound": "mfma", "achieved": round(ach, 2),
+                 "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                 "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches, "peak_measured": peaks[1],
+                 "frac_of_measured": (round(ach / peaks[1], 4) if peaks[1] else None)}
+            if big is not None:
+                bms, bn, bfl = big[1]
+                e["largest_shape"] = {"MxNxK": big[0], "avg_launch_ms": round(bms, 4), "launches_timed": bn,
+                                      "achieved": round(bfl / (bms * 1e-3) / 1e12, 2)}
+            rooflines.append(e)
+        out["rooflines"] = rooflines
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model_cfg, args.mel_len, args.text_len, args.cpu_budget_s)
         print(json.dumps(out), flush=True)

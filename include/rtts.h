@@ -84,20 +84,6 @@ int rtts_lsh_attn_bwd(const void* qk, const void* v, int64_t ld, const int32_t* 
 int rtts_lsh_bwd_reduce(const void* dqk_part, const void* dv_part, int B, int H, int T, int dh, int n_hashes,
                         void* dqk, void* dv, int64_t ld_d, void* stream);
 
-/* ---- backward of steps 4-11, ring form: one persistent workgroup per (head, round) walks the chunks in sorted
- * order, gathers every row once, and writes COMPLETE per-round gradients: 3 slots of (B*H, n_hashes, T, dh) bf16
- * (dq, dk, dv) plus two halo buffers (B*H, n_hashes, bucket_size, dh) holding the contribution of a round's first
- * chunk to the previous round's last chunk.  rtts_lsh_bwd_reduce_ring sums rounds and folds the halo in through
- * `undo` (token -> sorted slot within its round, from rtts_lsh_hash_sort).  Same replaced reference lines as
- * rtts_lsh_attn_bwd. */
-int rtts_lsh_attn_bwd_ring(const void* qk, const void* v, int64_t ld, const int32_t* st, const uint8_t* mask,
-                           const void* dout, int64_t ld_dout, const float* lse_tot, const float* delta,
-                           int B, int H, int T, int dh, int n_hashes, int bucket_size, int causal,
-                           void* dq_part, void* dk_part, void* dv_part, void* halo_dk, void* halo_dv, void* stream);
-int rtts_lsh_bwd_reduce_ring(const void* dq_part, const void* dk_part, const void* dv_part, const void* halo_dk,
-                             const void* halo_dv, const int32_t* undo, int B, int H, int T, int dh, int n_hashes,
-                             int bucket_size, void* dqk, void* dv, int64_t ld_d, void* stream);
-
 /* ---- optimizer step over the flat parameter buffer --------------------------------------
  * Replaces clip_grad_norm_ (pytorch-lightning gradient_clip_val, reference
  * reformer_tts/training/train.py:77-89) and transformers.optimization.AdamW.step as configured
@@ -309,6 +295,13 @@ int rtts_gemm_nt(const void* a, int64_t lda, const void* w, int64_t ldw, int w_i
                  int64_t ldc, const float* bias, int epilogue, const void* gate, int64_t ldg, float* colsum_partial,
                  void* stream);
 int rtts_gemm_nt_partial_rows(int M, int N);
+
+/* ---- on-box peak probes (bench.py; not on the training path) --------------------------------------
+ * rtts_peak_copy: dst = src, float4 stream copy of `bytes` (multiple of 16) -> achieved HBM rate = 2*bytes / time.
+ * rtts_peak_mfma: `workgroups` x 8 waves each issue iters x 8 back-to-back v_mfma_f32_16x16x32_bf16 on random register
+ *                 operands -> dense bf16 matrix rate = workgroups*8*iters*8*16384 FLOP / time. */
+int rtts_peak_copy(const void* src, void* dst, int64_t bytes, void* stream);
+int rtts_peak_mfma(float* sink, int workgroups, int iters, void* stream);
 
 /* ---- SqueezeWave vocoder, inference -----------------------------------
  * Activations are channels-last rows; the 1x1 convolutions are GEMMs outside.  Replaces, per WN layer

@@ -45,8 +45,6 @@ SIGNATURES = {
     "rtts_lsh_bwd_delta": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp],
     "rtts_lsh_attn_bwd": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     "rtts_lsh_bwd_reduce": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp],
-    "rtts_lsh_attn_bwd_ring": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
-    "rtts_lsh_bwd_reduce_ring": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp],
     "rtts_grad_clip_scale": [_vp, _i64, _f32, _f32, _vp, _vp, _vp],
     "rtts_ln_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp],
     "rtts_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f32, _u32, _vp, _vp],
@@ -81,6 +79,8 @@ SIGNATURES = {
     "rtts_gemm_tn_grouped": [C.POINTER(GemmTnProblem), _i32, _vp, _i64, _vp],
     "rtts_gemm_nt": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _vp],
     "rtts_gemm_nt_partial_rows": [_i32, _i32],
+    "rtts_peak_copy": [_vp, _vp, _i64, _vp],
+    "rtts_peak_mfma": [_vp, _i32, _i32, _vp],
     "rtts_sw_depthwise_k3": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "rtts_sw_gate": [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "rtts_sw_coupling_inv": [_vp, _i64, _vp, _i64, _i32, _vp],

@@ -245,6 +245,12 @@ __global__ __launch_bounds__(BS * 4 / AB_KT2, AB_KT2 == 2 ? 1 : 2) void lsh_attn
         for (int g = 0; g < 4; ++g) dso[k2][g] = ab_ds_off<BS>(myrow[k2], 2 * g + hh);
     const bool own_tile = wave * KT2 < BS / 32;  // wave-uniform (SGPR); the KT2 tiles of a wave sit on the same side
     const bool wrap = (cprev / nb) != (c / nb);
+#if defined(AB_STAGGER) && AB_STAGGER > 0
+    // The two waves of a SIMD run the same program from the same barrier: their MFMA bursts and their softmax arithmetic
+    // coincide, so the matrix pipe idles while both do vector work.  Holding the second-dispatched half back by a fraction
+    // of a tile puts one wave's vector phase under the other's MFMA burst (MI355X_MICROARCH.md, two waves per SIMD, item 9).
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= NTHR / 2) __builtin_amdgcn_s_sleep(AB_STAGGER);
+#endif
 
 #pragma unroll AB_UNROLL
     for (int qt = 0; qt < NQT; ++qt) {

@@ -1,0 +1,50 @@
+// On-box peak probes for bench.py's roofline lines ("peaks must be measured on the box"):
+//   rtts_peak_copy   float4 stream copy dst = src: the HBM rate a plain coalesced kernel reaches (read + write bytes / time)
+//   rtts_peak_mfma   back-to-back v_mfma_f32_16x16x32_bf16 on register operands (random, non-zero: zero operands let the chip
+//                    hold a higher clock, cdna_hip_programming.md rule 25), two waves per SIMD on every CU: the dense bf16
+//                    matrix rate the chip sustains at the clock it holds under that load
+// Neither is on the training path.
+#include "rtts_common.h"
+
+__global__ __launch_bounds__(256) void peak_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(512) void peak_mfma_kernel(float* __restrict__ sink, int iters) {
+    const int lane = threadIdx.x & 63;
+    // operands in [-1, 1), different in every lane
+    bf16x8 a, b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t h1 = rtts_drop_hash(17u + j, (uint32_t)(blockIdx.x * 512 + threadIdx.x));
+        const uint32_t h2 = rtts_drop_hash(91u + j, (uint32_t)(blockIdx.x * 512 + threadIdx.x));
+        a[j] = (__bf16)((float)(int)(h1 >> 8) * (1.f / 8388608.f) - 1.f);
+        b[j] = (__bf16)((float)(int)(h2 >> 8) * (1.f / 8388608.f) - 1.f);
+    }
+    f32x4 acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[k], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += acc[k][0] + acc[k][1] + acc[k][2] + acc[k][3];
+    if (s == 123.456f) sink[lane] = s;          // keeps the chain alive; (practically) never true
+}
+
+extern "C" int rtts_peak_copy(const void* src, void* dst, int64_t bytes, void* stream) {
+    RTTS_REQUIRE(src && dst && bytes > 0 && bytes % 16 == 0, "rtts_peak_copy: bytes must be a positive multiple of 16");
+    hipLaunchKernelGGL(peak_copy_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, (size_t)bytes / 16);
+    RTTS_LAUNCH_CHECK("rtts_peak_copy");
+    return 0;
+}
+
+// FLOP of one launch: workgroups * 8 waves * iters * 8 MFMAs * (16*16*32*2)
+extern "C" int rtts_peak_mfma(float* sink, int workgroups, int iters, void* stream) {
+    RTTS_REQUIRE(sink && workgroups > 0 && iters > 0, "rtts_peak_mfma: bad arguments");
+    hipLaunchKernelGGL(peak_mfma_kernel, dim3(workgroups), dim3(512), 0, (hipStream_t)stream, sink, iters);
+    RTTS_LAUNCH_CHECK("rtts_peak_mfma");
+    return 0;
+}

@@ -236,9 +236,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, kn: bool = False, bias: Optional[torc
             cs = torch.empty(rows, n, dtype=torch.float32, device=a.device)
     elif bias is not None:
         epi = 2 if relu else 1
+    ev = ops.TIMING.start(f"rtts_gemm_nt/{m}x{n}x{k}")
     _lib.call("rtts_gemm_nt", a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), int(kn), m, n, k, c.data_ptr(), n,
               None if bias is None else bias.data_ptr(), epi, None if gate is None else gate.data_ptr(),
               0 if gate is None else gate.stride(0), None if cs is None else cs.data_ptr(), _s())
+    ops.TIMING.stop(ev, 2.0 * m * n * k)
     if cs is not None:
         _queue_colsum(cs, 0, cs.shape[0], n, gate_bias_grad)
     return c

@@ -11,40 +11,44 @@ from . import _lib
 
 
 class _Timing:
-    """Optional HIP-event timing of one named launch on the stream it is launched on (bench.py's
-    roofline leg).  Off by default; events are resolved in ``summary`` after a device sync."""
+    """Optional HIP-event timing of named launches on the stream they are launched on (bench.py's roofline legs).  Off by
+    default; events are resolved in ``summary`` after a device sync.  A tag is enabled by name or by prefix
+    (``enable("rtts_gemm_nt")`` records every ``rtts_gemm_nt/<shape>``)."""
 
     def __init__(self):
-        self.tag = None
-        self.records = []
+        self.tags = ()
+        self.records = {}
 
-    def enable(self, tag: str):
-        self.tag, self.records = tag, []
+    def enable(self, *tags: str):
+        self.tags, self.records = tuple(tags), {}
 
     def disable(self):
-        self.tag = None
+        self.tags = ()
 
     def start(self, tag: str):
-        if self.tag != tag:
+        if not self.tags or not any(tag == t or tag.startswith(t + "/") for t in self.tags):
             return None
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
-        return ev
+        return (tag, ev)
 
-    def stop(self, ev, flops: float):
-        if ev is None:
+    def stop(self, started, work: float):
+        if started is None:
             return
+        tag, ev = started
         end = torch.cuda.Event(enable_timing=True)
         end.record(torch.cuda.current_stream())
-        self.records.append((ev, end, flops))
+        self.records.setdefault(tag, []).append((ev, end, work))
 
     def summary(self, tag: str):
-        """-> (average launch ms, launches, algorithmic FLOP per launch)."""
-        if not self.records:
+        """-> (average launch ms, launches, algorithmic work per launch) over every record whose tag is ``tag`` or starts
+        with ``tag + "/"``."""
+        recs = [r for k, v in self.records.items() if k == tag or k.startswith(tag + "/") for r in v]
+        if not recs:
             return 0.0, 0, 0.0
         torch.cuda.synchronize()
-        ms = [a.elapsed_time(b) for a, b, _ in self.records]
-        return sum(ms) / len(ms), len(ms), sum(f for _, _, f in self.records) / len(ms)
+        ms = [a.elapsed_time(b) for a, b, _ in recs]
+        return sum(ms) / len(ms), len(ms), sum(f for _, _, f in recs) / len(ms)
 
 
 TIMING = _Timing()
@@ -83,8 +87,12 @@ def lsh_hash_sort(qk: torch.Tensor, rotations: torch.Tensor, heads: int, bucket_
     st = torch.empty(b * heads, n_hashes, t, dtype=torch.int32, device=qk.device)
     buckets = torch.empty_like(st) if want_buckets else None
     undo = torch.empty_like(st) if want_undo else None
+    ev = TIMING.start(f"rtts_lsh_hash_sort/nb{t // bucket_size}")
     _lib.call("rtts_lsh_hash_sort", qk.data_ptr(), ld, rotations.data_ptr(), rows, b, heads, t, dh, n_hashes, bucket_size,
               _ptr(buckets), st.data_ptr(), _ptr(undo), _stream())
+    # SURVEY.md 8(d), per token and head: hash reads dh*2 B and writes n_hashes*4 B of bucket ids, the sort reads and writes
+    # n_hashes*(4+4) B (permutation + inverse) -- the algorithm's bytes, whatever the fused kernel keeps on chip
+    TIMING.stop(ev, float(b * heads * t) * (dh * 2 + n_hashes * 4 + n_hashes * 8))
     return st, buckets, undo
 
 
@@ -127,12 +135,8 @@ def lsh_combine_fwd(o, lse, batch: int, heads: int, out: Optional[torch.Tensor] 
 
 
 def lsh_attn_bwd(qk, v, st, out, dout, lse_tot, heads: int, bucket_size: int, causal: bool, mask=None,
-                 dqkv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, undo: Optional[torch.Tensor] = None):
-    """Backward of hash-sorted attention + round combine.  -> dqk, dv (B,T,H*dh) bf16.
-    With ``undo`` (token -> sorted slot, from ``lsh_hash_sort(want_undo=True)``) the ring kernels run (each row
-    gathered once, 3 complete gradient slots); without it the per-chunk kernels with 4 partial slots."""
-    if undo is not None:
-        return _lsh_attn_bwd_ring(qk, v, st, undo, out, dout, lse_tot, heads, bucket_size, causal, mask, dqkv)
+                 dqkv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+    """Backward of hash-sorted attention + round combine.  -> dqk, dv (B,T,H*dh) bf16."""
     ld = _check_rows(qk, "qk")
     if _check_rows(v, "v") != ld:
         raise ValueError("qk and v must share a row stride")
@@ -162,39 +166,4 @@ def lsh_attn_bwd(qk, v, st, out, dout, lse_tot, heads: int, bucket_size: int, ca
         raise ValueError("dqk and dv must share a row stride")
     _lib.call("rtts_lsh_bwd_reduce", dqk_part.data_ptr(), dv_part.data_ptr(), b, heads, t, dh, n_hashes, dqk.data_ptr(),
               dv.data_ptr(), ld_d, _stream())
-    return dqk, dv
-
-
-def _lsh_attn_bwd_ring(qk, v, st, undo, out, dout, lse_tot, heads, bucket_size, causal, mask, dqkv):
-    ld = _check_rows(qk, "qk")
-    if _check_rows(v, "v") != ld:
-        raise ValueError("qk and v must share a row stride")
-    ld_out, ld_do = _check_rows(out, "out"), _check_rows(dout, "dout")
-    b, t, d = qk.shape
-    dh = d // heads
-    n_hashes = st.shape[1]
-    if undo.shape != st.shape or undo.dtype != torch.int32 or not undo.is_contiguous():
-        raise ValueError("undo: expected contiguous int32 (B*H, n_hashes, T)")
-    mask = _check_mask(mask, b, t, qk.device)
-    dev = qk.device
-    delta = torch.empty(b * heads, t, dtype=torch.float32, device=dev)
-    _lib.call("rtts_lsh_bwd_delta", out.data_ptr(), ld_out, dout.data_ptr(), ld_do, b, heads, t, dh, delta.data_ptr(), _stream())
-    parts = torch.empty(3, b * heads, n_hashes, t, dh, dtype=torch.bfloat16, device=dev)
-    halo = torch.empty(2, b * heads, n_hashes, bucket_size, dh, dtype=torch.bfloat16, device=dev)
-    ev = TIMING.start(f"rtts_lsh_attn_bwd/bs{bucket_size}")
-    _lib.call("rtts_lsh_attn_bwd_ring", qk.data_ptr(), v.data_ptr(), ld, st.data_ptr(), _ptr(mask), dout.data_ptr(), ld_do,
-              lse_tot.data_ptr(), delta.data_ptr(), b, heads, t, dh, n_hashes, bucket_size, int(causal), parts[0].data_ptr(),
-              parts[1].data_ptr(), parts[2].data_ptr(), halo[0].data_ptr(), halo[1].data_ptr(), _stream())
-    # five MFMA products of 2*bs*(2bs)*dh FLOP per chunk, n_hashes*T/bs chunks per head
-    TIMING.stop(ev, 5.0 * 2.0 * bucket_size * (2 * bucket_size) * dh * (n_hashes * t // bucket_size) * b * heads)
-    if dqkv is None:
-        dqk = torch.empty(b, t, d, dtype=torch.bfloat16, device=dev)
-        dv = torch.empty(b, t, d, dtype=torch.bfloat16, device=dev)
-    else:
-        dqk, dv = dqkv
-    ld_d = _check_rows(dqk, "dqk")
-    if _check_rows(dv, "dv") != ld_d:
-        raise ValueError("dqk and dv must share a row stride")
-    _lib.call("rtts_lsh_bwd_reduce_ring", parts[0].data_ptr(), parts[1].data_ptr(), parts[2].data_ptr(), halo[0].data_ptr(),
-              halo[1].data_ptr(), undo.data_ptr(), b, heads, t, dh, n_hashes, bucket_size, dqk.data_ptr(), dv.data_ptr(), ld_d, _stream())
     return dqk, dv

@@ -122,23 +122,7 @@ def main():
                       delta.data_ptr(), s)
             us = timeit(bwd, args.iters)
             res["attn_bwd"] = (us, f"{5 * pair_flops / us / 1e6:8.1f} TFLOP/s")
-            _, _, undo = ops.lsh_hash_sort(qk, rot, h, bs, want_undo=True)
-            parts = torch.empty(3, b * h, nh, t, dh, dtype=torch.bfloat16, device=dev)
-            halo = torch.empty(2, b * h, nh, bs, dh, dtype=torch.bfloat16, device=dev)
-
-            def bwd_ring():
-                _lib.call("rtts_lsh_attn_bwd_ring", qk.data_ptr(), v.data_ptr(), ld, st.data_ptr(), mask.data_ptr(), dout.data_ptr(),
-                          dout.stride(1), lse_tot.data_ptr(), delta.data_ptr(), b, h, t, dh, nh, bs, int(causal), parts[0].data_ptr(),
-                          parts[1].data_ptr(), parts[2].data_ptr(), halo[0].data_ptr(), halo[1].data_ptr(), s)
-            us = timeit(bwd_ring, args.iters)
-            res["attn_bwd_ring"] = (us, f"{5 * pair_flops / us / 1e6:8.1f} TFLOP/s")
             dqk, dv = torch.empty_like(qk.contiguous()), torch.empty_like(qk.contiguous())
-
-            def red_ring():
-                _lib.call("rtts_lsh_bwd_reduce_ring", parts[0].data_ptr(), parts[1].data_ptr(), parts[2].data_ptr(), halo[0].data_ptr(),
-                          halo[1].data_ptr(), undo.data_ptr(), b, h, t, dh, nh, bs, dqk.data_ptr(), dv.data_ptr(), dqk.stride(1), s)
-            us = timeit(red_ring, args.iters)
-            res["reduce_ring"] = (us, f"{tok * (3 * nh * 128 + 256) / us / 1e3:8.1f} GB/s alg")
 
             def red():
                 _lib.call("rtts_lsh_bwd_reduce", dqk_part.data_ptr(), dv_part.data_ptr(), b, h, t, dh, nh, dqk.data_ptr(),

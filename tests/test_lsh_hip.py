@@ -143,9 +143,8 @@ def test_attention_forward_vs_oracle(ops, b, h, t, bs, nh, causal, masked):
 
 
 # ------------------------------------------------------------------ attention backward
-@pytest.mark.parametrize("ring", [True, False])
 @pytest.mark.parametrize("b,h,t,bs,nh,causal,masked", CASES)
-def test_attention_backward_vs_oracle_autograd(ops, b, h, t, bs, nh, causal, masked, ring):
+def test_attention_backward_vs_oracle_autograd(ops, b, h, t, bs, nh, causal, masked):
     """Gradients of sum(out * dout) w.r.t. qk and v against autograd through the oracle on the same
     permutation.  bf16 partials (16 per token) and bf16 P/dS operands bound the error at ~2%
     of the gradient scale."""
@@ -154,7 +153,7 @@ def test_attention_backward_vs_oracle_autograd(ops, b, h, t, bs, nh, causal, mas
     g = torch.Generator().manual_seed(11)
     dout = torch.randn(b, t, h * dh, generator=g).bfloat16()
     dqk, dv = ops.lsh_attn_bwd(r["qk_d"], r["v_d"], r["st"], r["out"], dout.cuda(), r["lse_tot"], h, bs, causal,
-                               None if r["mask"] is None else r["mask"].cuda(), undo=r["undo"] if ring else None)
+                               None if r["mask"] is None else r["mask"].cuda())
     torch.cuda.synchronize()
     qk = _heads_first(r["qkv"][..., :h * dh], b, t, h, dh).requires_grad_()
     v = _heads_first(r["qkv"][..., h * dh:], b, t, h, dh).requires_grad_()
@@ -163,11 +162,15 @@ def test_attention_backward_vs_oracle_autograd(ops, b, h, t, bs, nh, causal, mas
     out_ref = lsh_ref.lsh_attention_sorted(qk, v, sticker, undo, bs, nh, causal, m)
     out_ref.backward(_heads_first(dout, b, t, h, dh))
     dqk_h, dv_h = _heads_first(dqk, b, t, h, dh), _heads_first(dv, b, t, h, dh)
+    msgs = []
     for got, ref, name in ((dv_h, v.grad, "dv"), (dqk_h, qk.grad, "dqk")):
         scale = ref.abs().max().item()
         err = (got - ref).abs()
+        msgs.append(f"{name} max {err.max().item() / scale:.2e} mean {err.mean().item() / scale:.2e} rel-L2 {float((got - ref).norm() / ref.norm()):.2e}")
         assert err.max().item() < 4e-2 * scale + 1e-3, (name, err.max().item(), scale)
         assert err.mean().item() < 4e-3 * scale + 1e-4, (name, err.mean().item(), scale)
+    print(f"\n[lsh attention backward B={b} H={h} T={t} bs={bs} R={nh} causal={causal} masked={masked}] errors / max|ref|: " + "; ".join(msgs) +
+          " (tol max 4e-2, mean 4e-3)")
 
 
 def test_strided_qkv_views(ops):
