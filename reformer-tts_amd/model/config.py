@@ -94,6 +94,15 @@ class ReformerTTSConfig:
 
 
 @dataclass
+class LRSchedulerConfig:
+    """``training/config.py:5-10``: exponential decay from ``initial_lr`` to ``final_lr`` between two epochs."""
+    initial_lr: float = 1e-4
+    final_lr: float = 1e-4
+    start_schedule_epoch: int = 0
+    end_schedule_epoch: Optional[int] = None
+
+
+@dataclass
 class TTSTrainingConfig:
     batch_size: int = 8
     learning_rate: float = 1e-4
@@ -101,6 +110,8 @@ class TTSTrainingConfig:
     weight_decay: float = 1e-4
     accumulate_grad_batches: int = 1
     gradient_clip_val: float = 0.0
+    lr_scheduler: Optional[LRSchedulerConfig] = None
+    max_epochs: Optional[int] = None       # experiment.max_epochs: the schedule's end when end_schedule_epoch is None
     warmup_steps: Optional[int] = None
     raw_pred_loss_weight: float = 1.0
     post_pred_loss_weight: float = 1.0
@@ -132,10 +143,17 @@ def load_yaml(path: str):
     with open(path) as fh:
         raw = yaml.safe_load(fh) or {}
     model = model_config_from_dict(raw.get("model", {}))
-    tr = dict(raw.get("experiment", {}).get("tts_training", {}))
-    for k in ("num_visualizations", "early_stopping_epochs", "noise_std", "lr_scheduler"):
-        tr.pop(k, None)
-    return model, _merge(TTSTrainingConfig(), tr)
+    exp = raw.get("experiment", {})
+    tr = dict(exp.get("tts_training", {}))
+    for k in ("num_visualizations", "early_stopping_epochs", "noise_std"):      # plotting / early stopping / input noise: the
+        tr.pop(k, None)                                                         # harness around the step, not the step
+    sched = tr.pop("lr_scheduler", None)
+    cfg = _merge(TTSTrainingConfig(), tr)
+    if sched is not None:
+        cfg.lr_scheduler = _merge(LRSchedulerConfig(), dict(sched))
+    if exp.get("max_epochs") is not None:
+        cfg.max_epochs = int(exp["max_epochs"])
+    return model, cfg
 
 
 def baseline_model_config() -> ReformerTTSConfig:

@@ -49,6 +49,16 @@ def synthetic_batch(batch: int, text_len: int, mel_len: int, n_mels: int = 80, d
     return {k: v.to(device) for k, v in out.items()} if device is not None else out
 
 
+def stop_mae(stop_logits: torch.Tensor, stop_tokens: torch.Tensor) -> torch.Tensor:
+    """Mean absolute error, in frames, of the predicted end of the utterance (``wrappers.py:74-80``): the first frame whose
+    stop logit is positive -- frame 0 when there is none -- against the frame of the one-hot stop token."""
+    b, l = stop_tokens.shape
+    frames = torch.arange(l, device=stop_logits.device).expand(b, l)
+    first = torch.where(stop_logits.reshape(b, l) > 0, frames, torch.full_like(frames, l)).amin(dim=1)
+    first = torch.where(first == l, torch.zeros_like(first), first)
+    return (first - stop_tokens.argmax(dim=1)).abs().float().mean()
+
+
 class Trainer:
     def __init__(self, model: ReformerTTS, cfg: TTSTrainingConfig, device, process_group=None):
         self.model, self.cfg, self.device = model, cfg, torch.device(device)
@@ -58,6 +68,10 @@ class Trainer:
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.rank = dist.get_rank(process_group) if self.world > 1 else 0
         self.global_step = 0
+        self.epoch = 0                                   # finished epochs (drives the exponential LR schedule)
+        sch = cfg.lr_scheduler
+        self._base_lr = float(cfg.learning_rate if sch is None else sch.initial_lr)
+        self._lr = self._base_lr                         # what the reference's optimizer.param_groups[...]["lr"] holds
         self._decorrelate_replicas()
         self._flatten()
         self._make_buckets()
@@ -231,11 +245,26 @@ class Trainer:
         self.finish_allreduce()
 
     def lr_now(self) -> float:
-        """Linear warm-up ``lr * min(1, (step+1)/warmup)`` (``wrappers.py:284-294``)."""
-        lr = self.cfg.learning_rate
-        if self.cfg.warmup_steps is not None and self.global_step < self.cfg.warmup_steps:
-            lr *= min(1.0, float(self.global_step + 1) / self.cfg.warmup_steps)
-        return lr
+        return self.lr_now_for(self.global_step)
+
+    def end_epoch(self) -> float:
+        """The reference's per-epoch ``MultiplicativeLR`` step (``wrappers.py:258-279``): while start <= epoch <= end the rate is
+        multiplied by exp(-gamma), gamma = (ln initial_lr - ln final_lr) / (end - start).  -> the factor applied."""
+        self.epoch += 1
+        sch = self.cfg.lr_scheduler
+        if sch is None:
+            return 1.0
+        if sch.start_schedule_epoch < 1:
+            raise AssertionError("start_schedule_epoch has to be >= 1")
+        end = sch.end_schedule_epoch if sch.end_schedule_epoch is not None else self.cfg.max_epochs
+        if end is None:
+            raise ValueError("lr_scheduler: end_schedule_epoch or max_epochs must be set")
+        factor = 1.0
+        if sch.start_schedule_epoch <= self.epoch <= end:
+            gamma = (math.log(sch.initial_lr) - math.log(sch.final_lr)) / (end - sch.start_schedule_epoch)
+            factor = math.exp(-gamma)
+        self._lr *= factor
+        return factor
 
     def set_step_hyper(self, step_index: int):
         """Host -> device copy of this step's {lr, lr*sqrt(1-b2^t)/(1-b1^t)} (t = step_index + 1); outside any graph."""
@@ -272,10 +301,12 @@ class Trainer:
         WEIGHT_EPOCH[0] += 1
 
     def lr_now_for(self, step: int) -> float:
-        lr = self.cfg.learning_rate
+        """Rate of optimizer step ``step``: the warm-up hook (``wrappers.py:284-294``) ASSIGNS base * min(1, (step+1)/warmup)
+        while step < warmup (overwriting what the epoch schedule left, as the reference does); afterwards the rate is whatever
+        the last assignment / the epoch schedule (``end_epoch``) made of it."""
         if self.cfg.warmup_steps is not None and step < self.cfg.warmup_steps:
-            lr *= min(1.0, float(step + 1) / self.cfg.warmup_steps)
-        return lr
+            self._lr = min(1.0, float(step + 1) / self.cfg.warmup_steps) * self._base_lr
+        return self._lr
 
     def train_step(self, batch, update_hyper: bool = True):
         """One micro-batch: forward + loss + backward (+ all-reduce) + optimizer step."""
@@ -320,7 +351,7 @@ class Trainer:
     def validate(self, batch):
         """``LitReformerTTS.validation_step`` (``wrappers.py:107-140``): teacher-forced forward in eval mode (BatchNorm
         running statistics, no dropout), the four losses; the stacks run through the explicit executor's forward.
-        -> (total, raw, post, stop) device scalars.  Parameters and optimizer state are untouched."""
+        -> (total, raw, post, stop, stop_mae) device scalars.  Parameters and optimizer state are untouched."""
         was_training = self.model.training
         stacks = (self.model.enc.reformer.layers, self.model.dec.reformer.layers)
         self.model.eval()
@@ -329,7 +360,9 @@ class Trainer:
         try:
             spec = batch["spectrogram"]
             raw, post, stop, _ = self.model(batch["phonemes"], spec[:, :-1], spectrogram_mask=batch["loss_mask"].mean(dim=-1))
-            return self.loss(raw, post, stop.view(stop.shape[0], -1), spec[:, 1:], batch["stop_tokens"], batch["loss_mask"])
+            stop2 = stop.view(stop.shape[0], -1)
+            return (*self.loss(raw, post, stop2, spec[:, 1:], batch["stop_tokens"], batch["loss_mask"]),
+                    stop_mae(stop2, batch["stop_tokens"]))
         finally:
             for st in stacks:
                 st.fused_in_eval = False
@@ -341,7 +374,7 @@ class Trainer:
         vice versa), the Adam moments keyed by parameter name, and the step counter (drives warm-up and bias correction)."""
         moments = {n: (self.flat_m[s:e].detach().clone(), self.flat_v[s:e].detach().clone()) for n, (s, e) in self.offsets.items()}
         return {"model": {k: v.detach().clone() for k, v in self.model.state_dict().items()}, "adam": moments,
-                "global_step": self.global_step}
+                "global_step": self.global_step, "epoch": self.epoch, "lr": self._lr}
 
     def load_state_dict(self, state: dict) -> None:
         self.model.load_state_dict(state["model"])             # copies into the flat fp32 buffer the parameters view
@@ -350,6 +383,8 @@ class Trainer:
             self.flat_m[s:e].copy_(m.reshape(-1))
             self.flat_v[s:e].copy_(v.reshape(-1))
         self.global_step = int(state["global_step"])
+        self.epoch = int(state.get("epoch", 0))
+        self._lr = float(state.get("lr", self._base_lr))
         if self.device.type == "cuda":
             self.refresh_mirror()                              # the bf16 mirror the GEMMs read
             engine.WEIGHT_EPOCH[0] += 1                        # cached re-layouts of weights (conv permutations) are stale
@@ -358,6 +393,7 @@ class Trainer:
         """Eager training over an iterable of HOST batches (the output of ``dataset.custom_sequence_padder``; shapes may
         vary from batch to batch, which a captured graph cannot follow): the next batch is copied to HBM on a copy stream
         while the current step runs; ``cfg.accumulate_grad_batches`` micro-batches make one optimizer step.
+        One call = one epoch: the exponential LR schedule advances at its end (``end_epoch``).
         -> list of the (mean) total loss per optimizer step (device scalars; no per-step host sync)."""
         from ..dataset import BatchPrefetcher
         losses, group = [], []
@@ -371,6 +407,7 @@ class Trainer:
                     print(f"step {self.global_step}: loss {float(losses[-1]):.4f}", flush=True)
         if group:                                              # a trailing partial group still makes a step
             losses.append(self.train_accumulated(group))
+        self.end_epoch()
         return losses
 
     # ------------------------------------------------------------------ hipGraph replay of the whole step

@@ -1,0 +1,108 @@
+"""Host-side logic of the training harness against the oracle's restatement of the reference (no GPU): the learning-rate
+schedule (``/root/reference/reformer_tts/training/wrappers.py:258-294``: exponential per-epoch decay + warm-up hook), the
+stop-token MAE (``wrappers.py:74-80``) and the YAML -> config mapping of the ``lr_scheduler`` section
+(``training/config.py:5-10,24``)."""
+import os
+import tempfile
+
+import pytest
+import torch
+
+from oracle import optim_ref
+
+
+def _trainer(cfg):
+    """A Trainer shell that has only what the schedule needs (no model, no device buffers)."""
+    from reformer_tts_amd.training import Trainer
+    tr = Trainer.__new__(Trainer)
+    tr.cfg, tr.global_step, tr.epoch = cfg, 0, 0
+    sch = cfg.lr_scheduler
+    tr._base_lr = float(cfg.learning_rate if sch is None else sch.initial_lr)
+    tr._lr = tr._base_lr
+    return tr
+
+
+@pytest.mark.parametrize("warmup,sched", [
+    (None, None), (7, None),
+    (5, dict(initial_lr=3e-4, final_lr=3e-6, start_schedule_epoch=1, end_schedule_epoch=6)),
+    (30, dict(initial_lr=1e-3, final_lr=1e-5, start_schedule_epoch=2, end_schedule_epoch=None)),      # warm-up spans epochs
+    (None, dict(initial_lr=1e-4, final_lr=1e-4, start_schedule_epoch=1, end_schedule_epoch=3)),
+])
+def test_learning_rate_follows_the_reference_schedule(warmup, sched):
+    from reformer_tts_amd.model.config import LRSchedulerConfig, TTSTrainingConfig
+    cfg = TTSTrainingConfig(learning_rate=2e-4, warmup_steps=warmup, max_epochs=9,
+                            lr_scheduler=None if sched is None else LRSchedulerConfig(**sched))
+    tr = _trainer(cfg)
+    steps_per_epoch, epochs = 11, 9
+    want = optim_ref.lr_trajectory(steps_per_epoch, epochs, 2e-4, warmup, sched, max_epochs=9)
+    got = []
+    for _ in range(epochs):
+        for _ in range(steps_per_epoch):
+            got.append(tr.lr_now_for(tr.global_step))
+            tr.global_step += 1
+        tr.end_epoch()
+    assert len(got) == len(want)
+    rel = max(abs(a - b) / b for a, b in zip(got, want))
+    print(f"\n[lr schedule warmup={warmup} sched={sched}] max rel difference {rel:.2e} over {len(got)} steps; "
+          f"first {got[0]:.3e}, last {got[-1]:.3e}")
+    assert rel < 1e-12
+    if sched is not None and sched["final_lr"] != sched["initial_lr"] and (warmup or 0) < steps_per_epoch:
+        end = sched["end_schedule_epoch"] or 9
+        # after the schedule's last epoch the rate has arrived at final_lr * exp(-gamma) ** (extra closed end point) -- what
+        # the reference's inclusive range start <= epoch <= end gives: (end - start + 1) factors for (end - start) intervals
+        gamma = (torch.log(torch.tensor(sched["initial_lr"])) - torch.log(torch.tensor(sched["final_lr"]))) / (end - sched["start_schedule_epoch"])
+        assert abs(got[-1] - sched["final_lr"] * float(torch.exp(-gamma))) / got[-1] < 1e-5
+
+
+def test_schedule_rejects_a_start_before_epoch_one():
+    from reformer_tts_amd.model.config import LRSchedulerConfig, TTSTrainingConfig
+    tr = _trainer(TTSTrainingConfig(lr_scheduler=LRSchedulerConfig(start_schedule_epoch=0, end_schedule_epoch=3)))
+    with pytest.raises(AssertionError, match="start_schedule_epoch has to be >= 1"):
+        tr.end_epoch()
+
+
+def test_stop_mae_matches_the_reference_formula():
+    from reformer_tts_amd.training.trainer import stop_mae
+    g = torch.Generator().manual_seed(0)
+    for b, l in ((1, 5), (4, 37), (12, 1024)):
+        for case in range(6):
+            logits = torch.randn(b, l, generator=g) - (2.0 if case % 2 else 0.0)
+            if case == 2:
+                logits = -logits.abs()                    # no positive logit anywhere: the reference lands on frame 0
+            if case == 3:
+                logits = logits.abs()                     # every logit positive: frame 0
+            if case == 4:
+                logits[:, : l // 2] = -1.0                # first positive somewhere in the second half
+            tok = torch.zeros(b, l)
+            tok[torch.arange(b), torch.randint(0, l, (b,), generator=g)] = 1.0
+            assert torch.equal(stop_mae(logits, tok), optim_ref.stop_mae(logits.unsqueeze(-1), tok)), (b, l, case)
+
+
+def test_yaml_lr_scheduler_section_is_kept():
+    from reformer_tts_amd.model.config import load_yaml
+    text = """
+experiment:
+  max_epochs: 40
+  tts_training:
+    batch_size: 20
+    learning_rate: 0.0003
+    warmup_steps: 320
+    num_visualizations: 2
+    lr_scheduler:
+      initial_lr: 0.0003
+      final_lr: 0.00001
+      start_schedule_epoch: 3
+model:
+  pad_base: 256
+"""
+    with tempfile.NamedTemporaryFile("w", suffix=".yml", delete=False) as fh:
+        fh.write(text)
+    try:
+        _, tr = load_yaml(fh.name)
+    finally:
+        os.unlink(fh.name)
+    assert tr.lr_scheduler is not None and tr.lr_scheduler.final_lr == 1e-5 and tr.lr_scheduler.start_schedule_epoch == 3
+    assert tr.lr_scheduler.end_schedule_epoch is None and tr.max_epochs == 40 and tr.batch_size == 20
+    with pytest.raises(KeyError, match="unknown config key"):
+        from reformer_tts_amd.model.config import LRSchedulerConfig, _merge
+        _merge(LRSchedulerConfig(), dict(initial=1.0))
