@@ -117,29 +117,27 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
     const int nk = P.K / GN_BK;
     const int64_t lda = P.lda, ldw = P.ldw;
 
-    // ---- DMA sources (per lane), stage 0; a stage advances A by 64 columns, W by 64 columns ([N][K]) or 64 rows ([K][N])
-    const bf16_t* srcA[PA];
-    const bf16_t* srcW[PW];
-#pragma unroll
-    for (int t = 0; t < PA; ++t) {
-        const int p = wave + NW * t, row = 8 * p + (lane >> 3);
+    // ---- DMA sources: ONE per-lane pointer per operand (the wave's piece 0 of stage 0).  Piece t of a wave is 8 NW t rows
+    // further on ([row][k] images; (1024 / RP) NW t k rows for the [K][N] weight image) -- a wave-uniform offset -- and needs
+    // the same per-lane swizzle: the row bits the swizzles read ((row >> 1) & 7 resp. gn_kn_swz) do not change with t for an
+    // even wave count (checked below), so the pointers of the other pieces are scalar adds at issue time, not registers.
+    const bf16_t* srcA0;
+    const bf16_t* srcW0;
+    {
+        const int row = 8 * wave + (lane >> 3);
         const int lc = (lane & 7) ^ ((row >> 1) & 7);
-        srcA[t] = P.a + (size_t)(m0 + row) * lda + lc * 8;
-    }
-#pragma unroll
-    for (int t = 0; t < PW; ++t) {
-        const int p = wave + NW * t;
+        srcA0 = P.a + (size_t)(m0 + row) * lda + lc * 8;
         if constexpr (!W_KN) {
-            const int row = 8 * p + (lane >> 3);
-            const int lc = (lane & 7) ^ ((row >> 1) & 7);
-            srcW[t] = P.w + (size_t)(n0 + row) * ldw + lc * 8;
+            srcW0 = P.w + (size_t)(n0 + row) * ldw + lc * 8;
         } else {
             constexpr int UPR = RP / 16;                          // 16-byte units per k row
-            const int row = (1024 / RP) * p + lane / UPR, u = lane % UPR;
-            const int lchunk = (u >> 1) ^ gn_kn_swz<RP>(row);
-            srcW[t] = P.w + (size_t)row * ldw + n0 + lchunk * 16 + (u & 1) * 8;
+            const int krow = (1024 / RP) * wave + lane / UPR, u = lane % UPR;
+            const int lchunk = (u >> 1) ^ gn_kn_swz<RP>(krow);
+            srcW0 = P.w + (size_t)krow * ldw + n0 + lchunk * 16 + (u & 1) * 8;
         }
     }
+    static_assert(NW % 2 == 0 && (!W_KN || ((1024 / RP) * NW) % 16 == 0), "per-piece swizzle must not depend on the piece index");
+    const size_t pstepA = (size_t)8 * NW * lda, pstepW = W_KN ? (size_t)(1024 / RP) * NW * ldw : (size_t)8 * NW * ldw;
     const size_t wstep = W_KN ? (size_t)GN_BK * ldw : (size_t)GN_BK;
     const int conv_cpt = P.conv_cpt;
     // element offsets of K stage `st` into the A rows / the weight (wave-uniform scalar arithmetic)
@@ -158,10 +156,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
         unsigned char* sb_ = smem + (buf_) * STAGE;                                                                     \
         const int64_t ka_ = a_off(stage_), kw_ = w_off(stage_);                                                         \
         _Pragma("unroll") for (int t = 0; t < PA; ++t)                                                                  \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[t] + ka_),           \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA0 + t * pstepA + ka_), \
                                              (RTTS_LDS void*)(sb_ + (wave + NW * t) * 1024), 16, 0, 0);                 \
         _Pragma("unroll") for (int t = 0; t < PW; ++t)                                                                  \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[t] + kw_),           \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW0 + t * pstepW + kw_), \
                                              (RTTS_LDS void*)(sb_ + A_BYTES + (wave + NW * t) * 1024), 16, 0, 0);       \
     } while (0)
 
@@ -170,19 +168,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
     // [row][64 k] images: 16 rows x 4 chunks per fragment; k32-step 1 flips bit 2 of the chunk index (address ^ 64)
     const uint32_t offA0 = (uint32_t)(wm * (BM / WM) * 128 + r * 128 + ((g ^ ((r >> 1) & 7)) << 4));
     const uint32_t offA1 = offA0 ^ 64u;
-    uint32_t offW[W_KN ? TN : 2];
+    uint32_t offW[2];
     if constexpr (!W_KN) {
         offW[0] = (uint32_t)(A_BYTES + wn * (BN / WN) * 128 + r * 128 + ((g ^ ((r >> 1) & 7)) << 4));
         offW[1] = offW[0] ^ 64u;
     } else {
-        // transposed read: lane 4q+p of 16-lane group g supplies k row 8g + q (second read: + 4), columns 4p .. 4p+3 of tile j
+        // transposed read: lane 4q+p of 16-lane group g supplies k row 8g + q (second read: + 4), columns 4p .. 4p+3 of tile j.
+        // The physical 32-byte chunk of tile j is (jj0 + j) ^ fl with jj0 = the wave's first tile, a multiple of TN (a power of
+        // two), so (jj0 + j) ^ fl = (jj0 ^ fl) ^ j: ONE lane-dependent base, tile j at base ^ (j << 5) -- bits 5.. of the rest
+        // of the base (A image, k row * RP, 8 p) are zero below the chunk field.
+        static_assert((TN & (TN - 1)) == 0 && (A_BYTES % 256) == 0, "[K][N] image: tile count per wave must be a power of two");
         const int q = r >> 2, p = r & 3;
         const int fl = gn_kn_swz<RP>(8 * g + q);                   // does not depend on the k32-step or the half
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int jj = wn * (BN / WN) / 16 + j;
-            offW[j] = (uint32_t)(A_BYTES + (8 * g + q) * RP + ((jj ^ fl) << 5) + 8 * p);
-        }
+        const int jj0 = wn * TN;
+        offW[0] = (uint32_t)(A_BYTES + (8 * g + q) * RP + ((jj0 ^ fl) << 5) + 8 * p);
+        offW[1] = 0;
     }
 
     f32x4 acc[TM][TN];
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
         } else {                                                                                                           \
             gn_static_for<0, TN>([&](auto jc) {                                                                            \
                 constexpr int j = decltype(jc)::value;                                                                     \
-                const uint32_t aw_ = (sb_) + offW[j];                                                                      \
+                const uint32_t aw_ = (sb_) + (offW[0] ^ (uint32_t)(j << 5));                                               \
                 gn_rdtr<(32 * KS) * RP>(WL[j], aw_);                                                                       \
                 gn_rdtr<(32 * KS + 4) * RP>(WH[j], aw_);                                                                   \
             });                                                                                                            \
@@ -228,10 +228,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
         constexpr int q = decltype(qc)::value;
         unsigned char* sb_ = smem + bufi_ * STAGE;
         if constexpr (q < PA)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[q] + a_off(stage_)),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA0 + q * pstepA + a_off(stage_)),
                                              (RTTS_LDS void*)(sb_ + (wave + NW * q) * 1024), 16, 0, 0);
         else
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[q - PA] + w_off(stage_)),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW0 + (q - PA) * pstepW + w_off(stage_)),
                                              (RTTS_LDS void*)(sb_ + A_BYTES + (wave + NW * (q - PA)) * 1024), 16, 0, 0);
     };
 #define GN_MFMA(AF, WF, WL, WH, COND_, ST_, BUF_, Q0, Q1)                                                                  \
@@ -301,7 +301,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
         const uint32_t sb = smem_base + buf * STAGE;
         int nb = buf + 1 == NST ? 0 : buf + 1;
         GN_READ(a1, w1, wl1, wh1, sb, 1);
-        gn_wait_lgkm<RD_PER_KS>();                   // F0 is back (LDS returns in order; only F1's reads may be outstanding)
+        // F0 is back (LDS returns in order; only F1's reads may be outstanding).  The counter holds 15 at most: with more
+        // reads per half stage (the 256-wide tile's transposed weight fragments) "at most 15 outstanding" already implies it
+        gn_wait_lgkm<(RD_PER_KS < 15 ? RD_PER_KS : 15)>();
         __builtin_amdgcn_sched_barrier(0);
 #ifndef GN_ABL_NODMA
         GN_MFMA(a0, w0, wl0, wh0, s >= 1 && s - 1 + NST < nk, s - 1 + NST, pbuf, SPB, PER);
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
 
 // ring depth: as deep as 160 KB of LDS allow, at most 4 stages
 template <int BM, int BN>
-constexpr int gn_nst() { return (4 * (BM + BN) * 128 <= 160 * 1024) ? 4 : 3; }
+constexpr int gn_nst() { return (4 * (BM + BN) * 128 <= 160 * 1024) ? 4 : ((3 * (BM + BN) * 128 <= 160 * 1024) ? 3 : 2); }
 
 template <int BM, int BN, int WM, int WN, bool W_KN, int EPI, int NST>
 static int gn_launch3(const GnArgs& P, hipStream_t s) {
@@ -465,26 +467,32 @@ static int gn_launch(const GnArgs& P, int w_kn, hipStream_t s) {
     }
 }
 
-// tile choice: the largest tile that still gives the chip >= ~0.75 workgroups per CU
+// Tile choice.  The kernel is bound by operand ingest (bytes per workgroup and K stage ~ BM + BN), so the largest tile wins
+// as long as its grid fills the chip in WHOLE waves of one workgroup per CU: 256 x 256 when its workgroup count is a multiple
+// of 256 (M = 16384, N >= 1024: 46 vs 54 us at N = 2048; at M = 12288 its 192 / 384 workgroups leave a quarter of the chip
+// idle or a half-empty second wave and lose to 192 x 128: 23.4 vs 20.5 us, 43.1 vs 40.3 us; profiles/r02_gemm_nt_probe_256.log),
+// else 192 x 128 (M = 12288, N = 512: exactly one workgroup per CU), 256 x 128, and the 4-wave tiles for small problems.
+#define GN_NCAND 5
+static const int gn_cand[GN_NCAND][3] = {{256, 256, 4}, {192, 128, 4}, {256, 128, 4}, {96, 64, 2}, {128, 64, 2}};   // BM, BN, WM
 static int gn_pick(int M, int N) {
-    const int cand[4][2] = {{192, 128}, {256, 128}, {96, 64}, {128, 64}};
+    static const int no256 = [] { const char* e = getenv("RTTS_GEMM_NT_NO256"); return e ? atoi(e) : 0; }();      // A/B runs
     int best = -1;
-    for (int i = 0; i < 4; ++i) {
-        if (M % cand[i][0] || N % cand[i][1]) continue;
+    for (int i = (no256 ? 1 : 0); i < GN_NCAND; ++i) {
+        if (M % gn_cand[i][0] || N % gn_cand[i][1]) continue;
+        const int wgs = (M / gn_cand[i][0]) * (N / gn_cand[i][1]);
+        if (i == 0 && wgs % 256 != 0) continue;   // 256 x 256: whole waves only
         if (best < 0) best = i;                   // fallback: the first that tiles
-        if ((M / cand[i][0]) * (N / cand[i][1]) >= 192) return i;
+        if (wgs >= 192) return i;
     }
     // nothing reaches 192 workgroups: take the smallest tile that fits (most workgroups)
-    for (int i = 3; i >= 2; --i)
-        if (M % cand[i][0] == 0 && N % cand[i][1] == 0) return i;
+    for (int i = GN_NCAND - 1; i >= GN_NCAND - 2; --i)
+        if (M % gn_cand[i][0] == 0 && N % gn_cand[i][1] == 0) return i;
     return best;
 }
 
 extern "C" int rtts_gemm_nt_partial_rows(int M, int N) {
-    const int cand[4][2] = {{192, 128}, {256, 128}, {96, 64}, {128, 64}};
-    const int wm[4] = {4, 4, 2, 2};
     const int i = gn_pick(M, N);
-    return i < 0 ? -1 : (M / cand[i][0]) * wm[i];
+    return i < 0 ? -1 : (M / gn_cand[i][0]) * gn_cand[i][2];
 }
 
 static int gn_run(const void* a, int64_t lda, const void* w, int64_t ldw, int w_is_kn, int M, int N, int K, void* c, int64_t ldc,
@@ -501,7 +509,7 @@ static int gn_run(const void* a, int64_t lda, const void* w, int64_t ldw, int w_
     RTTS_REQUIRE((((uintptr_t)a | (uintptr_t)w) & 15) == 0 && (((uintptr_t)c | (uintptr_t)gate) & (epilogue == 4 ? 15 : 7)) == 0 &&
                  (((uintptr_t)bias | (uintptr_t)colsum_partial) & 15) == 0, "rtts_gemm_nt: misaligned buffer");
     const int pick = gn_pick(M, N);
-    RTTS_REQUIRE(pick >= 0, "rtts_gemm_nt: M x N = %d x %d tiles by none of 192x128, 256x128, 96x64, 128x64", M, N);
+    RTTS_REQUIRE(pick >= 0, "rtts_gemm_nt: M x N = %d x %d tiles by none of 256x256, 192x128, 256x128, 96x64, 128x64", M, N);
     GnArgs P;
     P.a = (const bf16_t*)a; P.w = (const bf16_t*)w; P.c = (bf16_t*)c; P.bias = bias; P.gate = (const bf16_t*)gate;
     P.colsum = colsum_partial; P.lda = lda; P.ldw = ldw; P.ldc = ldc; P.ldg = ldg; P.M = M; P.N = N; P.K = K; P.epi = epilogue;
@@ -509,9 +517,10 @@ static int gn_run(const void* a, int64_t lda, const void* w, int64_t ldw, int w_
     hipStream_t s = (hipStream_t)stream;
     int rc = 0;
     switch (pick) {
-        case 0: rc = gn_launch<192, 128, 4, 2>(P, w_is_kn, s); break;
-        case 1: rc = gn_launch<256, 128, 4, 2>(P, w_is_kn, s); break;
-        case 2: rc = gn_launch<96, 64, 2, 2>(P, w_is_kn, s); break;
+        case 0: rc = gn_launch<256, 256, 4, 2>(P, w_is_kn, s); break;
+        case 1: rc = gn_launch<192, 128, 4, 2>(P, w_is_kn, s); break;
+        case 2: rc = gn_launch<256, 128, 4, 2>(P, w_is_kn, s); break;
+        case 3: rc = gn_launch<96, 64, 2, 2>(P, w_is_kn, s); break;
         default: rc = gn_launch<128, 64, 2, 2>(P, w_is_kn, s); break;
     }
     if (rc) return rc;

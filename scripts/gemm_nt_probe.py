@@ -80,7 +80,7 @@ def main():
               (3072, 512, 512), (3072, 1024, 512), (3072, 2048, 512), (3072, 512, 2048), (3072, 512, 1024),
               (16384, 512, 512), (16384, 2048, 512), (16384, 512, 2048)]
     ok = True
-    for m, n, k in [(192, 128, 64), (384, 256, 192), (256, 128, 128), (96, 64, 64), (128, 64, 256)] + shapes[:10]:
+    for m, n, k in [(192, 128, 64), (384, 256, 192), (256, 128, 128), (96, 64, 64), (128, 64, 256), (512, 256, 128), (256, 512, 64), (49152, 256, 192)] + shapes[:10]:
         ok &= check(m, n, k)
     if not ok:
         print("CORRECTNESS FAILED", flush=True)

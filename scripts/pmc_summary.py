@@ -30,11 +30,12 @@ def main():
     ap.add_argument("dirs", nargs="+")
     ap.add_argument("--tag", default="r01")
     ap.add_argument("--kernel", default="lsh_attn_bwd_kernel<128, true, true>")
+    ap.add_argument("--suffix", default="lsh_kernels", help="file name suffix of the per-counter CSVs")
     args = ap.parse_args()
     means = {}
     for d in args.dirs:
         for counter, kernels in summarise(d).items():
-            out = os.path.join(ROOT, "profiles", f"{args.tag}_pmc_{counter}_lsh_kernels.csv")
+            out = os.path.join(ROOT, "profiles", f"{args.tag}_pmc_{counter}_{args.suffix}.csv")
             with open(out, "w") as fh:
                 fh.write("kernel|grid,launches,mean_counter_value_KB\n")
                 for k, v in kernels.items():
@@ -49,7 +50,10 @@ def main():
                   fetch_bytes_corrected=int(fetch), write_bytes=int(write), traffic_bytes=int(fetch + write),
                   correction="gfx950: FETCH_SIZE reports half of a wide coalesced read (MI355X_MICROARCH.md, HBM) -> doubled; WRITE_SIZE exact",
                   how="two separate passes: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --output-format csv -- python3 scripts/kbench.py --only fwd,bwd --iters 3")
-        out = os.path.join(ROOT, "profiles", f"{args.tag}_pmc_lsh_attn_bwd.json")
+        out = os.path.join(ROOT, "profiles", f"{args.tag}_pmc_lsh_attn_bwd.json" if args.suffix == "lsh_kernels" else f"{args.tag}_pmc_{args.suffix}.json")
+        if args.suffix != "lsh_kernels":
+            js["shape"] = "see the kernel|grid column of the per-counter CSVs"
+            js["how"] = js["how"].replace("scripts/kbench.py --only fwd,bwd --iters 3", "scripts/gemm_nt_once.py")
         json.dump(js, open(out, "w"), indent=1)
         print("wrote", out, js["traffic_bytes"])
 

@@ -43,7 +43,7 @@ BF16_HALF_ULP = 2.0 ** -8
 @pytest.mark.parametrize("m,n,k", [(192, 128, 64), (384, 256, 192), (256, 128, 128), (96, 64, 64), (128, 64, 256),
                                    (12288, 512, 512), (12288, 1024, 512), (12288, 2048, 512), (12288, 512, 2048),
                                    (12288, 512, 1024), (3072, 1024, 512), (3072, 512, 1024), (16384, 2048, 512),
-                                   (16384, 512, 2048), (768, 384, 384)])
+                                   (16384, 512, 2048), (768, 384, 384), (512, 256, 128), (256, 512, 64), (49152, 256, 192)])
 def test_gemm_nt_layouts_and_epilogues_vs_float64(gpu, m, n, k):
     g = torch.Generator(device=gpu).manual_seed(m * 7 + n * 3 + k)
     a = torch.randn(m, k, device=gpu, generator=g).bfloat16()
