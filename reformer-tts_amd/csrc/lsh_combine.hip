@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void lsh_bwd_reduce_kernel(const bf16_t* __res
         const size_t off = (((size_t)bh * n_hashes + r) * T + t) * CB_DH + piece * 8;
         float f[8];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < RTTS_LSH_BWD_QK_SLOTS; ++s) {
             unpack8(*reinterpret_cast<const uint4*>(dqk_part + s * slot_stride + off), f);
 #pragma unroll
             for (int k = 0; k < 8; ++k) aq[k] += f[k];

@@ -148,7 +148,7 @@ def lsh_attn_bwd(qk, v, st, out, dout, lse_tot, heads: int, bucket_size: int, ca
     dev = qk.device
     delta = torch.empty(b * heads, t, dtype=torch.float32, device=dev)
     _lib.call("rtts_lsh_bwd_delta", out.data_ptr(), ld_out, dout.data_ptr(), ld_do, b, heads, t, dh, delta.data_ptr(), _stream())
-    dqk_part = torch.empty(2, b * heads, n_hashes, t, dh, dtype=torch.bfloat16, device=dev)
+    dqk_part = torch.empty(_lib.load().rtts_lsh_bwd_qk_slots(), b * heads, n_hashes, t, dh, dtype=torch.bfloat16, device=dev)
     dv_part = torch.empty(2, b * heads, n_hashes, t, dh, dtype=torch.bfloat16, device=dev)
     ev = TIMING.start(f"rtts_lsh_attn_bwd/bs{bucket_size}")
     _lib.call("rtts_lsh_attn_bwd", qk.data_ptr(), v.data_ptr(), ld, st.data_ptr(), _ptr(mask), dout.data_ptr(), ld_do,

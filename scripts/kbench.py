@@ -109,7 +109,7 @@ def main():
             res["combine"] = (us, f"{tok * (nh * 132 + 132) / us / 1e3:8.1f} GB/s alg")
         if not only or "bwd" in only:
             delta = torch.empty(b * h, t, device=dev)
-            dqk_part = torch.empty(2, b * h, nh, t, dh, dtype=torch.bfloat16, device=dev)
+            dqk_part = torch.empty(_lib.load().rtts_lsh_bwd_qk_slots(), b * h, nh, t, dh, dtype=torch.bfloat16, device=dev)
             dv_part = torch.empty(2, b * h, nh, t, dh, dtype=torch.bfloat16, device=dev)
             s = torch.cuda.current_stream().cuda_stream
             ld = qkv.stride(1)
