@@ -50,10 +50,11 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the full-recompute leg and the peak probes")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
-    ap.add_argument("--recompute", default="stash", choices=["stash", "attention-stash", "full"],
+    ap.add_argument("--recompute", default="stash", choices=["stash", "output-stash", "attention-stash", "full"],
                     help="what the reversible backward recomputes: 'full' = everything, as the reference does; "
-                         "'attention-stash' = attention outputs kept; 'stash' (default) = attention outputs and block outputs "
-                         "f(x) kept, LayerNorm and the input projections recomputed, streams reconstructed by subtraction")
+                         "'attention-stash' = attention outputs kept; 'output-stash' = block outputs f(x) kept too; 'stash' (default) = attention outputs, block outputs f(x) and "
+                         "the sublayers' projections kept (~0.3 GB of 288 GB), LayerNorm recomputed inside the stream "
+                         "reconstruction, streams reconstructed by subtraction")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 12 if args.config == "baseline" else 4
@@ -147,7 +148,8 @@ def main():
 
     from reformer_tts_amd import engine, ops
     engine.STASH_ATTENTION = args.recompute != "full"
-    engine.STASH_BLOCK_OUTPUT = args.recompute == "stash"
+    engine.STASH_BLOCK_OUTPUT = args.recompute in ("stash", "output-stash")
+    engine.STASH_PROJECTIONS = args.recompute == "stash"
     from reformer_tts_amd.model.config import (baseline_model_config, baseline_training_config,
                                                long_sequence_model_config)
     from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
@@ -236,7 +238,7 @@ def main():
     # the same step with the reference's pure recompute, in the same run (a second capture on the same trainer)
     full_ms = None
     if not args.no_extra and args.recompute != "full":
-        engine.STASH_ATTENTION = engine.STASH_BLOCK_OUTPUT = False
+        engine.STASH_ATTENTION = engine.STASH_BLOCK_OUTPUT = engine.STASH_PROJECTIONS = False
         ok = capture() if use_graph else True
         fn = trainer.replay if (use_graph and ok) else (lambda: trainer.train_step(batch))
         for _ in range(2):
@@ -245,7 +247,8 @@ def main():
         dt, _ = timed(fn, k)
         full_ms = round(1e3 * dt / k, 3)
         engine.STASH_ATTENTION = args.recompute != "full"
-        engine.STASH_BLOCK_OUTPUT = args.recompute == "stash"
+        engine.STASH_BLOCK_OUTPUT = args.recompute in ("stash", "output-stash")
+    engine.STASH_PROJECTIONS = args.recompute == "stash"
         note(f"pure recompute (reference's mode): {full_ms} ms/step")
     peaks = (None, None)
     if rank == 0 and not args.no_extra:

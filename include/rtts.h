@@ -70,10 +70,8 @@ int rtts_lsh_combine_fwd(const void* o, const float* lse, int B, int H, int T, i
  * backward needs only lse_tot and delta = rowsum(out * dout) per (token, head):
  *   rtts_lsh_bwd_delta : delta f32 (B*H,T) from out, dout (bf16, strides ld_out, ld_dout)
  *   rtts_lsh_attn_bwd  : per chunk, writes bf16 partial gradients at unsorted positions
- *        dqk_part : (rtts_lsh_bwd_qk_slots() = 3, B*H, n_hashes, T, dh)  slot 0 = the token as a row of its own
- *                   chunk (key role + query role over the own keys, added on chip), slot 1 = key role as the
- *                   looked-back chunk, slot 2 = query role over the looked-back keys (a chunk is worked by two
- *                   independent workgroups, one per key half, so that two of them share a CU)
+ *        dqk_part : (rtts_lsh_bwd_qk_slots() = 2, B*H, n_hashes, T, dh)  slot 0 = the token as a row of its own
+ *                   chunk (query role + key role, added on chip), slot 1 = key role as the looked-back chunk
  *        dv_part  : (2, B*H, n_hashes, T, dh)  slot 0 = own chunk, slot 1 = looked-back chunk
  *        every (slot, head, round, token) row is written exactly once: no zero-fill needed
  *   rtts_lsh_bwd_reduce: dqk, dv bf16 (B,T,H*dh) stride ld_d = sum over slots and rounds */

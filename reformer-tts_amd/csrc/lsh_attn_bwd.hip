@@ -515,400 +515,6 @@ __global__ __launch_bounds__(BS * 4 / AB_KT2, AB_KT2 == 2 ? 1 : 2) void lsh_attn
 }
 
 
-// ======================================================================================================================
-// HALF-CHUNK form (the product kernel; RTTS_LSH_BWD_QK_SLOTS == 3).
-//
-// The kernel above keeps one 8-wave workgroup per CU: 250 registers per wave fill the file at two waves per SIMD, and
-// both waves of a SIMD belong to the SAME workgroup, run the same program from the same barriers, and leave the matrix
-// pipe idle through the gather, the softmax arithmetic, the dQ barrier and the row stores (phase probe: 22.5 k cycles per
-// chunk of which 5.1 k are MFMA issue).  Here a chunk is split by KEY HALF into two independent 4-wave workgroups:
-//     half 0: queries of chunk c x keys of chunk c         (the "own" keys)
-//     half 1: queries of chunk c x keys of chunk c-1       (the looked-back keys)
-// Same registers per wave, half the LDS (the dS'^T image holds one PAIR of query tiles at a time and the row staging
-// reuses it), so two workgroups share a CU: the two waves of a SIMD now belong to different workgroups in different
-// phases, and one's MFMA bursts run under the other's gather / softmax / stores.  The price is one more partial row per
-// token and round: the looked-back half cannot add its dQ to anybody's dK on chip, it leaves as dqk slot 2.
-//     dqk slot 0: dK(own keys) + dQ(over own keys)      rows of chunk c      written by half 0
-//     dqk slot 1: dK(looked-back keys)                  rows of chunk c-1    written by half 1
-//     dqk slot 2: dQ(over looked-back keys)             rows of chunk c      written by half 1
-//     dv  slot 0 / 1: dV of own / looked-back keys
-template <int BS, bool CAUSAL, bool MASKED>
-__global__ __launch_bounds__(BS * 2, 2) void lsh_attn_bwd_half_kernel(
-    const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v, int64_t ld, const int32_t* __restrict__ st,
-    const uint8_t* __restrict__ mask, const bf16_t* __restrict__ dout, int64_t ld_do, const float* __restrict__ lse_tot,
-    const float* __restrict__ delta, int H, int T, int n_hashes, bf16_t* __restrict__ dqk_part, bf16_t* __restrict__ dv_part,
-    size_t slot_stride) {
-    constexpr int NQT = BS / 32;          // query tiles = key tiles = waves
-    constexpr int NW = BS / 32;
-    constexpr int NTHR = 64 * NW;
-    constexpr int NPAIR = NQT / 2;        // the dS'^T image holds two query tiles: [BS keys][64 queries]
-    constexpr int DSROW = 128;
-    constexpr int NOUT = 4 / NW;          // (query tile of the pair, dh half) outputs of the dQ product per wave
-    static_assert(NW == 2 || NW == 4, "bucket size 64 or 128");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int* kpos = reinterpret_cast<int*>(smem);                  // [2*BS] position of every image row (queries, looked-back keys)
-    float* qlse = reinterpret_cast<float*>(kpos + 2 * BS);     // lse_tot * log2(e)
-    float* qdel = qlse + BS;                                   // MINUS delta
-    int* qpe_s = reinterpret_cast<int*>(qdel + BS);            // query-side effective position (-1: an invalid query)
-    unsigned char* Ks = reinterpret_cast<unsigned char*>(qpe_s + BS);   // [2*BS][128] qk rows: queries, then (half 1) keys
-    unsigned char* Os = Ks + 2 * BS * 128;                     // [BS][128] dout rows, later the parked dQ
-    unsigned char* Ds = Os + BS * 128;                         // [BS][128] dS'^T of one query-tile pair; later [NW][32][144] staging
-    unsigned char* Stg = Ds;
-
-    const int nb = T / BS;
-    const int C = n_hashes * nb;
-    const uint32_t wi = xcd_remap(blockIdx.x, gridDim.x);
-    const int half = __builtin_amdgcn_readfirstlane(wi & 1u);
-    const uint32_t ci = wi >> 1;
-    const int bh = ci / C, c = ci % C;
-    const int b = bh / H, h = bh % H;
-    const int cprev = (c == 0) ? C - 1 : c - 1;
-    const int ck = half ? cprev : c;                           // the chunk this workgroup's keys come from
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, hh = lane >> 5;
-
-    AB_STAMP(0);
-    const int32_t* st_row = st + (size_t)bh * n_hashes * T;
-    const bf16_t* qbase = qk + (size_t)b * T * ld + (size_t)h * AB_DH;
-    const bf16_t* vbase = v + (size_t)b * T * ld + (size_t)h * AB_DH;
-    const bf16_t* dobase = dout + (size_t)b * T * ld_do + (size_t)h * AB_DH;
-
-    // ---- gather: query rows + dout rows of chunk c, key rows of chunk c-1 (half 1), all by LDS-DMA ----------------------
-    constexpr int ITERS = BS * 8 / NTHR;   // 4: one pass fills BS/4 rows
-    int trow[ITERS], krow[ITERS];
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        const int row = (it * NTHR + tid) >> 3;
-        trow[it] = st_row[c * BS + row];
-        krow[it] = half ? st_row[cprev * BS + row] : 0;
-    }
-    const int myrow = wave * 32 + r;                            // this lane's key inside the key half
-    const int mypos = st_row[ck * BS + myrow];
-#ifdef AB_PHASE_TIMING
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the positions are here
-    AB_STAMP(10);
-#endif
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        const int rowb = it * (NTHR / 8) + wave * 8;            // wave-uniform: first row of this instruction
-        const int lp = (lane & 7) ^ ab_sw(rowb + (lane >> 3));
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qbase + (size_t)trow[it] * ld + lp * 8),
-                                         (RTTS_LDS void*)(Ks + rowb * 128), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dobase + (size_t)trow[it] * ld_do + lp * 8),
-                                         (RTTS_LDS void*)(Os + rowb * 128), 16, 0, 0);
-        if (half)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qbase + (size_t)krow[it] * ld + lp * 8),
-                                             (RTTS_LDS void*)(Ks + (BS + rowb) * 128), 16, 0, 0);
-    }
-    int rvalid[ITERS];
-    float rlse[ITERS], rdel[ITERS];
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        rvalid[it] = MASKED ? (int)mask[(size_t)b * T + trow[it]] : 1;
-        rlse[it] = lse_tot[(size_t)bh * T + trow[it]];
-        rdel[it] = delta[(size_t)bh * T + trow[it]];
-    }
-    const int myvalid = MASKED ? (int)mask[(size_t)b * T + mypos] : 1;
-    bf16x8 vf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) vf[ks] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)mypos * ld + ks * 16 + 8 * hh);
-#ifdef AB_PHASE_TIMING
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    AB_STAMP(11);
-#endif
-    // query-side words: lane `piece` of a row's eight lanes stores one word (0 position, 1 lse*log2e, 2 -delta,
-    // 3 effective position)
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        const int row = (it * NTHR + tid) >> 3, piece = tid & 7;
-        const int eff = CAUSAL ? trow[it] : 0;
-        int w = trow[it];
-        w = piece == 1 ? __float_as_int(rlse[it] * 1.4426950408889634f) : w;
-        w = piece == 2 ? __float_as_int(-rdel[it]) : w;
-        w = piece == 3 ? (rvalid[it] ? eff : -1) : w;             // an invalid query sees nothing but itself
-        int* dstw = piece == 0 ? kpos : piece == 1 ? reinterpret_cast<int*>(qlse) : piece == 2 ? reinterpret_cast<int*>(qdel) : qpe_s;
-        if (piece < 4) dstw[row] = w;
-    }
-    if (half && hh == 0) kpos[BS + myrow] = mypos;                // looked-back rows: only this wave reads them back
-    AB_STAMP(1);
-    __syncthreads();
-    AB_STAMP(2);
-
-    const unsigned char* Kk = Ks + (half ? BS * 128 : 0);         // key image: the query rows themselves for half 0
-    int fro[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) fro[ks] = ab_off(r, ks * 2 + hh);
-    bf16x8 kf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(Kk + wave * (32 * 128) + fro[ks]);
-    float ss = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const uint4 u4 = __builtin_bit_cast(uint4, kf[ks]);
-        const uint32_t u[4] = {u4.x, u4.y, u4.z, u4.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float a = __uint_as_float(u[k] << 16), bq = __uint_as_float(u[k] & 0xffff0000u);
-            ss = __builtin_fmaf(a, a, ss);
-            ss = __builtin_fmaf(bq, bq, ss);
-        }
-    }
-    ss = rtts_xhalf_sum(ss);
-    const float ksc = 0.125f * __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));   // dh^-1/2 / max(|k|, 1e-12)
-    const int kpk = myvalid ? (CAUSAL ? mypos : 0) : 0x40000000;
-
-    f32x16 dvacc[2], gacc[2];   // [dh tile]: rows = dh, lane = key
-#pragma unroll
-    for (int d = 0; d < 2; ++d) {
-        dvacc[d] = (f32x16){0};
-        gacc[d] = (f32x16){0};
-    }
-    const int trq = (lane & 15) >> 2, trp = lane & 3, trc = (lane >> 4) & 1;
-    int tro[2];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) tro[dt] = ab_off(4 * hh + trq, dt * 4 + 2 * trc + (trp >> 1)) + 8 * (trp & 1);
-    int dso[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) dso[g] = ab_ds_off<64>(myrow, 2 * g + hh);
-    const bool wrap = (cprev / nb) != (c / nb);
-    // dQ product: lane constants (see the kernel above)
-    const int rl = 8 * hh + trq;
-    int ko0[NOUT], ko1[NOUT];
-#pragma unroll
-    for (int di = 0; di < NOUT; ++di) {
-        const int dt = (NOUT == 2) ? di : (wave & 1);
-        const int kpc = dt * 4 + 2 * trc + (trp >> 1);
-        ko0[di] = ab_off(rl, kpc) + 8 * (trp & 1);
-        ko1[di] = ab_off(rl + 4, kpc) + 8 * (trp & 1);
-    }
-    const int q2w = (NOUT == 2) ? wave : (wave >> 1);             // query tile of the pair this wave finishes
-    const int gq = q2w * 8 + 4 * trc + trp;
-    const int do0 = ab_ds_off<64>(rl, gq), do1 = ab_ds_off<64>(rl + 4, gq);
-
-#pragma unroll
-    for (int pp = 0; pp < NPAIR; ++pp) {
-#pragma unroll
-        for (int q2 = 0; q2 < 2; ++q2) {
-            const int qt = 2 * pp + q2;
-            f32x16 pinit;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 d4 = *reinterpret_cast<const float4*>(qdel + qt * 32 + 8 * g + 4 * hh);
-                pinit[4 * g] = d4.x;
-                pinit[4 * g + 1] = d4.y;
-                pinit[4 * g + 2] = d4.z;
-                pinit[4 * g + 3] = d4.w;
-            }
-            bf16x8 qf[4], dof[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                qf[ks] = *reinterpret_cast<const bf16x8*>(Ks + qt * (32 * 128) + fro[ks]);
-                dof[ks] = *reinterpret_cast<const bf16x8*>(Os + qt * (32 * 128) + fro[ks]);
-            }
-            float4 l4[4];
-            int4 e4[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int q0 = qt * 32 + 8 * g + 4 * hh;
-                l4[g] = *reinterpret_cast<const float4*>(qlse + q0);
-                e4[g] = *reinterpret_cast<const int4*>(qpe_s + q0);
-            }
-            // Can a key of this tile BE one of this tile's queries (the self logit)?  Own keys: only on the diagonal tile.
-            // Looked-back keys: only when the previous chunk belongs to another hash round.
-            const bool chk_self = half ? wrap : (wave == qt);
-            f32x16 sacc = {0}, pacc = pinit;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[ks], sacc, 0, 0, 0);    // S[q][key]
-                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof[ks], vf[ks], pacc, 0, 0, 0);   // dP[q][key] - delta[q]
-            }
-            float pp_[16], ds[16];
-            const float ksc2 = ksc * 1.4426950408889634f;
-            if (chk_self) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float lv[4] = {l4[g].x, l4[g].y, l4[g].z, l4[g].w};
-                    const int4 p4 = *reinterpret_cast<const int4*>(kpos + qt * 32 + 8 * g + 4 * hh);
-                    const int pv[4] = {p4.x, p4.y, p4.z, p4.w}, ev[4] = {e4[g].x, e4[g].y, e4[g].z, e4[g].w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int i = 4 * g + j;
-                        const bool self = pv[j] == mypos;
-                        const bool dead = kpk > ev[j];
-                        float x = sacc[i] * ksc2;
-                        x = self ? (-5e4f * 1.4426950408889634f) : x;
-                        float p = __builtin_amdgcn_exp2f(x - lv[j]);
-                        p = (dead && !self) ? 0.f : p;
-                        pp_[i] = p;
-                        ds[i] = self ? 0.f : p * pacc[i] * ksc;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float lv[4] = {l4[g].x, l4[g].y, l4[g].z, l4[g].w};
-                    const int ev[4] = {e4[g].x, e4[g].y, e4[g].z, e4[g].w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int i = 4 * g + j;
-                        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[i], ksc2, -lv[j]));
-                        p = (kpk > ev[j]) ? 0.f : p;
-                        pp_[i] = p;
-                        ds[i] = p * pacc[i] * ksc;
-                    }
-                }
-            }
-            bf16x8 qtf[2][2], dotf[2][2];   // [s2][dh tile], read late: their registers are free during the arithmetic above
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const int blk = (qt * 32 + 16 * s2) * 128;
-                    qtf[s2][dt] = tr_frag(Ks + blk + tro[dt], Ks + blk + 8 * 128 + tro[dt ^ 1]);
-                    dotf[s2][dt] = tr_frag(Os + blk + tro[dt], Os + blk + 8 * 128 + tro[dt ^ 1]);
-                }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const float* pq = pp_ + 8 * s2;
-                const float* dq_ = ds + 8 * s2;
-                const bf16x8 pb = cvt_bf16x8(pq[0], pq[1], pq[2], pq[3], pq[4], pq[5], pq[6], pq[7]);
-                const bf16x8 db = cvt_bf16x8(dq_[0], dq_[1], dq_[2], dq_[3], dq_[4], dq_[5], dq_[6], dq_[7]);
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[s2][dt], pb, dvacc[dt], 0, 0, 0);
-                    gacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[s2][dt], db, gacc[dt], 0, 0, 0);
-                }
-            }
-            const int dsq = q2 << 6;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 pk;
-                pk.x = pack_bf16x2(ds[4 * g], ds[4 * g + 1]);
-                pk.y = pack_bf16x2(ds[4 * g + 2], ds[4 * g + 3]);
-                *reinterpret_cast<uint2*>(Ds + (dso[g] ^ dsq)) = pk;
-            }
-        }
-        AB_STAMP(pp ? 12 : 3);
-        __syncthreads();   // the pair's dS'^T tiles are in Ds; nobody reads the pair's dout rows any more
-        AB_STAMP(pp ? 13 : 4);
-        // ---- dQ^T[dh][q] = K^T dS'^T over this half's BS keys, parked (bf16) in the dout image's rows of the pair
-        {
-            f32x16 dq[NOUT];
-#pragma unroll
-            for (int di = 0; di < NOUT; ++di) dq[di] = (f32x16){0};
-#pragma unroll
-            for (int kb = 0; kb < BS; kb += 16) {
-                const bf16x8 bfrag = tr_frag(Ds + kb * DSROW + do0, Ds + kb * DSROW + do1);
-#pragma unroll
-                for (int di = 0; di < NOUT; ++di) {
-                    const bf16x8 afrag = tr_frag(Kk + kb * 128 + ko0[di], Kk + kb * 128 + ko1[di]);
-                    dq[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, dq[di], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int di = 0; di < NOUT; ++di) {
-                const int dt = (NOUT == 2) ? di : (wave & 1);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    uint2 pk;
-                    pk.x = pack_bf16x2(dq[di][4 * g], dq[di][4 * g + 1]);
-                    pk.y = pack_bf16x2(dq[di][4 * g + 2], dq[di][4 * g + 3]);
-                    *reinterpret_cast<uint2*>(Os + ab_off((2 * pp + q2w) * 32 + r, dt * 4 + g) + 8 * hh) = pk;
-                }
-            }
-        }
-        AB_STAMP(pp ? 14 : 5);
-        __syncthreads();   // Ds is free for the next pair (or the staging); the parked dQ is visible
-        AB_STAMP(pp ? 15 : 6);
-    }
-
-    // ---- row stores: a key per lane and dh down the registers -> [32][144 B] staging per wave -> full 128-byte rows
-    const int round = c / nb, round_k = ck / nb;
-    const size_t obase = ((size_t)bh * n_hashes + round_k) * T;
-    const int srow = lane >> 3, spiece = lane & 7;
-    unsigned char* stg = Stg + wave * (32 * AB_ROWB);
-    int rpos[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) rpos[i] = kpos[(half ? BS : 0) + wave * 32 + i * 8 + srow];
-    {
-        bf16_t* dvdst = dv_part + (half ? slot_stride : 0);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 pk;
-                pk.x = pack_bf16x2(dvacc[dt][4 * g], dvacc[dt][4 * g + 1]);
-                pk.y = pack_bf16x2(dvacc[dt][4 * g + 2], dvacc[dt][4 * g + 3]);
-                *reinterpret_cast<uint2*>(stg + r * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2) = pk;
-            }
-        __builtin_amdgcn_wave_barrier();
-        uint4 rowv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rowv[i] = *reinterpret_cast<const uint4*>(stg + (i * 8 + srow) * AB_ROWB + spiece * 16);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dvdst + (obase + rpos[i]) * AB_DH + spiece * 8) = rowv[i];
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (half) {   // dQ over the looked-back keys: rows of chunk c, straight from the parked image
-        const size_t qbase_o = ((size_t)bh * n_hashes + round) * T;
-        bf16_t* dqdst = dqk_part + 2 * slot_stride;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = wave * 32 + i * 8 + srow;
-            const uint4 val = *reinterpret_cast<const uint4*>(Os + ab_off(row, spiece));
-            *reinterpret_cast<uint4*>(dqdst + (qbase_o + kpos[row]) * AB_DH + spiece * 8) = val;
-        }
-    }
-    {
-        bf16_t* dkdst = dqk_part + (half ? slot_stride : 0);
-        // dK = G - k^ (k^ . G) with k^ = k / |k| = k * (8 ksc)
-        float kraw[2][16];
-        float dot = 0.f;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const uint2 kk = *reinterpret_cast<const uint2*>(Kk + ab_off(myrow, dt * 4 + g) + 8 * hh);
-                kraw[dt][4 * g] = __uint_as_float(kk.x << 16);
-                kraw[dt][4 * g + 1] = __uint_as_float(kk.x & 0xffff0000u);
-                kraw[dt][4 * g + 2] = __uint_as_float(kk.y << 16);
-                kraw[dt][4 * g + 3] = __uint_as_float(kk.y & 0xffff0000u);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dot = __builtin_fmaf(kraw[dt][4 * g + j], gacc[dt][4 * g + j], dot);
-            }
-        const float ncoef = -rtts_xhalf_sum(dot) * (ksc * 8.f) * (ksc * 8.f);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float dk[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dk[j] = __builtin_fmaf(kraw[dt][4 * g + j], ncoef, gacc[dt][4 * g + j]);
-                if (!half) {
-                    const uint2 dqv = *reinterpret_cast<const uint2*>(Os + ab_off(myrow, dt * 4 + g) + 8 * hh);
-                    dk[0] += __uint_as_float(dqv.x << 16);
-                    dk[1] += __uint_as_float(dqv.x & 0xffff0000u);
-                    dk[2] += __uint_as_float(dqv.y << 16);
-                    dk[3] += __uint_as_float(dqv.y & 0xffff0000u);
-                }
-                uint2 pk;
-                pk.x = pack_bf16x2(dk[0], dk[1]);
-                pk.y = pack_bf16x2(dk[2], dk[3]);
-                *reinterpret_cast<uint2*>(stg + r * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2) = pk;
-            }
-        __builtin_amdgcn_wave_barrier();
-        uint4 rowv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rowv[i] = *reinterpret_cast<const uint4*>(stg + (i * 8 + srow) * AB_ROWB + spiece * 16);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dkdst + (obase + rpos[i]) * AB_DH + spiece * 8) = rowv[i];
-    }
-    AB_STAMP(8);
-#ifdef AB_PHASE_TIMING
-    __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): the row stores have been acknowledged
-    AB_STAMP(9);
-#endif
-}
 
 extern "C" int rtts_lsh_bwd_qk_slots(void) { return RTTS_LSH_BWD_QK_SLOTS; }
 
@@ -916,25 +522,15 @@ template <int BS>
 static int launch_attn_bwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const int32_t* st, const uint8_t* mask,
                            const bf16_t* dout, int64_t ld_do, const float* lse_tot, const float* delta, int B, int H, int T,
                            int n_hashes, int causal, bf16_t* dqk_part, bf16_t* dv_part, hipStream_t stream) {
-#if RTTS_LSH_BWD_QK_SLOTS == 3
-    static const size_t lds_pad = getenv("RTTS_AB_LDS_PAD") ? (size_t)atoi(getenv("RTTS_AB_LDS_PAD")) : 0;   // occupancy experiments
-    const size_t lds = (size_t)BS * (5 * 4 + 2 * 128 + 128 + AB_ROWB) + lds_pad;
-    const dim3 grid(2 * B * H * n_hashes * (T / BS)), block(BS * 2);
-#else
     constexpr int NK = 2 * BS;
     const size_t lds = NK * 128 + BS * 128 + NK * (BS * 2) + (NK / 32) * 32 * AB_ROWB + NK * 12 + BS * 12;
     const dim3 grid(B * H * n_hashes * (T / BS)), block(BS * 4 / AB_KT2);
-#endif
     const size_t slot_stride = (size_t)B * H * n_hashes * T * AB_DH;
     const int vi = (causal ? 2 : 0) + (mask ? 1 : 0);
     static bool attr[64][4] = {};                // per device: the dynamic-LDS limit is an attribute of the loaded function
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-#if RTTS_LSH_BWD_QK_SLOTS == 3
-#define AB_KERN(C_, M_) lsh_attn_bwd_half_kernel<BS, C_, M_>
-#else
 #define AB_KERN(C_, M_) lsh_attn_bwd_kernel<BS, C_, M_>
-#endif
 #define AB_GO(C_, M_)                                                                                                      \
     do {                                                                                                                   \
         auto kern = AB_KERN(C_, M_);                                                                                       \

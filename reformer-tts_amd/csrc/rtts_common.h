@@ -77,11 +77,9 @@ __device__ __forceinline__ float rtts_xhalf_max(float x) {
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-// Partial-gradient slots of the LSH attention backward (lsh_attn_bwd.hip writes them, lsh_combine.hip's reduce sums
-// them): 3 = half-chunk workgroups (dqk: own rows, looked-back key rows, looked-back query rows), 2 = one workgroup per chunk.
-#ifndef RTTS_LSH_BWD_QK_SLOTS
-#define RTTS_LSH_BWD_QK_SLOTS 3
-#endif
+// Partial-gradient slots of the LSH attention backward (lsh_attn_bwd.hip writes them, lsh_combine.hip's reduce sums them;
+// callers size dqk_part by rtts_lsh_bwd_qk_slots()).
+#define RTTS_LSH_BWD_QK_SLOTS 2
 
 // XCD-aware bijective remap of a linear workgroup id: the hardware deals workgroups
 // round-robin over the 8 XCDs, so ids congruent mod 8 share an L2.  Give each XCD a

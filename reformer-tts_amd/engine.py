@@ -36,6 +36,10 @@ STASH_ATTENTION = True
 # the backward skips the output-projection / second FFN GEMM of the recompute (38.6 of 87 GFLOP per decoder layer).
 # What is still recomputed: LayerNorm, the QKV / q, kv / first FFN projections (their outputs are backward operands).
 STASH_BLOCK_OUTPUT = True
+# Keep the projections of a sublayer's forward (LSH: qk|v; cross attention: q and k|v; feed-forward: the hidden activation) for its
+# backward instead of recomputing them from the reconstructed input: ~0.3 GB at the baseline shapes against 288 GB of HBM,
+# and the backward then has no forward GEMM left in it.  Off = the reference's memory behaviour (everything recomputed).
+STASH_PROJECTIONS = True
 WEIGHT_EPOCH = [0]   # bumped by the trainer after every optimizer step (its kernels write parameters through raw pointers)
 
 
@@ -351,7 +355,7 @@ class LSHExec:
         # What a forward leaves for ITS backward lives in a per-call slot (a dict owned by FusedStackFn's ctx), never on the
         # executor: a second forward before the first backward (two losses, an eval forward in between, two models sharing
         # layers) must not hand the first backward the second forward's permutation / stash / dropout seed.  Keys:
-        #   st (sort permutation), stash ((out, lse_tot) when STASH_ATTENTION), g (f(x) when STASH_BLOCK_OUTPUT),
+        #   st (sort permutation), stash ((out, lse_tot) when STASH_ATTENTION), g (f(x) when STASH_BLOCK_OUTPUT), qkv (STASH_PROJECTIONS),
         #   drop ((p, seed) of the post-attention dropout)
         self._own_slot = {}   # direct use of one executor outside a stack (tests)
 
@@ -373,14 +377,15 @@ class LSHExec:
             return torch.as_strided(ga, (2 * ga.shape[0], ga.shape[1]), (ga.shape[1], 1)), None
         return None, (ga, gb)
 
-    def _internals(self, inp, b, t, mask, st, stash=None, g=None, pre=None):
+    def _internals(self, inp, b, t, mask, st, stash=None, g=None, pre=None, qkv=None):
         lyr = self.layer
         e = lyr.dim
         if t <= lyr.full_attn_thres:
             raise NotImplementedError("full-attention shortcut (T <= full_attn_thres) is outside the HIP path")
         xn, mean, rstd = pre if pre is not None else ln_fwd(inp, self.norm)
         wqkv = self._wqkv()
-        qkv = gemm(xn, wqkv).view(b, t, 2 * e)
+        if qkv is None:
+            qkv = gemm(xn, wqkv).view(b, t, 2 * e)
         if st is None:
             rot = lyr._rotations(qkv, t // lyr.bucket_size)
             st, _, _ = ops.lsh_hash_sort(qkv[..., :e], rot, lyr.heads, lyr.bucket_size)
@@ -396,11 +401,11 @@ class LSHExec:
 
     def forward(self, acc, inp, b, t, mask=None, pre=None, next_norm=None, slot=None, **_):
         slot = self._own_slot if slot is None else slot
-        *_, st, out, lse_tot, g = self._internals(inp, b, t, mask, None, pre=pre)
+        *_, qkv, st, out, lse_tot, g = self._internals(inp, b, t, mask, None, pre=pre)
         p = self.layer.post_attn_dropout.p if self.layer.training else 0.0
         slot.clear()
         slot.update(st=st, stash=(out, lse_tot) if STASH_ATTENTION else None, g=g if STASH_BLOCK_OUTPUT else None,
-                    drop=(p, next_seed()) if p > 0.0 else None)
+                    qkv=qkv if STASH_PROJECTIONS else None, drop=(p, next_seed()) if p > 0.0 else None)
         return residual(acc, g, self.layer.to_out.bias, 1.0, next_norm, slot["drop"])
 
     def backward(self, acc, inp, d_acc, d_inp, b, t, mask=None, pre=None, next_norm=None, pre_cast=None, next_cast=None, slot=None, **_):
@@ -409,7 +414,8 @@ class LSHExec:
             raise RuntimeError("LSHExec.backward: no forward state for this call (backward run twice, or without its forward)")
         lyr = self.layer
         e = lyr.dim
-        xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g = self._internals(inp, b, t, mask, slot["st"], slot["stash"], slot["g"], pre)
+        xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g = self._internals(inp, b, t, mask, slot["st"], slot["stash"], slot["g"], pre,
+                                                                         slot["qkv"])
         drop = slot["drop"]
         slot.clear()
         post = residual(acc, g, lyr.to_out.bias, -1.0, next_norm, drop)       # reconstruct the stream (same dropout mask)
@@ -447,26 +453,26 @@ class FFNExec:
         wn = mod.fn if hasattr(mod, "chunks") else mod
         return wn.fn.net[2].p == 0.0
 
-    def _internals(self, inp, g=None, pre=None):
+    def _internals(self, inp, g=None, pre=None, h=None):
         xn, mean, rstd = pre if pre is not None else ln_fwd(inp, self.norm)
-        # bias + ReLU ride in the GEMM's epilogue (fp32 accumulate and fp32 bias, one rounding to bf16)
-        h = gemm(xn, _bf16(self.l1.weight), bias=self.l1.bias, relu=True)
+        if h is None:   # bias + ReLU ride in the GEMM's epilogue (fp32 accumulate and fp32 bias, one rounding to bf16)
+            h = gemm(xn, _bf16(self.l1.weight), bias=self.l1.bias, relu=True)
         if g is None:
             g = gemm(h, _bf16(self.l2.weight))
         return xn, mean, rstd, h, g
 
     def forward(self, acc, inp, b, t, pre=None, next_norm=None, slot=None, **_):
         slot = self._own_slot if slot is None else slot
-        *_, g = self._internals(inp, pre=pre)
+        *_, h, g = self._internals(inp, pre=pre)
         slot.clear()
-        slot.update(g=g if STASH_BLOCK_OUTPUT else None)
+        slot.update(g=g if STASH_BLOCK_OUTPUT else None, h=h if STASH_PROJECTIONS else None)
         return residual(acc, g, self.l2.bias, 1.0, next_norm)
 
     def backward(self, acc, inp, d_acc, d_inp, b, t, pre=None, next_norm=None, pre_cast=None, next_cast=None, slot=None, **_):
         slot = self._own_slot if slot is None else slot
         if "g" not in slot:
             raise RuntimeError("FFNExec.backward: no forward state for this call (backward run twice, or without its forward)")
-        xn, mean, rstd, h, g = self._internals(inp, slot["g"], pre)
+        xn, mean, rstd, h, g = self._internals(inp, slot["g"], pre, slot["h"])
         slot.clear()
         post = residual(acc, g, self.l2.bias, -1.0, next_norm)
         dyb = _out_grad(d_acc, _grad(self.l2.bias), None, pre_cast)
@@ -492,14 +498,13 @@ class XAttnExec:
         m = withnorm.fn.layer      # dropout on the attention probabilities runs inside the kernels (counter-hash mask)
         return m.bias_k is None and not m.add_zero_attn and m._qkv_same_embed_dim
 
-    def _internals(self, inp, b, t, keys_bf16, kvalid, stash=None, g=None, pre=None, drop=None):
+    def _internals(self, inp, b, t, keys_bf16, kvalid, stash=None, g=None, pre=None, drop=None, proj=None):
         m = self.mha
         e, h = m.embed_dim, m.num_heads
         tk = keys_bf16.shape[0] // b
         w, bias = _bf16(m.in_proj_weight), m.in_proj_bias
         xn, mean, rstd = pre if pre is not None else ln_fwd(inp, self.norm)
-        q = gemm(xn, w[:e], bias=bias[:e])
-        kv = gemm(keys_bf16, w[e:], bias=bias[e:])
+        q, kv = proj if proj is not None else (gemm(xn, w[:e], bias=bias[:e]), gemm(keys_bf16, w[e:], bias=bias[e:]))
         if stash is not None:
             o, lse = stash
         else:
@@ -516,9 +521,10 @@ class XAttnExec:
         slot = self._own_slot if slot is None else slot
         p = self.mha.dropout if self.mha.training else 0.0
         pdrop = (p, next_seed()) if p > 0.0 else None
-        *_, o, lse, g, _ = self._internals(inp, b, t, keys_bf16, kvalid, pre=pre, drop=pdrop)
+        *_, q, kv, o, lse, g, _ = self._internals(inp, b, t, keys_bf16, kvalid, pre=pre, drop=pdrop)
         slot.clear()
-        slot.update(stash=(o, lse) if STASH_ATTENTION else None, g=g if STASH_BLOCK_OUTPUT else None, pdrop=pdrop)
+        slot.update(stash=(o, lse) if STASH_ATTENTION else None, g=g if STASH_BLOCK_OUTPUT else None, pdrop=pdrop,
+                    proj=(q, kv) if STASH_PROJECTIONS else None)
         return residual(acc, g, self.mha.out_proj.bias, 1.0, next_norm)
 
     def backward(self, acc, inp, d_acc, d_inp, b, t, keys_bf16=None, kvalid=None, dkeys=None, pre=None, next_norm=None,
@@ -529,7 +535,8 @@ class XAttnExec:
         m = self.mha
         e, h = m.embed_dim, m.num_heads
         drop = slot["pdrop"]
-        xn, mean, rstd, w, q, kv, o, lse, g, tk = self._internals(inp, b, t, keys_bf16, kvalid, slot["stash"], slot["g"], pre, drop)
+        xn, mean, rstd, w, q, kv, o, lse, g, tk = self._internals(inp, b, t, keys_bf16, kvalid, slot["stash"], slot["g"], pre, drop,
+                                                                  slot["proj"])
         slot.clear()
         post = residual(acc, g, m.out_proj.bias, -1.0, next_norm)
         dyb = _out_grad(d_acc, _grad(m.out_proj.bias), None, pre_cast)

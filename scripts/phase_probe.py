@@ -129,20 +129,23 @@ def main():
     buf = np.zeros(32 * 8192, dtype=np.uint64)
     rc = lib.rtts_debug_ab_phases(buf.ctypes.data)
     assert rc == 0, rc
-    allp = buf.reshape(8192, 32).astype(np.int64)
-    allp = allp[allp[:, 0] > 0]            # the first 8192 workgroups (two per chunk, one per key half) that ran
-    order = [0, 10, 11, 1, 2, 3, 4, 5, 6, 12, 13, 14, 15, 8, 9]
-    names = ["positions arrive", "rows arrive", "query words written", "wait barrier 1", "key consts + pair 0 main loop",
-             "wait barrier (dS of pair 0)", "dQ of pair 0 + park", "wait barrier", "pair 1 main loop", "wait barrier (dS of pair 1)",
-             "dQ of pair 1 + park", "wait barrier", "row stores issued", "stores acknowledged"]
-    ph = allp[:, order]
+    allp = buf.reshape(8192, 32)[: b * h * nh * (t // bs)].astype(np.int64)
+    ph = allp[:, :10]
     d = np.diff(ph, axis=1)
-    tot = ph[:, -1] - ph[:, 0]
-    print(f"workgroups sampled {len(ph)}; total per WG: median {np.median(tot):.0f} mean {tot.mean():.0f} cycles (s_memtime ticks)")
+    names = ["gather + LDS image", "wait barrier 1", "key consts + main loop", "dV rows staged + stores issued", "wait barrier 2",
+             "dQ phase + park", "wait barrier 3", "dK epilogue + stores issued", "stores acknowledged"]
+    tot = ph[:, 9] - ph[:, 0]
+    print(f"workgroups {len(ph)}; total per WG: median {np.median(tot):.0f} mean {tot.mean():.0f} cycles (s_memtime ticks)")
     for i, nm in enumerate(names):
         print(f"  {nm:34s} median {np.median(d[:, i]):8.0f}  mean {d[:, i].mean():8.0f}  p10 {np.percentile(d[:, i], 10):8.0f}  p90 {np.percentile(d[:, i], 90):8.0f}")
-    span = ph[:, -1].max() - ph[:, 0].min()
-    print(f"  first start -> last end of the sampled workgroups: {span} ticks; sum of WG totals / 256 CUs: {tot.sum() / 256:.0f}")
+    print(f"  inside the gather (wave 0): positions arrive {np.median(allp[:, 10] - ph[:, 0]):.0f} | rows arrive +{np.median(allp[:, 11] - allp[:, 10]):.0f}"
+          f" | LDS image written +{np.median(ph[:, 1] - allp[:, 11]):.0f}")
+    nw = bs * 4 // 64
+    print("  per wave, cycles after barrier 1:  main loop done | dV rows out (arrival at barrier 2)")
+    for w in range(nw):
+        print(f"    wave {w}: {np.median(allp[:, 16 + w] - ph[:, 2]):8.0f} | {np.median(allp[:, 24 + w] - ph[:, 2]):8.0f}")
+    span = ph[:, 9].max() - ph[:, 0].min()
+    print(f"  first start -> last end: {span} ticks; sum of WG totals / 256 CUs: {tot.sum() / 256:.0f}")
 
 
 if __name__ == "__main__":
