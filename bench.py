@@ -248,7 +248,7 @@ def main():
         full_ms = round(1e3 * dt / k, 3)
         engine.STASH_ATTENTION = args.recompute != "full"
         engine.STASH_BLOCK_OUTPUT = args.recompute in ("stash", "output-stash")
-    engine.STASH_PROJECTIONS = args.recompute == "stash"
+        engine.STASH_PROJECTIONS = args.recompute == "stash"
         note(f"pure recompute (reference's mode): {full_ms} ms/step")
     peaks = (None, None)
     if rank == 0 and not args.no_extra:
