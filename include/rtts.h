@@ -128,18 +128,21 @@ int rtts_ln_bwd(const void* dxn, const float* x, const float* mean, const float*
 /* dyb_next (may be NULL): bf16 copy of the completed dx_io, times the keep-scale of (drop_p, seed) -- the next block's
  * rtts_cast_colsum folded in; partial_next then receives that copy's partial column sums (same layout as partial_ws). */
 int rtts_cast_colsum(const float* dy, void* dyb, float* dbias, float* partial_ws, int M, int d, float drop_p, uint32_t seed,
-                     const uint32_t* seed_dev, void* stream);
+                     const uint32_t* seed_dev, const float* scale_dev, void* stream);
+/* scale_dev (may be NULL): one device float multiplied into dy first -- the upstream gradient of a scalar loss, so that the
+ * root of a backward needs no separate scaling pass.  gated_out (may be NULL = in place): where the gated dh goes. */
 int rtts_colsum_bf16(void* dh, const void* h, int64_t ld, float* dbias, float* partial_ws, int M, int d,
-                     int relu_gate, float gate_scale, void* stream);
+                     int relu_gate, float gate_scale, void* gated_out, void* stream);
 /* Deferred finalisation of the column sums: rtts_ln_bwd (dgamma = dbeta = NULL), rtts_cast_colsum / rtts_colsum_bf16
  * (dbias = NULL) then only write their partial rows -- rtts_colsum_partial_rows(M) rows of d floats; rtts_ln_bwd writes two
  * such blocks, the second 256*d floats after the first -- and ONE grouped launch adds the sums of up to
  * RTTS_COLSUM_MAX_GROUP partial buffers into their outputs (same fixed summation order: deterministic). */
 #define RTTS_COLSUM_MAX_GROUP 48
 typedef struct {
-    const float* partial;   /* (nrows, n) fp32 */
+    const float* partial;   /* (nrows, n) fp32, row stride ld */
     float* out;             /* (n): += column sums */
     int32_t nrows, n;
+    int32_t ld, reserved;   /* ld = 0: n (a block of columns of a wider partial buffer: ld = its width) */
 } rtts_colsum_job;
 int rtts_colsum_partial_rows(int M);
 int rtts_colsum_final_grouped(const rtts_colsum_job* jobs, int n, void* stream);
@@ -151,6 +154,8 @@ int rtts_residual_epilogue(const float* x, const void* g, const float* bias, flo
 int rtts_residual_ln(float* x, const void* g, const float* bias, float sign, const float* gamma, const float* beta,
                      void* xn, float* mean, float* rstd, int M, int d, float drop_p, uint32_t seed, const uint32_t* seed_dev,
                      void* stream);
+/* out = a + b (the two streams of a reversible stack); out (fp32) and / or out_bf16 may be NULL; n % 4 == 0 */
+int rtts_sum_streams(const float* a, const float* b, int64_t n, float* out, void* out_bf16, void* stream);
 int rtts_bias_act(void* h, const float* bias, int64_t M, int d, int relu, void* stream);
 int rtts_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 
@@ -214,8 +219,9 @@ int rtts_sum_slabs(const void* part, int nslabs, int64_t n, void* out, void* str
  * partial_ws: >= (2*256 + 2)*C floats (bn) / 1536 floats (loss). */
 int rtts_conv1d_k5(const void* x, int64_t ldx, const void* wp, int64_t ldw, int transposed, int M, int C_out, int C_in,
                    void* y, int64_t ldy, const float* bias, int out_f32, void* stream);
-int rtts_to_halo(const void* src, int64_t ld_src, int C_src, int src_f32, int B, int L, int halo, int C, void* dst, int lead,
-                 int64_t rows, void* stream);
+int rtts_to_halo(const void* src, int64_t ld_src, int64_t src_batch_stride, int C_src, int src_f32, int B, int L, int halo, int C,
+                 void* dst, int lead, int64_t rows, void* stream);
+/* src_batch_stride: elements between two samples of src (0 = L * ld_src; larger for a time-sliced view such as frames [0, L-1)) */
 int rtts_conv_w_perm(const float* w, int Co, int Ci, int CP, void* wp, void* stream);
 int rtts_conv_dw_unperm(const float* dwp, int Co, int Ci, int CP, float* dw, void* stream);
 /* All convolution weights of a step re-laid-out in ONE launch (they only change in the optimizer step, and a launch costs
@@ -242,9 +248,23 @@ int rtts_tts_loss(const float* raw, const float* post, int64_t ld_mel, const flo
                   int64_t ld_stop, const float* tstop, int rows, int NM, int kind, float pos_weight, float w_raw, float w_post,
                   float w_stop, float* d_raw, float* d_post, int64_t ld_grad, float* d_stop, float* losses, float* partial_ws,
                   int padded_len, int valid_len, const float* res, int64_t ld_res, int halo, int dpost_lead, int64_t dpost_rows,
-                  void* stream);
+                  int64_t tgt_batch_stride, void* stream);
+/* tgt_batch_stride: elements between two samples of tgt (0 = valid_len * NM; larger for the view frames [1, L) of the batch).
+ * rtts_heads_grad scale_dev (may be NULL): the upstream gradient of the total loss, multiplied into d_raw, d_post, d_stop. */
 int rtts_heads_grad(const float* d_raw, const float* d_post, int dpost_lead, const float* dx0, int64_t ld_dx0, const float* d_stop,
-                    int B, int L, int halo, int n_mels, int width, float* dheads, void* stream);
+                    int B, int L, int halo, int n_mels, int width, float* dheads, const float* scale_dev, void* stream);
+
+/* Up to RTTS_SEGMENTS_MAX flat copies / additions in one launch (per-step refreshes of padded GEMM operands, additions of
+ * padded gradient blocks into their parameters' gradients). */
+#define RTTS_SEGMENTS_MAX 12
+enum { RTTS_SEG_COPY_F32 = 0, RTTS_SEG_COPY_BF16 = 1, RTTS_SEG_ADD_F32 = 2, RTTS_SEG_CAST_F32_BF16 = 3 };
+typedef struct {
+    void* dst;
+    const void* src;
+    int64_t count;          /* elements */
+    int32_t kind, reserved;
+} rtts_segment;
+int rtts_segments(const rtts_segment* jobs, int n, void* stream);
 
 /* Scaled positional encoding (reference modules.py:172-192): out = y + alpha * dropout_p(table[t]), the mask shared over the
  * batch; dalpha += sum dy * dropout_p(table).  relu_drop: h = dropout_p(relu(h)) in place (decoder prenet, modules.py:82-100). */
@@ -254,9 +274,13 @@ int rtts_pe_dalpha(const float* dy, const float* table, float drop_p, uint32_t s
                    int d, float* dalpha, float* partial_ws, void* stream);
 int rtts_relu_drop(void* h, float drop_p, uint32_t seed, const uint32_t* seed_dev, int64_t n, void* stream);
 
-/* dE[id] += sum of dx rows whose id matches (nn.Embedding backward, reference modules.py:17,56); padding_idx skipped */
+/* nn.Embedding + the Dropout behind it (reference modules.py:17,22,56): out (rows, C) fp32 = dropout_p(E[ids]); backward:
+ * dE[id] += sum of (dx * the same keep-scales) over the rows whose id matches; padding_idx skipped.  dE accumulates: it may be
+ * the parameter's gradient itself. */
+int rtts_embedding_fwd(const int64_t* ids, const float* E, int rows, int C, int n_embeddings, float drop_p, uint32_t seed,
+                       const uint32_t* seed_dev, float* out, void* stream);
 int rtts_embedding_bwd(const int64_t* ids, const float* dx, int rows, int C, int n_embeddings, int padding_idx, float* dE,
-                       void* stream);
+                       float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
 
 /* ---- weight-gradient GEMM, split over the token dimension ------------------------------------
  * c[N][K] (fp32, stride ldc) (+)= sum_m a[m][N] * b[m][K]   (a, b bf16 with strides lda, ldb)

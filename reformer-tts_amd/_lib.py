@@ -24,10 +24,19 @@ GEMM_TN_MAX_GROUP = 8
 
 class ColsumJob(C.Structure):
     """rtts_colsum_job of include/rtts.h."""
-    _fields_ = [("partial", _vp), ("out", _vp), ("nrows", C.c_int32), ("n", C.c_int32)]
+    _fields_ = [("partial", _vp), ("out", _vp), ("nrows", C.c_int32), ("n", C.c_int32), ("ld", C.c_int32), ("reserved", C.c_int32)]
 
 
 COLSUM_MAX_GROUP = 48
+
+
+class Segment(C.Structure):
+    """rtts_segment of include/rtts.h."""
+    _fields_ = [("dst", _vp), ("src", _vp), ("count", C.c_int64), ("kind", C.c_int32), ("reserved", C.c_int32)]
+
+
+SEGMENTS_MAX = 12
+SEG_COPY_F32, SEG_COPY_BF16, SEG_ADD_F32, SEG_CAST_F32_BF16 = 0, 1, 2, 3
 
 
 class ConvPermJob(C.Structure):
@@ -49,8 +58,9 @@ SIGNATURES = {
     "rtts_grad_clip_scale": [_vp, _i64, _f32, _f32, _vp, _vp, _vp],
     "rtts_ln_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp],
     "rtts_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f32, _u32, _vp, _vp],
-    "rtts_cast_colsum": [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _u32, _vp, _vp],
-    "rtts_colsum_bf16": [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _f32, _vp],
+    "rtts_cast_colsum": [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _u32, _vp, _vp, _vp],
+    "rtts_colsum_bf16": [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp],
+    "rtts_sum_streams": [_vp, _vp, _i64, _vp, _vp, _vp],
     "rtts_residual_epilogue": [_vp, _vp, _vp, _f32, _vp, _i64, _i32, _f32, _u32, _vp, _vp],
     "rtts_colsum_partial_rows": [_i32],
     "rtts_colsum_final_grouped": [C.POINTER(ColsumJob), _i32, _vp],
@@ -61,8 +71,9 @@ SIGNATURES = {
     "rtts_xattn_bwd": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _f32, _u32, _vp, _vp],
     "rtts_sum_slabs": [_vp, _i32, _i64, _vp, _vp],
     "rtts_conv1d_k5": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _vp],
-    "rtts_to_halo": [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i64, _vp],
-    "rtts_heads_grad": [_vp, _vp, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
+    "rtts_to_halo": [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i64, _vp],
+    "rtts_heads_grad": [_vp, _vp, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "rtts_segments": [C.POINTER(Segment), _i32, _vp],
     "rtts_conv_w_perm": [_vp, _i32, _i32, _i32, _vp, _vp],
     "rtts_conv_dw_unperm": [_vp, _i32, _i32, _i32, _vp, _vp],
     "rtts_conv_w_perm_grouped": [C.POINTER(ConvPermJob), _i32, _vp],
@@ -71,11 +82,12 @@ SIGNATURES = {
     "rtts_bn_act_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _u32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i64, _vp],
     "rtts_bn_act_bwd": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _u32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i64, _vp, _vp, _vp, _vp],
     "rtts_tts_loss": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32,
-                      _vp, _i64, _i32, _i32, _i64, _vp],
+                      _vp, _i64, _i32, _i32, _i64, _i64, _vp],
     "rtts_pe_add": [_vp, _vp, _vp, _f32, _u32, _vp, _i32, _i64, _i32, _vp, _vp],
     "rtts_pe_dalpha": [_vp, _vp, _f32, _u32, _vp, _i32, _i64, _i32, _vp, _vp, _vp],
     "rtts_relu_drop": [_vp, _f32, _u32, _vp, _i64, _vp],
-    "rtts_embedding_bwd": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],
+    "rtts_embedding_bwd": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _f32, _u32, _vp, _vp],
+    "rtts_embedding_fwd": [_vp, _vp, _i32, _i32, _i32, _f32, _u32, _vp, _vp, _vp],
     "rtts_gemm_tn": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _i32, _vp, _i64, _vp],
     "rtts_gemm_tn_grouped": [C.POINTER(GemmTnProblem), _i32, _vp, _i64, _vp],
     "rtts_gemm_nt": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _vp],

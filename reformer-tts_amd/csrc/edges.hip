@@ -39,8 +39,8 @@ static inline EdHalo ed_halo(int B, int L, int halo) { return EdHalo{B, L, L + 2
 // dst (bf16 halo rows: `rows` rows of C channels, halo row 0 at row `lead`) = src (plain (B*L, ld_src) rows, fp32 or bf16);
 // every row outside the valid set is written as zero.  8 channels per thread.
 template <bool SRC_F32>
-__global__ __launch_bounds__(ED_THREADS) void to_halo_kernel(const void* __restrict__ src, int64_t ld_src, int C_src, EdHalo g, int C, int lead,
-                                                             long long rows, bf16_t* __restrict__ dst) {
+__global__ __launch_bounds__(ED_THREADS) void to_halo_kernel(const void* __restrict__ src, int64_t ld_src, int64_t bs_src, int C_src, EdHalo g, int C,
+                                                             int lead, long long rows, bf16_t* __restrict__ dst) {
     const int pieces = C / 8;
     const size_t total = (size_t)rows * pieces;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -49,14 +49,14 @@ __global__ __launch_bounds__(ED_THREADS) void to_halo_kernel(const void* __restr
         int b, t;
         uint4 o = make_uint4(0, 0, 0, 0);
         if (pc * 8 < C_src && ed_valid(g, r - lead, b, t)) {        // channels >= C_src: zero padding up to the GEMM's K granule
-            const size_t srow = (size_t)b * g.L + t;
+            const size_t soff = (size_t)b * bs_src + (size_t)t * ld_src;     // bs_src: elements between samples (a time-sliced view)
             if (SRC_F32) {
-                const float* p = reinterpret_cast<const float*>(src) + srow * ld_src + pc * 8;
+                const float* p = reinterpret_cast<const float*>(src) + soff + pc * 8;
                 const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + 4);
                 o.x = pack_bf16x2(v0.x, v0.y); o.y = pack_bf16x2(v0.z, v0.w);
                 o.z = pack_bf16x2(v1.x, v1.y); o.w = pack_bf16x2(v1.z, v1.w);
             } else {
-                o = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(src) + srow * ld_src + pc * 8);
+                o = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(src) + soff + pc * 8);
             }
         }
         *reinterpret_cast<uint4*>(dst + (size_t)r * C + pc * 8) = o;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(ED_THREADS) void tts_loss_kernel(const float* __res
                                                               float w_stop, float* __restrict__ d_raw, float* __restrict__ d_post,
                                                               int64_t ld_grad, float* __restrict__ d_stop, float* __restrict__ partial,
                                                               int Lp, int Lv, const float* __restrict__ res, int64_t ld_res, int hp, int dp_lead,
-                                                              long long dp_rows) {
+                                                              long long dp_rows, long long tgt_bs) {
     // res != NULL: the postnet prediction is raw + res, res in halo rows (halo hp) -- the residual add of
     // reformer_tts.py:139-140 happens here; d_post is then written in the same halo rows (dp_rows rows, halo row 0 at row
     // dp_lead, zero outside the valid set): it is the output gradient of the last convolution.
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(ED_THREADS) void tts_loss_kernel(const float* __res
             continue;
         }
         const size_t ti = ((row / Lp) * Lv + t) * NM + c;
-        const float mk = mask[ti], tg = tgt[ti];
+        const float mk = mask[ti], tg = tgt[(row / Lp) * (size_t)tgt_bs + (size_t)t * NM + c];   // tgt: a time-sliced view of the batch
         const float rv = raw[row * ld_mel + c];
         const float pv = res ? rv + res[hrow * ld_res + c] : post[row * ld_mel + c];
         const float r = rv * mk - tg, p = pv * mk - tg;
@@ -437,7 +437,11 @@ __global__ void tts_loss_finalize_kernel(const float* __restrict__ partial, int 
 // through the postnet's first convolution), column NM = d_stop  (reformer_tts.py:65-66,139-140 backward).  W = 128.
 __global__ __launch_bounds__(ED_THREADS) void heads_grad_kernel(const float* __restrict__ d_raw, const float* __restrict__ d_post, int dp_lead,
                                                                 const float* __restrict__ dx0, int64_t ld_dx0, const float* __restrict__ d_stop,
-                                                                EdHalo g, int NM, int W, float* __restrict__ out) {
+                                                                EdHalo g, int NM, int W, float* __restrict__ out,
+                                                                const float* __restrict__ scale_dev) {
+    // scale_dev: the upstream scalar gradient of the total loss; d_raw, d_post and d_stop were stored for an upstream of 1, dx0
+    // came back through the postnet from the already scaled d_post
+    const float up = scale_dev ? scale_dev[0] : 1.f;
     const size_t total = (size_t)g.B * g.L * (W / 4);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % (W / 4)) * 4;
@@ -445,11 +449,11 @@ __global__ __launch_bounds__(ED_THREADS) void heads_grad_kernel(const float* __r
         const size_t hrow = (row / g.L) * g.P + g.H + row % g.L;
         const float4 a = *reinterpret_cast<const float4*>(d_raw + row * W + c);
         const float4 b = *reinterpret_cast<const float4*>(d_post + ((size_t)dp_lead + hrow) * W + c);
-        float o[4] = {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+        float o[4] = {(a.x + b.x) * up, (a.y + b.y) * up, (a.z + b.z) * up, (a.w + b.w) * up};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (c + j < NM) o[j] += dx0[hrow * ld_dx0 + c + j];
-            else if (c + j == NM) o[j] = d_stop[row];
+            else if (c + j == NM) o[j] = d_stop[row] * up;
         }
         *reinterpret_cast<float4*>(out + row * W + c) = make_float4(o[0], o[1], o[2], o[3]);
     }
@@ -460,12 +464,14 @@ __global__ __launch_bounds__(ED_THREADS) void heads_grad_kernel(const float* __r
 // 64-row groups w, w+4, ...: the lanes compare 64 ids at once, the ballot lists the matching rows and they are added
 // in row order; the 4 wave sums are combined in wave order => deterministic, no atomics
 __global__ __launch_bounds__(ED_THREADS) void embedding_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dx, int rows,
-                                                                   int C, int padding_idx, float* __restrict__ dE) {
+                                                                   int C, int padding_idx, float* __restrict__ dE, uint32_t seed,
+                                                                   const uint32_t* __restrict__ seed_dev, uint32_t thresh, float dscale) {
     __shared__ float red[4][64];
     const int id = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + lane;
     if (id == padding_idx) return;
+    if (thresh && seed_dev) seed += seed_dev[0];
     float acc = 0.f;
     for (int base = wave * 64; base < rows; base += 4 * 64) {
         const int r = base + lane;
@@ -473,12 +479,65 @@ __global__ __launch_bounds__(ED_THREADS) void embedding_bwd_kernel(const int64_t
         while (m) {
             const int rr = base + __builtin_ctzll(m);
             m &= m - 1;
-            if (c < C) acc += dx[(size_t)rr * C + c];
+            if (c < C) acc += dx[(size_t)rr * C + c] * (thresh ? rtts_drop_keep(seed, (uint32_t)rr * C + c, thresh, dscale) : 1.f);
         }
     }
     red[wave][lane] = acc;
     __syncthreads();
     if (wave == 0 && c < C) dE[(size_t)id * C + c] += (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// out[row] = dropout_p(E[ids[row]]) (fp32; nn.Embedding + the Dropout in front of the encoder prenet's convolutions,
+// modules.py:17,22,56): 4 channels per thread, the keep decision of element (row, c) is hash(seed, row * C + c)
+__global__ __launch_bounds__(ED_THREADS) void embedding_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ E, size_t n4, int C,
+                                                                   int n_emb, uint32_t seed, const uint32_t* __restrict__ seed_dev, uint32_t thresh,
+                                                                   float dscale, float* __restrict__ out) {
+    if (thresh && seed_dev) seed += seed_dev[0];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * 4, row = e / C;
+        const int c = (int)(e % C);
+        long long id = ids[row];
+        id = id < 0 ? 0 : (id >= n_emb ? n_emb - 1 : id);          // ids are validated on the host side of the data pipeline
+        float4 v = *reinterpret_cast<const float4*>(E + (size_t)id * C + c);
+        if (thresh) {
+            v.x *= rtts_drop_keep(seed, (uint32_t)e, thresh, dscale);
+            v.y *= rtts_drop_keep(seed, (uint32_t)e + 1, thresh, dscale);
+            v.z *= rtts_drop_keep(seed, (uint32_t)e + 2, thresh, dscale);
+            v.w *= rtts_drop_keep(seed, (uint32_t)e + 3, thresh, dscale);
+        }
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------ small copies / adds of a step in ONE launch
+// Up to RTTS_SEGMENTS_MAX (dst, src, count) jobs: the per-step weight refreshes of padded GEMM operands (heads, padded biases,
+// K-padded weights) and the additions of padded gradient blocks into their parameters' gradients, which each cost a
+// ~5 us launch as separate copy_/add_ calls whatever their size.
+struct SgJob {
+    void* dst;
+    const void* src;
+    long long count;
+    int kind, blk_start;
+};
+struct SgGroup {
+    SgJob j[RTTS_SEGMENTS_MAX];
+    int n;
+};
+__global__ __launch_bounds__(ED_THREADS) void segments_kernel(const SgGroup grp) {
+    int ji = 0;
+#pragma unroll 1
+    for (int i = 1; i < grp.n; ++i)
+        if ((int)blockIdx.x >= grp.j[i].blk_start) ji = i;
+    const SgJob& J = grp.j[ji];
+    const int nblk = (ji + 1 < grp.n ? grp.j[ji + 1].blk_start : (int)gridDim.x) - J.blk_start;
+    for (long long i = (long long)((int)blockIdx.x - J.blk_start) * ED_THREADS + threadIdx.x; i < J.count; i += (long long)nblk * ED_THREADS) {
+        switch (J.kind) {
+        case RTTS_SEG_COPY_F32: reinterpret_cast<float*>(J.dst)[i] = reinterpret_cast<const float*>(J.src)[i]; break;
+        case RTTS_SEG_COPY_BF16: reinterpret_cast<bf16_t*>(J.dst)[i] = reinterpret_cast<const bf16_t*>(J.src)[i]; break;
+        case RTTS_SEG_ADD_F32: reinterpret_cast<float*>(J.dst)[i] += reinterpret_cast<const float*>(J.src)[i]; break;
+        default: reinterpret_cast<bf16_t*>(J.dst)[i] = f32_to_bf16(reinterpret_cast<const float*>(J.src)[i]); break;
+        }
+    }
 }
 
 // ------------------------------------------------------------------ scaled positional encoding (modules.py:172-192)
@@ -567,29 +626,32 @@ static inline unsigned ed_grid(size_t items) {
 }
 static inline uint32_t ed_thresh(float p) { return p <= 0.f ? 0u : (uint32_t)((double)p * 4294967296.0); }
 
-extern "C" int rtts_to_halo(const void* src, int64_t ld_src, int C_src, int src_f32, int B, int L, int halo, int C, void* dst, int lead,
-                            int64_t rows, void* stream) {
+extern "C" int rtts_to_halo(const void* src, int64_t ld_src, int64_t src_batch_stride, int C_src, int src_f32, int B, int L, int halo, int C,
+                            void* dst, int lead, int64_t rows, void* stream) {
     RTTS_REQUIRE(src && dst && B > 0 && L > 0 && halo >= 0 && C > 0 && C % 8 == 0 && C_src > 0 && C_src % 8 == 0 && C_src <= C && ld_src >= C_src &&
                      ld_src % (src_f32 ? 4 : 8) == 0, "rtts_to_halo: bad arguments");
+    if (src_batch_stride == 0) src_batch_stride = (int64_t)L * ld_src;
+    RTTS_REQUIRE(src_batch_stride >= (int64_t)L * ld_src && src_batch_stride % (src_f32 ? 4 : 8) == 0,
+                 "rtts_to_halo: src_batch_stride must cover L rows and keep 16-byte alignment");
     RTTS_REQUIRE(lead >= 0 && rows >= lead + (int64_t)B * (L + 2 * halo), "rtts_to_halo: dst has %lld rows, needs %lld", (long long)rows,
                  (long long)(lead + (int64_t)B * (L + 2 * halo)));
     const dim3 grid(ed_grid((size_t)rows * (C / 8)));
     if (src_f32)
-        hipLaunchKernelGGL(to_halo_kernel<true>, grid, dim3(ED_THREADS), 0, (hipStream_t)stream, src, ld_src, C_src, ed_halo(B, L, halo), C, lead,
-                           (long long)rows, (bf16_t*)dst);
+        hipLaunchKernelGGL(to_halo_kernel<true>, grid, dim3(ED_THREADS), 0, (hipStream_t)stream, src, ld_src, src_batch_stride, C_src, ed_halo(B, L, halo), C,
+                           lead, (long long)rows, (bf16_t*)dst);
     else
-        hipLaunchKernelGGL(to_halo_kernel<false>, grid, dim3(ED_THREADS), 0, (hipStream_t)stream, src, ld_src, C_src, ed_halo(B, L, halo), C, lead,
-                           (long long)rows, (bf16_t*)dst);
+        hipLaunchKernelGGL(to_halo_kernel<false>, grid, dim3(ED_THREADS), 0, (hipStream_t)stream, src, ld_src, src_batch_stride, C_src, ed_halo(B, L, halo), C,
+                           lead, (long long)rows, (bf16_t*)dst);
     RTTS_LAUNCH_CHECK("rtts_to_halo");
     return 0;
 }
 
 extern "C" int rtts_heads_grad(const float* d_raw, const float* d_post, int dpost_lead, const float* dx0, int64_t ld_dx0, const float* d_stop,
-                               int B, int L, int halo, int n_mels, int width, float* dheads, void* stream) {
+                               int B, int L, int halo, int n_mels, int width, float* dheads, const float* scale_dev, void* stream) {
     RTTS_REQUIRE(d_raw && d_post && dx0 && d_stop && dheads && B > 0 && L > 0 && halo >= 0 && width % 4 == 0 && n_mels < width && dpost_lead >= 0,
                  "rtts_heads_grad: bad arguments");
     hipLaunchKernelGGL(heads_grad_kernel, dim3(ed_grid((size_t)B * L * (width / 4))), dim3(ED_THREADS), 0, (hipStream_t)stream, d_raw, d_post,
-                       dpost_lead, dx0, ld_dx0, d_stop, ed_halo(B, L, halo), n_mels, width, dheads);
+                       dpost_lead, dx0, ld_dx0, d_stop, ed_halo(B, L, halo), n_mels, width, dheads, scale_dev);
     RTTS_LAUNCH_CHECK("rtts_heads_grad");
     return 0;
 }
@@ -705,7 +767,7 @@ extern "C" int rtts_tts_loss(const float* raw, const float* post, int64_t ld_mel
                              int64_t ld_stop, const float* tstop, int rows, int NM, int kind, float pos_weight, float w_raw, float w_post,
                              float w_stop, float* d_raw, float* d_post, int64_t ld_grad, float* d_stop, float* losses, float* partial_ws,
                              int padded_len, int valid_len, const float* res, int64_t ld_res, int halo, int dpost_lead, int64_t dpost_rows,
-                             void* stream) {
+                             int64_t tgt_batch_stride, void* stream) {
     RTTS_REQUIRE(raw && (post || res) && tgt && mask && stop && tstop && d_raw && d_post && d_stop && losses && partial_ws && rows > 0 && NM > 0 &&
                      ld_grad >= NM, "rtts_tts_loss: bad arguments");
     RTTS_REQUIRE(padded_len > 0 && valid_len > 0 && valid_len <= padded_len && rows % padded_len == 0,
@@ -715,10 +777,12 @@ extern "C" int rtts_tts_loss(const float* raw, const float* post, int64_t ld_mel
                         dpost_rows >= dpost_lead + (int64_t)(rows / padded_len) * (padded_len + 2 * halo))
                      : (halo == 0 && dpost_lead == 0),
                  "rtts_tts_loss: res / d_post in halo rows need halo > 0 and room for B*(L+2*halo) rows; without res: halo = lead = 0");
+    if (tgt_batch_stride == 0) tgt_batch_stride = (int64_t)valid_len * NM;
+    RTTS_REQUIRE(tgt_batch_stride >= (int64_t)valid_len * NM, "rtts_tts_loss: tgt_batch_stride below valid_len * NM");
     const int blocks = 512;
     hipLaunchKernelGGL(tts_loss_kernel, dim3(blocks), dim3(ED_THREADS), 0, (hipStream_t)stream, raw, post, ld_mel, tgt, mask, stop, ld_stop,
                        tstop, rows, NM, kind, pos_weight, w_raw, w_post, w_stop, d_raw, d_post, ld_grad, d_stop, partial_ws, padded_len,
-                       valid_len, res, ld_res, halo, dpost_lead, (long long)dpost_rows);
+                       valid_len, res, ld_res, halo, dpost_lead, (long long)dpost_rows, (long long)tgt_batch_stride);
     const float vrows = (float)(rows / padded_len) * (float)valid_len;
     hipLaunchKernelGGL(tts_loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_ws, blocks, 1.f / (vrows * NM),
                        1.f / vrows, w_raw, w_post, w_stop, losses);
@@ -727,11 +791,43 @@ extern "C" int rtts_tts_loss(const float* raw, const float* post, int64_t ld_mel
 }
 
 extern "C" int rtts_embedding_bwd(const int64_t* ids, const float* dx, int rows, int C, int n_embeddings, int padding_idx, float* dE,
-                                  void* stream) {
-    RTTS_REQUIRE(ids && dx && dE && rows > 0 && C > 0 && n_embeddings > 0, "rtts_embedding_bwd: bad arguments");
+                                  float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream) {
+    RTTS_REQUIRE(ids && dx && dE && rows > 0 && C > 0 && n_embeddings > 0 && drop_p >= 0.f && drop_p < 1.f, "rtts_embedding_bwd: bad arguments");
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3(n_embeddings, (C + 63) / 64), dim3(ED_THREADS), 0, (hipStream_t)stream,
-                       ids, dx, rows, C, padding_idx, dE);
+                       ids, dx, rows, C, padding_idx, dE, seed, seed_dev, ed_thresh(drop_p), 1.f / (1.f - drop_p));
     RTTS_LAUNCH_CHECK("rtts_embedding_bwd");
+    return 0;
+}
+
+extern "C" int rtts_embedding_fwd(const int64_t* ids, const float* E, int rows, int C, int n_embeddings, float drop_p, uint32_t seed,
+                                  const uint32_t* seed_dev, float* out, void* stream) {
+    RTTS_REQUIRE(ids && E && out && rows > 0 && C > 0 && C % 4 == 0 && n_embeddings > 0 && drop_p >= 0.f && drop_p < 1.f,
+                 "rtts_embedding_fwd: bad arguments");
+    const size_t n4 = (size_t)rows * C / 4;
+    hipLaunchKernelGGL(embedding_fwd_kernel, dim3(ed_grid(n4)), dim3(ED_THREADS), 0, (hipStream_t)stream, ids, E, n4, C, n_embeddings, seed,
+                       seed_dev, ed_thresh(drop_p), 1.f / (1.f - drop_p), out);
+    RTTS_LAUNCH_CHECK("rtts_embedding_fwd");
+    return 0;
+}
+
+extern "C" int rtts_segments(const rtts_segment* jobs, int n, void* stream) {
+    RTTS_REQUIRE(jobs && n > 0 && n <= RTTS_SEGMENTS_MAX, "rtts_segments: 1..%d jobs", RTTS_SEGMENTS_MAX);
+    SgGroup g;
+    g.n = n;
+    int blk = 0;
+    for (int i = 0; i < n; ++i) {
+        RTTS_REQUIRE(jobs[i].dst && jobs[i].src && jobs[i].count > 0 && jobs[i].kind >= 0 && jobs[i].kind <= RTTS_SEG_CAST_F32_BF16,
+                     "rtts_segments: bad job %d", i);
+        g.j[i].dst = jobs[i].dst;
+        g.j[i].src = jobs[i].src;
+        g.j[i].count = jobs[i].count;
+        g.j[i].kind = jobs[i].kind;
+        g.j[i].blk_start = blk;
+        long long b = (jobs[i].count + ED_THREADS * 4 - 1) / (ED_THREADS * 4);
+        blk += (int)(b > 256 ? 256 : b);
+    }
+    hipLaunchKernelGGL(segments_kernel, dim3(blk), dim3(ED_THREADS), 0, (hipStream_t)stream, g);
+    RTTS_LAUNCH_CHECK("rtts_segments");
     return 0;
 }
 

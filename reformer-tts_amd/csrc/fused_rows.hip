@@ -263,7 +263,8 @@ __global__ __launch_bounds__(FR_THREADS) void ln_bwd_kernel(const bf16_t* __rest
 template <int EPL, int VEC>
 __global__ __launch_bounds__(FR_THREADS) void cast_colsum_kernel(const float* __restrict__ dy, bf16_t* __restrict__ dyb,
                                                                  float* __restrict__ partial, int M, uint32_t seed,
-                                                                 const uint32_t* __restrict__ seed_dev, uint32_t thresh, float dscale) {
+                                                                 const uint32_t* __restrict__ seed_dev, uint32_t thresh, float dscale,
+                                                                 const float* __restrict__ scale_dev) {
     constexpr int D = EPL * 64;
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     const int lane = threadIdx.x & 63;
@@ -271,9 +272,14 @@ __global__ __launch_bounds__(FR_THREADS) void cast_colsum_kernel(const float* __
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
     if (thresh && seed_dev) seed += seed_dev[0];
+    const float up = scale_dev ? scale_dev[0] : 1.f;       // an upstream scalar gradient (the loss weight of a backward root)
     for (int row = blockIdx.x * FR_WAVES + (threadIdx.x >> 6); row < M; row += gridDim.x * FR_WAVES) {
         float v[EPL];
         load_row_f32<EPL, VEC>(dy + (size_t)row * D, lane, v);
+        if (scale_dev) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) v[e] *= up;
+        }
         if (thresh) {      // backward of the dropout that sat on this block's output: same (seed, element) decisions
 #pragma unroll
             for (int e = 0; e < EPL; ++e) v[e] *= rtts_drop_keep(seed, (uint32_t)row * D + row_col<VEC>(e, lane), thresh, dscale);
@@ -286,9 +292,9 @@ __global__ __launch_bounds__(FR_THREADS) void cast_colsum_kernel(const float* __
 }
 
 // ---------------------------------------------------------------- bf16 column sums, optionally gated by ReLU
-// RELU: dh = dh * (h > 0) written back in place, then summed
+// RELU: dst = dh * (h > 0) * gate_scale (dst == dh: in place), then summed
 template <int EPL, int VEC, bool RELU>
-__global__ __launch_bounds__(FR_THREADS) void colsum_bf16_kernel(bf16_t* __restrict__ dh, const bf16_t* __restrict__ h,
+__global__ __launch_bounds__(FR_THREADS) void colsum_bf16_kernel(const bf16_t* dh, const bf16_t* __restrict__ h, bf16_t* dst,
                                                                  int64_t ld, float* __restrict__ partial, int M, float gate_scale) {
     constexpr int D = EPL * 64;
     constexpr int AV = (EPL % 4 == 0) ? 4 : 2;
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(FR_THREADS) void colsum_bf16_kernel(bf16_t* __restr
             load_row_bf16<EPL, VEC>(h + (size_t)row * ld, lane, hv);
 #pragma unroll
             for (int e = 0; e < EPL; ++e) v[e] = hv[e] > 0.f ? v[e] * gate_scale : 0.f;
-            store_row_bf16<EPL, VEC>(dh + (size_t)row * ld, lane, v);
+            store_row_bf16<EPL, VEC>(dst + (size_t)row * ld, lane, v);
         }
 #pragma unroll
         for (int e = 0; e < EPL; ++e) acc[e] += v[e];
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(FR_THREADS) void colsum_final_kernel(const float* _
 struct CsJob {
     const float* partial;
     float* out;
-    int nrows, n, blk_start;
+    int nrows, n, ld, blk_start;
 };
 struct CsGroup {
     CsJob j[RTTS_COLSUM_MAX_GROUP];
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(FR_THREADS) void colsum_final_grouped_kernel(const 
     float s = 0.f;
     if (c < J.n) {
 #pragma unroll 8
-        for (int r = wave; r < J.nrows; r += FR_WAVES) s += J.partial[(size_t)r * J.n + c];
+        for (int r = wave; r < J.nrows; r += FR_WAVES) s += J.partial[(size_t)r * J.ld + c];
     }
     red[wave][lane] = s;
     __syncthreads();
@@ -493,12 +499,12 @@ extern "C" int rtts_ln_bwd(const void* dxn, const float* x, const float* mean, c
 }
 
 extern "C" int rtts_cast_colsum(const float* dy, void* dyb, float* dbias, float* partial_ws, int M, int d, float drop_p, uint32_t seed,
-                                const uint32_t* seed_dev, void* stream) {
+                                const uint32_t* seed_dev, const float* scale_dev, void* stream) {
     RTTS_REQUIRE(dy && dyb && partial_ws && M > 0 && drop_p >= 0.f && drop_p < 1.f, "rtts_cast_colsum: bad arguments");
     int blocks = (M + FR_WAVES - 1) / FR_WAVES;
     if (blocks > FR_PARTIAL_BLOCKS) blocks = FR_PARTIAL_BLOCKS;
     const size_t lds = (size_t)FR_WAVES * d * sizeof(float);
-#define CALL(EPL, VEC) hipLaunchKernelGGL((cast_colsum_kernel<EPL, VEC>), dim3(blocks), dim3(FR_THREADS), lds, (hipStream_t)stream, dy, (bf16_t*)dyb, partial_ws, M, seed, seed_dev, rtts_drop_thresh(drop_p), 1.f / (1.f - drop_p))
+#define CALL(EPL, VEC) hipLaunchKernelGGL((cast_colsum_kernel<EPL, VEC>), dim3(blocks), dim3(FR_THREADS), lds, (hipStream_t)stream, dy, (bf16_t*)dyb, partial_ws, M, seed, seed_dev, rtts_drop_thresh(drop_p), 1.f / (1.f - drop_p), scale_dev)
     FR_DISPATCH_D(d, CALL)
 #undef CALL
     if (dbias)
@@ -509,8 +515,9 @@ extern "C" int rtts_cast_colsum(const float* dy, void* dyb, float* dbias, float*
 }
 
 extern "C" int rtts_colsum_bf16(void* dh, const void* h, int64_t ld, float* dbias, float* partial_ws, int M, int d, int relu_gate,
-                                float gate_scale, void* stream) {
+                                float gate_scale, void* gated_out, void* stream) {
     RTTS_REQUIRE(dh && partial_ws && M > 0 && (!relu_gate || h), "rtts_colsum_bf16: bad arguments");
+    bf16_t* dst = (bf16_t*)(gated_out ? gated_out : dh);
     RTTS_REQUIRE(ld >= d && ld % 8 == 0, "rtts_colsum_bf16: bad row stride");
     int blocks = (M + FR_WAVES - 1) / FR_WAVES;
     if (blocks > FR_PARTIAL_BLOCKS) blocks = FR_PARTIAL_BLOCKS;
@@ -518,16 +525,36 @@ extern "C" int rtts_colsum_bf16(void* dh, const void* h, int64_t ld, float* dbia
 #define CALL(EPL, VEC)                                                                                                         \
     if (relu_gate)                                                                                                             \
         hipLaunchKernelGGL((colsum_bf16_kernel<EPL, VEC, true>), dim3(blocks), dim3(FR_THREADS), lds, (hipStream_t)stream,     \
-                           (bf16_t*)dh, (const bf16_t*)h, ld, partial_ws, M, gate_scale);                                      \
+                           (const bf16_t*)dh, (const bf16_t*)h, dst, ld, partial_ws, M, gate_scale);                           \
     else                                                                                                                       \
         hipLaunchKernelGGL((colsum_bf16_kernel<EPL, VEC, false>), dim3(blocks), dim3(FR_THREADS), lds, (hipStream_t)stream,    \
-                           (bf16_t*)dh, (const bf16_t*)h, ld, partial_ws, M, gate_scale)
+                           (const bf16_t*)dh, (const bf16_t*)h, dst, ld, partial_ws, M, gate_scale)
     FR_DISPATCH_D(d, CALL)
 #undef CALL
     if (dbias)
         hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 63) / 64), dim3(FR_THREADS), 0, (hipStream_t)stream,
                            partial_ws, blocks, d, dbias, (const float*)nullptr, (float*)nullptr);
     RTTS_LAUNCH_CHECK("rtts_colsum_bf16");
+    return 0;
+}
+
+// out = a + b (the two streams of a reversible stack, reversible.py:155-158 sums their halves): fp32 and / or a bf16 twin
+// for the consumer that reads it as a GEMM operand (the heads, the cross attention's keys)
+__global__ __launch_bounds__(FR_THREADS) void sum_streams_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n4,
+                                                                 float* __restrict__ out, bf16_t* __restrict__ out_bf16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+        const float4 o = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+        if (out) reinterpret_cast<float4*>(out)[i] = o;
+        if (out_bf16) reinterpret_cast<uint2*>(out_bf16)[i] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+    }
+}
+
+extern "C" int rtts_sum_streams(const float* a, const float* b, int64_t n, float* out, void* out_bf16, void* stream) {
+    RTTS_REQUIRE(a && b && (out || out_bf16) && n > 0 && n % 4 == 0, "rtts_sum_streams: bad arguments");
+    hipLaunchKernelGGL(sum_streams_kernel, dim3(stream_grid((size_t)n / 4)), dim3(FR_THREADS), 0, (hipStream_t)stream, a, b, (size_t)n / 4, out,
+                       (bf16_t*)out_bf16);
+    RTTS_LAUNCH_CHECK("rtts_sum_streams");
     return 0;
 }
 
@@ -547,6 +574,8 @@ extern "C" int rtts_colsum_final_grouped(const rtts_colsum_job* jobs, int n, voi
         grp.j[i].out = jobs[i].out;
         grp.j[i].nrows = jobs[i].nrows;
         grp.j[i].n = jobs[i].n;
+        RTTS_REQUIRE(jobs[i].ld == 0 || jobs[i].ld >= jobs[i].n, "rtts_colsum_final_grouped: job %d: row stride below the width", i);
+        grp.j[i].ld = jobs[i].ld ? jobs[i].ld : jobs[i].n;
         grp.j[i].blk_start = blk;
         blk += (jobs[i].n + 63) / 64;
     }

@@ -23,7 +23,7 @@ import torch
 
 from . import _lib
 from . import engine as _engine
-from .engine import WEIGHT_EPOCH, _WS, _bf16, _grad, cast_colsum, gemm, wgrad
+from .engine import WEIGHT_EPOCH, _WS, _bf16, _grad, bf16_twin, cast_colsum, gemm, wgrad
 
 from ._seeds import _seed_counter, seed_base  # noqa: E402,F401  (shared with engine.py)
 
@@ -232,7 +232,7 @@ class ConvStackFn(torch.autograd.Function):
         if x2.dtype not in (torch.float32, torch.bfloat16) or x2.stride(1) != 1:
             x2 = x2.float().contiguous()
         cur = g.new(c, x.device)
-        _lib.call("rtts_to_halo", x2.data_ptr(), x2.stride(0), c, int(x2.dtype == torch.float32), b, l, g.H, c, cur.data_ptr(), g.LEAD, g.alloc, _s())
+        _lib.call("rtts_to_halo", x2.data_ptr(), x2.stride(0), 0, c, int(x2.dtype == torch.float32), b, l, g.H, c, cur.data_ptr(), g.LEAD, g.alloc, _s())
         saved = []
         for i, layer in enumerate(stack):
             cur, s = layer.forward(cur, g, plain_out=(i == len(stack) - 1))
@@ -262,6 +262,20 @@ def encoder_prenet_stack(prenet) -> List[ConvBNAct]:
             ConvBNAct(c.conv3, c.bn3, 1, c.dropout3.p)]
 
 
+def segments(jobs):
+    """[(dst, src, kind)] flat copies / additions (``_lib.SEG_*``) in one launch per ``_lib.SEGMENTS_MAX`` jobs; dst and src
+    are contiguous and of equal size."""
+    jobs = list(jobs)
+    while jobs:
+        group, jobs = jobs[:_lib.SEGMENTS_MAX], jobs[_lib.SEGMENTS_MAX:]
+        arr = (_lib.Segment * len(group))()
+        for j, (dst, src, kind) in zip(arr, group):
+            if not (dst.is_contiguous() and src.is_contiguous() and dst.numel() == src.numel()):
+                raise ValueError("segments: operands must be contiguous and of equal size")
+            j.dst, j.src, j.count, j.kind = dst.data_ptr(), src.data_ptr(), dst.numel(), kind
+        _lib.call("rtts_segments", arr, len(group), _s())
+
+
 class PostnetLoss:
     """Heads + postnet + loss for the training step (forward values, then the gradient w.r.t. the decoder output)."""
 
@@ -275,19 +289,26 @@ class PostnetLoss:
         self.pos_weight = float(loss_mod.pos_weight)      # host copy: no device read inside a captured step
         self._wh = None
 
-    def _heads_weight(self):
+    def _operands(self):
+        """-> (heads weight (128, d) bf16 = [mel | stop | 0], heads bias (128) fp32, the last convolution's bias padded to its
+        GEMM width): persistent padded buffers refreshed from the parameters by ONE launch per step."""
         mel, stop = self.model.dec.mel_linear, self.model.dec.stop_linear
-        d = mel.weight.shape[1]
-        if self._wh is None or self._wh.device != mel.weight.device:
-            self._wh = torch.zeros(128, d, dtype=torch.bfloat16, device=mel.weight.device)
-            self._bh = torch.zeros(128, dtype=torch.float32, device=mel.weight.device)
-        self._wh[:self.nm].copy_(_bf16(mel.weight))
-        self._wh[self.nm:self.nm + 1].copy_(_bf16(stop.weight))
-        self._bh[:self.nm].copy_(mel.bias.detach())
-        self._bh[self.nm:self.nm + 1].copy_(stop.bias.detach())
-        return self._wh, self._bh
+        d, dev = mel.weight.shape[1], mel.weight.device
+        if self._wh is None or self._wh.device != dev:
+            self._wh = torch.zeros(128, d, dtype=torch.bfloat16, device=dev)
+            self._bh = torch.zeros(128, dtype=torch.float32, device=dev)
+        c, nm = self.convend, self.nm
+        if getattr(c, "_bias_pad", None) is None or c._bias_pad.device != dev:
+            c._bias_pad = torch.zeros(c.cop, dtype=torch.float32, device=dev)
+        wm, ws = _bf16(mel.weight), _bf16(stop.weight)
+        kind_w = _lib.SEG_COPY_BF16 if wm.dtype == torch.bfloat16 else _lib.SEG_CAST_F32_BF16
+        segments([(self._wh[:nm], wm.contiguous(), kind_w), (self._wh[nm:nm + 1], ws.contiguous(), kind_w),
+                  (self._bh[:nm], mel.bias.detach(), _lib.SEG_COPY_F32), (self._bh[nm:nm + 1], stop.bias.detach(), _lib.SEG_COPY_F32),
+                  (c._bias_pad[:c.co], c.conv.bias.detach(), _lib.SEG_COPY_F32)])
+        return self._wh, self._bh, c._bias_pad
 
     def apply(self, y_dec, true_mel, true_stop, true_mask):
+        """-> (total, raw, postnet, stop) losses; only the total is differentiable (the others are reported values)."""
         return _PostnetLossFn.apply(y_dec, true_mel, true_stop, true_mask, self)
 
 
@@ -299,16 +320,17 @@ class _PostnetLossFn(torch.autograd.Function):
         nm, dev = ex.nm, y_dec.device
         m = b * lp
         g = Halo(b, lp)
-        yb = y_dec.detach().reshape(m, d).to(torch.bfloat16)
-        wh, bh = ex._heads_weight()
+        yb = bf16_twin(y_dec)                       # the stack's own bf16 copy of its output when there is one
+        yb = yb.view(m, d) if yb is not None else y_dec.detach().reshape(m, d).to(torch.bfloat16)
+        wh, bh, bias_end = ex._operands()
         heads = gemm(yb, wh, bias=bh, out_f32=True)                         # (M,128) fp32: [mel(80) | stop | 0...]
         x0 = g.new(128, dev)                        # the first convolution's weights are zero for channels >= nm
-        _lib.call("rtts_to_halo", heads.data_ptr(), 128, 128, 1, b, lp, g.H, 128, x0.data_ptr(), g.LEAD, g.alloc, _s())
+        _lib.call("rtts_to_halo", heads.data_ptr(), 128, 0, 128, 1, b, lp, g.H, 128, x0.data_ptr(), g.LEAD, g.alloc, _s())
         saved, cur = [], x0
         for layer in ex.layers:
             cur, s = layer.forward(cur, g)
             saved.append(s)
-        res = ex.convend.forward(cur, g, bias=_pad_bias(ex.convend, dev))    # (mp, 128) fp32 halo rows; cols >= nm never read
+        res = ex.convend.forward(cur, g, bias=bias_end)                      # (mp, 128) fp32 halo rows; cols >= nm never read
         lm = ex.loss_mod
         losses = torch.empty(4, dtype=torch.float32, device=dev)
         # the three stored gradients share one buffer so that the backward scales them with one launch; d_post is the output
@@ -317,17 +339,26 @@ class _PostnetLossFn(torch.autograd.Function):
         gbuf = torch.empty(n_raw + n_post + m, dtype=torch.float32, device=dev)
         d_raw, d_post, g_stop = gbuf[:n_raw].view(m, 128), gbuf[n_raw:n_raw + n_post].view(g.alloc, 128), gbuf[n_raw + n_post:]
         pw = torch.empty(512 * 3, dtype=torch.float32, device=dev)
-        _lib.call("rtts_tts_loss", heads.data_ptr(), None, 128, true_mel.contiguous().data_ptr(), true_mask.contiguous().data_ptr(),
+        if true_mel.dtype != torch.float32 or true_mel.stride(2) != 1 or true_mel.stride(1) != nm:
+            true_mel = true_mel.float().contiguous()
+        # the targets are usually the view frames [1, L) of the batch: the kernel takes its batch stride, no copy
+        _lib.call("rtts_tts_loss", heads.data_ptr(), None, 128, true_mel.data_ptr(), true_mask.contiguous().data_ptr(),
                   heads[:, nm:].data_ptr(), 128, true_stop.contiguous().data_ptr(), m, nm, lm.kind, ex.pos_weight,
                   float(lm.raw_pred_loss_weight), float(lm.post_pred_loss_weight), float(lm.stop_loss_weight), d_raw.data_ptr(),
                   d_post.data_ptr(), 128, g_stop.data_ptr(), losses.data_ptr(), pw.data_ptr(), lp, l, res.data_ptr(), 128, g.H, g.LEAD,
-                  g.alloc, _s())
+                  g.alloc, true_mel.stride(0), _s())
         ctx.ex, ctx.state = ex, (yb, wh, saved, cur, gbuf, g, d)
-        return losses
+        ctx.set_materialize_grads(False)
+        return losses[0], losses[1], losses[2], losses[3]
 
     @staticmethod
-    def backward(ctx, dlosses):
+    def backward(ctx, g_total, g_raw, g_post, g_stop_loss):
         ex = ctx.ex
+        if g_raw is not None or g_post is not None or g_stop_loss is not None:
+            raise NotImplementedError("PostnetLoss: only the total loss is differentiable (the parts are reported values; "
+                                      "model.TTSLoss differentiates all four)")
+        if g_total is None:
+            return None, None, None, None, None
         if ctx.state is None:
             raise RuntimeError("PostnetLoss.backward: state already consumed")
         yb, wh, saved, z_last, gbuf, g, d = ctx.state
@@ -335,40 +366,29 @@ class _PostnetLossFn(torch.autograd.Function):
         nm, dev = ex.nm, yb.device
         b, lp = g.b, g.l
         m = b * lp
-        # the stored gradients are those of losses[0]; scale them by its upstream weight (1 in the trainer)
-        gbuf = gbuf * dlosses[0]
+        # the stored gradients are those of the total loss for an upstream gradient of 1; the upstream scalar (1 in the trainer)
+        # rides into the two kernels that read them (no scaling pass)
+        up = g_total.detach().reshape(1)
+        up = up if up.dtype == torch.float32 else up.float()
         n_raw, n_post = m * 128, g.alloc * 128
         d_raw, d_post, g_stop = gbuf[:n_raw].view(m, 128), gbuf[n_raw:n_raw + n_post].view(g.alloc, 128), gbuf[n_raw + n_post:]
-        # convend: res = conv(z_last) + bias;  d_res = d_post
-        zpad = torch.zeros(256, dtype=torch.float32, device=dev)
-        dbias_pad, bsum = zpad[:128], zpad[128:]
-        dresb = cast_colsum(d_post, dbias_pad, defer=False)                 # deterministic column sums (no ATen reduction)
-        _grad(ex.convend.conv.bias).add_(dbias_pad[:nm])
+        # convend: res = conv(z_last) + bias;  d_res = d_post.  Deterministic column sums (no ATen reduction), finalised with the
+        # other deferred sums straight into the bias gradient
+        dresb = cast_colsum(d_post, [(0, nm, _grad(ex.convend.conv.bias))], scale=up)
         dz = ex.convend.backward(dresb, z_last, g)
         for layer, s in zip(reversed(ex.layers[1:]), reversed(saved[1:])):
             dz = layer.backward(dz, True, s, g)
         dx0 = ex.layers[0].backward(dz, True, saved[0], g, need_dx=True, dx_f32=True)        # (mp, 128) fp32 halo rows
         dheads = torch.empty(m, 128, dtype=torch.float32, device=dev)
         _lib.call("rtts_heads_grad", d_raw.data_ptr(), d_post.data_ptr(), g.LEAD, dx0.data_ptr(), 128, g_stop.data_ptr(), b, lp, g.H, nm, 128,
-                  dheads.data_ptr(), _s())
-        dhb = cast_colsum(dheads, bsum, defer=False)      # read two lines below
+                  dheads.data_ptr(), up.data_ptr(), _s())
         mel, stop = ex.model.dec.mel_linear, ex.model.dec.stop_linear
-        _grad(mel.bias).add_(bsum[:nm])
-        _grad(stop.bias).add_(bsum[nm:nm + 1])
+        dhb = cast_colsum(dheads, [(0, nm, _grad(mel.bias)), (nm, 1, _grad(stop.bias))])
         dwh = torch.empty(128, d, dtype=torch.float32, device=dev)
         wgrad(dwh, dhb, yb, accumulate=False)
-        _grad(mel.weight).add_(dwh[:nm])
-        _grad(stop.weight).add_(dwh[nm:nm + 1])
-        dy = gemm(dhb, wh, kn=True).float().view(b, lp, d)
+        segments([(_grad(mel.weight), dwh[:nm], _lib.SEG_ADD_F32), (_grad(stop.weight), dwh[nm:nm + 1], _lib.SEG_ADD_F32)])
+        dy = gemm(dhb, wh, kn=True, out_f32=True).view(b, lp, d)
         return dy, None, None, None, None
-
-
-def _pad_bias(c: ConvK5, dev):
-    """The convolution's bias in a persistent zero-padded (cop) buffer: one copy per call, no fill."""
-    if getattr(c, "_bias_pad", None) is None or c._bias_pad.device != dev:
-        c._bias_pad = torch.zeros(c.cop, dtype=torch.float32, device=dev)
-    c._bias_pad[:c.co].copy_(c.conv.bias.detach())
-    return c._bias_pad
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -455,8 +475,11 @@ class _ReluDropLinearFn(torch.autograd.Function):
         from .engine import colsum_bf16
         lin = ctx.lin
         x, h, p, kpad = ctx.state
-        dh = dh.to(torch.bfloat16).contiguous().clone() if dh.dtype != torch.bfloat16 or not dh.is_contiguous() else dh.clone()
-        colsum_bf16(dh, _grad(lin.bias), h, 1.0 / (1.0 - p))        # gate (h > 0) * 1/(1-p) in place + bias gradient
+        if dh.dtype != torch.bfloat16 or not dh.is_contiguous():
+            dh = dh.to(torch.bfloat16).contiguous()
+        gated = torch.empty_like(dh)                                # the incoming gradient is autograd's: not written in place
+        colsum_bf16(dh, _grad(lin.bias), h, 1.0 / (1.0 - p), out=gated)      # gate (h > 0) * 1/(1-p) + bias gradient
+        dh = gated
         if kpad:
             k = lin.weight.shape[1]
             tmp = torch.empty(lin.weight.shape[0], 128, dtype=torch.float32, device=dh.device)
@@ -473,17 +496,18 @@ def decoder_prenet_pe(prenet, pe, spec):
     lyr = prenet.layer
     training = prenet.training
     m = b * l
-    s2 = spec.reshape(m, nm)
-    if s2.dtype != torch.float32 or s2.stride(1) != 1:
-        s2 = s2.float().contiguous()
     kpad = nm % 64 != 0
     if kpad:
         if nm % 8 != 0 or nm > 128:
             raise NotImplementedError(f"decoder prenet: {nm} mel channels (supported: multiples of 8 up to 128, or multiples of 64)")
-        x = torch.empty(m, 128, dtype=torch.bfloat16, device=spec.device)     # cast + zero padding of the channels in one launch
-        _lib.call("rtts_to_halo", s2.data_ptr(), s2.stride(0), nm, 1, b, l, 0, 128, x.data_ptr(), 0, m, _s())
+        # the input is usually the view frames [0, L-1) of the batch: the kernel takes its batch stride (no contiguous copy);
+        # cast + zero padding of the channels in the same launch
+        if spec.dtype != torch.float32 or spec.stride(2) != 1 or spec.stride(1) % 4 != 0 or spec.stride(0) % 4 != 0:
+            spec = spec.float().contiguous()
+        x = torch.empty(m, 128, dtype=torch.bfloat16, device=spec.device)
+        _lib.call("rtts_to_halo", spec.data_ptr(), spec.stride(1), spec.stride(0), nm, 1, b, l, 0, 128, x.data_ptr(), 0, m, _s())
     else:
-        x = s2.to(torch.bfloat16)
+        x = spec.reshape(m, nm).to(torch.bfloat16)
     h = _ReluDropLinearFn.apply(x, lyr.fc1, lyr.dropout1.p if training else 0.0, kpad, lyr.fc1.weight)
     h = _ReluDropLinearFn.apply(h, lyr.fc2, lyr.dropout2.p if training else 0.0, False, lyr.fc2.weight)
     return proj_pe(h.view(b, l, -1), lyr.projection, pe)

@@ -53,6 +53,15 @@ def _bf16(p: torch.Tensor) -> torch.Tensor:
     return m if m is not None else p.detach().to(torch.bfloat16)
 
 
+def bf16_twin(x: torch.Tensor) -> Optional[torch.Tensor]:
+    """The bf16 copy a producer of this package left with its fp32 output (FusedStackFn: the sum of the two streams is
+    written in both precisions by one launch), or None -- also when x was written since."""
+    tw = getattr(x, "_rtts_bf16", None)
+    if tw is None or tw[1] != x._version or tw[0].device != x.device:
+        return None
+    return tw[0]
+
+
 def _adjacent(a: torch.Tensor, b: torch.Tensor) -> bool:
     """b starts where a ends, inside one storage (true for neighbours in the trainer's flat buffers)."""
     return (a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and a.is_contiguous() and b.is_contiguous()
@@ -110,8 +119,9 @@ def _partial_rows(m: int) -> int:
     return min((m + 3) // 4, 256)
 
 
-def _queue_colsum(partial: torch.Tensor, offset_floats: int, rows: int, d: int, out: torch.Tensor):
-    _Q.colsums.append((partial, offset_floats, rows, d, out))
+def _queue_colsum(partial: torch.Tensor, offset_floats: int, rows: int, d: int, out: torch.Tensor, ld: int = 0):
+    """``ld``: row stride of the partial buffer when ``d`` columns are a block of a wider one (0: d)."""
+    _Q.colsums.append((partial, offset_floats, rows, d, out, ld))
     _queue_final_flush()
 
 
@@ -121,8 +131,8 @@ def flush_colsum():
         group = pending[:_lib.COLSUM_MAX_GROUP]
         del pending[:len(group)]
         arr = (_lib.ColsumJob * len(group))()
-        for j, (partial, off, rows, d, out) in zip(arr, group):
-            j.partial, j.out, j.nrows, j.n = partial.data_ptr() + 4 * off, out.data_ptr(), rows, d
+        for j, (partial, off, rows, d, out, ld) in zip(arr, group):
+            j.partial, j.out, j.nrows, j.n, j.ld = partial.data_ptr() + 4 * off, out.data_ptr(), rows, d, ld
         _lib.call("rtts_colsum_final_grouped", arr, len(group), _s())
 
 
@@ -165,33 +175,43 @@ def _out_grad(d_acc, dbias, drop, pre_cast):
     return cast_colsum(d_acc, dbias, drop)
 
 
-def cast_colsum(dy, dbias: Optional[torch.Tensor], drop=None, defer: bool = True):
-    """dyb (bf16) = dy [* keep-scale of ``drop`` = (p, seed)]; dbias += column sums of the same."""
+def cast_colsum(dy, dbias, drop=None, defer: bool = True, scale: Optional[torch.Tensor] = None):
+    """dyb (bf16) = dy [* keep-scale of ``drop`` = (p, seed)] [* the device scalar ``scale``]; dbias += column sums of the same.
+    ``dbias``: a tensor, None, or a list of (first column, columns, out) blocks -- the sums of a padded gradient go to several
+    parameters' gradients (always deferred to the grouped final launch)."""
     m, d = dy.shape
     dyb = torch.empty(m, d, dtype=torch.bfloat16, device=dy.device)
     p, seed = drop if drop else (0.0, 0)
-    if DEFER_COLSUM and defer and dbias is not None:
+    sc = None if scale is None else scale.data_ptr()
+    blocks = dbias if isinstance(dbias, (list, tuple)) else None
+    if blocks is not None or (DEFER_COLSUM and defer and dbias is not None):
         ws = torch.empty(256 * d, dtype=torch.float32, device=dy.device)
         _lib.call("rtts_cast_colsum", dy.data_ptr(), dyb.data_ptr(), None, ws.data_ptr(), m, d, float(p), seed,
-                  seed_base(dy.device).data_ptr(), _s())
-        _queue_colsum(ws, 0, _partial_rows(m), d, dbias)
+                  seed_base(dy.device).data_ptr(), sc, _s())
+        if blocks is not None:
+            for c0, n, out in blocks:
+                _queue_colsum(ws, c0, _partial_rows(m), n, out, ld=d)
+        else:
+            _queue_colsum(ws, 0, _partial_rows(m), d, dbias)
         return dyb
     _lib.call("rtts_cast_colsum", dy.data_ptr(), dyb.data_ptr(), None if dbias is None else dbias.data_ptr(),
-              _WS.partial(dy.device, d).data_ptr(), m, d, float(p), seed, seed_base(dy.device).data_ptr(), _s())
+              _WS.partial(dy.device, d).data_ptr(), m, d, float(p), seed, seed_base(dy.device).data_ptr(), sc, _s())
     return dyb
 
 
-def colsum_bf16(dh, dbias, h=None, gate_scale: float = 1.0):
-    """dbias += column sums of dh; with ``h``: dh *= (h > 0) * gate_scale in place first (ReLU [+ dropout] backward)."""
+def colsum_bf16(dh, dbias, h=None, gate_scale: float = 1.0, out: Optional[torch.Tensor] = None):
+    """dbias += column sums of dh; with ``h``: dh * (h > 0) * gate_scale first (ReLU [+ dropout] backward), written to ``out``
+    (same strides as dh) or back in place."""
     m, d = dh.shape
+    o = None if out is None else out.data_ptr()
     if DEFER_COLSUM and dbias.is_contiguous():
         ws = torch.empty(256 * d, dtype=torch.float32, device=dh.device)
         _lib.call("rtts_colsum_bf16", dh.data_ptr(), None if h is None else h.data_ptr(), dh.stride(0), None, ws.data_ptr(), m, d,
-                  int(h is not None), float(gate_scale), _s())
+                  int(h is not None), float(gate_scale), o, _s())
         _queue_colsum(ws, 0, _partial_rows(m), d, dbias)
         return
     _lib.call("rtts_colsum_bf16", dh.data_ptr(), None if h is None else h.data_ptr(), dh.stride(0), dbias.data_ptr(),
-              _WS.partial(dh.device, d).data_ptr(), m, d, int(h is not None), float(gate_scale), _s())
+              _WS.partial(dh.device, d).data_ptr(), m, d, int(h is not None), float(gate_scale), o, _s())
 
 
 def residual(acc, g, bias, sign: float, next_norm=None, drop=None):
@@ -690,9 +710,14 @@ class FusedStackFn(torch.autograd.Function):
             extra = {}
             if context is not None:
                 kpm = next((k.get("key_padding_mask") for k in kwargs_list if "key" in k), None)
-                extra = dict(keys_bf16=context.detach().reshape(-1, d).to(torch.bfloat16),
-                             kvalid=None if kpm is None else ((~kpm).contiguous().view(torch.uint8) if kpm.dtype == torch.bool
-                                                              else (~kpm).to(torch.uint8).contiguous()))
+                kb = bf16_twin(context)                           # the encoder stack's own bf16 copy of its output
+                kb = kb.view(-1, d) if kb is not None else context.detach().reshape(-1, d).to(torch.bfloat16)
+                kv = None
+                if kpm is not None:
+                    kv = getattr(kpm, "_rtts_not", None)          # the validity mask the caller inverted into kpm: no second inversion
+                    kv = ~kpm if kv is None or kv.shape != kpm.shape or kv.device != kpm.device else kv
+                    kv = kv.contiguous().view(torch.uint8) if kv.dtype == torch.bool else kv.to(torch.uint8).contiguous()
+                extra = dict(keys_bf16=kb, kvalid=kv)
             steps, mask_cache = [], {}
             for (kind, f, g), kwargs in zip(prog, kwargs_list):
                 kw, kwg = _step_kwargs(kind, kwargs, extra, mask_cache)
@@ -707,7 +732,15 @@ class FusedStackFn(torch.autograd.Function):
                 else:
                     chain.done(f.forward(s1, s2, b, t, slot=slots[(i, "f")], **kw, **chain.args(i, "f", s2)), s1)
                     chain.done(g.forward(s2, s1, b, t, slot=slots[(i, "g")], **chain.args(i, "g", s1)), s2)
-            out = (s1 + s2).view(b, t, d)
+            if x.dtype == torch.float32 and (b * t * d) % 4 == 0:
+                # the sum of the streams in fp32 (the autograd value) and in bf16 (what the heads / the cross attention's key
+                # projection read), one launch
+                out = torch.empty(b, t, d, dtype=torch.float32, device=x.device)
+                twin = torch.empty(b * t, d, dtype=torch.bfloat16, device=x.device)
+                _lib.call("rtts_sum_streams", s1.data_ptr(), s2.data_ptr(), b * t * d, out.data_ptr(), twin.data_ptr(), _s())
+                out._rtts_bf16 = (twin, out._version)
+            else:
+                out = (s1 + s2).view(b, t, d)
         ctx.state = (s1, s2, steps, extra, b, t, d, context is not None, seq, slots)
         return out
 

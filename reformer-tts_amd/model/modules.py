@@ -63,24 +63,36 @@ def _bf16_linear(x, lin: nn.Linear):
 
 
 class _EmbeddingFn(torch.autograd.Function):
-    """nn.Embedding lookup whose backward is the deterministic per-id row sum of csrc/edges.hip."""
+    """nn.Embedding lookup + the Dropout behind it in one launch (counter-hash mask, reproduced by the backward); the backward
+    is the deterministic per-id row sum of csrc/edges.hip, accumulated straight into the weight's gradient."""
 
     @staticmethod
-    def forward(ctx, ids, weight, padding_idx):
-        ctx.save_for_backward(ids)
-        ctx.shape, ctx.padding_idx = weight.shape, padding_idx
-        return weight[ids]
+    def forward(ctx, ids, weight, padding_idx, p):
+        from .. import _lib
+        from .._seeds import _seed_counter, seed_base
+        n, c = weight.shape
+        ids2 = ids.reshape(-1).contiguous()
+        out = torch.empty(*ids.shape, c, dtype=torch.float32, device=weight.device)
+        seed = next(_seed_counter) * 2654435761 % (1 << 32)
+        w = weight.detach()
+        w = w if w.dtype == torch.float32 and w.is_contiguous() else w.float().contiguous()
+        _lib.call("rtts_embedding_fwd", ids2.data_ptr(), w.data_ptr(), ids2.numel(), c, n, float(p), seed,
+                  seed_base(weight.device).data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        ctx.state = (ids2, weight, padding_idx, float(p), seed)
+        return out
 
     @staticmethod
     def backward(ctx, dx):
         from .. import _lib
-        (ids,) = ctx.saved_tensors
-        n, c = ctx.shape
-        dw = torch.zeros(n, c, dtype=torch.float32, device=dx.device)
-        dx2 = dx.reshape(-1, c).float().contiguous()
-        _lib.call("rtts_embedding_bwd", ids.reshape(-1).contiguous().data_ptr(), dx2.data_ptr(), dx2.shape[0], c, n,
-                  -1 if ctx.padding_idx is None else ctx.padding_idx, dw.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        return None, dw, None
+        from .._seeds import seed_base
+        from ..engine import _grad
+        ids2, weight, padding_idx, p, seed = ctx.state
+        n, c = weight.shape
+        dx2 = dx.reshape(-1, c)
+        dx2 = dx2 if dx2.dtype == torch.float32 and dx2.is_contiguous() else dx2.float().contiguous()
+        _lib.call("rtts_embedding_bwd", ids2.data_ptr(), dx2.data_ptr(), dx2.shape[0], c, n, -1 if padding_idx is None else padding_idx,
+                  _grad(weight).data_ptr(), p, seed, seed_base(dx.device).data_ptr(), torch.cuda.current_stream().cuda_stream)
+        return None, None, None, None          # accumulated into weight.grad here (like every parameter of the fused path)
 
 
 class EncoderPreNet(nn.Module):
@@ -104,7 +116,7 @@ class EncoderPreNet(nn.Module):
         """``pe``: when given (training on the GPU), the positional encoding is applied here, fused with the projection."""
         c = self.convolutions
         if self.use_fused and self.training and input_.is_cuda:
-            x = c.dropout0(_EmbeddingFn.apply(input_, self.embed.weight, self.embed.padding_idx))
+            x = _EmbeddingFn.apply(input_, self.embed.weight, self.embed.padding_idx, c.dropout0.p)     # dropout0 inside
         else:
             x = c.dropout0(self.embed(input_))                  # (B, L, C) channels-last throughout
         if self.use_fused and self.training and x.is_cuda and self.embedding_dim % 128 == 0 and (x.shape[0] * x.shape[1]) % 64 == 0:

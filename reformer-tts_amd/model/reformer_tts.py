@@ -103,7 +103,9 @@ class ReformerTTS(nn.Module):
         keys = self.enc(pad_phonemes, input_mask=phoneme_mask, stack_hook=enc_stack_hook)
         if keys_hook is not None:
             keys = keys_hook(keys)
-        return self.dec.hidden(pad_spec, keys=keys, key_padding_mask=~phoneme_mask, input_mask=spectrogram_mask)[0]
+        kpm = ~phoneme_mask
+        kpm._rtts_not = phoneme_mask          # the stack executor wants the validity mask back: spares it the second inversion
+        return self.dec.hidden(pad_spec, keys=keys, key_padding_mask=kpm, input_mask=spectrogram_mask)[0]
 
     def forward(self, phonemes: torch.LongTensor, spectrogram: torch.Tensor,
                 spectrogram_mask: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, list]:

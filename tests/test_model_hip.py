@@ -750,7 +750,7 @@ def test_post_attention_dropout_kernels_agree(gpu):
     dyb = torch.empty(m, d, dtype=torch.bfloat16, device=gpu)
     dbias = torch.zeros(d, device=gpu)
     ws = torch.empty(2 * 256 * d, device=gpu)
-    _lib.call("rtts_cast_colsum", dy.data_ptr(), dyb.data_ptr(), dbias.data_ptr(), ws.data_ptr(), m, d, p, seed, sd.data_ptr(), s)
+    _lib.call("rtts_cast_colsum", dy.data_ptr(), dyb.data_ptr(), dbias.data_ptr(), ws.data_ptr(), m, d, p, seed, sd.data_ptr(), None, s)
     torch.cuda.synchronize()
     assert torch.equal(dyb, (dy * keep).bfloat16())
     torch.testing.assert_close(dbias, (dy * keep).sum(0), rtol=1e-4, atol=1e-3)
@@ -1273,3 +1273,96 @@ def test_validate_is_side_effect_free_and_tracks_training(gpu):
         tr.train_step(batch)
     assert float(tr.validate(batch)[0]) < v0[0]
 
+
+
+def test_segments_copy_add_and_cast_in_one_launch(gpu):
+    """rtts_segments: the per-step refreshes of padded operands and the additions of padded gradient blocks (exact)."""
+    from reformer_tts_amd import _lib
+    from reformer_tts_amd.edges import segments
+    g = torch.Generator().manual_seed(5)
+    a, b = torch.randn(80, 512, generator=g).to(gpu), torch.randn(1, 512, generator=g).to(gpu)
+    dst = torch.zeros(128, 512, device=gpu)
+    acc = torch.randn(80, 512, generator=g).to(gpu)
+    acc0 = acc.clone()
+    hb = torch.randn(300_001, generator=g).to(gpu)                 # longer than one block's stride: the grid-stride loop
+    hb16 = torch.empty(300_001, dtype=torch.bfloat16, device=gpu)
+    src16 = torch.randn(77, generator=g).bfloat16().to(gpu)
+    dst16 = torch.zeros(77, dtype=torch.bfloat16, device=gpu)
+    segments([(dst[:80], a, _lib.SEG_COPY_F32), (dst[80:81], b, _lib.SEG_COPY_F32), (acc, a, _lib.SEG_ADD_F32),
+              (hb16, hb, _lib.SEG_CAST_F32_BF16), (dst16, src16, _lib.SEG_COPY_BF16)])
+    torch.cuda.synchronize()
+    assert torch.equal(dst[:80], a) and torch.equal(dst[80:81], b) and float(dst[81:].abs().max()) == 0.0
+    assert torch.equal(acc, acc0 + a)
+    assert torch.equal(hb16, hb.bfloat16()) and torch.equal(dst16, src16)
+    with pytest.raises(ValueError):
+        segments([(dst[:, :5], a[:, :5], _lib.SEG_COPY_F32)])      # not contiguous
+
+
+def test_sum_streams_writes_both_precisions(gpu):
+    from reformer_tts_amd import _lib
+    g = torch.Generator().manual_seed(6)
+    a, b = torch.randn(1000, 512, generator=g).to(gpu), torch.randn(1000, 512, generator=g).to(gpu)
+    out, tw = torch.empty_like(a), torch.empty(1000, 512, dtype=torch.bfloat16, device=gpu)
+    _lib.call("rtts_sum_streams", a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(), tw.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(out, a + b) and torch.equal(tw, (a + b).bfloat16())
+
+
+def test_embedding_with_dropout_forward_and_backward(gpu):
+    """rtts_embedding_fwd / _bwd: lookup + dropout in one launch; the backward applies the same keep-scales and skips padding_idx
+    (float64 check; ``modules.py:17,22,56``)."""
+    from reformer_tts_amd.model.modules import _EmbeddingFn
+    g = torch.Generator().manual_seed(7)
+    n, c, p = 60, 512, 0.5
+    w = torch.randn(n, c, generator=g).to(gpu).requires_grad_(True)
+    ids = torch.randint(0, n, (3, 100), generator=g).to(gpu)
+    ids[0, -7:] = 0
+    out = _EmbeddingFn.apply(ids, w, 0, p)
+    plain = w.detach()[ids]
+    keep = out != 0
+    frac = float(keep.float().mean())
+    assert abs(frac - (1 - p)) < 0.02, frac
+    assert torch.equal(out[keep], (plain * 2.0)[keep])             # kept elements: exactly 1 / (1 - p) times the row
+    dy = torch.randn(3, 100, c, generator=g).to(gpu)
+    out.backward(dy)
+    torch.cuda.synchronize()
+    want = torch.zeros(n, c, dtype=torch.float64, device=gpu)
+    want.index_add_(0, ids.reshape(-1), (dy.double() * keep.double() * 2.0).reshape(-1, c))
+    want[0] = 0                                                    # padding_idx
+    err = float((w.grad.double() - want).abs().max() / want.abs().max())
+    print(f"\n[parity] embedding + dropout backward vs float64: {err:.2e} (tol 1e-6)")
+    assert err < 1e-6
+    out0 = _EmbeddingFn.apply(ids, w, 0, 0.0)
+    assert torch.equal(out0, plain)
+
+
+def test_upstream_gradient_of_the_total_loss_scales_every_gradient(gpu):
+    """The fused heads + postnet + loss backward takes the upstream scalar inside its first kernels (no scaling pass): a loss
+    weighted by 3 gives 3 x the gradients, up to the bf16 rounding of the scaled intermediates."""
+    from reformer_tts_amd import _seeds
+    from reformer_tts_amd.model.config import TTSTrainingConfig, model_config_from_dict
+    from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
+    cfg = model_ref.small_cfg()
+    cfg["enc_reformer_kwargs"]["attn_kwargs"]["implementation"] = "hip"
+    cfg["dec_reformer_kwargs"]["self_attn_kwargs"]["implementation"] = "hip"
+    batch = synthetic_batch(2, 100, 256, device=gpu)
+    grads = []
+    for scale in (1.0, 3.0):
+        _seeds.reset(0)
+        torch.manual_seed(11)
+        torch.cuda.manual_seed(11)
+        model = build_model(model_config_from_dict(cfg), gpu)
+        tr = Trainer(model, TTSTrainingConfig(batch_size=2), gpu)
+        model.train()
+        tr.zero_grad()
+        losses = tr.forward_loss(batch)
+        assert len(losses) == 4 and all(x.dim() == 0 for x in losses)
+        tr.backward(losses[0] * scale)
+        torch.cuda.synchronize()
+        grads.append(tr.flat_g.clone())
+    err = float((grads[1] - 3.0 * grads[0]).norm() / (3.0 * grads[0]).norm())
+    print(f"\n[parity] gradients of 3 x loss vs 3 x gradients of the loss: rel-L2 {err:.2e} (tol 5e-3)")
+    assert err < 5e-3
+    with pytest.raises(NotImplementedError):
+        tr.zero_grad()
+        tr.forward_loss(batch)[1].backward()
