@@ -50,11 +50,12 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the full-recompute leg and the peak probes")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
-    ap.add_argument("--recompute", default="stash", choices=["stash", "output-stash", "attention-stash", "full"],
+    ap.add_argument("--recompute", default="stash", choices=["stash", "projection-stash", "output-stash", "attention-stash", "full"],
                     help="what the reversible backward recomputes: 'full' = everything, as the reference does; "
-                         "'attention-stash' = attention outputs kept; 'output-stash' = block outputs f(x) kept too; 'stash' (default) = attention outputs, block outputs f(x) and "
-                         "the sublayers' projections kept (~0.3 GB of 288 GB), LayerNorm recomputed inside the stream "
-                         "reconstruction, streams reconstructed by subtraction")
+                         "'attention-stash' = attention outputs kept; 'output-stash' = block outputs f(x) kept too; 'projection-stash' = and the "
+                         "projections, streams still reconstructed by subtraction; 'stash' (default) = and the streams: every "
+                         "sublayer's LayerNorm input / output and projections stay in HBM (~1 GB of 288 GB), the backward "
+                         "recomputes nothing")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 12 if args.config == "baseline" else 4
@@ -148,8 +149,9 @@ def main():
 
     from reformer_tts_amd import engine, ops
     engine.STASH_ATTENTION = args.recompute != "full"
-    engine.STASH_BLOCK_OUTPUT = args.recompute in ("stash", "output-stash")
-    engine.STASH_PROJECTIONS = args.recompute == "stash"
+    engine.STASH_BLOCK_OUTPUT = args.recompute in ("stash", "projection-stash", "output-stash")
+    engine.STASH_PROJECTIONS = args.recompute in ("stash", "projection-stash")
+    engine.STASH_STREAMS = args.recompute == "stash"
     from reformer_tts_amd.model.config import (baseline_model_config, baseline_training_config,
                                                long_sequence_model_config)
     from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
@@ -247,8 +249,8 @@ def main():
         dt, _ = timed(fn, k)
         full_ms = round(1e3 * dt / k, 3)
         engine.STASH_ATTENTION = args.recompute != "full"
-        engine.STASH_BLOCK_OUTPUT = args.recompute in ("stash", "output-stash")
-        engine.STASH_PROJECTIONS = args.recompute == "stash"
+        engine.STASH_BLOCK_OUTPUT = args.recompute in ("stash", "projection-stash", "output-stash")
+        engine.STASH_PROJECTIONS = args.recompute in ("stash", "projection-stash")
         note(f"pure recompute (reference's mode): {full_ms} ms/step")
     peaks = (None, None)
     if rank == 0 and not args.no_extra:

@@ -148,12 +148,12 @@ int rtts_colsum_partial_rows(int M);
 int rtts_colsum_final_grouped(const rtts_colsum_job* jobs, int n, void* stream);
 int rtts_residual_epilogue(const float* x, const void* g, const float* bias, float sign, float* y,
                            int64_t M, int d, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
-/* The same epilogue fused with the NEXT block's LayerNorm: x += sign*(g + bias) in place, then
- * xn(bf16) = LayerNorm(x)*gamma + beta with mean/rstd per row (reformer.py:25-33 applied to the stream a
+/* The same epilogue fused with the NEXT block's LayerNorm: y = x + sign*(g + bias) (y = NULL: in place), then
+ * xn(bf16) = LayerNorm(y)*gamma + beta with mean/rstd per row (reformer.py:25-33 applied to the stream a
  * reversible block has just updated or reconstructed, reversible.py:56-98). */
 int rtts_residual_ln(float* x, const void* g, const float* bias, float sign, const float* gamma, const float* beta,
                      void* xn, float* mean, float* rstd, int M, int d, float drop_p, uint32_t seed, const uint32_t* seed_dev,
-                     void* stream);
+                     float* y, void* stream);
 /* out = a + b (the two streams of a reversible stack); out (fp32) and / or out_bf16 may be NULL; n % 4 == 0 */
 int rtts_sum_streams(const float* a, const float* b, int64_t n, float* out, void* out_bf16, void* stream);
 int rtts_bias_act(void* h, const float* bias, int64_t M, int d, int relu, void* stream);

@@ -64,7 +64,7 @@ SIGNATURES = {
     "rtts_residual_epilogue": [_vp, _vp, _vp, _f32, _vp, _i64, _i32, _f32, _u32, _vp, _vp],
     "rtts_colsum_partial_rows": [_i32],
     "rtts_colsum_final_grouped": [C.POINTER(ColsumJob), _i32, _vp],
-    "rtts_residual_ln": [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _u32, _vp, _vp],
+    "rtts_residual_ln": [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _u32, _vp, _vp, _vp],
     "rtts_bias_act": [_vp, _vp, _i64, _i32, _i32, _vp],
     "rtts_cast_f32_bf16": [_vp, _vp, _i64, _vp],
     "rtts_xattn_fwd": [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _f32, _u32, _vp, _vp],

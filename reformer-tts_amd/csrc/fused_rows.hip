@@ -153,7 +153,7 @@ __global__ __launch_bounds__(FR_THREADS) void ln_fwd_kernel(const float* __restr
 // block has just updated (forward) or reconstructed (backward) is exactly the next block's LayerNorm input, so the
 // row is normalised while it is still in registers instead of being read back by a separate launch.
 template <int EPL, int VEC>
-__global__ __launch_bounds__(FR_THREADS) void residual_ln_kernel(float* __restrict__ x, const bf16_t* __restrict__ g,
+__global__ __launch_bounds__(FR_THREADS) void residual_ln_kernel(const float* x, float* y, const bf16_t* __restrict__ g,
                                                                  const float* __restrict__ bias, float sign,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  bf16_t* __restrict__ xn, float* __restrict__ mean,
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(FR_THREADS) void residual_ln_kernel(float* __restri
     }
 #pragma unroll
     for (int e = 0; e < EPL; ++e) v[e] += sign * gv[e];
-    store_row_f32<EPL, VEC>(x + (size_t)row * D, lane, v);
+    store_row_f32<EPL, VEC>(y + (size_t)row * D, lane, v);      // y == x: the stream is updated in place
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) s += v[e];
@@ -596,10 +596,11 @@ extern "C" int rtts_residual_epilogue(const float* x, const void* g, const float
 
 extern "C" int rtts_residual_ln(float* x, const void* g, const float* bias, float sign, const float* gamma, const float* beta,
                                 void* xn, float* mean, float* rstd, int M, int d, float drop_p, uint32_t seed,
-                                const uint32_t* seed_dev, void* stream) {
+                                const uint32_t* seed_dev, float* y, void* stream) {
+    if (!y) y = x;
     RTTS_REQUIRE(x && g && gamma && beta && xn && mean && rstd && M > 0 && drop_p >= 0.f && drop_p < 1.f, "rtts_residual_ln: bad arguments");
     const dim3 grid((M + FR_WAVES - 1) / FR_WAVES);
-#define CALL(EPL, VEC) hipLaunchKernelGGL((residual_ln_kernel<EPL, VEC>), grid, dim3(FR_THREADS), 0, (hipStream_t)stream, x, (const bf16_t*)g, bias, sign, gamma, beta, (bf16_t*)xn, mean, rstd, M, seed, seed_dev, rtts_drop_thresh(drop_p), 1.f / (1.f - drop_p))
+#define CALL(EPL, VEC) hipLaunchKernelGGL((residual_ln_kernel<EPL, VEC>), grid, dim3(FR_THREADS), 0, (hipStream_t)stream, x, y, (const bf16_t*)g, bias, sign, gamma, beta, (bf16_t*)xn, mean, rstd, M, seed, seed_dev, rtts_drop_thresh(drop_p), 1.f / (1.f - drop_p))
     FR_DISPATCH_D(d, CALL)
 #undef CALL
     RTTS_LAUNCH_CHECK("rtts_residual_ln");

@@ -40,6 +40,16 @@ STASH_BLOCK_OUTPUT = True
 # backward instead of recomputing them from the reconstructed input: ~0.3 GB at the baseline shapes against 288 GB of HBM,
 # and the backward then has no forward GEMM left in it.  Off = the reference's memory behaviour (everything recomputed).
 STASH_PROJECTIONS = True
+# Keep the streams themselves: every sublayer writes its updated stream to a NEW buffer (same traffic as the in-place update)
+# and leaves its LayerNorm input and output where they are, so the backward neither reconstructs a stream nor re-normalises it
+# (the reference reconstructs x2 = y2 - g(y1), x1 = y1 - f(x2): reversible.py:69-98).  25 MB per sublayer and stream at the
+# baseline shapes.  Needs the three switches above (a recomputing backward has to run on reconstructed streams).
+STASH_STREAMS = True
+_NO_G = object()          # "the block output is not needed" (no reconstruction): _internals then skips its GEMM
+
+
+def _streams_kept() -> bool:
+    return STASH_STREAMS and STASH_ATTENTION and STASH_BLOCK_OUTPUT and STASH_PROJECTIONS
 WEIGHT_EPOCH = [0]   # bumped by the trainer after every optimizer step (its kernels write parameters through raw pointers)
 
 
@@ -214,23 +224,23 @@ def colsum_bf16(dh, dbias, h=None, gate_scale: float = 1.0, out: Optional[torch.
               _WS.partial(dh.device, d).data_ptr(), m, d, int(h is not None), float(gate_scale), o, _s())
 
 
-def residual(acc, g, bias, sign: float, next_norm=None, drop=None):
-    """acc = acc + sign * dropout(g + bias), in place (``drop`` = (p, seed) or None).  With ``next_norm`` (the LayerNorm
-    of the block that reads ``acc`` next) the row is normalised in the same launch: returns (xn, mean, rstd) of
-    LayerNorm(acc), else None."""
+def residual(acc, g, bias, sign: float, next_norm=None, drop=None, out=None):
+    """out = acc + sign * dropout(g + bias) (``out`` None: in place; ``drop`` = (p, seed) or None).  With ``next_norm`` (the
+    LayerNorm of the block that reads the result next) the row is normalised in the same launch: returns (xn, mean, rstd) of
+    LayerNorm(result), else None."""
     m, d = acc.shape
     p, seed = drop if drop else (0.0, 0)
     sb = seed_base(acc.device).data_ptr()
     if next_norm is None:
         _lib.call("rtts_residual_epilogue", acc.data_ptr(), g.data_ptr(), None if bias is None else bias.data_ptr(), float(sign),
-                  acc.data_ptr(), m, d, float(p), seed, sb, _s())
+                  (acc if out is None else out).data_ptr(), m, d, float(p), seed, sb, _s())
         return None
     xn = torch.empty(m, d, dtype=torch.bfloat16, device=acc.device)
     mean = torch.empty(m, dtype=torch.float32, device=acc.device)
     rstd = torch.empty(m, dtype=torch.float32, device=acc.device)
     _lib.call("rtts_residual_ln", acc.data_ptr(), g.data_ptr(), None if bias is None else bias.data_ptr(), float(sign),
               next_norm.weight.data_ptr(), next_norm.bias.data_ptr(), xn.data_ptr(), mean.data_ptr(), rstd.data_ptr(), m, d,
-              float(p), seed, sb, _s())
+              float(p), seed, sb, None if out is None else out.data_ptr(), _s())
     return xn, mean, rstd
 
 
@@ -366,6 +376,18 @@ def wgrad(grad_view: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, accumulate
 
 
 # ------------------------------------------------------------------------------------------ blocks
+def _keep_streams(slot, acc, inp, xn, mean, rstd):
+    """STASH_STREAMS: -> the fresh buffer the updated stream goes to (also left in slot["acc_out"] for the stack loop), with
+    the sublayer's LayerNorm input and output kept in the slot for its backward; else None (update in place)."""
+    if not _streams_kept():
+        return None
+    out = torch.empty_like(acc)
+    slot.update(inp=inp, pre=(xn, mean, rstd), acc_out=out)
+    if STASH_BLOCK_OUTPUT:
+        slot["g"] = None                      # no reconstruction: f(x) is not read again
+    return out
+
+
 class LSHExec:
     """WithNorm(LayerNorm, LSHSelfAttentionWrapper): acc += to_out(LSH(LN(inp)))."""
 
@@ -421,12 +443,12 @@ class LSHExec:
 
     def forward(self, acc, inp, b, t, mask=None, pre=None, next_norm=None, slot=None, **_):
         slot = self._own_slot if slot is None else slot
-        *_, qkv, st, out, lse_tot, g = self._internals(inp, b, t, mask, None, pre=pre)
+        xn, mean, rstd, _, qkv, st, out, lse_tot, g = self._internals(inp, b, t, mask, None, pre=pre)
         p = self.layer.post_attn_dropout.p if self.layer.training else 0.0
         slot.clear()
         slot.update(st=st, stash=(out, lse_tot) if STASH_ATTENTION else None, g=g if STASH_BLOCK_OUTPUT else None,
                     qkv=qkv if STASH_PROJECTIONS else None, drop=(p, next_seed()) if p > 0.0 else None)
-        return residual(acc, g, self.layer.to_out.bias, 1.0, next_norm, slot["drop"])
+        return residual(acc, g, self.layer.to_out.bias, 1.0, next_norm, slot["drop"], out=_keep_streams(slot, acc, inp, xn, mean, rstd))
 
     def backward(self, acc, inp, d_acc, d_inp, b, t, mask=None, pre=None, next_norm=None, pre_cast=None, next_cast=None, slot=None, **_):
         slot = self._own_slot if slot is None else slot
@@ -434,11 +456,14 @@ class LSHExec:
             raise RuntimeError("LSHExec.backward: no forward state for this call (backward run twice, or without its forward)")
         lyr = self.layer
         e = lyr.dim
-        xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g = self._internals(inp, b, t, mask, slot["st"], slot["stash"], slot["g"], pre,
-                                                                         slot["qkv"])
+        kept = "inp" in slot                       # STASH_STREAMS: the forward's own LayerNorm input / output, nothing reconstructed
+        if kept:
+            inp, pre = slot["inp"], slot["pre"]
+        xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g = self._internals(inp, b, t, mask, slot["st"], slot["stash"],
+                                                                         _NO_G if kept else slot["g"], pre, slot["qkv"])
         drop = slot["drop"]
         slot.clear()
-        post = residual(acc, g, lyr.to_out.bias, -1.0, next_norm, drop)       # reconstruct the stream (same dropout mask)
+        post = None if kept else residual(acc, g, lyr.to_out.bias, -1.0, next_norm, drop)   # reconstruct the stream (same dropout mask)
         dyb = _out_grad(d_acc, _grad(lyr.to_out.bias), drop, pre_cast)
         out2 = out.view(b * t, e)
         wgrad(_grad(lyr.to_out.weight), dyb, out2)
@@ -483,18 +508,21 @@ class FFNExec:
 
     def forward(self, acc, inp, b, t, pre=None, next_norm=None, slot=None, **_):
         slot = self._own_slot if slot is None else slot
-        *_, h, g = self._internals(inp, pre=pre)
+        xn, mean, rstd, h, g = self._internals(inp, pre=pre)
         slot.clear()
         slot.update(g=g if STASH_BLOCK_OUTPUT else None, h=h if STASH_PROJECTIONS else None)
-        return residual(acc, g, self.l2.bias, 1.0, next_norm)
+        return residual(acc, g, self.l2.bias, 1.0, next_norm, out=_keep_streams(slot, acc, inp, xn, mean, rstd))
 
     def backward(self, acc, inp, d_acc, d_inp, b, t, pre=None, next_norm=None, pre_cast=None, next_cast=None, slot=None, **_):
         slot = self._own_slot if slot is None else slot
         if "g" not in slot:
             raise RuntimeError("FFNExec.backward: no forward state for this call (backward run twice, or without its forward)")
-        xn, mean, rstd, h, g = self._internals(inp, slot["g"], pre, slot["h"])
+        kept = "inp" in slot
+        if kept:
+            inp, pre = slot["inp"], slot["pre"]
+        xn, mean, rstd, h, g = self._internals(inp, _NO_G if kept else slot["g"], pre, slot["h"])
         slot.clear()
-        post = residual(acc, g, self.l2.bias, -1.0, next_norm)
+        post = None if kept else residual(acc, g, self.l2.bias, -1.0, next_norm)
         dyb = _out_grad(d_acc, _grad(self.l2.bias), None, pre_cast)
         wgrad(_grad(self.l2.weight), dyb, h)
         # the ReLU gate and the partial column sums of db1 ride in the epilogue of the dgrad GEMM
@@ -541,11 +569,11 @@ class XAttnExec:
         slot = self._own_slot if slot is None else slot
         p = self.mha.dropout if self.mha.training else 0.0
         pdrop = (p, next_seed()) if p > 0.0 else None
-        *_, q, kv, o, lse, g, _ = self._internals(inp, b, t, keys_bf16, kvalid, pre=pre, drop=pdrop)
+        xn, mean, rstd, _, q, kv, o, lse, g, _ = self._internals(inp, b, t, keys_bf16, kvalid, pre=pre, drop=pdrop)
         slot.clear()
         slot.update(stash=(o, lse) if STASH_ATTENTION else None, g=g if STASH_BLOCK_OUTPUT else None, pdrop=pdrop,
                     proj=(q, kv) if STASH_PROJECTIONS else None)
-        return residual(acc, g, self.mha.out_proj.bias, 1.0, next_norm)
+        return residual(acc, g, self.mha.out_proj.bias, 1.0, next_norm, out=_keep_streams(slot, acc, inp, xn, mean, rstd))
 
     def backward(self, acc, inp, d_acc, d_inp, b, t, keys_bf16=None, kvalid=None, dkeys=None, pre=None, next_norm=None,
                  pre_cast=None, next_cast=None, slot=None, **_):
@@ -555,10 +583,13 @@ class XAttnExec:
         m = self.mha
         e, h = m.embed_dim, m.num_heads
         drop = slot["pdrop"]
-        xn, mean, rstd, w, q, kv, o, lse, g, tk = self._internals(inp, b, t, keys_bf16, kvalid, slot["stash"], slot["g"], pre, drop,
-                                                                  slot["proj"])
+        kept = "inp" in slot
+        if kept:
+            inp, pre = slot["inp"], slot["pre"]
+        xn, mean, rstd, w, q, kv, o, lse, g, tk = self._internals(inp, b, t, keys_bf16, kvalid, slot["stash"],
+                                                                  _NO_G if kept else slot["g"], pre, drop, slot["proj"])
         slot.clear()
-        post = residual(acc, g, m.out_proj.bias, -1.0, next_norm)
+        post = None if kept else residual(acc, g, m.out_proj.bias, -1.0, next_norm)
         dyb = _out_grad(d_acc, _grad(m.out_proj.bias), None, pre_cast)
         wgrad(_grad(m.out_proj.weight), dyb, o)
         do = gemm(dyb, _bf16(m.out_proj.weight), kn=True)
@@ -703,10 +734,16 @@ class FusedStackFn(torch.autograd.Function):
         b, t, d = x.shape
         prog = seq._program
         with torch.no_grad():
-            # both streams start as x: one broadcast copy into a (2, B*T, d) buffer (x is read once, one launch)
-            both = torch.empty(2, b * t, d, dtype=x.dtype, device=x.device)
-            both.copy_(x.detach().reshape(1, b * t, d).expand(2, -1, -1))
-            s1, s2 = both[0], both[1]
+            kept = _streams_kept()
+            if kept:
+                # every sublayer writes its updated stream to a new buffer: both streams simply start as x itself
+                s1 = x.detach().reshape(b * t, d)
+                s1 = s2 = s1 if s1.dtype == torch.float32 and s1.is_contiguous() else s1.float().contiguous()
+            else:
+                # both streams start as x: one broadcast copy into a (2, B*T, d) buffer (x is read once, one launch)
+                both = torch.empty(2, b * t, d, dtype=x.dtype, device=x.device)
+                both.copy_(x.detach().reshape(1, b * t, d).expand(2, -1, -1))
+                s1, s2 = both[0], both[1]
             extra = {}
             if context is not None:
                 kpm = next((k.get("key_padding_mask") for k in kwargs_list if "key" in k), None)
@@ -728,10 +765,16 @@ class FusedStackFn(torch.autograd.Function):
                 if kind == "swap":
                     s1, s2 = s2, s1
                 elif kind == "half":
-                    chain.done(f.forward(s1, s2, b, t, slot=slots[(i, "f")], **kw, **chain.args(i, "f", s2)), s1)
+                    post = f.forward(s1, s2, b, t, slot=slots[(i, "f")], **kw, **chain.args(i, "f", s2))
+                    s1 = slots[(i, "f")].pop("acc_out", s1)
+                    chain.done(post, s1)
                 else:
-                    chain.done(f.forward(s1, s2, b, t, slot=slots[(i, "f")], **kw, **chain.args(i, "f", s2)), s1)
-                    chain.done(g.forward(s2, s1, b, t, slot=slots[(i, "g")], **chain.args(i, "g", s1)), s2)
+                    post = f.forward(s1, s2, b, t, slot=slots[(i, "f")], **kw, **chain.args(i, "f", s2))
+                    s1 = slots[(i, "f")].pop("acc_out", s1)
+                    chain.done(post, s1)
+                    post = g.forward(s2, s1, b, t, slot=slots[(i, "g")], **chain.args(i, "g", s1))
+                    s2 = slots[(i, "g")].pop("acc_out", s2)
+                    chain.done(post, s2)
             if x.dtype == torch.float32 and (b * t * d) % 4 == 0:
                 # the sum of the streams in fp32 (the autograd value) and in bf16 (what the heads / the cross attention's key
                 # projection read), one launch

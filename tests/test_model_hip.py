@@ -591,10 +591,11 @@ def test_attention_stash_matches_pure_recompute(gpu):
     cfg["dec_reformer_kwargs"]["self_attn_kwargs"]["implementation"] = "hip"
     batch = synthetic_batch(2, 100, 256, device=gpu)
     grads = []
-    old = engine.STASH_ATTENTION, engine.STASH_BLOCK_OUTPUT, engine.STASH_PROJECTIONS
+    old = engine.STASH_ATTENTION, engine.STASH_BLOCK_OUTPUT, engine.STASH_PROJECTIONS, engine.STASH_STREAMS
     try:
-        for stash, stash_out, stash_proj in ((True, True, True), (True, True, False), (True, False, False), (False, False, False)):
-            engine.STASH_ATTENTION, engine.STASH_BLOCK_OUTPUT, engine.STASH_PROJECTIONS = stash, stash_out, stash_proj
+        for stash, stash_out, stash_proj, streams in ((True, True, True, True), (True, True, True, False), (True, True, False, False),
+                                                      (True, False, False, False), (False, False, False, False)):
+            engine.STASH_ATTENTION, engine.STASH_BLOCK_OUTPUT, engine.STASH_PROJECTIONS, engine.STASH_STREAMS = stash, stash_out, stash_proj, streams
             model = build_model(model_config_from_dict(cfg), gpu)
             tr = Trainer(model, TTSTrainingConfig(batch_size=2), gpu)
             model.train()
@@ -603,10 +604,10 @@ def test_attention_stash_matches_pure_recompute(gpu):
             torch.cuda.synchronize()
             grads.append(tr.flat_g.clone())
     finally:
-        engine.STASH_ATTENTION, engine.STASH_BLOCK_OUTPUT, engine.STASH_PROJECTIONS = old
-    errs = [((g - grads[3]).norm() / grads[3].norm()).item() for g in grads[:3]]
-    print(f"\n[parity] stash modes vs pure recompute, relative gradient distance: all three {errs[0]:.2e}, without projections "
-          f"{errs[1]:.2e}, attention only {errs[2]:.2e} (tol 1e-2)")
+        engine.STASH_ATTENTION, engine.STASH_BLOCK_OUTPUT, engine.STASH_PROJECTIONS, engine.STASH_STREAMS = old
+    errs = [((g - grads[4]).norm() / grads[4].norm()).item() for g in grads[:4]]
+    print(f"\n[parity] stash modes vs pure recompute, relative gradient distance: streams kept {errs[0]:.2e}, streams reconstructed "
+          f"{errs[1]:.2e}, without projections {errs[2]:.2e}, attention only {errs[3]:.2e} (tol 1e-2)")
     assert max(errs) < 1e-2
 
 
@@ -683,7 +684,7 @@ def test_long_sequence_config_runs_on_the_executor(gpu):
     grads = []
     batch = synthetic_batch(1, 200, 4096, device=gpu)
     old = engine.STASH_ATTENTION, engine.STASH_BLOCK_OUTPUT, engine.STASH_PROJECTIONS
-    try:
+    try:       # (STASH_STREAMS stays on: it only acts when the other three are)
         for seed0, stash in ((0, True), (0, True), (0, False), (1000, True)):
             engine.STASH_ATTENTION = engine.STASH_BLOCK_OUTPUT = engine.STASH_PROJECTIONS = stash
             _seeds.reset(seed0)
@@ -742,7 +743,7 @@ def test_post_attention_dropout_kernels_agree(gpu):
     xn = torch.empty(m, d, dtype=torch.bfloat16, device=gpu)
     mean, rstd = torch.empty(m, device=gpu), torch.empty(m, device=gpu)
     _lib.call("rtts_residual_ln", x2.data_ptr(), gg.data_ptr(), bias.data_ptr(), -1.0, gamma.data_ptr(), beta.data_ptr(), xn.data_ptr(),
-              mean.data_ptr(), rstd.data_ptr(), m, d, p, seed, sd.data_ptr(), s)
+              mean.data_ptr(), rstd.data_ptr(), m, d, p, seed, sd.data_ptr(), None, s)
     torch.testing.assert_close(x1, want, rtol=1e-6, atol=1e-6)
     assert torch.equal(x1, x2)
     torch.testing.assert_close(xn.float(), torch.nn.functional.layer_norm(want, (d,), gamma, beta, 1e-5), rtol=2e-2, atol=2e-2)
