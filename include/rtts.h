@@ -159,21 +159,26 @@ int rtts_sum_streams(const float* a, const float* b, int64_t n, float* out, void
 int rtts_bias_act(void* h, const float* bias, int64_t M, int d, int relu, void* stream);
 int rtts_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 
-/* ---- dense encoder-decoder attention (T_k = 128 or 256 keys on chip) ------------------------
+/* ---- dense encoder-decoder attention (T_k a multiple of 128, 128 or 256 keys on chip at a time) ----
  * Replaces the attention core of nn.MultiheadAttention inside MultiheadAttentionWrapper
  * (reference reformer_tts/model/reformer.py:161-186); projections stay GEMMs outside.
  *   q   bf16 (B,Tq,H*dh) stride ld_q;  kv bf16 (B,Tk,2*H*dh) = [k | v] stride ld_kv
  *   kvalid u8 (B,Tk) 1 = attend (i.e. NOT key_padding_mask), or NULL
  *   o   bf16 (B,Tq,H*dh) stride ld_o;  lse f32 (B*H,Tq)
  *   backward: delta f32 (B*H,Tq) = rowsum(o*do) (rtts_lsh_bwd_delta), dq bf16 like q,
- *   dkv_part bf16 (Tq/128, B, Tk, 2*H*dh) partial slabs -> rtts_sum_slabs -> dkv (B,Tk,2*H*dh) */
+ *   dkv_part bf16 (Tq/128, B, Tk, 2*H*dh) partial slabs -> rtts_sum_slabs -> dkv (B,Tk,2*H*dh)
+ *   T_k > 256 (or 384, 640, ...): the forward walks the keys in rtts_xattn_key_chunks(T_k) chunks with a running maximum and
+ *   normaliser; the backward gives every chunk its own workgroups (P = exp(s - lse) needs only the forward's lse), which
+ *   write their shares of dQ to dq_chunks (chunks, B*Tq, H*dh) bf16 -- summed into dq (ld_dq == H*dh) by the same call;
+ *   one chunk: dq_chunks may be NULL */
+int rtts_xattn_key_chunks(int Tk);
 int rtts_xattn_fwd(const void* q, int64_t ld_q, const void* kv, int64_t ld_kv, const uint8_t* kvalid,
                    int B, int H, int Tq, int Tk, int dh, void* o, int64_t ld_o, float* lse,
                    float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
 int rtts_xattn_bwd(const void* q, int64_t ld_q, const void* kv, int64_t ld_kv, const uint8_t* kvalid,
                    const void* dout, int64_t ld_dout, const float* lse, const float* delta,
                    int B, int H, int Tq, int Tk, int dh, void* dq, int64_t ld_dq, void* dkv_part,
-                   float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
+                   float drop_p, uint32_t seed, const uint32_t* seed_dev, void* dq_chunks, void* stream);
 /* drop_p = nn.MultiheadAttention's dropout on the normalised attention probabilities (config #4: 0.15); the keep
  * decision of (head, query, key) is hash(seed + *seed_dev, index), identical in the forward and the backward. */
 int rtts_sum_slabs(const void* part, int nslabs, int64_t n, void* out, void* stream);

@@ -68,7 +68,8 @@ SIGNATURES = {
     "rtts_bias_act": [_vp, _vp, _i64, _i32, _i32, _vp],
     "rtts_cast_f32_bf16": [_vp, _vp, _i64, _vp],
     "rtts_xattn_fwd": [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _f32, _u32, _vp, _vp],
-    "rtts_xattn_bwd": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _f32, _u32, _vp, _vp],
+    "rtts_xattn_bwd": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _f32, _u32, _vp, _vp, _vp],
+    "rtts_xattn_key_chunks": [_i32],
     "rtts_sum_slabs": [_vp, _i32, _i64, _vp, _vp],
     "rtts_conv1d_k5": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _vp],
     "rtts_to_halo": [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i64, _vp],

@@ -45,10 +45,12 @@ __device__ __forceinline__ int xa_ds_off(int key, int gran) {
 
 template <int TK>
 __global__ __launch_bounds__(256) void xattn_fwd_kernel(const bf16_t* __restrict__ q, int64_t ld_q, const bf16_t* __restrict__ kv,
-                                                        int64_t ld_kv, const uint8_t* __restrict__ kvalid, int H, int Tq,
+                                                        int64_t ld_kv, const uint8_t* __restrict__ kvalid, int H, int Tq, int TKtot,
                                                         bf16_t* __restrict__ o, int64_t ld_o, float* __restrict__ lse,
                                                         uint32_t seed, const uint32_t* __restrict__ seed_dev, uint32_t thresh,
                                                         float dscale) {
+    // TK = keys held on chip at a time; TKtot (a multiple of TK) keys are walked chunk by chunk with a running maximum and
+    // normaliser (one chunk: exactly the single-pass softmax)
     constexpr int NKT = TK / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Ks = smem;
@@ -63,98 +65,113 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const bf16_t* __restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
 
-    const bf16_t* kbase = kv + (size_t)b * TK * ld_kv + (size_t)h * XA_DH;
-    const bf16_t* vbase = kbase + d;
-    constexpr int ITERS = TK * 8 / 256;
-    uint4 kreg[ITERS], vreg[ITERS];
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        const int row = (it * 256 + tid) >> 3, piece = tid & 7;
-        kreg[it] = *reinterpret_cast<const uint4*>(kbase + (size_t)row * ld_kv + piece * 8);
-        vreg[it] = *reinterpret_cast<const uint4*>(vbase + (size_t)row * ld_kv + piece * 8);
-    }
     // Q fragments straight from global: lane (r, hh) holds Q[q0 + r][16 ks + 8 hh .. +8]
     const int qrow = qb * XA_QB + wave * 32 + r;
     const bf16_t* qptr = q + ((size_t)b * Tq + qrow) * ld_q + (size_t)h * XA_DH;
     bf16x8 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qptr + ks * 16 + 8 * hh);
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        const int row = (it * 256 + tid) >> 3, piece = tid & 7;
-        *reinterpret_cast<uint4*>(Ks + row * XA_ROWB + piece * 16) = kreg[it];
-        *reinterpret_cast<uint4*>(Vs + xa_off(row, piece)) = vreg[it];       // V: unpadded rows, swizzled (transposed reads)
-    }
-    for (int j = tid; j < TK; j += 256) kval[j] = kvalid ? (int)kvalid[(size_t)b * TK + j] : 1;
-    __syncthreads();
+    if (thresh && seed_dev) seed += seed_dev[0];
 
-    f32x16 s[NKT];
+    float m_run = -FLT_MAX, l_run = 0.f;
+    f32x16 oacc[2] = {{0}, {0}};
+    const int trq = (lane & 15) >> 2, trp = lane & 3, trc = (lane >> 4) & 1;
+#pragma unroll 1
+    for (int c0 = 0; c0 < TKtot; c0 += TK) {
+        const bf16_t* kbase = kv + ((size_t)b * TKtot + c0) * ld_kv + (size_t)h * XA_DH;
+        const bf16_t* vbase = kbase + d;
+        constexpr int ITERS = TK * 8 / 256;
+        uint4 kreg[ITERS], vreg[ITERS];
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-        f32x16 acc = {0};
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + r) * XA_ROWB + (ks * 16 + 8 * hh) * 2);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc, 0, 0, 0);
+        for (int it = 0; it < ITERS; ++it) {
+            const int row = (it * 256 + tid) >> 3, piece = tid & 7;
+            kreg[it] = *reinterpret_cast<const uint4*>(kbase + (size_t)row * ld_kv + piece * 8);
+            vreg[it] = *reinterpret_cast<const uint4*>(vbase + (size_t)row * ld_kv + piece * 8);
         }
-        s[kt] = acc;
-    }
-    float m = -FLT_MAX;
+        if (c0) __syncthreads();        // every wave is done with the previous chunk's images
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
+        for (int it = 0; it < ITERS; ++it) {
+            const int row = (it * 256 + tid) >> 3, piece = tid & 7;
+            *reinterpret_cast<uint4*>(Ks + row * XA_ROWB + piece * 16) = kreg[it];
+            *reinterpret_cast<uint4*>(Vs + xa_off(row, piece)) = vreg[it];       // V: unpadded rows, swizzled (transposed reads)
+        }
+        for (int j = tid; j < TK; j += 256) kval[j] = kvalid ? (int)kvalid[(size_t)b * TKtot + c0 + j] : 1;
+        __syncthreads();
+
+        f32x16 s[NKT];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int4 kvv = *reinterpret_cast<const int4*>(kval + kt * 32 + 8 * g + 4 * hh);
-            const int vv[4] = {kvv.x, kvv.y, kvv.z, kvv.w};
+        for (int kt = 0; kt < NKT; ++kt) {
+            f32x16 acc = {0};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float x = vv[j] ? s[kt][4 * g + j] * 0.125f : -FLT_MAX;
-                s[kt][4 * g + j] = x;
-                m = fmaxf(m, x);
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + r) * XA_ROWB + (ks * 16 + 8 * hh) * 2);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc, 0, 0, 0);
             }
+            s[kt] = acc;
         }
-    m = rtts_xhalf_max(m);
-    float l = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float p = s[kt][i] == -FLT_MAX ? 0.f : __expf(s[kt][i] - m);
-            s[kt][i] = p;
-            l += p;
-        }
-    l = rtts_xhalf_sum(l);
-    if (thresh) {
-        // nn.MultiheadAttention(dropout=p): dropout on the NORMALISED probabilities; l above is the full normaliser, the
-        // keep-scale of element (head, query, key) multiplies the unnormalised p before P V
-        if (seed_dev) seed += seed_dev[0];
-        const uint32_t base = ((uint32_t)bh * (uint32_t)Tq + (uint32_t)qrow) * (uint32_t)TK;
+        float m = -FLT_MAX;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                s[kt][i] *= rtts_drop_keep(seed, base + (uint32_t)(kt * 32 + 8 * (i >> 2) + 4 * hh + (i & 3)), thresh, dscale);
-    }
-
-    f32x16 oacc[2] = {{0}, {0}};
-    const int trq = (lane & 15) >> 2, trp = lane & 3, trc = (lane >> 4) & 1;
+            for (int g = 0; g < 4; ++g) {
+                const int4 kvv = *reinterpret_cast<const int4*>(kval + kt * 32 + 8 * g + 4 * hh);
+                const int vv[4] = {kvv.x, kvv.y, kvv.z, kvv.w};
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const int o8 = 8 * s2;
-            const bf16x8 pf = cvt_bf16x8(s[kt][o8], s[kt][o8 + 1], s[kt][o8 + 2], s[kt][o8 + 3], s[kt][o8 + 4], s[kt][o8 + 5],
-                                         s[kt][o8 + 6], s[kt][o8 + 7]);
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const int blk = (kt * 32 + 16 * s2) * 128;
-                const int t0 = xa_off(4 * hh + trq, dt * 4 + 2 * trc + (trp >> 1)) + 8 * (trp & 1);
-                const int t1 = xa_off(4 * hh + trq, (dt ^ 1) * 4 + 2 * trc + (trp >> 1)) + 8 * (trp & 1);   // row + 8: sw flips bit 2
-                const bf16x8 vf = xa_tr_frag(Vs + blk + t0, Vs + blk + 8 * 128 + t1);
-                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    const float x = vv[j] ? s[kt][4 * g + j] * 0.125f : -FLT_MAX;
+                    s[kt][4 * g + j] = x;
+                    m = fmaxf(m, x);
+                }
             }
+        m = fmaxf(rtts_xhalf_max(m), m_run);
+        // rescale what the earlier chunks left (first chunk: m_run = -FLT_MAX, l_run = 0, oacc = 0; a chunk of masked keys only
+        // leaves m = m_run and alpha = 1)
+        const float alpha = (m_run == -FLT_MAX) ? 0.f : __expf(m_run - m);
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float p = s[kt][i] == -FLT_MAX ? 0.f : __expf(s[kt][i] - m);
+                s[kt][i] = p;
+                l += p;
+            }
+        l_run = l_run * alpha + rtts_xhalf_sum(l);
+        m_run = m;
+        if (c0) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
         }
-    const float inv_l = 1.f / l;
+        if (thresh) {
+            // nn.MultiheadAttention(dropout=p): dropout on the NORMALISED probabilities; the normaliser is the full one, the
+            // keep-scale of element (head, query, key) multiplies the unnormalised p before P V
+            const uint32_t base = ((uint32_t)bh * (uint32_t)Tq + (uint32_t)qrow) * (uint32_t)TKtot + (uint32_t)c0;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    s[kt][i] *= rtts_drop_keep(seed, base + (uint32_t)(kt * 32 + 8 * (i >> 2) + 4 * hh + (i & 3)), thresh, dscale);
+        }
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int o8 = 8 * s2;
+                const bf16x8 pf = cvt_bf16x8(s[kt][o8], s[kt][o8 + 1], s[kt][o8 + 2], s[kt][o8 + 3], s[kt][o8 + 4], s[kt][o8 + 5],
+                                             s[kt][o8 + 6], s[kt][o8 + 7]);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int blk = (kt * 32 + 16 * s2) * 128;
+                    const int t0 = xa_off(4 * hh + trq, dt * 4 + 2 * trc + (trp >> 1)) + 8 * (trp & 1);
+                    const int t1 = xa_off(4 * hh + trq, (dt ^ 1) * 4 + 2 * trc + (trp >> 1)) + 8 * (trp & 1);   // row + 8: sw flips bit 2
+                    const bf16x8 vf = xa_tr_frag(Vs + blk + t0, Vs + blk + 8 * 128 + t1);
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
+                }
+            }
+    }
+    const float inv_l = 1.f / l_run;
     bf16_t* optr = o + ((size_t)b * Tq + qrow) * ld_o + (size_t)h * XA_DH;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -165,7 +182,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const bf16_t* __restrict
             pk.y = pack_bf16x2(oacc[dt][4 * g + 2] * inv_l, oacc[dt][4 * g + 3] * inv_l);
             *reinterpret_cast<uint2*>(optr + dt * 32 + 8 * g + 4 * hh) = pk;
         }
-    if (hh == 0) lse[(size_t)bh * Tq + qrow] = m + logf(l);
+    if (hh == 0) lse[(size_t)bh * Tq + qrow] = m_run + logf(l_run);
 }
 
 // ------------------------------------------------------------------------------ backward
@@ -178,9 +195,15 @@ template <int TK, bool DROP>
 __global__ __launch_bounds__(TK * 2 / XA_KT2) void xattn_bwd_kernel(const bf16_t* __restrict__ q, int64_t ld_q, const bf16_t* __restrict__ kv,
                                                        int64_t ld_kv, const uint8_t* __restrict__ kvalid,
                                                        const bf16_t* __restrict__ dout, int64_t ld_do, const float* __restrict__ lse,
-                                                       const float* __restrict__ delta, int H, int Tq, bf16_t* __restrict__ dq,
-                                                       int64_t ld_dq, bf16_t* __restrict__ dkv_part, int B, uint32_t seed,
-                                                       const uint32_t* __restrict__ seed_dev, uint32_t thresh, float dscale) {
+                                                       const float* __restrict__ delta, int H, int Tq, int TKtot, bf16_t* __restrict__ dq,
+                                                       int64_t ld_dq, size_t dq_chunk_stride, bf16_t* __restrict__ dkv_part, int B,
+                                                       uint32_t seed, const uint32_t* __restrict__ seed_dev, uint32_t thresh,
+                                                       float dscale) {
+    // blockIdx.y = key chunk: this workgroup owns keys [kc0, kc0 + TK) of TKtot.  P = exp(s - lse) needs only the forward's
+    // global lse, so the chunks are independent: dK/dV of the chunk are complete for this query block, dQ is the chunk's
+    // share (dq_chunk_stride elements between the chunks' partial dQ arrays; one chunk: dq itself)
+    const int kc0 = blockIdx.y * TK;
+    dq += (size_t)blockIdx.y * dq_chunk_stride;
     constexpr int KT2 = XA_KT2;
     constexpr int NTHR = TK * 2 / KT2;       // one wave per 32 * KT2 keys
     constexpr int NW = NTHR / 64;
@@ -202,7 +225,7 @@ __global__ __launch_bounds__(TK * 2 / XA_KT2) void xattn_bwd_kernel(const bf16_t
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
 
-    const bf16_t* kbase = kv + (size_t)b * TK * ld_kv + (size_t)h * XA_DH;
+    const bf16_t* kbase = kv + ((size_t)b * TKtot + kc0) * ld_kv + (size_t)h * XA_DH;
     const bf16_t* vbase = kbase + d;
     const bf16_t* qbase = q + ((size_t)b * Tq + (size_t)qb * XA_QB) * ld_q + (size_t)h * XA_DH;
     const bf16_t* dobase = dout + ((size_t)b * Tq + (size_t)qb * XA_QB) * ld_do + (size_t)h * XA_DH;
@@ -235,7 +258,7 @@ __global__ __launch_bounds__(TK * 2 / XA_KT2) void xattn_bwd_kernel(const bf16_t
             vf[k2][ks] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)myrow[k2] * ld_kv + ks * 16 + 8 * hh);
             kf[k2][ks] = *reinterpret_cast<const bf16x8*>(kbase + (size_t)myrow[k2] * ld_kv + ks * 16 + 8 * hh);
         }
-        kvl[k2] = kvalid ? (int)kvalid[(size_t)b * TK + myrow[k2]] : 1;
+        kvl[k2] = kvalid ? (int)kvalid[(size_t)b * TKtot + kc0 + myrow[k2]] : 1;
     }
     __syncthreads();
 
@@ -298,7 +321,7 @@ __global__ __launch_bounds__(TK * 2 / XA_KT2) void xattn_bwd_kernel(const bf16_t
                     // dropout on P: O = (D*P) V  =>  dV += (D*P)^T dO,  dS = P * (D*dP - delta)   (delta = O.dO as ever);
                     // DROP is a template parameter: nn.MultiheadAttention's dropout is 0 in config/baseline.yml
                     const float keep = DROP ? rtts_drop_keep(seed, ((uint32_t)bh * (uint32_t)Tq + (uint32_t)(qb * XA_QB + q0 + j)) *
-                                                                         (uint32_t)TK + (uint32_t)myrow[k2], thresh, dscale)
+                                                                         (uint32_t)TKtot + (uint32_t)(kc0 + myrow[k2]), thresh, dscale)
                                               : 1.f;
                     pp[i] = p * keep;
                     ds[i] = p * (pacc[i] * keep - dl[j]) * 0.125f;
@@ -326,8 +349,8 @@ __global__ __launch_bounds__(TK * 2 / XA_KT2) void xattn_bwd_kernel(const bf16_t
         }
     }
 
-    // dK | dV partial slab of this query block: layout (nqb, B, TK, 2d)
-    bf16_t* slab = dkv_part + (((size_t)qb * B + b) * TK) * (size_t)(2 * d) + (size_t)h * XA_DH;
+    // dK | dV partial slab of this query block: layout (nqb, B, TKtot, 2d)
+    bf16_t* slab = dkv_part + (((size_t)qb * B + b) * TKtot + kc0) * (size_t)(2 * d) + (size_t)h * XA_DH;
 #pragma unroll
     for (int k2 = 0; k2 < KT2; ++k2) {
         bf16_t* dkp = slab + (size_t)myrow[k2] * (2 * d);
@@ -397,16 +420,22 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const bf16_t* __restrict
     }
 }
 
-static bool g_xa_attr[3][2];
+static bool g_xa_attr[64][3][2];     // per device: the dynamic-LDS limit is an attribute of the loaded function
+static int xa_dev() { int d = 0; return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) ? d : 0; }
+extern "C" int rtts_sum_slabs(const void* part, int nslabs, int64_t n, void* out, void* stream);
 
 static int xa_check(const char* fn, int B, int H, int Tq, int Tk, int dh, int64_t ld_q, int64_t ld_kv) {
     RTTS_REQUIRE(dh == XA_DH, "%s: dh=%d unsupported (this build: 64)", fn, dh);
-    RTTS_REQUIRE(Tk == 128 || Tk == 256, "%s: T_k=%d unsupported (128 or 256 keys on chip)", fn, Tk);
+    RTTS_REQUIRE(Tk >= 128 && Tk % 128 == 0 && Tk <= 2048, "%s: T_k=%d unsupported (a multiple of 128 up to 2048)", fn, Tk);
     RTTS_REQUIRE(Tq > 0 && Tq % XA_QB == 0, "%s: T_q=%d must be a multiple of 128", fn, Tq);
     RTTS_REQUIRE(B > 0 && H > 0, "%s: bad B/H", fn);
     RTTS_REQUIRE(ld_q >= (int64_t)H * dh && ld_q % 8 == 0 && ld_kv >= (int64_t)2 * H * dh && ld_kv % 8 == 0, "%s: bad row strides", fn);
     return 0;
 }
+
+// keys held on chip at a time: 256 when T_k is a multiple of it, else 128
+static inline int xa_chunk(int Tk) { return Tk % 256 == 0 ? 256 : 128; }
+extern "C" int rtts_xattn_key_chunks(int Tk) { return (Tk >= 128 && Tk % 128 == 0) ? Tk / xa_chunk(Tk) : -1; }
 
 extern "C" int rtts_xattn_fwd(const void* q, int64_t ld_q, const void* kv, int64_t ld_kv, const uint8_t* kvalid, int B, int H, int Tq,
                               int Tk, int dh, void* o, int64_t ld_o, float* lse, float drop_p, uint32_t seed, const uint32_t* seed_dev,
@@ -416,18 +445,19 @@ extern "C" int rtts_xattn_fwd(const void* q, int64_t ld_q, const void* kv, int64
     RTTS_REQUIRE(ld_o >= (int64_t)H * dh && ld_o % 8 == 0, "rtts_xattn_fwd: bad ld_o");
     RTTS_REQUIRE((((uintptr_t)q | (uintptr_t)kv | (uintptr_t)o) & 15) == 0, "rtts_xattn_fwd: buffers must be 16-byte aligned");
     const dim3 grid(B * H * (Tq / XA_QB));
-    const size_t lds = 2 * (size_t)Tk * XA_ROWB + (size_t)Tk * 4;
+    const int chunk = xa_chunk(Tk);
+    const size_t lds = 2 * (size_t)chunk * XA_ROWB + (size_t)chunk * 4;
 #define GO(TK_)                                                                                                           \
     do {                                                                                                                  \
         auto kern = xattn_fwd_kernel<TK_>;                                                                                \
-        if (!g_xa_attr[0][TK_ == 256]) {                                                                                  \
+        if (!g_xa_attr[xa_dev()][0][TK_ == 256]) {                                                                                  \
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            g_xa_attr[0][TK_ == 256] = true;                                                                              \
+            g_xa_attr[xa_dev()][0][TK_ == 256] = true;                                                                              \
         }                                                                                                                 \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q, ld_q, (const bf16_t*)kv, ld_kv, \
-                           kvalid, H, Tq, (bf16_t*)o, ld_o, lse, seed, seed_dev, rtts_drop_thresh(drop_p), 1.f / (1.f - drop_p)); \
+                           kvalid, H, Tq, Tk, (bf16_t*)o, ld_o, lse, seed, seed_dev, rtts_drop_thresh(drop_p), 1.f / (1.f - drop_p)); \
     } while (0)
-    if (Tk == 256) GO(256); else GO(128);
+    if (chunk == 256) GO(256); else GO(128);
 #undef GO
     RTTS_LAUNCH_CHECK("rtts_xattn_fwd");
     return 0;
@@ -435,29 +465,39 @@ extern "C" int rtts_xattn_fwd(const void* q, int64_t ld_q, const void* kv, int64
 
 extern "C" int rtts_xattn_bwd(const void* q, int64_t ld_q, const void* kv, int64_t ld_kv, const uint8_t* kvalid, const void* dout,
                               int64_t ld_dout, const float* lse, const float* delta, int B, int H, int Tq, int Tk, int dh, void* dq,
-                              int64_t ld_dq, void* dkv_part, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream) {
+                              int64_t ld_dq, void* dkv_part, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* dq_chunks,
+                              void* stream) {
     RTTS_REQUIRE(q && kv && dout && lse && delta && dq && dkv_part && drop_p >= 0.f && drop_p < 1.f, "rtts_xattn_bwd: bad arguments");
     if (xa_check("rtts_xattn_bwd", B, H, Tq, Tk, dh, ld_q, ld_kv)) return -1;
     RTTS_REQUIRE(ld_dout >= (int64_t)H * dh && ld_dout % 8 == 0 && ld_dq >= (int64_t)H * dh && ld_dq % 8 == 0,
                  "rtts_xattn_bwd: bad strides");
     RTTS_REQUIRE((((uintptr_t)q | (uintptr_t)kv | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dkv_part) & 15) == 0,
                  "rtts_xattn_bwd: buffers must be 16-byte aligned");
-    const dim3 grid(B * H * (Tq / XA_QB));
-    const size_t lds = (size_t)Tk * 128 + 2 * (size_t)XA_QB * 128 + (size_t)Tk * (XA_QB * 2) + XA_QB * 8;
+    const int chunk = xa_chunk(Tk), nchunks = Tk / chunk;
+    // more than one key chunk: each chunk's workgroups write their share of dQ to dq_chunks (nchunks, B*Tq, H*dh) bf16 and
+    // the shares are summed into dq (compact rows) by the slab-sum kernel
+    RTTS_REQUIRE(nchunks == 1 || (dq_chunks && ld_dq == (int64_t)H * dh && ((uintptr_t)dq_chunks & 15) == 0),
+                 "rtts_xattn_bwd: T_k=%d is worked in %d key chunks: needs dq_chunks (%d x B*T_q x H*dh bf16) and ld_dq == H*dh", Tk, nchunks,
+                 nchunks);
+    const dim3 grid(B * H * (Tq / XA_QB), nchunks);
+    const size_t dq_stride = nchunks > 1 ? (size_t)B * Tq * H * dh : 0;
+    bf16_t* dq_dst = (bf16_t*)(nchunks > 1 ? dq_chunks : dq);
+    const size_t lds = (size_t)chunk * 128 + 2 * (size_t)XA_QB * 128 + (size_t)chunk * (XA_QB * 2) + XA_QB * 8;
 #define GO(TK_)                                                                                                           \
     do {                                                                                                                  \
         auto kern = drop_p > 0.f ? xattn_bwd_kernel<TK_, true> : xattn_bwd_kernel<TK_, false>;                            \
-        if (!g_xa_attr[1 + (drop_p > 0.f)][TK_ == 256]) {                                                                                  \
+        if (!g_xa_attr[xa_dev()][1 + (drop_p > 0.f)][TK_ == 256]) {                                                                                  \
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            g_xa_attr[1 + (drop_p > 0.f)][TK_ == 256] = true;                                                                              \
+            g_xa_attr[xa_dev()][1 + (drop_p > 0.f)][TK_ == 256] = true;                                                                              \
         }                                                                                                                 \
         hipLaunchKernelGGL(kern, grid, dim3(TK_ * 2 / XA_KT2), lds, (hipStream_t)stream, (const bf16_t*)q, ld_q, (const bf16_t*)kv, ld_kv, \
-                           kvalid, (const bf16_t*)dout, ld_dout, lse, delta, H, Tq, (bf16_t*)dq, ld_dq, (bf16_t*)dkv_part, B,    \
+                           kvalid, (const bf16_t*)dout, ld_dout, lse, delta, H, Tq, Tk, dq_dst, ld_dq, dq_stride, (bf16_t*)dkv_part, B, \
                            seed, seed_dev, rtts_drop_thresh(drop_p), 1.f / (1.f - drop_p));                               \
     } while (0)
-    if (Tk == 256) GO(256); else GO(128);
+    if (chunk == 256) GO(256); else GO(128);
 #undef GO
     RTTS_LAUNCH_CHECK("rtts_xattn_bwd");
+    if (nchunks > 1) return rtts_sum_slabs(dq_chunks, nchunks, (int64_t)dq_stride, dq, stream);
     return 0;
 }
 

@@ -600,9 +600,11 @@ class XAttnExec:
         nqb = t // 128
         part = torch.empty(nqb, b * tk, 2 * e, dtype=torch.bfloat16, device=dev)
         dp, dseed = drop if drop else (0.0, 0)
+        nkc = _lib.load().rtts_xattn_key_chunks(tk)          # > 256 keys: worked in chunks, each with its share of dQ
+        dq_chunks = torch.empty(nkc, b * t, e, dtype=torch.bfloat16, device=dev) if nkc > 1 else None
         _lib.call("rtts_xattn_bwd", q.data_ptr(), e, kv.data_ptr(), 2 * e, None if kvalid is None else kvalid.data_ptr(),
                   do.data_ptr(), e, lse.data_ptr(), delta.data_ptr(), b, h, t, tk, e // h, dq.data_ptr(), e, part.data_ptr(),
-                  float(dp), dseed, seed_base(dev).data_ptr(), _s())
+                  float(dp), dseed, seed_base(dev).data_ptr(), None if dq_chunks is None else dq_chunks.data_ptr(), _s())
         dkv = torch.empty(b * tk, 2 * e, dtype=torch.bfloat16, device=dev)
         _lib.call("rtts_sum_slabs", part.data_ptr(), nqb, dkv.numel(), dkv.data_ptr(), _s())
         gb, gw = _grad(m.in_proj_bias), _grad(m.in_proj_weight)

@@ -190,9 +190,9 @@ class ReversibleSequence(nn.Module):
     def forward_sum(self, x, kwargs_list=None, context=None):
         """Both streams start as ``x``; returns their sum after the stack (``reformer.py:81-93,139-158``)."""
         kwargs_list = kwargs_list if kwargs_list is not None else [{}] * len(self.blocks)
-        # the on-chip cross-attention kernels hold 128 or 256 keys (text padded to pad_base = 256); longer texts take the
-        # general path below (torch SDPA) instead of failing
-        keys_ok = context is None or context.shape[1] in (128, 256)
+        # the cross-attention kernels hold 128 or 256 keys on chip at a time and walk longer texts in chunks (text is padded
+        # to pad_base = 256); other lengths take the general path below (torch SDPA) instead of failing
+        keys_ok = context is None or (context.shape[1] % 128 == 0 and 128 <= context.shape[1] <= 2048)
         if self.use_fused and keys_ok and x.is_cuda and (self.training or (self.fused_in_eval and not torch.is_grad_enabled())):
             if not self._program_built:
                 from ..engine import build_program
@@ -204,7 +204,7 @@ class ReversibleSequence(nn.Module):
             note_general_path("reversible stack", "a block is outside the executors' envelope (e.g. feed-forward dropout > 0)")
         elif self.use_fused and x.is_cuda and not keys_ok:
             from .._lib import note_general_path
-            note_general_path("decoder stack", f"{context.shape[1]} encoder keys: the on-chip cross-attention holds 128 or 256")
+            note_general_path("decoder stack", f"{context.shape[1]} encoder keys: the cross-attention kernels take multiples of 128 up to 2048")
         y1, y2 = self.forward_halves(x, x, kwargs_list, context)
         return y1 + y2
 

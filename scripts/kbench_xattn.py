@@ -23,6 +23,8 @@ lse = torch.empty(b * h, t, dtype=torch.float32, device=dev)
 delta = torch.empty(b * h, t, dtype=torch.float32, device=dev)
 dq = torch.empty(b * t, e, dtype=torch.bfloat16, device=dev)
 part = torch.empty(t // 128, b * tk, 2 * e, dtype=torch.bfloat16, device=dev)
+nkc = _lib.load().rtts_xattn_key_chunks(tk)
+dq_chunks = torch.empty(nkc, b * t, e, dtype=torch.bfloat16, device=dev) if nkc > 1 else None
 s = torch.cuda.current_stream().cuda_stream
 sb = seed_base(dev)
 
@@ -34,7 +36,8 @@ def fwd():
 
 def bwd():
     _lib.call("rtts_xattn_bwd", q.data_ptr(), e, kv.data_ptr(), 2 * e, kvalid.data_ptr(), do.data_ptr(), e, lse.data_ptr(),
-              delta.data_ptr(), b, h, t, tk, e // h, dq.data_ptr(), e, part.data_ptr(), 0.0, 0, sb.data_ptr(), s)
+              delta.data_ptr(), b, h, t, tk, e // h, dq.data_ptr(), e, part.data_ptr(), 0.0, 0, sb.data_ptr(),
+              None if dq_chunks is None else dq_chunks.data_ptr(), s)
 
 
 fwd()

@@ -924,12 +924,67 @@ def test_cross_attention_dropout_vs_autograd(gpu):
     dq = torch.empty(b * t, e, dtype=torch.bfloat16, device=gpu)
     part = torch.empty(t // 128, b * tk, 2 * e, dtype=torch.bfloat16, device=gpu)
     _lib.call("rtts_xattn_bwd", q.data_ptr(), e, kv.data_ptr(), 2 * e, None, do.data_ptr(), e, lse.data_ptr(), delta.data_ptr(), b, h, t,
-              tk, dh, dq.data_ptr(), e, part.data_ptr(), p, seed, sd.data_ptr(), s)
+              tk, dh, dq.data_ptr(), e, part.data_ptr(), p, seed, sd.data_ptr(), None, s)
     torch.cuda.synchronize()
     dkv = part.float().sum(0).view(b, tk, 2, h, dh)
     for got, ref, name in ((dq.float().view(b, t, h, dh).transpose(1, 2), qr.grad, "dq"), (dkv[:, :, 0].transpose(1, 2), kr.grad, "dk"),
                            (dkv[:, :, 1].transpose(1, 2), vr.grad, "dv")):
         assert float((got - ref).norm() / ref.norm()) < 3e-2, name
+
+
+@pytest.mark.parametrize("tk", [128, 256, 384, 512, 768])
+def test_cross_attention_key_chunks_vs_autograd(gpu, tk):
+    """rtts_xattn_fwd / rtts_xattn_bwd for every supported key count: one on-chip pass (128, 256) or chunks with a running
+    maximum / per-chunk dQ shares (384 = 3 x 128, 512 = 2 x 256, 768 = 3 x 256), with a key_padding_mask that empties a whole
+    chunk of one sample, against torch autograd in fp32 on the same bf16 inputs."""
+    from reformer_tts_amd import _lib
+    b, h, t, dh = 2, 2, 256, 64
+    e = h * dh
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(tk)
+    q = (torch.randn(b * t, e, generator=g) * 1.5).bfloat16().to(gpu)
+    kv = torch.randn(b * tk, 2 * e, generator=g).bfloat16().to(gpu)
+    do = torch.randn(b * t, e, generator=g).bfloat16().to(gpu)
+    valid = torch.ones(b, tk, dtype=torch.uint8, device=gpu)
+    valid[0, tk - 100:] = 0                        # padding that ends inside a chunk
+    if tk >= 384:
+        valid[1, :tk // _lib.load().rtts_xattn_key_chunks(tk)] = 0      # the whole FIRST chunk of sample 1 is padding
+    assert _lib.load().rtts_xattn_key_chunks(tk) == {128: 1, 256: 1, 384: 3, 512: 2, 768: 3}[tk]
+    o = torch.empty(b * t, e, dtype=torch.bfloat16, device=gpu)
+    lse = torch.empty(b * h, t, device=gpu)
+    _lib.call("rtts_xattn_fwd", q.data_ptr(), e, kv.data_ptr(), 2 * e, valid.data_ptr(), b, h, t, tk, dh, o.data_ptr(), e, lse.data_ptr(),
+              0.0, 0, None, s)
+    qr = q.float().view(b, t, h, dh).transpose(1, 2).requires_grad_()
+    kr = kv.float().view(b, tk, 2, h, dh)[:, :, 0].transpose(1, 2).requires_grad_()
+    vr = kv.float().view(b, tk, 2, h, dh)[:, :, 1].transpose(1, 2).requires_grad_()
+    sc = (qr @ kr.transpose(-1, -2) / 8.0).masked_fill(valid.view(b, 1, 1, tk) == 0, float("-inf"))
+    oref = torch.softmax(sc, dim=-1) @ vr
+    e_o = float((o.float().view(b, t, h, dh).transpose(1, 2) - oref.detach()).abs().max())
+    e_l = float((lse.view(b, h, t) - torch.logsumexp(sc.detach(), dim=-1)).abs().max())
+    oref.backward(do.float().view(b, t, h, dh).transpose(1, 2))
+    delta = torch.empty(b * h, t, device=gpu)
+    _lib.call("rtts_lsh_bwd_delta", o.data_ptr(), e, do.data_ptr(), e, b, h, t, dh, delta.data_ptr(), s)
+    dq = torch.empty(b * t, e, dtype=torch.bfloat16, device=gpu)
+    part = torch.empty(t // 128, b * tk, 2 * e, dtype=torch.bfloat16, device=gpu)
+    nkc = _lib.load().rtts_xattn_key_chunks(tk)
+    ws = torch.empty(nkc, b * t, e, dtype=torch.bfloat16, device=gpu) if nkc > 1 else None
+    if nkc > 1:
+        with pytest.raises(_lib.RttsError):
+            _lib.call("rtts_xattn_bwd", q.data_ptr(), e, kv.data_ptr(), 2 * e, valid.data_ptr(), do.data_ptr(), e, lse.data_ptr(),
+                      delta.data_ptr(), b, h, t, tk, dh, dq.data_ptr(), e, part.data_ptr(), 0.0, 0, None, None, s)
+    _lib.call("rtts_xattn_bwd", q.data_ptr(), e, kv.data_ptr(), 2 * e, valid.data_ptr(), do.data_ptr(), e, lse.data_ptr(), delta.data_ptr(),
+              b, h, t, tk, dh, dq.data_ptr(), e, part.data_ptr(), 0.0, 0, None, None if ws is None else ws.data_ptr(), s)
+    torch.cuda.synchronize()
+    dkv = part.float().sum(0).view(b, tk, 2, h, dh)
+    errs = {}
+    for got, ref, name in ((dq.float().view(b, t, h, dh).transpose(1, 2), qr.grad, "dq"), (dkv[:, :, 0].transpose(1, 2), kr.grad, "dk"),
+                           (dkv[:, :, 1].transpose(1, 2), vr.grad, "dv")):
+        errs[name] = float((got - ref).norm() / ref.norm())
+    print(f"\n[parity] cross attention, {tk} keys in {nkc} chunk(s): out max-abs {e_o:.2e} (tol 2e-2), lse max-abs {e_l:.2e} (tol 2e-3), "
+          + ", ".join(f"{k} rel-L2 {v:.2e}" for k, v in errs.items()) + " (tol 2e-2)")
+    assert e_o < 2e-2 and e_l < 2e-3 and max(errs.values()) < 2e-2
+    masked = dkv[0, tk - 100:]
+    assert float(masked.abs().max()) == 0.0          # padded keys get no gradient
 
 
 def test_batch_prefetcher_feeds_captured_buffers(gpu):
@@ -1146,12 +1201,11 @@ def test_odd_batch_shapes_on_the_executor(gpu, b, text, mel):
     _lib._NOTED.clear()                  # notices are once per process: start this test's count afresh
     first_new = len(_lib.PATHS_LEFT)
     losses = [float(tr.train_step(batch)[0]) for _ in range(4)]
-    # 300 phonemes pad to 512 keys: more than the on-chip cross-attention holds -> the decoder stack takes the general path
-    assert (model.dec.reformer.layers._program is not None) == (text <= 256)
-    assert model.enc.reformer.layers._program is not None
-    # ... and says so, once: a user can tell which path produced a number
+    # 300 phonemes pad to 512 keys: the cross-attention kernels walk them in two chunks of 256 -- still the executor path,
+    # and no notice of a general path (a user can tell which path produced a number)
+    assert model.dec.reformer.layers._program is not None and model.enc.reformer.layers._program is not None
     noted = [w for w, _ in _lib.PATHS_LEFT[first_new:]]
-    assert noted == (["decoder stack"] if text > 256 else []), _lib.PATHS_LEFT[first_new:]
+    assert noted == [], _lib.PATHS_LEFT[first_new:]
     assert all(np.isfinite(losses)) and min(losses[1:]) < losses[0], losses
     assert torch.isfinite(tr.flat_p).all()
 
