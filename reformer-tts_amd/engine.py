@@ -376,10 +376,11 @@ def wgrad(grad_view: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, accumulate
 
 
 # ------------------------------------------------------------------------------------------ blocks
-def _keep_streams(slot, acc, inp, xn, mean, rstd):
-    """STASH_STREAMS: -> the fresh buffer the updated stream goes to (also left in slot["acc_out"] for the stack loop), with
-    the sublayer's LayerNorm input and output kept in the slot for its backward; else None (update in place)."""
-    if not _streams_kept():
+def _keep_streams(keep, slot, acc, inp, xn, mean, rstd):
+    """``keep`` (the stack loop asks for it under STASH_STREAMS): -> the fresh buffer the updated stream goes to (also left in
+    slot["acc_out"] for the loop to pick up), with the sublayer's LayerNorm input and output kept in the slot for its
+    backward; else None: the stream is updated in place (an executor used on its own, or a recomputing mode)."""
+    if not keep:
         return None
     out = torch.empty_like(acc)
     slot.update(inp=inp, pre=(xn, mean, rstd), acc_out=out)
@@ -441,14 +442,14 @@ class LSHExec:
             g = gemm(out.view(b * t, e), _bf16(lyr.to_out.weight))
         return xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g
 
-    def forward(self, acc, inp, b, t, mask=None, pre=None, next_norm=None, slot=None, **_):
+    def forward(self, acc, inp, b, t, mask=None, pre=None, next_norm=None, slot=None, keep_streams=False, **_):
         slot = self._own_slot if slot is None else slot
         xn, mean, rstd, _, qkv, st, out, lse_tot, g = self._internals(inp, b, t, mask, None, pre=pre)
         p = self.layer.post_attn_dropout.p if self.layer.training else 0.0
         slot.clear()
         slot.update(st=st, stash=(out, lse_tot) if STASH_ATTENTION else None, g=g if STASH_BLOCK_OUTPUT else None,
                     qkv=qkv if STASH_PROJECTIONS else None, drop=(p, next_seed()) if p > 0.0 else None)
-        return residual(acc, g, self.layer.to_out.bias, 1.0, next_norm, slot["drop"], out=_keep_streams(slot, acc, inp, xn, mean, rstd))
+        return residual(acc, g, self.layer.to_out.bias, 1.0, next_norm, slot["drop"], out=_keep_streams(keep_streams, slot, acc, inp, xn, mean, rstd))
 
     def backward(self, acc, inp, d_acc, d_inp, b, t, mask=None, pre=None, next_norm=None, pre_cast=None, next_cast=None, slot=None, **_):
         slot = self._own_slot if slot is None else slot
@@ -506,12 +507,12 @@ class FFNExec:
             g = gemm(h, _bf16(self.l2.weight))
         return xn, mean, rstd, h, g
 
-    def forward(self, acc, inp, b, t, pre=None, next_norm=None, slot=None, **_):
+    def forward(self, acc, inp, b, t, pre=None, next_norm=None, slot=None, keep_streams=False, **_):
         slot = self._own_slot if slot is None else slot
         xn, mean, rstd, h, g = self._internals(inp, pre=pre)
         slot.clear()
         slot.update(g=g if STASH_BLOCK_OUTPUT else None, h=h if STASH_PROJECTIONS else None)
-        return residual(acc, g, self.l2.bias, 1.0, next_norm, out=_keep_streams(slot, acc, inp, xn, mean, rstd))
+        return residual(acc, g, self.l2.bias, 1.0, next_norm, out=_keep_streams(keep_streams, slot, acc, inp, xn, mean, rstd))
 
     def backward(self, acc, inp, d_acc, d_inp, b, t, pre=None, next_norm=None, pre_cast=None, next_cast=None, slot=None, **_):
         slot = self._own_slot if slot is None else slot
@@ -565,7 +566,7 @@ class XAttnExec:
             g = gemm(o, _bf16(m.out_proj.weight))
         return xn, mean, rstd, w, q, kv, o, lse, g, tk
 
-    def forward(self, acc, inp, b, t, keys_bf16=None, kvalid=None, pre=None, next_norm=None, slot=None, **_):
+    def forward(self, acc, inp, b, t, keys_bf16=None, kvalid=None, pre=None, next_norm=None, slot=None, keep_streams=False, **_):
         slot = self._own_slot if slot is None else slot
         p = self.mha.dropout if self.mha.training else 0.0
         pdrop = (p, next_seed()) if p > 0.0 else None
@@ -573,7 +574,7 @@ class XAttnExec:
         slot.clear()
         slot.update(stash=(o, lse) if STASH_ATTENTION else None, g=g if STASH_BLOCK_OUTPUT else None, pdrop=pdrop,
                     proj=(q, kv) if STASH_PROJECTIONS else None)
-        return residual(acc, g, self.mha.out_proj.bias, 1.0, next_norm, out=_keep_streams(slot, acc, inp, xn, mean, rstd))
+        return residual(acc, g, self.mha.out_proj.bias, 1.0, next_norm, out=_keep_streams(keep_streams, slot, acc, inp, xn, mean, rstd))
 
     def backward(self, acc, inp, d_acc, d_inp, b, t, keys_bf16=None, kvalid=None, dkeys=None, pre=None, next_norm=None,
                  pre_cast=None, next_cast=None, slot=None, **_):
@@ -767,14 +768,14 @@ class FusedStackFn(torch.autograd.Function):
                 if kind == "swap":
                     s1, s2 = s2, s1
                 elif kind == "half":
-                    post = f.forward(s1, s2, b, t, slot=slots[(i, "f")], **kw, **chain.args(i, "f", s2))
+                    post = f.forward(s1, s2, b, t, slot=slots[(i, "f")], keep_streams=kept, **kw, **chain.args(i, "f", s2))
                     s1 = slots[(i, "f")].pop("acc_out", s1)
                     chain.done(post, s1)
                 else:
-                    post = f.forward(s1, s2, b, t, slot=slots[(i, "f")], **kw, **chain.args(i, "f", s2))
+                    post = f.forward(s1, s2, b, t, slot=slots[(i, "f")], keep_streams=kept, **kw, **chain.args(i, "f", s2))
                     s1 = slots[(i, "f")].pop("acc_out", s1)
                     chain.done(post, s1)
-                    post = g.forward(s2, s1, b, t, slot=slots[(i, "g")], **chain.args(i, "g", s1))
+                    post = g.forward(s2, s1, b, t, slot=slots[(i, "g")], keep_streams=kept, **chain.args(i, "g", s1))
                     s2 = slots[(i, "g")].pop("acc_out", s2)
                     chain.done(post, s2)
             if x.dtype == torch.float32 and (b * t * d) % 4 == 0:
