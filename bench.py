@@ -168,6 +168,8 @@ def main():
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
     dec_bucket = int(model_cfg.dec_reformer_kwargs.self_attn_kwargs.bucket_size)
+    heads_dec = int(model_cfg.dec_reformer_kwargs.self_attn_kwargs.heads)
+    n_hashes_dec = int(model_cfg.dec_reformer_kwargs.self_attn_kwargs.n_hashes)
     t_dec = -(-args.mel_len // 256) * 256
     tags = dict(bwd=f"rtts_lsh_attn_bwd/bs{dec_bucket}", hash=f"rtts_lsh_hash_sort/nb{t_dec // dec_bucket}", gemm="rtts_gemm_nt")
     note(f"model built ({trainer.n_params} parameters), warming up")
@@ -287,12 +289,15 @@ def main():
         if launches:
             traffic = None      # HBM bytes per launch from the committed rocprofv3 PMC passes (collected outside this process)
             try:
-                with open(os.path.join(ROOT, "profiles", "r02_pmc_lsh_attn_bwd.json")) as fh:
+                with open(os.path.join(ROOT, "profiles", "r02b_pmc_lsh_attn_bwd.json")) as fh:
                     traffic = json.load(fh)["traffic_bytes"] if (args.batch, args.mel_len, args.config) == (12, 1024, "baseline") else None
             except OSError:
                 pass
             ach = flops / (avg_ms * 1e-3) / 1e12
-            entry = {"kernel": "lsh_attn_bwd_kernel", "bound": "mfma", "achieved": round(ach, 2), "peak": BF16_DENSE_PEAK_TFLOPS,
+            from reformer_tts_amd import _lib
+            run = _lib.load().rtts_lsh_attn_bwd_run_length(args.batch, heads_dec, t_dec, n_hashes_dec, dec_bucket)
+            entry = {"kernel": "lsh_attn_bwd_walk_kernel" if run > 0 else "lsh_attn_bwd_kernel", "chunks_per_workgroup": max(run, 1),
+                     "bound": "mfma", "achieved": round(ach, 2), "peak": BF16_DENSE_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
                      "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches, "peak_measured": peaks[1],
                      "frac_of_measured": (round(ach / peaks[1], 4) if peaks[1] else None)}

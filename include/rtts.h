@@ -76,6 +76,9 @@ int rtts_lsh_combine_fwd(const void* o, const float* lse, int B, int H, int T, i
  *        every (slot, head, round, token) row is written exactly once: no zero-fill needed
  *   rtts_lsh_bwd_reduce: dqk, dv bf16 (B,T,H*dh) stride ld_d = sum over slots and rounds */
 int rtts_lsh_bwd_qk_slots(void);
+/* how rtts_lsh_attn_bwd works a shape: 0 = one workgroup per chunk (lsh_attn_bwd_kernel), R > 0 = workgroups that walk R
+ * consecutive chunks of a ring with the next chunk's rows prefetched (lsh_attn_bwd_walk_kernel); same results bit for bit */
+int rtts_lsh_attn_bwd_run_length(int B, int H, int T, int n_hashes, int bucket_size);
 int rtts_lsh_bwd_delta(const void* out, int64_t ld_out, const void* dout, int64_t ld_dout,
                        int B, int H, int T, int dh, float* delta, void* stream);
 int rtts_lsh_attn_bwd(const void* qk, const void* v, int64_t ld, const int32_t* st, const uint8_t* mask,

@@ -516,20 +516,513 @@ __global__ __launch_bounds__(BS * 4 / AB_KT2, AB_KT2 == 2 ? 1 : 2) void lsh_attn
 
 
 
+// LDS-DMA issued from inline assembly: the compiler's wait-count pass treats a __builtin_amdgcn_global_load_lds as a store
+// to LDS that MAY alias any later ds_read (all images live in one dynamic array at run-time offsets), and makes the next
+// LDS read of the main loop wait for the DMA to complete -- ~850 cycles per instruction (measured: the prefetch of 32 KB
+// cost the main loop 3.4 k cycles).  The prefetched slot is read by nobody before the barrier at the top of the next step,
+// which is preceded by an explicit s_waitcnt vmcnt(0), so the ordering the compiler tried to enforce is not needed.
+// (Its own vmcnt(N) waits stay correct with these loads in the queue: returns are in order, extra entries only lengthen a wait.)
+__device__ __forceinline__ void ab_dma16(const void* gptr, RTTS_LDS void* lds_dst_wave_uniform) {
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_dst_wave_uniform);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(m0v) : "m0");
+}
+
+// ======================================================================================================================
+// WALKING form: one workgroup works R consecutive chunks of one (batch, head) ring.
+//
+// The kernel above spends 6 k of its 22.5 k cycles per chunk in the gather (positions -> rows -> LDS image: two dependent
+// round trips with the MFMA pipe idle) and holds one workgroup per CU, so nothing runs under it.  Consecutive chunks share
+// rows: the own chunk of step j is the looked-back chunk of step j + 1.  Here the K rows live in a ring of three chunk slots
+// (looked-back, own, next), the dout rows and the query words in two, the sort positions in four; while chunk j is worked,
+// the rows of chunk j + 1 arrive by LDS-DMA (no registers held), the positions of chunk j + 2 and the query words of chunk
+// j + 1 by plain loads that are stored to LDS late in the step.  After the first chunk of a run a step starts with its
+// operands already on chip, and only half the K rows are fetched at all.  Same arithmetic, same outputs, same partial-row
+// layout as the kernel above (the row staging reuses the dS'^T image, so dV leaves after the dQ product, not before it).
+template <int BS, bool CAUSAL, bool MASKED>
+__global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
+    const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v, int64_t ld, const int32_t* __restrict__ st,
+    const uint8_t* __restrict__ mask, const bf16_t* __restrict__ dout, int64_t ld_do, const float* __restrict__ lse_tot,
+    const float* __restrict__ delta, int H, int T, int n_hashes, bf16_t* __restrict__ dqk_part, bf16_t* __restrict__ dv_part,
+    size_t slot_stride, int R) {
+    constexpr int NK = 2 * BS;
+    constexpr int NQT = BS / 32;
+    constexpr int NW = NK / 32;
+    constexpr int NTHR = 64 * NW;
+    constexpr int DSROW = BS * 2;
+    constexpr int KSLOT = BS * 128;        // bytes of one chunk's row image
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* kposS = reinterpret_cast<int*>(smem);                       // [4][BS] sort positions of the chunks in flight
+    float* qlseS = reinterpret_cast<float*>(kposS + 4 * BS);         // [2][BS] lse_tot * log2(e)
+    float* qdelS = qlseS + 2 * BS;                                   // [2][BS] MINUS delta
+    int* qpeS = reinterpret_cast<int*>(qdelS + 2 * BS);              // [2][BS] query-side effective position
+    unsigned char* KsR = reinterpret_cast<unsigned char*>(qpeS + 2 * BS);   // [3][BS][128] qk rows, swizzled
+    unsigned char* OsR = KsR + 3 * KSLOT;                            // [2][BS][128] dout rows, later the parked dQ
+    unsigned char* Ds = OsR + 2 * KSLOT;                             // [NK][DSROW] dS'^T; after the dQ product: row staging
+    unsigned char* Stg = Ds;
+
+    const int nb = T / BS;
+    const int C = n_hashes * nb;
+    const int runs = C / R;
+    const uint32_t run = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = run / runs, c0 = (run % runs) * R;
+    const int b = bh / H, h = bh % H;
+    const int32_t* st_row = st + (size_t)bh * n_hashes * T;
+    const bf16_t* qbase = qk + (size_t)b * T * ld + (size_t)h * AB_DH;
+    const bf16_t* vbase = v + (size_t)b * T * ld + (size_t)h * AB_DH;
+    const bf16_t* dobase = dout + (size_t)b * T * ld_do + (size_t)h * AB_DH;
+
+    // ---- prologue: the full gather of the first step (looked-back chunk -> slot 0, own chunk -> slot 1)
+    {
+        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int cp0 = (c0 == 0) ? C - 1 : c0 - 1;
+        constexpr int ITERS = NK * 8 / NTHR;   // 4
+        int trow[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int row = (it * NTHR + tid) >> 3;
+            trow[it] = st_row[(row < BS) ? c0 * BS + row : cp0 * BS + (row - BS)];
+        }
+        int pnext = 0;
+        if (R > 1 && tid < BS) pnext = st_row[(c0 + 1) * BS + tid];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int rowb = it * (NTHR / 8) + wave * 8;            // wave-uniform: first row of this instruction
+            const int lp = (lane & 7) ^ ab_sw(rowb + (lane >> 3));
+            unsigned char* kdst = (rowb < BS) ? KsR + KSLOT + rowb * 128 : KsR + (rowb - BS) * 128;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qbase + (size_t)trow[it] * ld + lp * 8),
+                                             (RTTS_LDS void*)kdst, 16, 0, 0);
+            if (it < ITERS / 2)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dobase + (size_t)trow[it] * ld_do + lp * 8),
+                                                 (RTTS_LDS void*)(OsR + rowb * 128), 16, 0, 0);
+        }
+        int rvalid[ITERS / 2];
+        float rlse[ITERS / 2], rdel[ITERS / 2];
+#pragma unroll
+        for (int it = 0; it < ITERS / 2; ++it) {
+            rvalid[it] = MASKED ? (int)mask[(size_t)b * T + trow[it]] : 1;
+            rlse[it] = lse_tot[(size_t)bh * T + trow[it]];
+            rdel[it] = delta[(size_t)bh * T + trow[it]];
+        }
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int row = (it * NTHR + tid) >> 3, piece = tid & 7;
+            if (piece == 1) kposS[(row < BS) ? BS + row : row - BS] = trow[it];      // own chunk: slot 1, looked-back: slot 0
+            if (it < ITERS / 2) {
+                if (piece == 3) qlseS[row] = rlse[it] * 1.4426950408889634f;
+                if (piece == 4) qdelS[row] = -rdel[it];
+                // an invalid query sees nothing but itself: its effective position is below every key's
+                if (piece == 5) qpeS[row] = rvalid[it] ? (CAUSAL ? trow[it] : 0) : -1;
+            }
+        }
+        if (R > 1 && tid < BS) kposS[2 * BS + tid] = pnext;
+    }
+
+    bf16x8 vf[4];           // V rows of this wave's keys: those of the NEXT step are requested as soon as a step's main loop is
+    int myvalid = 1;        // done with them (the only per-lane state that crosses a step)
+#pragma unroll 1
+    for (int j = 0; j < R; ++j) {
+        // nothing else but scalars is carried from one step to the next: the lane id goes through an opaque move so that no address
+        // arithmetic of the body is hoisted out of the loop and held in registers across it
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int r = lane & 31, hh = lane >> 5;
+        const int c = c0 + j;
+        const int cprev = (c == 0) ? C - 1 : c - 1;
+        const int ks_own = (j + 1) % 3, ks_lb = j % 3, kp_own = (j + 1) & 3, kp_lb = j & 3, par = j & 1;
+        unsigned char* Kown = KsR + ks_own * KSLOT;
+        unsigned char* Klb = KsR + ks_lb * KSLOT;
+        unsigned char* Os = OsR + par * KSLOT;
+        const float* qlse = qlseS + par * BS;
+        const float* qdel = qdelS + par * BS;
+        const int* qpe_s = qpeS + par * BS;
+        const int* kq = kposS + kp_own * BS;                   // positions of the own chunk's rows (queries = own keys)
+        const int* kl = kposS + kp_lb * BS;
+
+#define AB_JSTAMP(i) do { if (j == 2) AB_STAMP(i); } while (0)
+        AB_JSTAMP(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the prefetch (issued from assembly) has landed
+        __syncthreads();   // this step's rows and words are on chip (each wave waited for its own DMA); the previous step is over
+        AB_JSTAMP(1);
+
+        // ---- prefetch of chunk j + 1 (rows by LDS-DMA, query words, positions of chunk j + 2): issued piecewise INSIDE the main
+        //      loop below -- a CU takes in ~31 B/clk beside the MFMA work, so 32 KB of rows issued in one go would hold every wave
+        //      at the vector-memory queue for ~3 k cycles (measured) before the step's arithmetic starts
+        const bool more = j + 1 < R;
+        const int* kn = kposS + ((j + 2) & 3) * BS;
+        unsigned char* Knext = KsR + ((j + 2) % 3) * KSLOT;
+        unsigned char* Onext = OsR + (par ^ 1) * KSLOT;
+        float nlse = 0.f, ndel = 0.f;
+        int nval = 1, npos = 0, p2 = 0;
+        constexpr int PF_IT = BS * 8 / NTHR;                 // 2: DMA instructions per wave and operand
+        constexpr int PF_PER_TILE = 2 * PF_IT / NQT;         // 1 (BS = 128) or 2 (BS = 64) per query tile
+        static_assert(PF_PER_TILE * NQT == 2 * PF_IT, "prefetch pieces must tile the query loop");
+        AB_JSTAMP(2);
+        // ---- this wave's key tile
+        const bool own_tile = wave < NW / 2;                     // wave-uniform
+        const int myrow = wave * 32 + r;                         // row of the dS'^T image: own keys first
+        const int mypos = own_tile ? kq[myrow] : kl[myrow - BS];
+        const unsigned char* Kt = own_tile ? Kown + wave * (32 * 128) : Klb + (wave - NW / 2) * (32 * 128);
+        if (j == 0) {      // later steps: requested by the previous one
+            myvalid = MASKED ? (int)mask[(size_t)b * T + mypos] : 1;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) vf[ks] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)mypos * ld + ks * 16 + 8 * hh);
+        }
+        int fro[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fro[ks] = ab_off(r, ks * 2 + hh);
+        bf16x8 kf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(Kt + fro[ks]);
+        float ss = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const uint4 u4 = __builtin_bit_cast(uint4, kf[ks]);
+            const uint32_t u[4] = {u4.x, u4.y, u4.z, u4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float a = __uint_as_float(u[k] << 16), bq = __uint_as_float(u[k] & 0xffff0000u);
+                ss = __builtin_fmaf(a, a, ss);
+                ss = __builtin_fmaf(bq, bq, ss);
+            }
+        }
+        ss = rtts_xhalf_sum(ss);
+        const float ksc = 0.125f * __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));   // dh^-1/2 / max(|k|, 1e-12)
+        const int kpk = myvalid ? (CAUSAL ? mypos : 0) : 0x40000000;
+
+        f32x16 dvacc[2], gacc[2];   // [dh tile]: rows = dh, lane = key
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            dvacc[d] = (f32x16){0};
+            gacc[d] = (f32x16){0};
+        }
+        const int trq = (lane & 15) >> 2, trp = lane & 3, trc = (lane >> 4) & 1;
+        int tro[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) tro[dt] = ab_off(4 * hh + trq, dt * 4 + 2 * trc + (trp >> 1)) + 8 * (trp & 1);
+        int dso[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dso[g] = ab_ds_off<BS>(myrow, 2 * g + hh);
+        const bool wrap = (cprev / nb) != (c / nb);
+#ifdef AB_PHASE_TIMING
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): V fragments (and this wave's share of the prefetch) have arrived
+        AB_JSTAMP(3);
+#endif
+
+#pragma unroll AB_UNROLL
+        for (int qt = 0; qt < NQT; ++qt) {
+            if (more) {
+#pragma unroll
+                for (int pf = 0; pf < PF_PER_TILE; ++pf) {
+                    const int piece = qt * PF_PER_TILE + pf;         // 0 .. 2 * PF_IT - 1: (iteration, K | dout)
+                    const int it = piece >> 1;
+                    const int rowb = it * (NTHR / 8) + wave * 8;
+                    const int pos = kn[rowb + (lane >> 3)];
+                    const int lp = (lane & 7) ^ ab_sw(rowb + (lane >> 3));
+                    if ((piece & 1) == 0)
+                        ab_dma16(qbase + (size_t)pos * ld + lp * 8, (RTTS_LDS void*)(Knext + rowb * 128));
+                    else
+                        ab_dma16(dobase + (size_t)pos * ld_do + lp * 8, (RTTS_LDS void*)(Onext + rowb * 128));
+                }
+                if (qt == 0 && tid < BS) {
+                    npos = kn[tid];
+                    nval = MASKED ? (int)mask[(size_t)b * T + npos] : 1;
+                    nlse = lse_tot[(size_t)bh * T + npos];
+                    ndel = delta[(size_t)bh * T + npos];
+                    if (j + 2 < R) p2 = st_row[(c + 2) * BS + tid];
+                }
+            }
+            f32x16 pinit;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 d4 = *reinterpret_cast<const float4*>(qdel + qt * 32 + 8 * g + 4 * hh);
+                pinit[4 * g] = d4.x;
+                pinit[4 * g + 1] = d4.y;
+                pinit[4 * g + 2] = d4.z;
+                pinit[4 * g + 3] = d4.w;
+            }
+            bf16x8 qf[4], dof[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                qf[ks] = *reinterpret_cast<const bf16x8*>(Kown + qt * (32 * 128) + fro[ks]);
+                dof[ks] = *reinterpret_cast<const bf16x8*>(Os + qt * (32 * 128) + fro[ks]);
+            }
+            float4 l4[4];
+            int4 e4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int q0 = qt * 32 + 8 * g + 4 * hh;
+                l4[g] = *reinterpret_cast<const float4*>(qlse + q0);
+                e4[g] = *reinterpret_cast<const int4*>(qpe_s + q0);
+            }
+            const bool chk_self = own_tile ? (wave == qt) : wrap;
+            f32x16 sacc = {0}, pacc = pinit;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[ks], sacc, 0, 0, 0);    // S[q][key]
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof[ks], vf[ks], pacc, 0, 0, 0);   // dP[q][key] - delta[q]
+            }
+            float pp[16], ds[16];
+            const float ksc2 = ksc * 1.4426950408889634f;
+            if (chk_self) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float lv[4] = {l4[g].x, l4[g].y, l4[g].z, l4[g].w};
+                    const int4 p4 = *reinterpret_cast<const int4*>(kq + qt * 32 + 8 * g + 4 * hh);
+                    const int pv[4] = {p4.x, p4.y, p4.z, p4.w}, ev[4] = {e4[g].x, e4[g].y, e4[g].z, e4[g].w};
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int i = 4 * g + jj;
+                        const bool self = pv[jj] == mypos;
+                        const bool dead = kpk > ev[jj];
+                        float x = sacc[i] * ksc2;
+                        x = self ? (-5e4f * 1.4426950408889634f) : x;
+                        float p = __builtin_amdgcn_exp2f(x - lv[jj]);
+                        p = (dead && !self) ? 0.f : p;
+                        pp[i] = p;
+                        ds[i] = self ? 0.f : p * pacc[i] * ksc;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float lv[4] = {l4[g].x, l4[g].y, l4[g].z, l4[g].w};
+                    const int ev[4] = {e4[g].x, e4[g].y, e4[g].z, e4[g].w};
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int i = 4 * g + jj;
+                        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[i], ksc2, -lv[jj]));
+                        p = (kpk > ev[jj]) ? 0.f : p;
+                        pp[i] = p;
+                        ds[i] = p * pacc[i] * ksc;
+                    }
+                }
+            }
+            bf16x8 qtf[2][2], dotf[2][2];   // [s2][dh tile]
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int blk = (qt * 32 + 16 * s2) * 128;
+                    qtf[s2][dt] = tr_frag(Kown + blk + tro[dt], Kown + blk + 8 * 128 + tro[dt ^ 1]);
+                    dotf[s2][dt] = tr_frag(Os + blk + tro[dt], Os + blk + 8 * 128 + tro[dt ^ 1]);
+                }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const float* pq = pp + 8 * s2;
+                const float* dq_ = ds + 8 * s2;
+                const bf16x8 pb = cvt_bf16x8(pq[0], pq[1], pq[2], pq[3], pq[4], pq[5], pq[6], pq[7]);
+                const bf16x8 db = cvt_bf16x8(dq_[0], dq_[1], dq_[2], dq_[3], dq_[4], dq_[5], dq_[6], dq_[7]);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[s2][dt], pb, dvacc[dt], 0, 0, 0);
+                    gacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[s2][dt], db, gacc[dt], 0, 0, 0);
+                }
+            }
+            const int dsq = qt << 6;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 pk;
+                pk.x = pack_bf16x2(ds[4 * g], ds[4 * g + 1]);
+                pk.y = pack_bf16x2(ds[4 * g + 2], ds[4 * g + 3]);
+                *reinterpret_cast<uint2*>(Ds + (dso[g] ^ dsq)) = pk;
+            }
+        }
+
+        AB_JSTAMP(4);
+        __syncthreads();   // every dS'^T tile is in Ds; nobody reads Os as dout any more
+        AB_JSTAMP(5);
+        if (more) {        // V rows and validity of this wave's keys in the NEXT step: own waves take chunk j + 1, the others this one
+            const int nmypos = own_tile ? kn[myrow] : kq[myrow - BS];
+            myvalid = MASKED ? (int)mask[(size_t)b * T + nmypos] : 1;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) vf[ks] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)nmypos * ld + ks * 16 + 8 * hh);
+        }
+
+        // ---- dQ^T[dh][q] = K^T dS'^T over the own keys, then the looked-back keys; parked (bf16) in the dout image's rows
+        {
+            const int qt = wave >> 1, dt = wave & 1;
+            f32x16 dq = {0};
+            const int rl = 8 * hh + trq;
+            const int kpc = dt * 4 + 2 * trc + (trp >> 1);
+            const int ko0 = ab_off(rl, kpc) + 8 * (trp & 1), ko1 = ab_off(rl + 4, kpc) + 8 * (trp & 1);
+            const int gq = qt * 8 + 4 * trc + trp;
+            const int do0 = ab_ds_off<BS>(rl, gq), do1 = ab_ds_off<BS>(rl + 4, gq);
+            if (qt < NQT) {        // BS = 64: NW = 4 waves, 2 * NQT = 4 outputs -- every wave has one; BS = 128: 8 and 8
+#pragma unroll AB_DQ_UNROLL
+                for (int kb = 0; kb < BS; kb += 16) {
+                    const bf16x8 bfrag = tr_frag(Ds + kb * DSROW + do0, Ds + kb * DSROW + do1);
+                    const bf16x8 afrag = tr_frag(Kown + kb * 128 + ko0, Kown + kb * 128 + ko1);
+                    dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, dq, 0, 0, 0);
+                }
+#pragma unroll AB_DQ_UNROLL
+                for (int kb = 0; kb < BS; kb += 16) {
+                    const bf16x8 bfrag = tr_frag(Ds + (BS + kb) * DSROW + do0, Ds + (BS + kb) * DSROW + do1);
+                    const bf16x8 afrag = tr_frag(Klb + kb * 128 + ko0, Klb + kb * 128 + ko1);
+                    dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, dq, 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(dq[4 * g], dq[4 * g + 1]);
+                    pk.y = pack_bf16x2(dq[4 * g + 2], dq[4 * g + 3]);
+                    *reinterpret_cast<uint2*>(Os + ab_off(qt * 32 + r, dt * 4 + g) + 8 * hh) = pk;
+                }
+            }
+        }
+        AB_JSTAMP(6);
+        __syncthreads();   // dQ parked; the dS'^T image is free: it becomes the row staging
+        AB_JSTAMP(7);
+
+        // the prefetched words of the next chunk have long arrived: publish them (read after the barrier at the top of the next step)
+        if (more && tid < BS) {
+            qlseS[(par ^ 1) * BS + tid] = nlse * 1.4426950408889634f;
+            qdelS[(par ^ 1) * BS + tid] = -ndel;
+            qpeS[(par ^ 1) * BS + tid] = nval ? (CAUSAL ? npos : 0) : -1;
+            if (j + 2 < R) kposS[((j + 3) & 3) * BS + tid] = p2;
+        }
+
+        // ---- row stores: dV, then dK (+ dQ on own rows), each 32-key tile through its [32][144 B] staging
+        const int round = c / nb, round_prev = cprev / nb;
+        const size_t obase = ((size_t)bh * n_hashes + (own_tile ? round : round_prev)) * T;
+        const int srow = lane >> 3, spiece = lane & 7;
+        unsigned char* stg = Stg + wave * (32 * AB_ROWB);
+        int rpos[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rpos[i] = own_tile ? kq[wave * 32 + i * 8 + srow] : kl[(wave - NW / 2) * 32 + i * 8 + srow];
+        {
+            bf16_t* dvdst = dv_part + (own_tile ? 0 : slot_stride);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(dvacc[dt][4 * g], dvacc[dt][4 * g + 1]);
+                    pk.y = pack_bf16x2(dvacc[dt][4 * g + 2], dvacc[dt][4 * g + 3]);
+                    *reinterpret_cast<uint2*>(stg + r * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2) = pk;
+                }
+            __builtin_amdgcn_wave_barrier();
+            uint4 rowv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rowv[i] = *reinterpret_cast<const uint4*>(stg + (i * 8 + srow) * AB_ROWB + spiece * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dvdst + (obase + rpos[i]) * AB_DH + spiece * 8) = rowv[i];
+            __builtin_amdgcn_wave_barrier();
+        }
+        {
+            bf16_t* dkdst = dqk_part + (own_tile ? 0 : slot_stride);
+            float kraw[2][16];
+            float dot = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint2 kk = *reinterpret_cast<const uint2*>(Kt + ab_off(r, dt * 4 + g) + 8 * hh);
+                    kraw[dt][4 * g] = __uint_as_float(kk.x << 16);
+                    kraw[dt][4 * g + 1] = __uint_as_float(kk.x & 0xffff0000u);
+                    kraw[dt][4 * g + 2] = __uint_as_float(kk.y << 16);
+                    kraw[dt][4 * g + 3] = __uint_as_float(kk.y & 0xffff0000u);
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) dot = __builtin_fmaf(kraw[dt][4 * g + jj], gacc[dt][4 * g + jj], dot);
+                }
+            const float ncoef = -rtts_xhalf_sum(dot) * (ksc * 8.f) * (ksc * 8.f);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float dk[4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) dk[jj] = __builtin_fmaf(kraw[dt][4 * g + jj], ncoef, gacc[dt][4 * g + jj]);
+                    if (own_tile) {
+                        const uint2 dqv = *reinterpret_cast<const uint2*>(Os + ab_off(myrow, dt * 4 + g) + 8 * hh);
+                        dk[0] += __uint_as_float(dqv.x << 16);
+                        dk[1] += __uint_as_float(dqv.x & 0xffff0000u);
+                        dk[2] += __uint_as_float(dqv.y << 16);
+                        dk[3] += __uint_as_float(dqv.y & 0xffff0000u);
+                    }
+                    uint2 pk;
+                    pk.x = pack_bf16x2(dk[0], dk[1]);
+                    pk.y = pack_bf16x2(dk[2], dk[3]);
+                    *reinterpret_cast<uint2*>(stg + r * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2) = pk;
+                }
+            __builtin_amdgcn_wave_barrier();
+            uint4 rowv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rowv[i] = *reinterpret_cast<const uint4*>(stg + (i * 8 + srow) * AB_ROWB + spiece * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dkdst + (obase + rpos[i]) * AB_DH + spiece * 8) = rowv[i];
+        }
+        AB_JSTAMP(8);
+#ifdef AB_PHASE_TIMING
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        AB_JSTAMP(9);
+#endif
+    }
+#undef AB_JSTAMP
+}
+
 extern "C" int rtts_lsh_bwd_qk_slots(void) { return RTTS_LSH_BWD_QK_SLOTS; }
+
+// chunks a workgroup walks: the longest run (8, 4) that divides the ring and still leaves >= 3 workgroups per CU, for the
+// 128-row buckets only (measured, kbench: decoder shape 275 -> 255 us at runs of 8, 264 at 4; with 64-row buckets two
+// one-chunk workgroups share a CU and already overlap each other's gather: 50.7 us against 52.8 / 58.3 walking); 0 = the
+// one-chunk kernel.  RTTS_LSH_BWD_WALK=<run> forces a run length for tests and A/B runs (0: the one-chunk kernel).
+extern "C" int rtts_lsh_attn_bwd_run_length(int B, int H, int T, int n_hashes, int bucket_size) {
+    if (B <= 0 || H <= 0 || n_hashes <= 0 || bucket_size <= 0 || T <= 0 || T % bucket_size) return -1;
+    const int C = n_hashes * (T / bucket_size);
+    const long long chunks = (long long)B * H * C;
+    int R = 0;
+    if (bucket_size == 128 && AB_KT2 == 1)
+        for (int cand = 8; cand >= 4; cand >>= 1)
+            if (C % cand == 0 && chunks / cand >= 768) { R = cand; break; }
+    const char* walk_s = getenv("RTTS_LSH_BWD_WALK");
+    if (walk_s && AB_KT2 == 1) {
+        const int w = atoi(walk_s);
+        R = (w >= 1 && C % w == 0) ? w : 0;
+    }
+    return R;
+}
 
 template <int BS>
 static int launch_attn_bwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const int32_t* st, const uint8_t* mask,
                            const bf16_t* dout, int64_t ld_do, const float* lse_tot, const float* delta, int B, int H, int T,
                            int n_hashes, int causal, bf16_t* dqk_part, bf16_t* dv_part, hipStream_t stream) {
     constexpr int NK = 2 * BS;
-    const size_t lds = NK * 128 + BS * 128 + NK * (BS * 2) + (NK / 32) * 32 * AB_ROWB + NK * 12 + BS * 12;
-    const dim3 grid(B * H * n_hashes * (T / BS)), block(BS * 4 / AB_KT2);
     const size_t slot_stride = (size_t)B * H * n_hashes * T * AB_DH;
     const int vi = (causal ? 2 : 0) + (mask ? 1 : 0);
-    static bool attr[64][4] = {};                // per device: the dynamic-LDS limit is an attribute of the loaded function
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    const int C = n_hashes * (T / BS);
+    const long long chunks = (long long)B * H * C;
+    const int R = rtts_lsh_attn_bwd_run_length(B, H, T, n_hashes, BS);
+    if (R >= 1 && AB_KT2 == 1) {
+        const size_t ds_bytes = (size_t)NK * (BS * 2), stg_bytes = (size_t)(NK / 32) * 32 * AB_ROWB;
+        const size_t wlds = (size_t)BS * 40 + 5 * (size_t)BS * 128 + (ds_bytes > stg_bytes ? ds_bytes : stg_bytes);
+        static bool wattr[64][4] = {};
+        const dim3 wgrid((unsigned)(chunks / R)), wblock(BS * 4);
+#define AB_WGO(C_, M_)                                                                                                     \
+    do {                                                                                                                   \
+        auto kern = lsh_attn_bwd_walk_kernel<BS, C_, M_>;                                                                  \
+        if (!wattr[dev][vi]) {                                                                                             \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds); \
+            RTTS_REQUIRE(e == hipSuccess, "rtts_lsh_attn_bwd: cannot raise the dynamic LDS limit to %zu bytes", wlds);     \
+            wattr[dev][vi] = true;                                                                                         \
+        }                                                                                                                  \
+        hipLaunchKernelGGL(kern, wgrid, wblock, wlds, stream, qk, v, ld, st, mask, dout, ld_do, lse_tot, delta, H, T, n_hashes, \
+                           dqk_part, dv_part, slot_stride, R);                                                             \
+    } while (0)
+        if (causal) {
+            if (mask) AB_WGO(true, true); else AB_WGO(true, false);
+        } else {
+            if (mask) AB_WGO(false, true); else AB_WGO(false, false);
+        }
+#undef AB_WGO
+        RTTS_LAUNCH_CHECK("rtts_lsh_attn_bwd");
+        return 0;
+    }
+    const size_t lds = NK * 128 + BS * 128 + NK * (BS * 2) + (NK / 32) * 32 * AB_ROWB + NK * 12 + BS * 12;
+    const dim3 grid(B * H * n_hashes * (T / BS)), block(BS * 4 / AB_KT2);
+    static bool attr[64][4] = {};                // per device: the dynamic-LDS limit is an attribute of the loaded function
 #define AB_KERN(C_, M_) lsh_attn_bwd_kernel<BS, C_, M_>
 #define AB_GO(C_, M_)                                                                                                      \
     do {                                                                                                                   \

@@ -129,7 +129,21 @@ def main():
     buf = np.zeros(32 * 8192, dtype=np.uint64)
     rc = lib.rtts_debug_ab_phases(buf.ctypes.data)
     assert rc == 0, rc
-    allp = buf.reshape(8192, 32)[: b * h * nh * (t // bs)].astype(np.int64)
+    allp = buf.reshape(8192, 32).astype(np.int64)
+    allp = allp[allp[:, 0] > 0]
+    walk = os.environ.get("RTTS_LSH_BWD_WALK", "")
+    if walk not in ("", "0"):
+        # walking kernel: the stamps are those of step 2 of every run (a step whose operands were prefetched)
+        names = ["wait barrier (operands of this step on chip)", "issue prefetch of the next chunk", "key tile: K fragments, V rows arrive",
+                 "main loop", "wait barrier (dS)", "dQ product + park", "wait barrier", "row stores issued", "stores acknowledged"]
+        ph = allp[:, :10]
+        d = np.diff(ph, axis=1)
+        tot = ph[:, 9] - ph[:, 0]
+        print(f"runs {len(ph)}; one prefetched step: median {np.median(tot):.0f} mean {tot.mean():.0f} cycles")
+        for i, nm in enumerate(names):
+            print(f"  {nm:46s} median {np.median(d[:, i]):8.0f}  mean {d[:, i].mean():8.0f}  p10 {np.percentile(d[:, i], 10):8.0f}  p90 {np.percentile(d[:, i], 90):8.0f}")
+        return
+    allp = allp[: b * h * nh * (t // bs)]
     ph = allp[:, :10]
     d = np.diff(ph, axis=1)
     names = ["gather + LDS image", "wait barrier 1", "key consts + main loop", "dV rows staged + stores issued", "wait barrier 2",

@@ -173,6 +173,28 @@ def test_attention_backward_vs_oracle_autograd(ops, b, h, t, bs, nh, causal, mas
           " (tol max 4e-2, mean 4e-3)")
 
 
+@pytest.mark.parametrize("b,h,t,bs,nh,causal,masked", CASES)
+def test_walking_backward_equals_the_one_chunk_kernel(ops, monkeypatch, b, h, t, bs, nh, causal, masked):
+    """lsh_attn_bwd as workgroups that walk R consecutive chunks of a ring (operands of the next chunk prefetched by
+    LDS-DMA, the looked-back rows kept on chip) does the same arithmetic in the same order as the one-chunk kernel:
+    bit-identical gradients for every run length that divides the ring, including runs that cross a hash round."""
+    r = _run_fwd(ops, b, h, t, bs, nh, causal, masked, seed=5)
+    dout = torch.randn(b, t, h * r["dh"], generator=torch.Generator().manual_seed(13)).bfloat16().cuda()
+    m = None if r["mask"] is None else r["mask"].cuda()
+    outs = {}
+    ring = nh * (t // bs)
+    for run in (0, 1, 2, 4, 8):
+        if run and ring % run:
+            continue
+        monkeypatch.setenv("RTTS_LSH_BWD_WALK", str(run))
+        dqk, dv = ops.lsh_attn_bwd(r["qk_d"], r["v_d"], r["st"], r["out"], dout, r["lse_tot"], h, bs, causal, m)
+        torch.cuda.synchronize()
+        outs[run] = (dqk.clone(), dv.clone())
+    assert len(outs) >= 3
+    for run, (dqk, dv) in outs.items():
+        assert torch.equal(dqk, outs[0][0]) and torch.equal(dv, outs[0][1]), f"run length {run}"
+
+
 def test_strided_qkv_views(ops):
     """qk and v as the two halves of one (B,T,2d) buffer (row stride 2d) give the same result as
     separate contiguous tensors."""
