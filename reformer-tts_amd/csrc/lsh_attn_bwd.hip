@@ -657,6 +657,9 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
         constexpr int PF_IT = BS * 8 / NTHR;                 // 2: DMA instructions per wave and operand
         constexpr int PF_PER_TILE = 2 * PF_IT / NQT;         // 1 (BS = 128) or 2 (BS = 64) per query tile
         static_assert(PF_PER_TILE * NQT == 2 * PF_IT, "prefetch pieces must tile the query loop");
+        int pfpos[PF_IT];                                    // read now: no LDS round trip in front of a DMA issue inside the loop
+#pragma unroll
+        for (int it = 0; it < PF_IT; ++it) pfpos[it] = more ? kn[it * (NTHR / 8) + wave * 8 + (lane >> 3)] : 0;
         AB_JSTAMP(2);
         // ---- this wave's key tile
         const bool own_tile = wave < NW / 2;                     // wave-uniform
@@ -717,7 +720,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
                     const int piece = qt * PF_PER_TILE + pf;         // 0 .. 2 * PF_IT - 1: (iteration, K | dout)
                     const int it = piece >> 1;
                     const int rowb = it * (NTHR / 8) + wave * 8;
-                    const int pos = kn[rowb + (lane >> 3)];
+                    const int pos = pfpos[it];
                     const int lp = (lane & 7) ^ ab_sw(rowb + (lane >> 3));
                     if ((piece & 1) == 0)
                         ab_dma16(qbase + (size_t)pos * ld + lp * 8, (RTTS_LDS void*)(Knext + rowb * 128));
