@@ -617,8 +617,13 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
         if (R > 1 && tid < BS) kposS[2 * BS + tid] = pnext;
     }
 
-    bf16x8 vf[4];           // V rows of this wave's keys: those of the NEXT step are requested as soon as a step's main loop is
-    int myvalid = 1;        // done with them (the only per-lane state that crosses a step)
+    // Per-lane state that crosses a step: the K and V fragments, scale and position of this wave's 32 keys.  The wave groups
+    // swap roles every step -- the group that works the OWN keys of chunk j works the same keys as LOOKED-BACK keys of chunk
+    // j + 1 and keeps them in registers; only the other group fetches (the V rows of its next keys are requested as soon as
+    // its main loop is done with the old ones, the K fragments come from the prefetched image).
+    bf16x8 vf[4], kf[4];
+    float ksc = 0.f;
+    int myvalid = 1, mypos = 0, kpk = 0;
 #pragma unroll 1
     for (int j = 0; j < R; ++j) {
         // nothing else but scalars is carried from one step to the next: the lane id goes through an opaque move so that no address
@@ -662,36 +667,39 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
         for (int it = 0; it < PF_IT; ++it) pfpos[it] = more ? kn[it * (NTHR / 8) + wave * 8 + (lane >> 3)] : 0;
         AB_JSTAMP(2);
         // ---- this wave's key tile
-        const bool own_tile = wave < NW / 2;                     // wave-uniform
-        const int myrow = wave * 32 + r;                         // row of the dS'^T image: own keys first
-        const int mypos = own_tile ? kq[myrow] : kl[myrow - BS];
-        const unsigned char* Kt = own_tile ? Kown + wave * (32 * 128) : Klb + (wave - NW / 2) * (32 * 128);
-        if (j == 0) {      // later steps: requested by the previous one
-            myvalid = MASKED ? (int)mask[(size_t)b * T + mypos] : 1;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) vf[ks] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)mypos * ld + ks * 16 + 8 * hh);
-        }
+        const int grp = wave / (NW / 2), wt = wave % (NW / 2);   // wave-uniform
+        const bool own_tile = grp == (j & 1);                    // the groups take turns: own keys in one step, looked-back in the next
+        const int myrow = (own_tile ? 0 : BS) + wt * 32 + r;     // row of the dS'^T image: own keys first
+        const unsigned char* Kt = (own_tile ? Kown : Klb) + wt * (32 * 128);
         int fro[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fro[ks] = ab_off(r, ks * 2 + hh);
-        bf16x8 kf[4];
+        if (own_tile || j == 0) {          // fresh keys (the looked-back group of the first step has nothing to keep either)
+            const int pos_now = own_tile ? kq[wt * 32 + r] : kl[wt * 32 + r];
+            if (j == 0) {                  // later steps: V rows and validity were requested by the previous one
+                myvalid = MASKED ? (int)mask[(size_t)b * T + pos_now] : 1;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(Kt + fro[ks]);
-        float ss = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const uint4 u4 = __builtin_bit_cast(uint4, kf[ks]);
-            const uint32_t u[4] = {u4.x, u4.y, u4.z, u4.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float a = __uint_as_float(u[k] << 16), bq = __uint_as_float(u[k] & 0xffff0000u);
-                ss = __builtin_fmaf(a, a, ss);
-                ss = __builtin_fmaf(bq, bq, ss);
+                for (int ks = 0; ks < 4; ++ks) vf[ks] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)pos_now * ld + ks * 16 + 8 * hh);
             }
+            mypos = pos_now;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(Kt + fro[ks]);
+            float ss = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const uint4 u4 = __builtin_bit_cast(uint4, kf[ks]);
+                const uint32_t u[4] = {u4.x, u4.y, u4.z, u4.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float a = __uint_as_float(u[k] << 16), bq = __uint_as_float(u[k] & 0xffff0000u);
+                    ss = __builtin_fmaf(a, a, ss);
+                    ss = __builtin_fmaf(bq, bq, ss);
+                }
+            }
+            ss = rtts_xhalf_sum(ss);
+            ksc = 0.125f * __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));   // dh^-1/2 / max(|k|, 1e-12)
+            kpk = myvalid ? (CAUSAL ? mypos : 0) : 0x40000000;
         }
-        ss = rtts_xhalf_sum(ss);
-        const float ksc = 0.125f * __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));   // dh^-1/2 / max(|k|, 1e-12)
-        const int kpk = myvalid ? (CAUSAL ? mypos : 0) : 0x40000000;
 
         f32x16 dvacc[2], gacc[2];   // [dh tile]: rows = dh, lane = key
 #pragma unroll
@@ -758,7 +766,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
                 l4[g] = *reinterpret_cast<const float4*>(qlse + q0);
                 e4[g] = *reinterpret_cast<const int4*>(qpe_s + q0);
             }
-            const bool chk_self = own_tile ? (wave == qt) : wrap;
+            const bool chk_self = own_tile ? (wt == qt) : wrap;
             f32x16 sacc = {0}, pacc = pinit;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -835,8 +843,8 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
         AB_JSTAMP(4);
         __syncthreads();   // every dS'^T tile is in Ds; nobody reads Os as dout any more
         AB_JSTAMP(5);
-        if (more) {        // V rows and validity of this wave's keys in the NEXT step: own waves take chunk j + 1, the others this one
-            const int nmypos = own_tile ? kn[myrow] : kq[myrow - BS];
+        if (more && !own_tile) {        // this group works the own keys of chunk j + 1 next: its V rows and validity
+            const int nmypos = kn[wt * 32 + r];
             myvalid = MASKED ? (int)mask[(size_t)b * T + nmypos] : 1;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) vf[ks] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)nmypos * ld + ks * 16 + 8 * hh);
@@ -892,7 +900,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
         unsigned char* stg = Stg + wave * (32 * AB_ROWB);
         int rpos[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rpos[i] = own_tile ? kq[wave * 32 + i * 8 + srow] : kl[(wave - NW / 2) * 32 + i * 8 + srow];
+        for (int i = 0; i < 4; ++i) rpos[i] = own_tile ? kq[wt * 32 + i * 8 + srow] : kl[wt * 32 + i * 8 + srow];
         {
             bf16_t* dvdst = dv_part + (own_tile ? 0 : slot_stride);
 #pragma unroll
