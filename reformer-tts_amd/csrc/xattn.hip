@@ -43,26 +43,28 @@ __device__ __forceinline__ int xa_ds_off(int key, int gran) {
     return key * 256 + ((gran ^ ((k1 << 4) | (k0 << 3) | (k1 << 2) | (k2 << 1) | k3)) << 3);
 }
 
-template <int TK>
+template <int TK, bool MULTI>
 __global__ __launch_bounds__(256) void xattn_fwd_kernel(const bf16_t* __restrict__ q, int64_t ld_q, const bf16_t* __restrict__ kv,
-                                                        int64_t ld_kv, const uint8_t* __restrict__ kvalid, int H, int Tq, int TKtot,
+                                                        int64_t ld_kv, const uint8_t* __restrict__ kvalid, int H, int Tq, int TKtot_,
                                                         bf16_t* __restrict__ o, int64_t ld_o, float* __restrict__ lse,
                                                         uint32_t seed, const uint32_t* __restrict__ seed_dev, uint32_t thresh,
                                                         float dscale) {
     // TK = keys held on chip at a time; TKtot (a multiple of TK) keys are walked chunk by chunk with a running maximum and
-    // normaliser (one chunk: exactly the single-pass softmax)
+    // normaliser.  MULTI = false: TKtot == TK is a compile-time fact -- the loop below runs once, the running state folds away
+    // and the kernel is the single-pass softmax (two waves per SIMD; the general form needs one wave's worth of registers more)
+    const int TKtot = MULTI ? TKtot_ : TK;
     constexpr int NKT = TK / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* Ks = smem;
-    unsigned char* Vs = Ks + TK * XA_ROWB;
-    int* kval = reinterpret_cast<int*>(Vs + TK * XA_ROWB);
+    unsigned char* Ks = smem;                       // [TK][128] swizzled (xa_off), like V
+    unsigned char* Vs = Ks + TK * 128;
+    int* kval = reinterpret_cast<int*>(Vs + TK * 128);
 
     const int nqb = Tq / XA_QB;
     const uint32_t wi = xcd_remap(blockIdx.x, gridDim.x);
     const int bh = wi / nqb, qb = wi % nqb;
     const int b = bh / H, h = bh % H;
     const int d = H * XA_DH;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
 
     // Q fragments straight from global: lane (r, hh) holds Q[q0 + r][16 ks + 8 hh .. +8]
@@ -80,20 +82,19 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const bf16_t* __restrict
     for (int c0 = 0; c0 < TKtot; c0 += TK) {
         const bf16_t* kbase = kv + ((size_t)b * TKtot + c0) * ld_kv + (size_t)h * XA_DH;
         const bf16_t* vbase = kbase + d;
-        constexpr int ITERS = TK * 8 / 256;
-        uint4 kreg[ITERS], vreg[ITERS];
-#pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            const int row = (it * 256 + tid) >> 3, piece = tid & 7;
-            kreg[it] = *reinterpret_cast<const uint4*>(kbase + (size_t)row * ld_kv + piece * 8);
-            vreg[it] = *reinterpret_cast<const uint4*>(vbase + (size_t)row * ld_kv + piece * 8);
-        }
         if (c0) __syncthreads();        // every wave is done with the previous chunk's images
+        // K and V rows go global -> LDS by DMA (no staging registers, no ds_write pass): one wave-instruction fills 8 consecutive
+        // 128-byte rows in lane order, so the swizzle goes on the SOURCE side (lsh_attn_bwd.hip's gather)
+        constexpr int ITERS = TK * 8 / 256;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int row = (it * 256 + tid) >> 3, piece = tid & 7;
-            *reinterpret_cast<uint4*>(Ks + row * XA_ROWB + piece * 16) = kreg[it];
-            *reinterpret_cast<uint4*>(Vs + xa_off(row, piece)) = vreg[it];       // V: unpadded rows, swizzled (transposed reads)
+            const int rowb = it * 32 + wave * 8;                     // wave-uniform: first row of this instruction
+            const int row = rowb + (lane >> 3);
+            const int lp = (lane & 7) ^ xa_sw(row);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + (size_t)row * ld_kv + lp * 8),
+                                             (RTTS_LDS void*)(Ks + rowb * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + (size_t)row * ld_kv + lp * 8),
+                                             (RTTS_LDS void*)(Vs + rowb * 128), 16, 0, 0);
         }
         for (int j = tid; j < TK; j += 256) kval[j] = kvalid ? (int)kvalid[(size_t)b * TKtot + c0 + j] : 1;
         __syncthreads();
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const bf16_t* __restrict
             f32x16 acc = {0};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + r) * XA_ROWB + (ks * 16 + 8 * hh) * 2);
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + xa_off(kt * 32 + r, ks * 2 + hh));
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc, 0, 0, 0);
             }
             s[kt] = acc;
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const bf16_t* __restrict
     }
 }
 
-static bool g_xa_attr[64][3][2];     // per device: the dynamic-LDS limit is an attribute of the loaded function
+static bool g_xa_attr[64][4][2];     // per device: the dynamic-LDS limit is an attribute of the loaded function
 static int xa_dev() { int d = 0; return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) ? d : 0; }
 extern "C" int rtts_sum_slabs(const void* part, int nslabs, int64_t n, void* out, void* stream);
 
@@ -446,13 +447,13 @@ extern "C" int rtts_xattn_fwd(const void* q, int64_t ld_q, const void* kv, int64
     RTTS_REQUIRE((((uintptr_t)q | (uintptr_t)kv | (uintptr_t)o) & 15) == 0, "rtts_xattn_fwd: buffers must be 16-byte aligned");
     const dim3 grid(B * H * (Tq / XA_QB));
     const int chunk = xa_chunk(Tk);
-    const size_t lds = 2 * (size_t)chunk * XA_ROWB + (size_t)chunk * 4;
+    const size_t lds = 2 * (size_t)chunk * 128 + (size_t)chunk * 4;
 #define GO(TK_)                                                                                                           \
     do {                                                                                                                  \
-        auto kern = xattn_fwd_kernel<TK_>;                                                                                \
-        if (!g_xa_attr[xa_dev()][0][TK_ == 256]) {                                                                                  \
+        auto kern = Tk == TK_ ? xattn_fwd_kernel<TK_, false> : xattn_fwd_kernel<TK_, true>;                               \
+        if (!g_xa_attr[xa_dev()][Tk == TK_ ? 0 : 3][TK_ == 256]) {                                                                                  \
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            g_xa_attr[xa_dev()][0][TK_ == 256] = true;                                                                              \
+            g_xa_attr[xa_dev()][Tk == TK_ ? 0 : 3][TK_ == 256] = true;                                                            \
         }                                                                                                                 \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q, ld_q, (const bf16_t*)kv, ld_kv, \
                            kvalid, H, Tq, Tk, (bf16_t*)o, ld_o, lse, seed, seed_dev, rtts_drop_thresh(drop_p), 1.f / (1.f - drop_p)); \
