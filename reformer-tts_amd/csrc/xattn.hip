@@ -231,17 +231,24 @@ __global__ __launch_bounds__(TK * 2 / XA_KT2) void xattn_bwd_kernel(const bf16_t
     const bf16_t* qbase = q + ((size_t)b * Tq + (size_t)qb * XA_QB) * ld_q + (size_t)h * XA_DH;
     const bf16_t* dobase = dout + ((size_t)b * Tq + (size_t)qb * XA_QB) * ld_do + (size_t)h * XA_DH;
 
-    for (int idx = tid; idx < TK * 8; idx += NTHR) {
-        const int row = idx >> 3, piece = idx & 7;
-        *reinterpret_cast<uint4*>(Ks + xa_off(row, piece)) =
-            *reinterpret_cast<const uint4*>(kbase + (size_t)row * ld_kv + piece * 8);
-    }
-    for (int idx = tid; idx < XA_QB * 8; idx += NTHR) {
-        const int row = idx >> 3, piece = idx & 7;
-        *reinterpret_cast<uint4*>(Qs + xa_off(row, piece)) =
-            *reinterpret_cast<const uint4*>(qbase + (size_t)row * ld_q + piece * 8);
-        *reinterpret_cast<uint4*>(Os + xa_off(row, piece)) =
-            *reinterpret_cast<const uint4*>(dobase + (size_t)row * ld_do + piece * 8);
+    // images by LDS-DMA (one wave-instruction = 8 rows of 128 B in lane order, the swizzle on the SOURCE side)
+    {
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+        for (int it = 0; it < TK * 8 / NTHR; ++it) {
+            const int rowb = it * (NTHR / 8) + wv * 8, row = rowb + (lane >> 3);
+            const int lp = (lane & 7) ^ xa_sw(row);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + (size_t)row * ld_kv + lp * 8),
+                                             (RTTS_LDS void*)(Ks + rowb * 128), 16, 0, 0);
+        }
+        for (int rowb = wv * 8; rowb < XA_QB; rowb += NTHR / 8) {
+            const int row = rowb + (lane >> 3);
+            const int lp = (lane & 7) ^ xa_sw(row);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qbase + (size_t)row * ld_q + lp * 8),
+                                             (RTTS_LDS void*)(Qs + rowb * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dobase + (size_t)row * ld_do + lp * 8),
+                                             (RTTS_LDS void*)(Os + rowb * 128), 16, 0, 0);
+        }
     }
     for (int j = tid; j < XA_QB; j += NTHR) {
         qlse[j] = lse[(size_t)bh * Tq + qb * XA_QB + j] * 1.4426950408889634f;   // base-2 softmax: exp2(s * c - lse * log2 e)
