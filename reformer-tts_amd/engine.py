@@ -17,6 +17,8 @@ from __future__ import annotations
 
 from typing import List, Optional
 
+import os
+
 import torch
 
 from . import _lib, ops
@@ -287,6 +289,12 @@ _SLAB_FLOATS = 16 * 1024 * 1024   # 64 MB: 16 splits of a 2048 x 512 gradient
 # rtts_gemm_tn_grouped call: one grid of ~240 tiles per decoder layer instead of seven grids of 16..64 tiles, so the
 # split factor and the fp32 slab traffic drop ~7x and launch ramps/tails are paid once per layer.
 DEFER_WGRAD = True
+# The queue is flushed once per layer's worth of problems, on one GPU too, where nobody waits for a block's gradients: holding
+# the weight gradients of the WHOLE backward back for a few large mixed groups at its end (RTTS_WGRAD_FLUSH=end) measured
+# 6.57 against 6.23 ms/step -- a layer's dy / x operands are still in the 256 MB Infinity Cache right after its backward and
+# have left it by the end of the step.
+WGRAD_FLUSH_PER_LAYER = os.environ.get("RTTS_WGRAD_FLUSH", "layer") == "layer"
+WGRAD_MAX_PENDING = 64
 # (A second HIP stream for the weight gradients, forked/joined by events = parallel branches of the captured hipGraph,
 #  was measured SLOWER on MI355X in round 1: 9.35 vs 8.94 ms/step; the cross-branch dependencies of the replayed graph
 #  cost more than the overlapped tails recover.  Removed.)
@@ -828,13 +836,18 @@ class FusedStackFn(torch.autograd.Function):
                     chain.done(post, s1)
                     chain.grad_done(nxt, g2)
                 done.append(i)
-                if pending_wgrads() >= 7 or i == 0:
-                    # one grouped launch per layer's worth of weight gradients; only then are the finished blocks'
-                    # gradient slices final, so their all-reduce hooks run here
-                    flush_wgrad()
-                    if seq.block_done_hook is not None:
-                        for j in done:
-                            seq.block_done_hook(seq, j)
-                    done.clear()
+                hook = seq.block_done_hook
+                if WGRAD_FLUSH_PER_LAYER or (hook is not None and getattr(hook, "active", lambda: True)()):
+                    if pending_wgrads() >= 7 or i == 0:
+                        # one grouped launch per layer's worth of weight gradients; only then are the finished blocks'
+                        # gradient slices final, so their all-reduce hooks run here
+                        flush_wgrad()
+                        if seq.block_done_hook is not None:
+                            for j in done:
+                                seq.block_done_hook(seq, j)
+                        done.clear()
+                elif pending_wgrads() >= WGRAD_MAX_PENDING:
+                    flush_wgrad()      # nobody waits for a block's gradients (one GPU): they go out in a few large groups at the
+                    #                    end of the backward; this only bounds the operands held
             dx = (g1 + g2).view(b, t, d)
         return dx, (None if dkeys is None else dkeys.view(b, -1, d)), None, None

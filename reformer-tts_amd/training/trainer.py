@@ -171,6 +171,8 @@ class Trainer:
             if self.world > 1 and not self._bulk_allreduce and not self._accumulating and (stack_name, i) in self.block_bucket:
                 s, e = self.block_bucket[(stack_name, i)]
                 self._pending.append(dist.all_reduce(self.flat_g[s:e], group=self.pg, async_op=True))
+        # the stack loop flushes a block's weight gradients early only while somebody waits for them (engine.py)
+        hook.active = lambda: self.world > 1 and not self._bulk_allreduce and not self._accumulating
         return hook
 
     # ------------------------------------------------------------------ step pieces
