@@ -74,7 +74,12 @@ int rtts_lsh_combine_fwd(const void* o, const float* lse, int B, int H, int T, i
  *                   chunk (query role + key role, added on chip), slot 1 = key role as the looked-back chunk
  *        dv_part  : (2, B*H, n_hashes, T, dh)  slot 0 = own chunk, slot 1 = looked-back chunk
  *        every (slot, head, round, token) row is written exactly once: no zero-fill needed
- *   rtts_lsh_bwd_reduce: dqk, dv bf16 (B,T,H*dh) stride ld_d = sum over slots and rounds */
+ *        row_flags : u8 (B*H, n_hashes, T), required where rtts_lsh_attn_bwd_run_length() > 0 (else it may be NULL and is
+ *                   not written): the walking kernel carries a chunk's dK/dV accumulators through the two steps that work
+ *                   its keys and writes each key row ONCE into slot 0; only the ends of a run leave a slot-1 partner, and
+ *                   row_flags[row] = 1 marks the slot-0 rows that have one (slot-1 rows without a flag are never written)
+ *   rtts_lsh_bwd_reduce: dqk, dv bf16 (B,T,H*dh) stride ld_d = sum over slots and rounds; row_flags as written by the
+ *        backward, or NULL = every row has both slots */
 int rtts_lsh_bwd_qk_slots(void);
 /* how rtts_lsh_attn_bwd works a shape: 0 = one workgroup per chunk (lsh_attn_bwd_kernel), R > 0 = workgroups that walk R
  * consecutive chunks of a ring with the next chunk's rows prefetched (lsh_attn_bwd_walk_kernel); same results bit for bit */
@@ -84,9 +89,9 @@ int rtts_lsh_bwd_delta(const void* out, int64_t ld_out, const void* dout, int64_
 int rtts_lsh_attn_bwd(const void* qk, const void* v, int64_t ld, const int32_t* st, const uint8_t* mask,
                       const void* dout, int64_t ld_dout, const float* lse_tot, const float* delta,
                       int B, int H, int T, int dh, int n_hashes, int bucket_size, int causal,
-                      void* dqk_part, void* dv_part, void* stream);
+                      void* dqk_part, void* dv_part, uint8_t* row_flags, void* stream);
 int rtts_lsh_bwd_reduce(const void* dqk_part, const void* dv_part, int B, int H, int T, int dh, int n_hashes,
-                        void* dqk, void* dv, int64_t ld_d, void* stream);
+                        void* dqk, void* dv, int64_t ld_d, const uint8_t* row_flags, void* stream);
 
 /* ---- optimizer step over the flat parameter buffer --------------------------------------
  * Replaces clip_grad_norm_ (pytorch-lightning gradient_clip_val, reference

@@ -543,7 +543,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
     const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v, int64_t ld, const int32_t* __restrict__ st,
     const uint8_t* __restrict__ mask, const bf16_t* __restrict__ dout, int64_t ld_do, const float* __restrict__ lse_tot,
     const float* __restrict__ delta, int H, int T, int n_hashes, bf16_t* __restrict__ dqk_part, bf16_t* __restrict__ dv_part,
-    size_t slot_stride, int R) {
+    size_t slot_stride, int R, uint8_t* __restrict__ row_flags) {
     constexpr int NK = 2 * BS;
     constexpr int NQT = BS / 32;
     constexpr int NW = NK / 32;
@@ -621,9 +621,15 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
     // swap roles every step -- the group that works the OWN keys of chunk j works the same keys as LOOKED-BACK keys of chunk
     // j + 1 and keeps them in registers; only the other group fetches (the V rows of its next keys are requested as soon as
     // its main loop is done with the old ones, the K fragments come from the prefetched image).
+    // The same holds for the gradients: the dV / dK accumulators of a chunk's keys run through BOTH steps (own role, then
+    // looked-back role), so every key row is written ONCE, complete, with the query-role gradient of the row folded in when it
+    // is parked (sdq remembers k . dQ, which the projection of the key-normalisation gradient must not see).  Only the ends of a
+    // run leave partial rows: the looked-back keys of its first step (slot 1; their own part was the previous run's last step)
+    // and the own keys of its last step (slot 0, flagged: rtts_lsh_bwd_reduce adds slot 1 only to flagged rows).
     bf16x8 vf[4], kf[4];
-    float ksc = 0.f;
+    float ksc = 0.f, sdq = 0.f;
     int myvalid = 1, mypos = 0, kpk = 0;
+    f32x16 dvacc[2], gacc[2];   // [dh tile]: rows = dh, lane = key
 #pragma unroll 1
     for (int j = 0; j < R; ++j) {
         // nothing else but scalars is carried from one step to the next: the lane id goes through an opaque move so that no address
@@ -701,11 +707,13 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
             kpk = myvalid ? (CAUSAL ? mypos : 0) : 0x40000000;
         }
 
-        f32x16 dvacc[2], gacc[2];   // [dh tile]: rows = dh, lane = key
+        if (own_tile || j == 0) {          // fresh keys start from zero; looked-back keys continue what their own step left
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            dvacc[d] = (f32x16){0};
-            gacc[d] = (f32x16){0};
+            for (int d = 0; d < 2; ++d) {
+                dvacc[d] = (f32x16){0};
+                gacc[d] = (f32x16){0};
+            }
+            sdq = 0.f;
         }
         const int trq = (lane & 15) >> 2, trp = lane & 3, trc = (lane >> 4) & 1;
         int tro[2];
@@ -893,75 +901,97 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
             if (j + 2 < R) kposS[((j + 3) & 3) * BS + tid] = p2;
         }
 
-        // ---- row stores: dV, then dK (+ dQ on own rows), each 32-key tile through its [32][144 B] staging
-        const int round = c / nb, round_prev = cprev / nb;
-        const size_t obase = ((size_t)bh * n_hashes + (own_tile ? round : round_prev)) * T;
-        const int srow = lane >> 3, spiece = lane & 7;
-        unsigned char* stg = Stg + wave * (32 * AB_ROWB);
-        int rpos[4];
+        // ---- end of the step.  Own keys: the parked query-role gradient of the row joins the key-role accumulator (they are the
+        //      same rows).  Looked-back keys (and the own keys of a run's last step): the row is complete -- dK = G - k^ (k^ . G) on
+        //      the key part only, + dQ -- and leaves through a [32][144 B] staging as full 128-byte rows, with dV.
+        float kraw[2][16];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rpos[i] = own_tile ? kq[wt * 32 + i * 8 + srow] : kl[wt * 32 + i * 8 + srow];
-        {
-            bf16_t* dvdst = dv_part + (own_tile ? 0 : slot_stride);
+        for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    uint2 pk;
-                    pk.x = pack_bf16x2(dvacc[dt][4 * g], dvacc[dt][4 * g + 1]);
-                    pk.y = pack_bf16x2(dvacc[dt][4 * g + 2], dvacc[dt][4 * g + 3]);
-                    *reinterpret_cast<uint2*>(stg + r * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2) = pk;
-                }
-            __builtin_amdgcn_wave_barrier();
-            uint4 rowv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) rowv[i] = *reinterpret_cast<const uint4*>(stg + (i * 8 + srow) * AB_ROWB + spiece * 16);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dvdst + (obase + rpos[i]) * AB_DH + spiece * 8) = rowv[i];
-            __builtin_amdgcn_wave_barrier();
-        }
-        {
-            bf16_t* dkdst = dqk_part + (own_tile ? 0 : slot_stride);
-            float kraw[2][16];
-            float dot = 0.f;
+            for (int g = 0; g < 4; ++g) {
+                const uint2 kk = *reinterpret_cast<const uint2*>(Kt + ab_off(r, dt * 4 + g) + 8 * hh);
+                kraw[dt][4 * g] = __uint_as_float(kk.x << 16);
+                kraw[dt][4 * g + 1] = __uint_as_float(kk.x & 0xffff0000u);
+                kraw[dt][4 * g + 2] = __uint_as_float(kk.y << 16);
+                kraw[dt][4 * g + 3] = __uint_as_float(kk.y & 0xffff0000u);
+            }
+        if (own_tile) {
+            float sd = 0.f;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const uint2 kk = *reinterpret_cast<const uint2*>(Kt + ab_off(r, dt * 4 + g) + 8 * hh);
-                    kraw[dt][4 * g] = __uint_as_float(kk.x << 16);
-                    kraw[dt][4 * g + 1] = __uint_as_float(kk.x & 0xffff0000u);
-                    kraw[dt][4 * g + 2] = __uint_as_float(kk.y << 16);
-                    kraw[dt][4 * g + 3] = __uint_as_float(kk.y & 0xffff0000u);
+                    const uint2 dqv = *reinterpret_cast<const uint2*>(Os + ab_off(myrow, dt * 4 + g) + 8 * hh);
+                    const float dqf[4] = {__uint_as_float(dqv.x << 16), __uint_as_float(dqv.x & 0xffff0000u), __uint_as_float(dqv.y << 16),
+                                          __uint_as_float(dqv.y & 0xffff0000u)};
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) dot = __builtin_fmaf(kraw[dt][4 * g + jj], gacc[dt][4 * g + jj], dot);
-                }
-            const float ncoef = -rtts_xhalf_sum(dot) * (ksc * 8.f) * (ksc * 8.f);
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float dk[4];
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) dk[jj] = __builtin_fmaf(kraw[dt][4 * g + jj], ncoef, gacc[dt][4 * g + jj]);
-                    if (own_tile) {
-                        const uint2 dqv = *reinterpret_cast<const uint2*>(Os + ab_off(myrow, dt * 4 + g) + 8 * hh);
-                        dk[0] += __uint_as_float(dqv.x << 16);
-                        dk[1] += __uint_as_float(dqv.x & 0xffff0000u);
-                        dk[2] += __uint_as_float(dqv.y << 16);
-                        dk[3] += __uint_as_float(dqv.y & 0xffff0000u);
+                    for (int jj = 0; jj < 4; ++jj) {
+                        gacc[dt][4 * g + jj] += dqf[jj];
+                        sd = __builtin_fmaf(kraw[dt][4 * g + jj], dqf[jj], sd);
                     }
-                    uint2 pk;
-                    pk.x = pack_bf16x2(dk[0], dk[1]);
-                    pk.y = pack_bf16x2(dk[2], dk[3]);
-                    *reinterpret_cast<uint2*>(stg + r * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2) = pk;
                 }
-            __builtin_amdgcn_wave_barrier();
-            uint4 rowv[4];
+            sdq = rtts_xhalf_sum(sd);
+        }
+        if (!own_tile || j == R - 1) {
+            const int slot = (!own_tile && j == 0) ? 1 : 0;
+            const size_t obase = ((size_t)bh * n_hashes + (own_tile ? c / nb : cprev / nb)) * T;
+            const int srow = lane >> 3, spiece = lane & 7;
+            unsigned char* stg = Stg + wave * (32 * AB_ROWB);
+            int rpos[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rowv[i] = *reinterpret_cast<const uint4*>(stg + (i * 8 + srow) * AB_ROWB + spiece * 16);
+            for (int i = 0; i < 4; ++i) rpos[i] = own_tile ? kq[wt * 32 + i * 8 + srow] : kl[wt * 32 + i * 8 + srow];
+            {
+                bf16_t* dvdst = dv_part + slot * slot_stride;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dkdst + (obase + rpos[i]) * AB_DH + spiece * 8) = rowv[i];
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        uint2 pk;
+                        pk.x = pack_bf16x2(dvacc[dt][4 * g], dvacc[dt][4 * g + 1]);
+                        pk.y = pack_bf16x2(dvacc[dt][4 * g + 2], dvacc[dt][4 * g + 3]);
+                        *reinterpret_cast<uint2*>(stg + r * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2) = pk;
+                    }
+                __builtin_amdgcn_wave_barrier();
+                uint4 rowv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rowv[i] = *reinterpret_cast<const uint4*>(stg + (i * 8 + srow) * AB_ROWB + spiece * 16);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dvdst + (obase + rpos[i]) * AB_DH + spiece * 8) = rowv[i];
+                __builtin_amdgcn_wave_barrier();
+            }
+            {
+                bf16_t* dkdst = dqk_part + slot * slot_stride;
+                float dot = 0.f;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) dot = __builtin_fmaf(kraw[dt][e], gacc[dt][e], dot);
+                // k . (G + dQ) - k . dQ = k . G; k^ = k / |k| = k * (8 ksc)
+                const float ncoef = -(rtts_xhalf_sum(dot) - sdq) * (ksc * 8.f) * (ksc * 8.f);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float dk[4];
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) dk[jj] = __builtin_fmaf(kraw[dt][4 * g + jj], ncoef, gacc[dt][4 * g + jj]);
+                        uint2 pk;
+                        pk.x = pack_bf16x2(dk[0], dk[1]);
+                        pk.y = pack_bf16x2(dk[2], dk[3]);
+                        *reinterpret_cast<uint2*>(stg + r * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2) = pk;
+                    }
+                __builtin_amdgcn_wave_barrier();
+                uint4 rowv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rowv[i] = *reinterpret_cast<const uint4*>(stg + (i * 8 + srow) * AB_ROWB + spiece * 16);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dkdst + (obase + rpos[i]) * AB_DH + spiece * 8) = rowv[i];
+            }
+            // slot-0 rows say whether a slot-1 partner exists: only the own keys of a run's last step have one
+            if (slot == 0 && spiece == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) row_flags[obase + rpos[i]] = own_tile ? 1 : 0;
+            }
         }
         AB_JSTAMP(8);
 #ifdef AB_PHASE_TIMING
@@ -997,7 +1027,7 @@ extern "C" int rtts_lsh_attn_bwd_run_length(int B, int H, int T, int n_hashes, i
 template <int BS>
 static int launch_attn_bwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const int32_t* st, const uint8_t* mask,
                            const bf16_t* dout, int64_t ld_do, const float* lse_tot, const float* delta, int B, int H, int T,
-                           int n_hashes, int causal, bf16_t* dqk_part, bf16_t* dv_part, hipStream_t stream) {
+                           int n_hashes, int causal, bf16_t* dqk_part, bf16_t* dv_part, uint8_t* row_flags, hipStream_t stream) {
     constexpr int NK = 2 * BS;
     const size_t slot_stride = (size_t)B * H * n_hashes * T * AB_DH;
     const int vi = (causal ? 2 : 0) + (mask ? 1 : 0);
@@ -1007,6 +1037,8 @@ static int launch_attn_bwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const 
     const long long chunks = (long long)B * H * C;
     const int R = rtts_lsh_attn_bwd_run_length(B, H, T, n_hashes, BS);
     if (R >= 1 && AB_KT2 == 1) {
+        RTTS_REQUIRE(row_flags, "rtts_lsh_attn_bwd: this shape is worked by the walking kernel (rtts_lsh_attn_bwd_run_length() = %d): "
+                                "row_flags (B*H*n_hashes*T bytes) is required", R);
         const size_t ds_bytes = (size_t)NK * (BS * 2), stg_bytes = (size_t)(NK / 32) * 32 * AB_ROWB;
         const size_t wlds = (size_t)BS * 40 + 5 * (size_t)BS * 128 + (ds_bytes > stg_bytes ? ds_bytes : stg_bytes);
         static bool wattr[64][4] = {};
@@ -1020,7 +1052,7 @@ static int launch_attn_bwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const 
             wattr[dev][vi] = true;                                                                                         \
         }                                                                                                                  \
         hipLaunchKernelGGL(kern, wgrid, wblock, wlds, stream, qk, v, ld, st, mask, dout, ld_do, lse_tot, delta, H, T, n_hashes, \
-                           dqk_part, dv_part, slot_stride, R);                                                             \
+                           dqk_part, dv_part, slot_stride, R, row_flags);                                                  \
     } while (0)
         if (causal) {
             if (mask) AB_WGO(true, true); else AB_WGO(true, false);
@@ -1060,7 +1092,7 @@ static int launch_attn_bwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const 
 extern "C" int rtts_lsh_attn_bwd(const void* qk, const void* v, int64_t ld, const int32_t* st, const uint8_t* mask,
                                  const void* dout, int64_t ld_dout, const float* lse_tot, const float* delta, int B, int H,
                                  int T, int dh, int n_hashes, int bucket_size, int causal, void* dqk_part, void* dv_part,
-                                 void* stream) {
+                                 uint8_t* row_flags, void* stream) {
     RTTS_REQUIRE(qk && v && st && dout && lse_tot && delta && dqk_part && dv_part, "rtts_lsh_attn_bwd: null pointer");
     RTTS_REQUIRE(dh == AB_DH, "rtts_lsh_attn_bwd: dh=%d unsupported (this build: 64)", dh);
     RTTS_REQUIRE(bucket_size == 64 || bucket_size == 128, "rtts_lsh_attn_bwd: bucket_size=%d unsupported (64 or 128)", bucket_size);
@@ -1074,7 +1106,7 @@ extern "C" int rtts_lsh_attn_bwd(const void* qk, const void* v, int64_t ld, cons
     hipStream_t s = (hipStream_t)stream;
     if (bucket_size == 64)
         return launch_attn_bwd<64>((const bf16_t*)qk, (const bf16_t*)v, ld, st, mask, (const bf16_t*)dout, ld_dout, lse_tot, delta,
-                                   B, H, T, n_hashes, causal, (bf16_t*)dqk_part, (bf16_t*)dv_part, s);
+                                   B, H, T, n_hashes, causal, (bf16_t*)dqk_part, (bf16_t*)dv_part, row_flags, s);
     return launch_attn_bwd<128>((const bf16_t*)qk, (const bf16_t*)v, ld, st, mask, (const bf16_t*)dout, ld_dout, lse_tot, delta, B,
-                                H, T, n_hashes, causal, (bf16_t*)dqk_part, (bf16_t*)dv_part, s);
+                                H, T, n_hashes, causal, (bf16_t*)dqk_part, (bf16_t*)dv_part, row_flags, s);
 }

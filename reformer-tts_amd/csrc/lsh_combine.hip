@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void lsh_bwd_delta_kernel(const bf16_t* __rest
 
 __global__ __launch_bounds__(256) void lsh_bwd_reduce_kernel(const bf16_t* __restrict__ dqk_part, const bf16_t* __restrict__ dv_part,
                                                              int H, int T, int n_hashes, size_t rows, size_t slot_stride,
-                                                             bf16_t* __restrict__ dqk, bf16_t* __restrict__ dv, int64_t ld_d) {
+                                                             bf16_t* __restrict__ dqk, bf16_t* __restrict__ dv, int64_t ld_d,
+                                                             const uint8_t* __restrict__ row_flags) {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t row = gid >> 3;
     const int piece = gid & 7;
@@ -91,16 +92,15 @@ __global__ __launch_bounds__(256) void lsh_bwd_reduce_kernel(const bf16_t* __res
     const int b = bh / H, h = bh % H;
     float aq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, av[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int r = 0; r < n_hashes; ++r) {
-        const size_t off = (((size_t)bh * n_hashes + r) * T + t) * CB_DH + piece * 8;
+        const size_t rr = ((size_t)bh * n_hashes + r) * T + t;
+        const size_t off = rr * CB_DH + piece * 8;
+        // row_flags (the walking backward): most slot-0 rows are complete and have no slot-1 partner
+        const int nslot = (row_flags == nullptr || row_flags[rr]) ? 2 : 1;
         float f[8];
-#pragma unroll
-        for (int s = 0; s < RTTS_LSH_BWD_QK_SLOTS; ++s) {
+        for (int s = 0; s < nslot; ++s) {
             unpack8(*reinterpret_cast<const uint4*>(dqk_part + s * slot_stride + off), f);
 #pragma unroll
             for (int k = 0; k < 8; ++k) aq[k] += f[k];
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
             unpack8(*reinterpret_cast<const uint4*>(dv_part + s * slot_stride + off), f);
 #pragma unroll
             for (int k = 0; k < 8; ++k) av[k] += f[k];
@@ -141,7 +141,7 @@ extern "C" int rtts_lsh_bwd_delta(const void* out, int64_t ld_out, const void* d
 }
 
 extern "C" int rtts_lsh_bwd_reduce(const void* dqk_part, const void* dv_part, int B, int H, int T, int dh, int n_hashes, void* dqk,
-                                   void* dv, int64_t ld_d, void* stream) {
+                                   void* dv, int64_t ld_d, const uint8_t* row_flags, void* stream) {
     RTTS_REQUIRE(dqk_part && dv_part && dqk && dv, "rtts_lsh_bwd_reduce: null pointer");
     RTTS_REQUIRE(dh == CB_DH && B > 0 && H > 0 && T > 0 && n_hashes > 0, "rtts_lsh_bwd_reduce: need dh == 64");
     RTTS_REQUIRE(ld_d >= (int64_t)H * dh && ld_d % 8 == 0, "rtts_lsh_bwd_reduce: bad stride");
@@ -151,7 +151,7 @@ extern "C" int rtts_lsh_bwd_reduce(const void* dqk_part, const void* dv_part, in
     const size_t slot_stride = rows * n_hashes * CB_DH;
     const unsigned grid = (unsigned)((rows * 8 + 255) / 256);
     hipLaunchKernelGGL(lsh_bwd_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dqk_part,
-                       (const bf16_t*)dv_part, H, T, n_hashes, rows, slot_stride, (bf16_t*)dqk, (bf16_t*)dv, ld_d);
+                       (const bf16_t*)dv_part, H, T, n_hashes, rows, slot_stride, (bf16_t*)dqk, (bf16_t*)dv, ld_d, row_flags);
     RTTS_LAUNCH_CHECK("rtts_lsh_bwd_reduce");
     return 0;
 }

@@ -150,10 +150,13 @@ def lsh_attn_bwd(qk, v, st, out, dout, lse_tot, heads: int, bucket_size: int, ca
     _lib.call("rtts_lsh_bwd_delta", out.data_ptr(), ld_out, dout.data_ptr(), ld_do, b, heads, t, dh, delta.data_ptr(), _stream())
     dqk_part = torch.empty(_lib.load().rtts_lsh_bwd_qk_slots(), b * heads, n_hashes, t, dh, dtype=torch.bfloat16, device=dev)
     dv_part = torch.empty(2, b * heads, n_hashes, t, dh, dtype=torch.bfloat16, device=dev)
+    # the walking kernel writes most key rows once (slot 0 only) and flags the few that have a slot-1 partner
+    walks = _lib.load().rtts_lsh_attn_bwd_run_length(b, heads, t, n_hashes, bucket_size) > 0
+    flags = torch.empty(b * heads, n_hashes, t, dtype=torch.uint8, device=dev) if walks else None
     ev = TIMING.start(f"rtts_lsh_attn_bwd/bs{bucket_size}")
     _lib.call("rtts_lsh_attn_bwd", qk.data_ptr(), v.data_ptr(), ld, st.data_ptr(), _ptr(mask), dout.data_ptr(), ld_do,
               lse_tot.data_ptr(), delta.data_ptr(), b, heads, t, dh, n_hashes, bucket_size, int(causal), dqk_part.data_ptr(),
-              dv_part.data_ptr(), _stream())
+              dv_part.data_ptr(), _ptr(flags), _stream())
     # five MFMA products of 2*bs*(2bs)*dh FLOP per chunk, n_hashes*T/bs chunks per head
     TIMING.stop(ev, 5.0 * 2.0 * bucket_size * (2 * bucket_size) * dh * (n_hashes * t // bucket_size) * b * heads)
     if dqkv is None:
@@ -165,5 +168,5 @@ def lsh_attn_bwd(qk, v, st, out, dout, lse_tot, heads: int, bucket_size: int, ca
     if _check_rows(dv, "dv") != ld_d:
         raise ValueError("dqk and dv must share a row stride")
     _lib.call("rtts_lsh_bwd_reduce", dqk_part.data_ptr(), dv_part.data_ptr(), b, heads, t, dh, n_hashes, dqk.data_ptr(),
-              dv.data_ptr(), ld_d, _stream())
+              dv.data_ptr(), ld_d, _ptr(flags), _stream())
     return dqk, dv

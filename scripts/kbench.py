@@ -111,13 +111,15 @@ def main():
             delta = torch.empty(b * h, t, device=dev)
             dqk_part = torch.empty(_lib.load().rtts_lsh_bwd_qk_slots(), b * h, nh, t, dh, dtype=torch.bfloat16, device=dev)
             dv_part = torch.empty(2, b * h, nh, t, dh, dtype=torch.bfloat16, device=dev)
+            flags = torch.ones(b * h, nh, t, dtype=torch.uint8, device=dev)
+            walks = _lib.load().rtts_lsh_attn_bwd_run_length(b, h, t, nh, bs) > 0
             s = torch.cuda.current_stream().cuda_stream
             ld = qkv.stride(1)
 
             def bwd():
                 _lib.call("rtts_lsh_attn_bwd", qk.data_ptr(), v.data_ptr(), ld, st.data_ptr(), mask.data_ptr(), dout.data_ptr(),
                           dout.stride(1), lse_tot.data_ptr(), delta.data_ptr(), b, h, t, dh, nh, bs, int(causal),
-                          dqk_part.data_ptr(), dv_part.data_ptr(), s)
+                          dqk_part.data_ptr(), dv_part.data_ptr(), flags.data_ptr(), s)
             _lib.call("rtts_lsh_bwd_delta", out.data_ptr(), out.stride(1), dout.data_ptr(), dout.stride(1), b, h, t, dh,
                       delta.data_ptr(), s)
             us = timeit(bwd, args.iters)
@@ -126,7 +128,7 @@ def main():
 
             def red():
                 _lib.call("rtts_lsh_bwd_reduce", dqk_part.data_ptr(), dv_part.data_ptr(), b, h, t, dh, nh, dqk.data_ptr(),
-                          dv.data_ptr(), dqk.stride(1), s)
+                          dv.data_ptr(), dqk.stride(1), flags.data_ptr() if walks else None, s)
             us = timeit(red, args.iters)
             res["bwd_reduce"] = (us, f"{tok * (4 * nh * 128 + 256) / us / 1e3:8.1f} GB/s alg")
         for k, (us, extra) in res.items():

@@ -108,13 +108,14 @@ def main():
     delta = torch.empty(b * h, t, device=dev)
     dqk_part = torch.empty(_lib.load().rtts_lsh_bwd_qk_slots(), b * h, nh, t, dh, dtype=torch.bfloat16, device=dev)
     dv_part = torch.empty(2, b * h, nh, t, dh, dtype=torch.bfloat16, device=dev)
+    flags = torch.empty(b * h, nh, t, dtype=torch.uint8, device=dev)
     s = torch.cuda.current_stream().cuda_stream
     _lib.call("rtts_lsh_bwd_delta", out.data_ptr(), out.stride(1), dout.data_ptr(), dout.stride(1), b, h, t, dh, delta.data_ptr(), s)
 
     def run():
         rc = lib.rtts_lsh_attn_bwd(qk.data_ptr(), v.data_ptr(), qkv.stride(1), st.data_ptr(), mask.data_ptr(), dout.data_ptr(),
                                    dout.stride(1), lse_tot.data_ptr(), delta.data_ptr(), b, h, t, dh, nh, bs, int(causal),
-                                   dqk_part.data_ptr(), dv_part.data_ptr(), s)
+                                   dqk_part.data_ptr(), dv_part.data_ptr(), flags.data_ptr(), s)
         assert rc == 0
     for _ in range(3):
         run()

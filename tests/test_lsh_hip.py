@@ -143,11 +143,16 @@ def test_attention_forward_vs_oracle(ops, b, h, t, bs, nh, causal, masked):
 
 
 # ------------------------------------------------------------------ attention backward
+@pytest.mark.parametrize("walk", ["0", "4"])
 @pytest.mark.parametrize("b,h,t,bs,nh,causal,masked", CASES)
-def test_attention_backward_vs_oracle_autograd(ops, b, h, t, bs, nh, causal, masked):
+def test_attention_backward_vs_oracle_autograd(ops, monkeypatch, b, h, t, bs, nh, causal, masked, walk):
     """Gradients of sum(out * dout) w.r.t. qk and v against autograd through the oracle on the same
-    permutation.  bf16 partials (16 per token) and bf16 P/dS operands bound the error at ~2%
-    of the gradient scale."""
+    permutation, for both forms of the kernel (``walk``: one workgroup per chunk / workgroups walking 4 chunks --
+    the library picks by shape, the small test shapes would all get the first).  bf16 partials and bf16 P/dS operands
+    bound the error at ~2% of the gradient scale."""
+    if (nh * (t // bs)) % int(walk or 1):
+        pytest.skip("the run length does not divide this ring")
+    monkeypatch.setenv("RTTS_LSH_BWD_WALK", walk)
     r = _run_fwd(ops, b, h, t, bs, nh, causal, masked, seed=3)
     dh = r["dh"]
     g = torch.Generator().manual_seed(11)
@@ -169,15 +174,17 @@ def test_attention_backward_vs_oracle_autograd(ops, b, h, t, bs, nh, causal, mas
         msgs.append(f"{name} max {err.max().item() / scale:.2e} mean {err.mean().item() / scale:.2e} rel-L2 {float((got - ref).norm() / ref.norm()):.2e}")
         assert err.max().item() < 4e-2 * scale + 1e-3, (name, err.max().item(), scale)
         assert err.mean().item() < 4e-3 * scale + 1e-4, (name, err.mean().item(), scale)
-    print(f"\n[lsh attention backward B={b} H={h} T={t} bs={bs} R={nh} causal={causal} masked={masked}] errors / max|ref|: " + "; ".join(msgs) +
+    print(f"\n[lsh attention backward B={b} H={h} T={t} bs={bs} R={nh} causal={causal} masked={masked} walk={walk}] errors / max|ref|: " + "; ".join(msgs) +
           " (tol max 4e-2, mean 4e-3)")
 
 
 @pytest.mark.parametrize("b,h,t,bs,nh,causal,masked", CASES)
-def test_walking_backward_equals_the_one_chunk_kernel(ops, monkeypatch, b, h, t, bs, nh, causal, masked):
+def test_walking_backward_matches_the_one_chunk_kernel(ops, monkeypatch, b, h, t, bs, nh, causal, masked):
     """lsh_attn_bwd as workgroups that walk R consecutive chunks of a ring (operands of the next chunk prefetched by
-    LDS-DMA, the looked-back rows kept on chip) does the same arithmetic in the same order as the one-chunk kernel:
-    bit-identical gradients for every run length that divides the ring, including runs that cross a hash round."""
+    LDS-DMA, a chunk's keys worked by the same waves in their own and their looked-back step, every key row written
+    once) against the one-chunk kernel: the same sums, with ONE bf16 rounding per key row where the one-chunk kernel
+    rounds the own and the looked-back partial separately -- equal to a bf16 rounding of the partials, for every run
+    length that divides the ring, including runs that cross a hash round and run length 1 (both slots everywhere)."""
     r = _run_fwd(ops, b, h, t, bs, nh, causal, masked, seed=5)
     dout = torch.randn(b, t, h * r["dh"], generator=torch.Generator().manual_seed(13)).bfloat16().cuda()
     m = None if r["mask"] is None else r["mask"].cuda()
@@ -189,10 +196,19 @@ def test_walking_backward_equals_the_one_chunk_kernel(ops, monkeypatch, b, h, t,
         monkeypatch.setenv("RTTS_LSH_BWD_WALK", str(run))
         dqk, dv = ops.lsh_attn_bwd(r["qk_d"], r["v_d"], r["st"], r["out"], dout, r["lse_tot"], h, bs, causal, m)
         torch.cuda.synchronize()
-        outs[run] = (dqk.clone(), dv.clone())
+        outs[run] = (dqk.float(), dv.float())
     assert len(outs) >= 3
+    # (run length 1: every chunk is both ends of its run -- two partial rows per key like the one-chunk kernel, dV bit-identical;
+    #  dK differs in the last fp32 bits: the projection sees k.(G + dQ) - k.dQ instead of k.G)
+    assert torch.equal(outs[1][1], outs[0][1])
+    worst = 0.0
     for run, (dqk, dv) in outs.items():
-        assert torch.equal(dqk, outs[0][0]) and torch.equal(dv, outs[0][1]), f"run length {run}"
+        for got, ref in ((dqk, outs[0][0]), (dv, outs[0][1])):
+            scale = float(ref.abs().max())
+            worst = max(worst, float((got - ref).abs().max()) / scale)
+    print(f"\n[lsh walking backward B={b} H={h} T={t} bs={bs}] run lengths {sorted(outs)}: max |diff| / max|ref| vs the one-chunk kernel "
+          f"{worst:.2e} (tol 1.2e-2: the two results differ by the bf16 roundings of their partial rows, <= 2^-8 of a row's value each)")
+    assert worst < 1.2e-2
 
 
 def test_strided_qkv_views(ops):
