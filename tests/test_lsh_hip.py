@@ -150,7 +150,7 @@ def test_attention_backward_vs_oracle_autograd(ops, monkeypatch, b, h, t, bs, nh
     permutation, for both forms of the kernel (``walk``: one workgroup per chunk / workgroups walking 4 chunks --
     the library picks by shape, the small test shapes would all get the first).  bf16 partials and bf16 P/dS operands
     bound the error at ~2% of the gradient scale."""
-    if (nh * (t // bs)) % int(walk or 1):
+    if (nh * (t // bs)) % max(int(walk), 1):
         pytest.skip("the run length does not divide this ring")
     monkeypatch.setenv("RTTS_LSH_BWD_WALK", walk)
     r = _run_fwd(ops, b, h, t, bs, nh, causal, masked, seed=3)
