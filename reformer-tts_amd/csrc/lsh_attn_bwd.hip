@@ -1004,16 +1004,17 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
 
 extern "C" int rtts_lsh_bwd_qk_slots(void) { return RTTS_LSH_BWD_QK_SLOTS; }
 
-// chunks a workgroup walks: the longest run (8, 4) that divides the ring and still leaves >= 3 workgroups per CU, for the
-// 128-row buckets only (measured, kbench: decoder shape 275 -> 255 us at runs of 8, 264 at 4; with 64-row buckets two
-// one-chunk workgroups share a CU and already overlap each other's gather: 50.7 us against 52.8 / 58.3 walking); 0 = the
-// one-chunk kernel.  RTTS_LSH_BWD_WALK=<run> forces a run length for tests and A/B runs (0: the one-chunk kernel).
+// chunks a workgroup walks: the longest run (8, 4) that divides the ring and still leaves >= 3 workgroups per CU; 0 = the
+// one-chunk kernel (small problems).  Measured (kbench, backward + reduce, us): decoder shape (128-row buckets) 272 + 83 ->
+// 231 + 40 at runs of 8; encoder shape (64-row buckets, T = 256) 50.8 + 16.0 -> 46.9 + 13.9 at runs of 4 (51.2 + 12.3 at 8:
+// too few workgroups); T = 4096 with 64-row buckets 246 + 109 -> 206 + 72 at runs of 8.
+// RTTS_LSH_BWD_WALK=<run> forces a run length for tests and A/B runs (0: the one-chunk kernel).
 extern "C" int rtts_lsh_attn_bwd_run_length(int B, int H, int T, int n_hashes, int bucket_size) {
     if (B <= 0 || H <= 0 || n_hashes <= 0 || bucket_size <= 0 || T <= 0 || T % bucket_size) return -1;
     const int C = n_hashes * (T / bucket_size);
     const long long chunks = (long long)B * H * C;
     int R = 0;
-    if (bucket_size == 128 && AB_KT2 == 1)
+    if (AB_KT2 == 1)
         for (int cand = 8; cand >= 4; cand >>= 1)
             if (C % cand == 0 && chunks / cand >= 768) { R = cand; break; }
     const char* walk_s = getenv("RTTS_LSH_BWD_WALK");
