@@ -333,6 +333,15 @@ int rtts_gemm_nt(const void* a, int64_t lda, const void* w, int64_t ldw, int w_i
                  int64_t ldc, const float* bias, int epilogue, const void* gate, int64_t ldg, float* colsum_partial,
                  void* stream);
 int rtts_gemm_nt_partial_rows(int M, int N);
+/* FeedForward pair with a 1-bit ReLU gate: the forward GEMM (epilogue 2: bias + ReLU) also writes one 64-bit word per
+ * lane and tile -- bit b set <=> the b-th output of that lane is a positive bf16 -- and the input-gradient GEMM of the same
+ * (M, N) (epilogue 3, [K][N] weight) reads the words instead of re-reading the (M, N) activation (50 MB at the baseline
+ * shapes).  Both calls get the same tile shape for the same (M, N), hence the same lane -> element map; gate_words holds
+ * rtts_gemm_nt_gate_words(M, N) words (0: the tile chosen for this shape has no word form -- use rtts_gemm_nt with the
+ * activation as `gate`). */
+int64_t rtts_gemm_nt_gate_words(int M, int N);
+int rtts_gemm_nt_gated(const void* a, int64_t lda, const void* w, int64_t ldw, int w_is_kn, int M, int N, int K, void* c,
+                       int64_t ldc, const float* bias, int epilogue, uint64_t* gate_words, float* colsum_partial, void* stream);
 
 /* ---- on-box peak probes (bench.py; not on the training path) --------------------------------------
  * rtts_peak_copy: dst = src, float4 stream copy of `bytes` (multiple of 16) -> achieved HBM rate = 2*bytes / time.

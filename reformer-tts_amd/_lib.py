@@ -94,6 +94,8 @@ SIGNATURES = {
     "rtts_gemm_tn_grouped": [C.POINTER(GemmTnProblem), _i32, _vp, _i64, _vp],
     "rtts_gemm_nt": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _vp],
     "rtts_gemm_nt_partial_rows": [_i32, _i32],
+    "rtts_gemm_nt_gate_words": [_i32, _i32],
+    "rtts_gemm_nt_gated": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _vp, _vp, _vp],
     "rtts_peak_copy": [_vp, _vp, _i64, _vp],
     "rtts_peak_mfma": [_vp, _i32, _i32, _vp],
     "rtts_sw_depthwise_k3": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
@@ -144,6 +146,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.argtypes = args
             fn.restype = C.c_int
+        lib.rtts_gemm_nt_gate_words.restype = C.c_int64
         _lib = lib
     return _lib
 

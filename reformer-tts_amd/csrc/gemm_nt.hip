@@ -66,6 +66,7 @@ struct GnArgs {
     const float* bias;
     const bf16_t* gate;
     float* colsum;       // [(M / BM) * WM][N] partial rows (epilogue 3), may be null
+    unsigned long long* bits;   // 1-bit ReLU gate, one word per lane and tile: written by epilogue 2, read by epilogue 3 (instead of `gate`); may be null
     int64_t lda, ldw, ldc, ldg;
     int M, N, K, epi;
     // implicit-GEMM Conv1d(k = 5): conv_cpt = 64-deep channel blocks per tap (0 = plain GEMM).  K stage s is tap s / conv_cpt,
@@ -340,6 +341,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
     f32x4 cs[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) cs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // 1-bit gate: bit ((i * TN + j) * 4 + e) of this lane's word <=> output (i, j, e) of this lane is a positive bf16.  The
+    // forward (epilogue 2) and the input gradient (epilogue 3) of one (M, N) get the same tile shape, hence the same lane ->
+    // element map; 16 x TM x TN bits fit one word for every tile but 256 x 256 (rtts_gemm_nt_gate_words() = 0 there).
+    constexpr bool kBitsFit = TM * TN * 4 <= 64;
+    unsigned long long gbits = 0;
+    const size_t widx = ((size_t)(m0 / BM) * (P.N / BN) + (size_t)(n0 / BN)) * (64 * WM * WN) + tid;
+    bool use_bits = false;
+    if constexpr (kBitsFit && (epi == 2 || epi == 3)) use_bits = P.bits != nullptr;
+    if constexpr (kBitsFit && epi == 3) if (use_bits) gbits = P.bits[widx];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = ncol + 16 * j;
@@ -353,12 +363,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
             if constexpr (epi == 2) {
                 v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
             } else if constexpr (epi == 3) {
-                const uint2 hv = *reinterpret_cast<const uint2*>(P.gate + m * P.ldg + n);
-                // bf16 h > 0  <=>  sign bit clear and magnitude non-zero
-                v[0] = ((hv.x & 0x8000u) == 0 && (hv.x & 0x7FFFu) != 0) ? v[0] : 0.f;
-                v[1] = ((hv.x & 0x80000000u) == 0 && (hv.x & 0x7FFF0000u) != 0) ? v[1] : 0.f;
-                v[2] = ((hv.y & 0x8000u) == 0 && (hv.y & 0x7FFFu) != 0) ? v[2] : 0.f;
-                v[3] = ((hv.y & 0x80000000u) == 0 && (hv.y & 0x7FFF0000u) != 0) ? v[3] : 0.f;
+                if (kBitsFit && use_bits) {
+                    const unsigned nib = (unsigned)(gbits >> ((i * TN + j) * 4)) & 15u;
+                    v[0] = (nib & 1u) ? v[0] : 0.f;
+                    v[1] = (nib & 2u) ? v[1] : 0.f;
+                    v[2] = (nib & 4u) ? v[2] : 0.f;
+                    v[3] = (nib & 8u) ? v[3] : 0.f;
+                } else {
+                    const uint2 hv = *reinterpret_cast<const uint2*>(P.gate + m * P.ldg + n);
+                    // bf16 h > 0  <=>  sign bit clear and magnitude non-zero
+                    v[0] = ((hv.x & 0x8000u) == 0 && (hv.x & 0x7FFFu) != 0) ? v[0] : 0.f;
+                    v[1] = ((hv.x & 0x80000000u) == 0 && (hv.x & 0x7FFF0000u) != 0) ? v[1] : 0.f;
+                    v[2] = ((hv.y & 0x8000u) == 0 && (hv.y & 0x7FFFu) != 0) ? v[2] : 0.f;
+                    v[3] = ((hv.y & 0x80000000u) == 0 && (hv.y & 0x7FFF0000u) != 0) ? v[3] : 0.f;
+                }
                 cs[j] += v;
             }
             if constexpr (epi == 4) {          // unrounded fp32 result (rows of ldc floats): in front of a BatchNorm / the loss
@@ -368,6 +386,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
             uint2 o;
             o.x = pack_bf16x2(v[0], v[1]);
             o.y = pack_bf16x2(v[2], v[3]);
+            if constexpr (kBitsFit && epi == 2) {      // the values are >= 0: positive <=> the rounded bf16 is not zero
+                const unsigned nib = ((o.x & 0xFFFFu) ? 1u : 0u) | ((o.x >> 16) ? 2u : 0u) | ((o.y & 0xFFFFu) ? 4u : 0u) | ((o.y >> 16) ? 8u : 0u);
+                gbits |= (unsigned long long)nib << ((i * TN + j) * 4);
+            }
 #ifdef GN_NT_STORE
             __builtin_nontemporal_store(o.x, reinterpret_cast<uint32_t*>(P.c + m * P.ldc + n));
             __builtin_nontemporal_store(o.y, reinterpret_cast<uint32_t*>(P.c + m * P.ldc + n) + 1);
@@ -376,6 +398,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
 #endif
         }
     }
+    if constexpr (kBitsFit && epi == 2) if (use_bits) P.bits[widx] = gbits;
     if constexpr (epi == 3) if (P.colsum != nullptr) {
         // sum over the wave's rows: the 16 lanes of a group hold 16 different rows of the same 4 columns
         float* dst = P.colsum + ((size_t)(m0 / BM) * WM + wm) * P.N;
@@ -497,12 +520,13 @@ extern "C" int rtts_gemm_nt_partial_rows(int M, int N) {
 
 static int gn_run(const void* a, int64_t lda, const void* w, int64_t ldw, int w_is_kn, int M, int N, int K, void* c, int64_t ldc,
                   const float* bias, int epilogue, const void* gate, int64_t ldg, float* colsum_partial, int conv_cpt, int conv_sign,
-                  int64_t conv_wtap, void* stream) {
+                  int64_t conv_wtap, void* stream, unsigned long long* gate_bits = nullptr) {
     RTTS_REQUIRE(a && w && c, "rtts_gemm_nt: null pointer");
     RTTS_REQUIRE(M > 0 && N > 0 && K > 0 && K % GN_BK == 0, "rtts_gemm_nt: K must be a positive multiple of 64 (got M=%d N=%d K=%d)", M, N, K);
     RTTS_REQUIRE(epilogue >= 0 && epilogue <= 4, "rtts_gemm_nt: epilogue 0..4");
     RTTS_REQUIRE(!(epilogue == 1 || epilogue == 2) || bias, "rtts_gemm_nt: epilogue %d needs a bias", epilogue);
-    RTTS_REQUIRE(epilogue != 3 || (gate && ldg >= N && ldg % 4 == 0), "rtts_gemm_nt: epilogue 3 needs a gate (M, N) with ldg %% 4 == 0");
+    RTTS_REQUIRE(epilogue != 3 || gate_bits || (gate && ldg >= N && ldg % 4 == 0),
+                 "rtts_gemm_nt: epilogue 3 needs a gate (M, N) with ldg %% 4 == 0, or the forward's gate words");
     RTTS_REQUIRE(lda % 8 == 0 && (conv_cpt || lda >= K) && ldc >= N && ldc % 4 == 0, "rtts_gemm_nt: bad leading dimensions (lda=%lld ldc=%lld)",
                  (long long)lda, (long long)ldc);
     RTTS_REQUIRE(ldw % 8 == 0 && (conv_cpt || ldw >= (w_is_kn ? N : K)), "rtts_gemm_nt: bad ldw=%lld", (long long)ldw);
@@ -514,6 +538,10 @@ static int gn_run(const void* a, int64_t lda, const void* w, int64_t ldw, int w_
     P.a = (const bf16_t*)a; P.w = (const bf16_t*)w; P.c = (bf16_t*)c; P.bias = bias; P.gate = (const bf16_t*)gate;
     P.colsum = colsum_partial; P.lda = lda; P.ldw = ldw; P.ldc = ldc; P.ldg = ldg; P.M = M; P.N = N; P.K = K; P.epi = epilogue;
     P.conv_cpt = conv_cpt; P.conv_sign = conv_sign; P.conv_wtap = conv_wtap;
+    P.bits = gate_bits;
+    RTTS_REQUIRE(!gate_bits || (pick != 0 && (epilogue == 2 || epilogue == 3) && ((uintptr_t)gate_bits & 7) == 0),
+                 "rtts_gemm_nt_gated: gate words go with epilogue 2 (written) or 3 (read) and a tile shape that has them "
+                 "(rtts_gemm_nt_gate_words(M, N) > 0)");
     hipStream_t s = (hipStream_t)stream;
     int rc = 0;
     switch (pick) {
@@ -532,6 +560,19 @@ extern "C" int rtts_gemm_nt(const void* a, int64_t lda, const void* w, int64_t l
                             int64_t ldc, const float* bias, int epilogue, const void* gate, int64_t ldg, float* colsum_partial,
                             void* stream) {
     return gn_run(a, lda, w, ldw, w_is_kn, M, N, K, c, ldc, bias, epilogue, gate, ldg, colsum_partial, 0, 0, 0, stream);
+}
+
+extern "C" int64_t rtts_gemm_nt_gate_words(int M, int N) {
+    const int i = gn_pick(M, N);
+    if (i <= 0) return 0;          // no tile, or 256 x 256 (its lanes hold more outputs than a word has bits)
+    return (int64_t)(M / gn_cand[i][0]) * (N / gn_cand[i][1]) * 64 * gn_cand[i][2] * 2;
+}
+
+extern "C" int rtts_gemm_nt_gated(const void* a, int64_t lda, const void* w, int64_t ldw, int w_is_kn, int M, int N, int K, void* c,
+                                  int64_t ldc, const float* bias, int epilogue, uint64_t* gate_words, float* colsum_partial, void* stream) {
+    RTTS_REQUIRE(gate_words && (epilogue == 2 || epilogue == 3), "rtts_gemm_nt_gated: epilogue 2 (bias + ReLU, writes the words) or 3 (reads them)");
+    return gn_run(a, lda, w, ldw, w_is_kn, M, N, K, c, ldc, bias, epilogue, nullptr, 0, colsum_partial, 0, 0, 0, stream,
+                  (unsigned long long*)gate_words);
 }
 
 extern "C" int rtts_conv1d_k5(const void* x, int64_t ldx, const void* wp, int64_t ldw, int transposed, int M, int C_out, int C_in,

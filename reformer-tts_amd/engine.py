@@ -246,13 +246,24 @@ def residual(acc, g, bias, sign: float, next_norm=None, drop=None, out=None):
     return xn, mean, rstd
 
 
+def gate_words(m: int, n: int, device) -> Optional[torch.Tensor]:
+    """Buffer for the 1-bit ReLU gate of an (m, n) feed-forward activation (one word per lane and tile of the GEMM that
+    produces it), or None where the tile shape chosen for (m, n) has no word form."""
+    if os.environ.get("RTTS_NO_GATE_WORDS"):          # A/B runs: gate by the activation
+        return None
+    words = _lib.load().rtts_gemm_nt_gate_words(m, n)
+    return torch.empty(words, dtype=torch.int64, device=device) if words > 0 else None
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, kn: bool = False, bias: Optional[torch.Tensor] = None, relu: bool = False,
-         gate: Optional[torch.Tensor] = None, gate_bias_grad: Optional[torch.Tensor] = None, out_f32: bool = False) -> torch.Tensor:
+         gate: Optional[torch.Tensor] = None, gate_bias_grad: Optional[torch.Tensor] = None, out_f32: bool = False,
+         words: Optional[torch.Tensor] = None) -> torch.Tensor:
     """C (M, N) bf16 = epilogue(a (M, K) @ W), csrc/gemm_nt.hip (hand-written MFMA kernel; no library GEMM on the stack path).
     ``kn=False``: w is (N, K) -- y = x W^T, the forward of nn.Linear; ``kn=True``: w is (K, N) -- dx = dy W, its input gradient.
     ``bias`` (fp32, N) [+ ``relu``] ride in the epilogue; ``gate`` (M, N) bf16: C = acc * (gate > 0), the backward of ReLU,
     with ``gate_bias_grad`` += column sums of C (queued with the other deferred column sums).  ``out_f32``: the unrounded fp32
-    result (+ bias) instead of bf16."""
+    result (+ bias) instead of bf16.  ``words`` (``gate_words(m, n)``): with ``relu`` the epilogue also WRITES the sign pattern of
+    its outputs there, one bit each; with ``gate=True`` the gate is READ from those words instead of an (M, N) activation."""
     m, k = a.shape
     n = w.shape[1] if kn else w.shape[0]
     if (w.shape[0] if kn else w.shape[1]) != k or a.stride(1) != 1 or w.stride(1) != 1:
@@ -265,6 +276,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, kn: bool = False, bias: Optional[torc
         epi = 4
     elif gate is not None:
         epi = 3
+        if gate is True and words is None:
+            raise ValueError("gemm: gate=True takes the forward's gate words")
         if gate_bias_grad is not None:
             rows = _lib.load().rtts_gemm_nt_partial_rows(m, n)
             if rows <= 0:
@@ -273,9 +286,13 @@ def gemm(a: torch.Tensor, w: torch.Tensor, kn: bool = False, bias: Optional[torc
     elif bias is not None:
         epi = 2 if relu else 1
     ev = ops.TIMING.start(f"rtts_gemm_nt/{m}x{n}x{k}")
-    _lib.call("rtts_gemm_nt", a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), int(kn), m, n, k, c.data_ptr(), n,
-              None if bias is None else bias.data_ptr(), epi, None if gate is None else gate.data_ptr(),
-              0 if gate is None else gate.stride(0), None if cs is None else cs.data_ptr(), _s())
+    if words is not None and epi in (2, 3):
+        _lib.call("rtts_gemm_nt_gated", a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), int(kn), m, n, k, c.data_ptr(), n,
+                  None if bias is None else bias.data_ptr(), epi, words.data_ptr(), None if cs is None else cs.data_ptr(), _s())
+    else:
+        _lib.call("rtts_gemm_nt", a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), int(kn), m, n, k, c.data_ptr(), n,
+                  None if bias is None else bias.data_ptr(), epi, None if gate is None else gate.data_ptr(),
+                  0 if gate is None else gate.stride(0), None if cs is None else cs.data_ptr(), _s())
     ops.TIMING.stop(ev, 2.0 * m * n * k)
     if cs is not None:
         _queue_colsum(cs, 0, cs.shape[0], n, gate_bias_grad)
@@ -508,11 +525,14 @@ class FFNExec:
         return wn.fn.net[2].p == 0.0
 
     def _internals(self, inp, g=None, pre=None, h=None):
+        """h: (activation, gate words | None) kept from the forward, or None: computed here."""
         xn, mean, rstd = pre if pre is not None else ln_fwd(inp, self.norm)
-        if h is None:   # bias + ReLU ride in the GEMM's epilogue (fp32 accumulate and fp32 bias, one rounding to bf16)
-            h = gemm(xn, _bf16(self.l1.weight), bias=self.l1.bias, relu=True)
+        if h is None:   # bias + ReLU ride in the GEMM's epilogue (fp32 accumulate and fp32 bias, one rounding to bf16), which also
+            #             leaves the 1-bit gate for the input gradient (the backward then does not re-read the activation for it)
+            words = gate_words(xn.shape[0], self.l1.weight.shape[0], xn.device)
+            h = (gemm(xn, _bf16(self.l1.weight), bias=self.l1.bias, relu=True, words=words), words)
         if g is None:
-            g = gemm(h, _bf16(self.l2.weight))
+            g = gemm(h[0], _bf16(self.l2.weight))
         return xn, mean, rstd, h, g
 
     def forward(self, acc, inp, b, t, pre=None, next_norm=None, slot=None, keep_streams=False, **_):
@@ -529,13 +549,14 @@ class FFNExec:
         kept = "inp" in slot
         if kept:
             inp, pre = slot["inp"], slot["pre"]
-        xn, mean, rstd, h, g = self._internals(inp, _NO_G if kept else slot["g"], pre, slot["h"])
+        xn, mean, rstd, (h, words), g = self._internals(inp, _NO_G if kept else slot["g"], pre, slot["h"])
         slot.clear()
         post = None if kept else residual(acc, g, self.l2.bias, -1.0, next_norm)
         dyb = _out_grad(d_acc, _grad(self.l2.bias), None, pre_cast)
         wgrad(_grad(self.l2.weight), dyb, h)
-        # the ReLU gate and the partial column sums of db1 ride in the epilogue of the dgrad GEMM
-        dh = gemm(dyb, _bf16(self.l2.weight), kn=True, gate=h, gate_bias_grad=_grad(self.l1.bias))
+        # the ReLU gate (1 bit per element, left by the forward's epilogue) and the partial column sums of db1 ride in the
+        # epilogue of the dgrad GEMM
+        dh = gemm(dyb, _bf16(self.l2.weight), kn=True, gate=h if words is None else True, gate_bias_grad=_grad(self.l1.bias), words=words)
         wgrad(_grad(self.l1.weight), dh, xn)
         dxn = gemm(dh, _bf16(self.l1.weight), kn=True)
         return post, ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp, next_cast)

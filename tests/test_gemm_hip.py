@@ -75,6 +75,37 @@ def test_gemm_nt_layouts_and_epilogues_vs_float64(gpu, m, n, k):
     print(f"\n[gemm_nt {m}x{n}x{k}] " + "; ".join(msgs) + f"; colsum {ecs:.2e} (tol: max {1.02 * BF16_HALF_ULP:.2e}, l2 2e-3, colsum 1e-5)")
 
 
+@pytest.mark.parametrize("m,n,k", [(12288, 2048, 512), (3072, 2048, 512), (768, 384, 384), (256, 128, 128), (96, 64, 64)])
+def test_one_bit_relu_gate_equals_the_activation_gate(gpu, m, n, k):
+    """The feed-forward pair with the 1-bit gate: the words the forward's bias + ReLU epilogue leaves say exactly "this output is a
+    positive bf16", so the input gradient gated by them is bit-identical to the one gated by the activation, column sums too
+    (every tile shape that has a word form; the forward's output is unchanged by writing them)."""
+    from reformer_tts_amd import _lib, engine
+    g = torch.Generator().manual_seed(m + n)
+    x = torch.randn(m, k, generator=g).bfloat16().to(gpu)
+    w1 = (torch.randn(n, k, generator=g) / k ** 0.5).bfloat16().to(gpu)
+    b1 = torch.randn(n, generator=g).to(gpu)
+    dy = torch.randn(m, 512, generator=g).bfloat16().to(gpu)
+    w2 = (torch.randn(512, n, generator=g) / 512 ** 0.5).bfloat16().to(gpu)          # (K, N) of the input gradient dh = dy W2
+    words = engine.gate_words(m, n, gpu)
+    assert words is not None and words.numel() == _lib.load().rtts_gemm_nt_gate_words(m, n)
+    h_plain = _gemm(x, w1, bias=b1, relu=True)
+    h = _gemm(x, w1, bias=b1, relu=True, words=words)
+    assert torch.equal(h, h_plain)
+    rows = _lib.load().rtts_gemm_nt_partial_rows(m, n)
+    outs = []
+    for kw in (dict(gate=h), dict(gate=True, words=words)):
+        cs = torch.zeros(n, device=gpu)
+        c = _gemm(dy, w2, kn=True, gate_bias_grad=cs, **kw)
+        engine.flush_colsum()
+        torch.cuda.synchronize()
+        outs.append((c, cs))
+    assert rows > 0 and torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    frac = float((h > 0).float().mean())
+    print(f"\n[one-bit gate {m}x{n}x{k}] {words.numel()} words for {m * n} outputs ({frac:.2f} positive): input gradient and bias sums "
+          f"bit-identical to the activation-gated ones")
+
+
 def test_gemm_nt_rejects_shapes_it_cannot_tile(gpu):
     from reformer_tts_amd import _lib
     a = torch.zeros(100, 64, device=gpu, dtype=torch.bfloat16)
