@@ -308,7 +308,7 @@ int rtts_gemm_tn(const void* a, int64_t lda, const void* b, int64_t ldb, int M, 
 /* Up to RTTS_GEMM_TN_MAX_GROUP independent weight gradients in ONE pair of launches (the deferred gradients of a
  * reversible layer): the grid holds every problem's tiles, so the split factor -- and with it the slab traffic --
  * drops to what the whole group needs to fill the chip.  Same arithmetic per problem as rtts_gemm_tn. */
-#define RTTS_GEMM_TN_MAX_GROUP 8
+#define RTTS_GEMM_TN_MAX_GROUP 16
 typedef struct {
     const void* a; int64_t lda;    /* dY (M x N) bf16 */
     const void* b; int64_t ldb;    /* X  (M x K) bf16 */

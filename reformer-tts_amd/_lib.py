@@ -19,7 +19,7 @@ class GemmTnProblem(C.Structure):
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("accumulate", C.c_int32)]
 
 
-GEMM_TN_MAX_GROUP = 8
+GEMM_TN_MAX_GROUP = 16
 
 
 class ColsumJob(C.Structure):

@@ -74,14 +74,33 @@ class Halo:
 
 class _DwQueue(threading.local):
     def __init__(self):
-        self.items = []
+        self.items = []           # weight gradients in GEMM layout waiting for their re-layout
+        self.gemms = []           # (problem fields, operands kept alive) of convolutions whose weight-gradient GEMMs are not launched yet
 
 
 _DW = _DwQueue()
 
 
+import os as _os
+CONVS_PER_WGRAD_LAUNCH = int(_os.environ.get("RTTS_CONVS_PER_WGRAD", "3"))   # 15 tap problems: one grid (and one slab reduction) instead of three
+
+
+def flush_conv_wgrad() -> None:
+    """The queued tap problems (five per convolution, dW_k = dY^T X shifted by k - 2) as ONE grouped split-K launch."""
+    q = _DW.gemms
+    while q:
+        chunk = q[:_lib.GEMM_TN_MAX_GROUP]
+        del q[:len(chunk)]
+        arr = (_lib.GemmTnProblem * len(chunk))()
+        for dst, (fields, _keep) in zip(arr, chunk):
+            dst.a, dst.lda, dst.b, dst.ldb, dst.c, dst.ldc, dst.M, dst.N, dst.K, dst.accumulate = fields
+        ws = _engine._slab_ws(chunk[0][1][0].device)
+        _lib.call("rtts_gemm_tn_grouped", arr, len(chunk), ws.data_ptr(), ws.numel(), _s())
+
+
 def flush_conv_dw() -> None:
     """dw[co][ci][k] += dwp[co][k][ci] for every convolution whose backward has run since the last flush (one launch)."""
+    flush_conv_wgrad()
     pending = _DW.items
     while pending:
         chunk = pending[:_lib.CONV_PERM_MAX_GROUP]
@@ -153,15 +172,15 @@ class ConvK5:
         in halo rows (row 0 = halo row 0; rows outside the valid set hold no meaning)."""
         dev = dyh.device
         dwp = torch.empty(self.cop, 5 * self.cp, dtype=torch.float32, device=dev)
-        # weight gradient of tap k = (dy)^T (x shifted by k - 2): five problems of one grouped split-K launch
-        arr = (_lib.GemmTnProblem * 5)()
+        # weight gradient of tap k = (dy)^T (x shifted by k - 2): five problems, queued so that up to three convolutions of a
+        # stack share one grouped split-K launch (their operands are still in the Infinity Cache a layer or two later)
         dyb = g.body(dyh)
-        for k, q in enumerate(arr):
+        for k in range(5):
             xs, ck = g.body(xh, k - 2), dwp[:, k * self.cp:(k + 1) * self.cp]
-            q.a, q.lda, q.b, q.ldb, q.c, q.ldc = dyb.data_ptr(), self.cop, xs.data_ptr(), self.cp, ck.data_ptr(), 5 * self.cp
-            q.M, q.N, q.K, q.accumulate = g.mp, self.cop, self.cp, 0
-        ws = _engine._slab_ws(dev)
-        _lib.call("rtts_gemm_tn_grouped", arr, 5, ws.data_ptr(), ws.numel(), _s())
+            _DW.gemms.append(((dyb.data_ptr(), self.cop, xs.data_ptr(), self.cp, ck.data_ptr(), 5 * self.cp, g.mp, self.cop, self.cp, 0),
+                              (dyh, xh, dwp)))
+        if len(_DW.gemms) >= 5 * CONVS_PER_WGRAD_LAUNCH:
+            flush_conv_wgrad()
         # dW goes back to nn.Conv1d's (Co, Ci, 5) layout with the other deferred gradient work of the backward: one grouped
         # launch for all convolutions (engine.flush_wgrad runs the hook before anything reads the gradients)
         _DW.items.append((dwp, self.co, self.ci, self.cp, _grad(self.conv.weight)))
