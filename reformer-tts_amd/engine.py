@@ -340,10 +340,15 @@ def _queue_final_flush():
             pass
 
 
-def flush_wgrad():
-    """Launch every queued weight gradient and column-sum finalisation (grouped), release the held operands."""
+def flush_wgrad(colsums: bool = True):
+    """Launch every queued weight gradient and (``colsums``) column-sum finalisation, grouped; release the held operands.
+    ``colsums=False`` (the per-layer flush of the stack loop when nobody waits for a block's gradients): the small partial
+    buffers stay queued for fewer, fuller launches -- the end-of-backward flush takes them."""
     _Q.flush_queued = False            # the next deferral queues a fresh end-of-backward callback (extra ones are no-ops);
-    flush_colsum()                     # a backward that died half-way therefore cannot leave the flag stuck
+    if colsums or len(_Q.colsums) >= _lib.COLSUM_MAX_GROUP - 8:       # a backward that died half-way cannot leave the flag stuck
+        flush_colsum()
+    else:
+        _queue_final_flush()
     pending = _Q.wgrads
     while pending:
         group = pending[:_lib.GEMM_TN_MAX_GROUP]
@@ -858,11 +863,12 @@ class FusedStackFn(torch.autograd.Function):
                     chain.grad_done(nxt, g2)
                 done.append(i)
                 hook = seq.block_done_hook
-                if WGRAD_FLUSH_PER_LAYER or (hook is not None and getattr(hook, "active", lambda: True)()):
+                waited_for = hook is not None and getattr(hook, "active", lambda: True)()
+                if WGRAD_FLUSH_PER_LAYER or waited_for:
                     if pending_wgrads() >= 7 or i == 0:
                         # one grouped launch per layer's worth of weight gradients; only then are the finished blocks'
                         # gradient slices final, so their all-reduce hooks run here
-                        flush_wgrad()
+                        flush_wgrad(colsums=waited_for)
                         if seq.block_done_hook is not None:
                             for j in done:
                                 seq.block_done_hook(seq, j)
