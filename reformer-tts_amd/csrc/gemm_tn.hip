@@ -412,16 +412,13 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const GtGroup grp) {
 }
 
 template <int WN, int WK, int TN, int TK>
-static void gt_launch(const GtGroup& grp, int wg, hipStream_t s) {
+static int gt_launch(const GtGroup& grp, int wg, hipStream_t s) {
     constexpr int BN = 32 * TN * WN, BK = 32 * TK * WK;
     const size_t lds = 2 * GT_BM * (BN * 2 + GT_PAD) + 2 * GT_BM * (BK * 2 + GT_PAD);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<WN, WK, TN, TK>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        attr = true;
-    }
+    static RttsLdsState st = {};
+    RTTS_ENSURE_LDS("rtts_gemm_tn", (gemm_tn_kernel<WN, WK, TN, TK>), lds, st);
     hipLaunchKernelGGL((gemm_tn_kernel<WN, WK, TN, TK>), dim3(wg), dim3(64 * WN * WK), lds, s, grp);
+    return 0;
 }
 
 extern "C" int rtts_gemm_tn_grouped(const rtts_gemm_tn_problem* problems, int n, float* slab_ws, int64_t slab_ws_floats, void* stream) {
@@ -487,14 +484,12 @@ extern "C" int rtts_gemm_tn_grouped(const rtts_gemm_tn_problem* problems, int n,
     static const bool ring = getenv("RTTS_GEMM_TN_NO_RING") == nullptr;
     if (big && ring) {
         const size_t lds = 2 * GT_NST * GT_RS * 512;
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_ring_kernel<4, 2, 2, 4>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr = true;
-        }
+        static RttsLdsState st = {};
+        RTTS_ENSURE_LDS("rtts_gemm_tn", (gemm_tn_ring_kernel<4, 2, 2, 4>), lds, st);
         hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 2, 2, 4>), dim3(wg), dim3(512), lds, s, grp);
-    } else if (big) gt_launch<4, 2, 2, 4>(grp, wg, s); else gt_launch<2, 2, 2, 2>(grp, wg, s);
+    } else if (big) {
+        if (gt_launch<4, 2, 2, 4>(grp, wg, s)) return -1;
+    } else if (gt_launch<2, 2, 2, 2>(grp, wg, s)) return -1;
     if (any_split) hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(256), 0, s, grp);
     RTTS_LAUNCH_CHECK("rtts_gemm_tn");
     return 0;

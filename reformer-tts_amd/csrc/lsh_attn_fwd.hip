@@ -295,7 +295,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
     AF_STAMP(5);
 }
 
-static bool g_fwd_attr_set[2][4];
+static RttsLdsState g_fwd_lds[2][4];
 
 template <int BS>
 static int launch_attn_fwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const int32_t* st, const uint8_t* mask, int B, int H,
@@ -307,10 +307,7 @@ static int launch_attn_fwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const 
 #define AF_GO(C_, M_)                                                                                                      \
     do {                                                                                                                   \
         auto kern = lsh_attn_fwd_kernel<BS, C_, M_>;                                                                       \
-        if (!g_fwd_attr_set[BS == 128][vi]) {                                                                              \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            g_fwd_attr_set[BS == 128][vi] = true;                                                                          \
-        }                                                                                                                  \
+        RTTS_ENSURE_LDS("rtts_lsh_attn_fwd", kern, lds, g_fwd_lds[BS == 128][vi]);                                         \
         hipLaunchKernelGGL(kern, grid, block, lds, stream, qk, v, ld, st, mask, H, T, n_hashes, o, lse);                   \
     } while (0)
     if (causal) {

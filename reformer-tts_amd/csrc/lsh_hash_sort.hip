@@ -261,12 +261,8 @@ template <int HALF, int WAVES>
 static int launch_hash_sort_w(const bf16_t* qk, int64_t ld, const float* rot, int rot_rows, int B, int H, int T,
                               int n_hashes, int32_t* buckets, int32_t* st, int32_t* undo, int half, hipStream_t stream) {
     const size_t lds = ((HS_DH * HALF * 4 + 15) & ~15) + WAVES * 64 * HS_ROWB + ((T * 2 + 15) & ~15) + (WAVES * 64 + 64) * 4;
-    static bool attr = false;
-    if (!attr && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lsh_hash_sort_kernel<HALF, WAVES>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    static RttsLdsState lds_state = {};
+    RTTS_ENSURE_LDS("rtts_lsh_hash_sort", (lsh_hash_sort_kernel<HALF, WAVES>), lds, lds_state);
     const dim3 grid(B * H * n_hashes);
     hipLaunchKernelGGL((lsh_hash_sort_kernel<HALF, WAVES>), grid, dim3(64 * WAVES), lds, stream, qk, ld, rot, rot_rows, H, T,
                        n_hashes, buckets, st, undo, half);

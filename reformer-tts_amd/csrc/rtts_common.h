@@ -30,9 +30,31 @@ extern "C" void rtts_set_error(const char* fmt, ...);
     do {                                                                     \
         hipError_t e_ = hipGetLastError();                                   \
         if (e_ != hipSuccess) {                                              \
-            rtts_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            int dev_ = -1;                                                   \
+            (void)hipGetDevice(&dev_);                                       \
+            rtts_set_error("%s: launch failed: %s (current device %d; the entry points launch on the caller's current device: " \
+                           "the stream and every pointer must belong to it)", name, hipGetErrorString(e_), dev_); \
             return -2;                                                       \
         }                                                                    \
+    } while (0)
+
+// The dynamic-LDS limit is an attribute of a LOADED function, i.e. per device: raise it once per (function, device), again when
+// a later call needs more, and report a failure at the call that caused it instead of at some later launch.
+struct RttsLdsState { size_t set[64]; };
+static inline hipError_t rtts_ensure_lds(const void* func, size_t lds, RttsLdsState& st) {
+    if (lds <= 64 * 1024) return hipSuccess;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (st.set[dev] >= lds) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) st.set[dev] = lds;
+    return e;
+}
+#define RTTS_ENSURE_LDS(name, func, lds, state)                                                                   \
+    do {                                                                                                          \
+        const hipError_t e_lds_ = rtts_ensure_lds(reinterpret_cast<const void*>(func), (lds), (state));           \
+        RTTS_REQUIRE(e_lds_ == hipSuccess, "%s: cannot raise the dynamic LDS limit to %zu bytes: %s", name, (size_t)(lds), \
+                     hipGetErrorString(e_lds_));                                                                  \
     } while (0)
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t x) { return __uint_as_float(((uint32_t)x) << 16); }

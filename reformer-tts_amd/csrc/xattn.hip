@@ -428,8 +428,7 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const bf16_t* __restrict
     }
 }
 
-static bool g_xa_attr[64][4][2];     // per device: the dynamic-LDS limit is an attribute of the loaded function
-static int xa_dev() { int d = 0; return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) ? d : 0; }
+static RttsLdsState g_xa_lds[4][2];
 extern "C" int rtts_sum_slabs(const void* part, int nslabs, int64_t n, void* out, void* stream);
 
 static int xa_check(const char* fn, int B, int H, int Tq, int Tk, int dh, int64_t ld_q, int64_t ld_kv) {
@@ -458,10 +457,7 @@ extern "C" int rtts_xattn_fwd(const void* q, int64_t ld_q, const void* kv, int64
 #define GO(TK_)                                                                                                           \
     do {                                                                                                                  \
         auto kern = Tk == TK_ ? xattn_fwd_kernel<TK_, false> : xattn_fwd_kernel<TK_, true>;                               \
-        if (!g_xa_attr[xa_dev()][Tk == TK_ ? 0 : 3][TK_ == 256]) {                                                                                  \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            g_xa_attr[xa_dev()][Tk == TK_ ? 0 : 3][TK_ == 256] = true;                                                            \
-        }                                                                                                                 \
+        RTTS_ENSURE_LDS("rtts_xattn_fwd", kern, lds, g_xa_lds[Tk == TK_ ? 0 : 3][TK_ == 256]);                            \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q, ld_q, (const bf16_t*)kv, ld_kv, \
                            kvalid, H, Tq, Tk, (bf16_t*)o, ld_o, lse, seed, seed_dev, rtts_drop_thresh(drop_p), 1.f / (1.f - drop_p)); \
     } while (0)
@@ -494,10 +490,7 @@ extern "C" int rtts_xattn_bwd(const void* q, int64_t ld_q, const void* kv, int64
 #define GO(TK_)                                                                                                           \
     do {                                                                                                                  \
         auto kern = drop_p > 0.f ? xattn_bwd_kernel<TK_, true> : xattn_bwd_kernel<TK_, false>;                            \
-        if (!g_xa_attr[xa_dev()][1 + (drop_p > 0.f)][TK_ == 256]) {                                                                                  \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            g_xa_attr[xa_dev()][1 + (drop_p > 0.f)][TK_ == 256] = true;                                                                              \
-        }                                                                                                                 \
+        RTTS_ENSURE_LDS("rtts_xattn_bwd", kern, lds, g_xa_lds[1 + (drop_p > 0.f)][TK_ == 256]);                           \
         hipLaunchKernelGGL(kern, grid, dim3(TK_ * 2 / XA_KT2), lds, (hipStream_t)stream, (const bf16_t*)q, ld_q, (const bf16_t*)kv, ld_kv, \
                            kvalid, (const bf16_t*)dout, ld_dout, lse, delta, H, Tq, Tk, dq_dst, ld_dq, dq_stride, (bf16_t*)dkv_part, B, \
                            seed, seed_dev, rtts_drop_thresh(drop_p), 1.f / (1.f - drop_p));                               \
