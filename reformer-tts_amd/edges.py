@@ -82,20 +82,27 @@ _DW = _DwQueue()
 
 
 import os as _os
-CONVS_PER_WGRAD_LAUNCH = int(_os.environ.get("RTTS_CONVS_PER_WGRAD", "3"))   # 15 tap problems: one grid (and one slab reduction) instead of three
+CONVS_PER_WGRAD_LAUNCH = int(_os.environ.get("RTTS_CONVS_PER_WGRAD", "4"))   # tap problems of up to 4 convolutions are launched together
 
 
 def flush_conv_wgrad() -> None:
     """The queued tap problems (five per convolution, dW_k = dY^T X shifted by k - 2) as ONE grouped split-K launch."""
     q = _DW.gemms
-    while q:
-        chunk = q[:_lib.GEMM_TN_MAX_GROUP]
-        del q[:len(chunk)]
-        arr = (_lib.GemmTnProblem * len(chunk))()
-        for dst, (fields, _keep) in zip(arr, chunk):
-            dst.a, dst.lda, dst.b, dst.ldb, dst.c, dst.ldc, dst.M, dst.N, dst.K, dst.accumulate = fields
-        ws = _engine._slab_ws(chunk[0][1][0].device)
-        _lib.call("rtts_gemm_tn_grouped", arr, len(chunk), ws.data_ptr(), ws.numel(), _s())
+    # problems whose N and K tile by 256 go together: a group of them is large enough for the 256 x 256 ring kernel
+    # (rtts_gemm_tn_grouped takes it only when EVERY problem of the group tiles); the 128-wide first / last convolution of the
+    # postnet would drag its neighbours down to the 128-tile kernel
+    wide = [p for p in q if p[0][7] % 256 == 0 and p[0][8] % 256 == 0]
+    rest = [p for p in q if not (p[0][7] % 256 == 0 and p[0][8] % 256 == 0)]
+    del q[:]
+    for part in (wide, rest):
+        while part:
+            chunk = part[:_lib.GEMM_TN_MAX_GROUP]
+            del part[:len(chunk)]
+            arr = (_lib.GemmTnProblem * len(chunk))()
+            for dst, (fields, _keep) in zip(arr, chunk):
+                dst.a, dst.lda, dst.b, dst.ldb, dst.c, dst.ldc, dst.M, dst.N, dst.K, dst.accumulate = fields
+            ws = _engine._slab_ws(chunk[0][1][0].device)
+            _lib.call("rtts_gemm_tn_grouped", arr, len(chunk), ws.data_ptr(), ws.numel(), _s())
 
 
 def flush_conv_dw() -> None:
