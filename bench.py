@@ -7,8 +7,10 @@ backward + gradient all-reduce + clip + AdamW) on synthetic LJSpeech-shaped batc
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement): whole-job mel-frames/s of the default (``stash``) mode, plus
-  config.full_recompute_ms   the same step with the reference's pure recompute (``reversible_recompute: full``), same run
+Prints ONE JSON line on rank 0 (contract in the task statement): whole-job mel-frames/s of the default (``stash``) mode -- every
+activation the backward needs is kept in HBM (about 1 GB at these shapes; the reference recomputes them because it was written
+for 16-32 GB devices; same gradients) -- plus
+  config.full_recompute_ms   the same step with the reference's pure recompute (``--recompute full``), same run
   roofline        the dominant kernel (LSH chunk-attention backward, MFMA-bound): algorithmic FLOP per launch / its average
                   duration measured with HIP events on the launch stream
   rooflines       that entry plus lsh_hash_sort (HBM-bound, SURVEY.md 8(d) bytes) and rtts_gemm_nt (every projection /
