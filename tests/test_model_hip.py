@@ -877,11 +877,13 @@ def test_unsynchronised_replays_match_synchronised_steps(gpu):
     assert diff == 0.0
 
 
-def test_cross_attention_dropout_vs_autograd(gpu):
+@pytest.mark.parametrize("tk", [256, 512])
+def test_cross_attention_dropout_vs_autograd(gpu, tk):
     """rtts_xattn_fwd / rtts_xattn_bwd with dropout on the probabilities against torch autograd using the mask the kernel
-    drew (read back with Q = K = 0, i.e. uniform probabilities, and V = one 64-key block of the identity at a time)."""
+    drew (read back with Q = K = 0, i.e. uniform probabilities, and V = one 64-key block of the identity at a time); 512 keys:
+    two key chunks, the mask indexed by the global key."""
     from reformer_tts_amd import _lib
-    b, h, t, tk, dh, p, seed = 2, 2, 256, 256, 64, 0.15, 777
+    b, h, t, dh, p, seed = 2, 2, 256, 64, 0.15, 777
     e = h * dh
     sd = torch.tensor([5], dtype=torch.int32, device=gpu)
     s = torch.cuda.current_stream().cuda_stream
@@ -923,8 +925,10 @@ def test_cross_attention_dropout_vs_autograd(gpu):
     _lib.call("rtts_lsh_bwd_delta", o.data_ptr(), e, do.data_ptr(), e, b, h, t, dh, delta.data_ptr(), s)
     dq = torch.empty(b * t, e, dtype=torch.bfloat16, device=gpu)
     part = torch.empty(t // 128, b * tk, 2 * e, dtype=torch.bfloat16, device=gpu)
+    nkc = _lib.load().rtts_xattn_key_chunks(tk)
+    ws = torch.empty(nkc, b * t, e, dtype=torch.bfloat16, device=gpu) if nkc > 1 else None
     _lib.call("rtts_xattn_bwd", q.data_ptr(), e, kv.data_ptr(), 2 * e, None, do.data_ptr(), e, lse.data_ptr(), delta.data_ptr(), b, h, t,
-              tk, dh, dq.data_ptr(), e, part.data_ptr(), p, seed, sd.data_ptr(), None, s)
+              tk, dh, dq.data_ptr(), e, part.data_ptr(), p, seed, sd.data_ptr(), None if ws is None else ws.data_ptr(), s)
     torch.cuda.synchronize()
     dkv = part.float().sum(0).view(b, tk, 2, h, dh)
     for got, ref, name in ((dq.float().view(b, t, h, dh).transpose(1, 2), qr.grad, "dq"), (dkv[:, :, 0].transpose(1, 2), kr.grad, "dk"),
