@@ -30,9 +30,34 @@ struct EdHalo {
 };
 __device__ __forceinline__ bool ed_valid(const EdHalo& g, long long m, int& b, int& t) {
     if (m < 0 || m >= (long long)g.B * g.P) return false;
-    b = (int)(m / g.P);
-    t = (int)(m - (long long)b * g.P) - g.H;
+    // m / P without the 64-bit division sequence (~100 instructions in every element of three streaming kernels): the float
+    // quotient is within one of the truth for m < 2^31 (B * P rows), two compares put it right
+    const int mi = (int)m;
+    int q = (int)((float)mi * __builtin_amdgcn_rcpf((float)g.P));
+    int r = mi - q * g.P;
+    if (r < 0) { --q; r += g.P; }
+    if (r >= g.P) { ++q; r -= g.P; }
+    b = q;
+    t = r - g.H;
     return (unsigned)t < (unsigned)g.L;
+}
+// element index -> (row, channel) for a row of C channels (the index fits 32 bits: checked on the host); C is a power of two in
+// every configuration (shift / mask), anything else takes the 32-bit division
+__device__ __forceinline__ void ed_row_col(unsigned e, int C, int cshift, unsigned& row, int& c) {
+    if (cshift >= 0) {
+        row = e >> cshift;
+        c = (int)(e & (unsigned)(C - 1));
+    } else {
+        row = e / (unsigned)C;
+        c = (int)(e - row * (unsigned)C);
+    }
+}
+static inline int ed_cshift(int C) { return (C & (C - 1)) == 0 ? __builtin_ctz((unsigned)C) : -1; }
+// tanh(x) = 1 - 2 / (e^{2x} + 1): two fast-math instructions instead of libm's branchy polynomial (the results go to bf16 or
+// into a gradient that is rounded to bf16; |error| ~ 1e-6)
+__device__ __forceinline__ float ed_tanh(float x) {
+    const float t = __builtin_amdgcn_exp2f(x * 2.885390081777927f);      // e^{2x}
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
 }
 static inline EdHalo ed_halo(int B, int L, int halo) { return EdHalo{B, L, L + 2 * halo, halo}; }
 
@@ -159,7 +184,7 @@ __global__ __launch_bounds__(ED_THREADS) void col_partial_kernel(const float* __
                     const float pre = __builtin_fmaf(yh, ga[j], be[j]);
                     float da;
                     if (act == 1) da = pre > 0.f ? 1.f : 0.f;
-                    else { const float th = tanhf(pre); da = 1.f - th * th; }
+                    else { const float th = ed_tanh(pre); da = 1.f - th * th; }
                     const float g = dd[j] * da * (thresh ? ed_drop(seed, (uint32_t)((size_t)row * C + c + j), thresh, dscale) : 1.f);
                     sa[j] += g;
                     sb[j] = __builtin_fmaf(g, yh, sb[j]);
@@ -241,12 +266,13 @@ __global__ __launch_bounds__(ED_THREADS) void bn_act_fwd_kernel(const float* __r
                                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, int act, uint32_t seed, const uint32_t* __restrict__ seed_dev,
                                                                 uint32_t thresh, float dscale, EdHalo g, int z_halo, int z_lead, size_t n4, int C,
-                                                                bf16_t* __restrict__ z) {
+                                                                int cshift, bf16_t* __restrict__ z) {
     if (seed_dev) seed += seed_dev[0];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t ze = i * 4;
-        const int c = (int)(ze % C);
-        const long long zr = (long long)(ze / C);
+        unsigned zrow;
+        int c;
+        ed_row_col((unsigned)i * 4u, C, cshift, zrow, c);
+        const long long zr = (long long)zrow;
         long long ym;
         bool ok = true;
         if (z_halo) {
@@ -262,11 +288,16 @@ __global__ __launch_bounds__(ED_THREADS) void bn_act_fwd_kernel(const float* __r
             const size_t e = (size_t)ym * C + c;
             const float4 yv = *reinterpret_cast<const float4*>(y + e);
             const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+            // the four per-channel vectors as 16-byte loads: scalar loads made this kernel 17 memory instructions per 16 bytes of y
+            const float4 m4 = *reinterpret_cast<const float4*>(mean + c), r4 = *reinterpret_cast<const float4*>(rstd + c);
+            const float4 g4 = *reinterpret_cast<const float4*>(gamma + c), b4 = *reinterpret_cast<const float4*>(beta + c);
+            const float mu[4] = {m4.x, m4.y, m4.z, m4.w}, rs[4] = {r4.x, r4.y, r4.z, r4.w};
+            const float ga[4] = {g4.x, g4.y, g4.z, g4.w}, be[4] = {b4.x, b4.y, b4.z, b4.w};
             float o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float pre = __builtin_fmaf((yy[j] - mean[c + j]) * rstd[c + j], gamma[c + j], beta[c + j]);
-                float a = act == 1 ? fmaxf(pre, 0.f) : tanhf(pre);
+                const float pre = __builtin_fmaf((yy[j] - mu[j]) * rs[j], ga[j], be[j]);
+                float a = act == 1 ? fmaxf(pre, 0.f) : ed_tanh(pre);
                 if (thresh) a *= ed_drop(seed, (uint32_t)(e + j), thresh, dscale);
                 o[j] = a;
             }
@@ -284,12 +315,13 @@ __global__ __launch_bounds__(ED_THREADS) void bn_act_bwd_apply_kernel(const floa
                                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int act,
                                                                       uint32_t seed, const uint32_t* __restrict__ seed_dev, uint32_t thresh, float dscale,
                                                                       const float* __restrict__ sums, float inv_m, EdHalo g, int dz_halo, int dy_lead,
-                                                                      size_t n4, int C, bf16_t* __restrict__ dy) {
+                                                                      size_t n4, int C, int cshift, bf16_t* __restrict__ dy) {
     if (seed_dev) seed += seed_dev[0];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t de = i * 4;
-        const int c = (int)(de % C);
-        const long long ym = (long long)(de / C) - dy_lead;
+        unsigned drow_;
+        int c;
+        ed_row_col((unsigned)i * 4u, C, cshift, drow_, c);
+        const long long ym = (long long)drow_ - dy_lead;
         int b, t;
         uint2 pk = make_uint2(0u, 0u);
         if (ed_valid(g, ym, b, t)) {
@@ -300,17 +332,23 @@ __global__ __launch_bounds__(ED_THREADS) void bn_act_bwd_apply_kernel(const floa
             const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
             const float dd[4] = {__uint_as_float(dv.x << 16), __uint_as_float(dv.x & 0xffff0000u), __uint_as_float(dv.y << 16),
                                  __uint_as_float(dv.y & 0xffff0000u)};
+            const float4 m4 = *reinterpret_cast<const float4*>(mean + c), r4 = *reinterpret_cast<const float4*>(rstd + c);
+            const float4 g4 = *reinterpret_cast<const float4*>(gamma + c), b4 = *reinterpret_cast<const float4*>(beta + c);
+            const float4 s0 = *reinterpret_cast<const float4*>(sums + c), s1 = *reinterpret_cast<const float4*>(sums + C + c);
+            const float mu4[4] = {m4.x, m4.y, m4.z, m4.w}, rs4[4] = {r4.x, r4.y, r4.z, r4.w};
+            const float ga4[4] = {g4.x, g4.y, g4.z, g4.w}, be4[4] = {b4.x, b4.y, b4.z, b4.w};
+            const float sa4[4] = {s0.x, s0.y, s0.z, s0.w}, sb4[4] = {s1.x, s1.y, s1.z, s1.w};
             float o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float rs = rstd[c + j], ga = gamma[c + j];
-                const float yh = (yy[j] - mean[c + j]) * rs;
-                const float pre = __builtin_fmaf(yh, ga, beta[c + j]);
+                const float rs = rs4[j], ga = ga4[j];
+                const float yh = (yy[j] - mu4[j]) * rs;
+                const float pre = __builtin_fmaf(yh, ga, be4[j]);
                 float da;
                 if (act == 1) da = pre > 0.f ? 1.f : 0.f;
-                else { const float th = tanhf(pre); da = 1.f - th * th; }
+                else { const float th = ed_tanh(pre); da = 1.f - th * th; }
                 const float gg = dd[j] * da * (thresh ? ed_drop(seed, (uint32_t)(e + j), thresh, dscale) : 1.f);
-                o[j] = ga * rs * (gg - sums[c + j] * inv_m - yh * sums[C + c + j] * inv_m);
+                o[j] = ga * rs * (gg - sa4[j] * inv_m - yh * sb4[j] * inv_m);
             }
             pk.x = pack_bf16x2(o[0], o[1]);
             pk.y = pack_bf16x2(o[2], o[3]);
@@ -733,8 +771,9 @@ extern "C" int rtts_bn_act_fwd(const float* y, const float* mean, const float* r
     RTTS_REQUIRE(z_halo ? (halo > 0 && z_lead >= 0 && z_rows >= z_lead + (int64_t)B * g.P) : (z_rows == (int64_t)B * L && z_lead == 0),
                  "rtts_bn_act_fwd: z must be a halo array with room for B*(L+2*halo) rows behind its lead-in, or B*L plain rows");
     const size_t n4 = (size_t)z_rows * C / 4;
+    RTTS_REQUIRE(n4 < (1ull << 30), "rtts_bn_act_fwd: more than 2^32 elements");
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ed_grid(n4)), dim3(ED_THREADS), 0, (hipStream_t)stream, y, mean, rstd, gamma, beta, act, seed, seed_dev,
-                       ed_thresh(drop_p), 1.f / (1.f - drop_p), g, z_halo, z_lead, n4, C, (bf16_t*)z);
+                       ed_thresh(drop_p), 1.f / (1.f - drop_p), g, z_halo, z_lead, n4, C, ed_cshift(C), (bf16_t*)z);
     RTTS_LAUNCH_CHECK("rtts_bn_act_fwd");
     return 0;
 }
@@ -757,8 +796,9 @@ extern "C" int rtts_bn_act_bwd(const float* y, const void* dz, int dz_halo, cons
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 63) / 64), dim3(ED_THREADS), 0, (hipStream_t)stream, partial_ws,
                        (int)grid.x, C, sums, dgamma, dbeta);
     const size_t n4 = (size_t)dy_rows * C / 4;
+    RTTS_REQUIRE(n4 < (1ull << 30), "rtts_bn_act_bwd: more than 2^32 elements");
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ed_grid(n4)), dim3(ED_THREADS), 0, (hipStream_t)stream, y, (const bf16_t*)dz, mean, rstd,
-                       gamma, beta, act, seed, seed_dev, th, ds, sums, 1.f / (float)((size_t)B * L), g, dzh, dy_lead, n4, C, (bf16_t*)dy);
+                       gamma, beta, act, seed, seed_dev, th, ds, sums, 1.f / (float)((size_t)B * L), g, dzh, dy_lead, n4, C, ed_cshift(C), (bf16_t*)dy);
     RTTS_LAUNCH_CHECK("rtts_bn_act_bwd");
     return 0;
 }
