@@ -205,30 +205,46 @@ __global__ __launch_bounds__(ED_THREADS) void col_partial_kernel(const float* __
 
 // column sums of the two partial planes: a block owns 64 channels, its 4 waves each sum every 4th partial row
 // (coalesced 256-B reads), then the 4 wave sums are combined in wave order (deterministic)
+#define ED_FIN_WAVES 16     // waves of a finalize block: 8 blocks of 4 waves walked 64 partial rows each in a dependent chain (9 us)
 __device__ __forceinline__ void ed_reduce_partials(const float* __restrict__ partial, int nrows, int C, int c, float& s, float& q,
-                                                   float (*red)[4][64]) {
+                                                   float (*red)[ED_FIN_WAVES][64]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float a = 0.f, b = 0.f;
     if (c < C) {
-#pragma unroll 4
-        for (int r = wave; r < nrows; r += 4) {
-            a += partial[(size_t)r * 2 * C + c];
-            b += partial[(size_t)r * 2 * C + C + c];
+        // up to 16 rows per wave, all loads in flight at once, added in row order (fixed order: deterministic)
+        float va[16], vb[16];
+        for (int r0 = wave; r0 < nrows; r0 += ED_FIN_WAVES * 16) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int r = r0 + u * ED_FIN_WAVES;
+                va[u] = r < nrows ? partial[(size_t)r * 2 * C + c] : 0.f;
+                vb[u] = r < nrows ? partial[(size_t)r * 2 * C + C + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                a += va[u];
+                b += vb[u];
+            }
         }
     }
     red[0][wave][lane] = a;
     red[1][wave][lane] = b;
     __syncthreads();
-    s = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
-    q = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+    s = 0.f;
+    q = 0.f;
+#pragma unroll
+    for (int w = 0; w < ED_FIN_WAVES; ++w) {
+        s += red[0][w][lane];
+        q += red[1][w][lane];
+    }
 }
 
 // mean/rstd from the partials (+ running statistics, momentum 0.1, unbiased variance)
-__global__ __launch_bounds__(ED_THREADS) void bn_finalize_stats_kernel(const float* __restrict__ partial, int nrows, int M, int C,
+__global__ __launch_bounds__(64 * ED_FIN_WAVES) void bn_finalize_stats_kernel(const float* __restrict__ partial, int nrows, int M, int C,
                                                                        float* __restrict__ mean, float* __restrict__ rstd,
                                                                        float* __restrict__ run_mean, float* __restrict__ run_var,
                                                                        const float* __restrict__ mean_shift, long long* __restrict__ num_batches) {
-    __shared__ float red[2][4][64];
+    __shared__ float red[2][ED_FIN_WAVES][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     float s, q;
     ed_reduce_partials(partial, nrows, C, c, s, q, red);
@@ -245,10 +261,10 @@ __global__ __launch_bounds__(ED_THREADS) void bn_finalize_stats_kernel(const flo
 }
 
 // sums of the backward partials: sums[0..C) = sum g, sums[C..2C) = sum g*yhat; dbeta += , dgamma +=
-__global__ __launch_bounds__(ED_THREADS) void bn_finalize_bwd_kernel(const float* __restrict__ partial, int nrows, int C,
+__global__ __launch_bounds__(64 * ED_FIN_WAVES) void bn_finalize_bwd_kernel(const float* __restrict__ partial, int nrows, int C,
                                                                      float* __restrict__ sums, float* __restrict__ dgamma,
                                                                      float* __restrict__ dbeta) {
-    __shared__ float red[2][4][64];
+    __shared__ float red[2][ED_FIN_WAVES][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     float s, q;
     ed_reduce_partials(partial, nrows, C, c, s, q, red);
@@ -756,7 +772,7 @@ extern "C" int rtts_bn_stats(const float* y, int B, int L, int halo, int C, floa
     hipLaunchKernelGGL((col_partial_kernel<0>), grid, dim3(ED_THREADS), 0, (hipStream_t)stream, y, (const bf16_t*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0u, (const uint32_t*)nullptr, 0u, 1.f, g, 1, C,
                        partial_ws);
-    hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((C + 63) / 64), dim3(ED_THREADS), 0, (hipStream_t)stream, partial_ws,
+    hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((C + 63) / 64), dim3(64 * ED_FIN_WAVES), 0, (hipStream_t)stream, partial_ws,
                        (int)grid.x, B * L, C, mean, rstd, run_mean, run_var, mean_shift, (long long*)num_batches);
     RTTS_LAUNCH_CHECK("rtts_bn_stats");
     return 0;
@@ -793,7 +809,7 @@ extern "C" int rtts_bn_act_bwd(const float* y, const void* dz, int dz_halo, cons
     const int dzh = (halo > 0 && dz_halo) ? 1 : 0;
     hipLaunchKernelGGL((col_partial_kernel<1>), grid, dim3(ED_THREADS), 0, (hipStream_t)stream, y, (const bf16_t*)dz, mean, rstd, gamma, beta, act,
                        seed, seed_dev, th, ds, g, dzh, C, partial_ws);
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 63) / 64), dim3(ED_THREADS), 0, (hipStream_t)stream, partial_ws,
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 63) / 64), dim3(64 * ED_FIN_WAVES), 0, (hipStream_t)stream, partial_ws,
                        (int)grid.x, C, sums, dgamma, dbeta);
     const size_t n4 = (size_t)dy_rows * C / 4;
     RTTS_REQUIRE(n4 < (1ull << 30), "rtts_bn_act_bwd: more than 2^32 elements");
