@@ -72,22 +72,15 @@ class Halo:
         return body[:self.rows].view(self.b, self.p, -1)[:, self.H:self.H + self.l]
 
 
-class _DwQueue(threading.local):
-    def __init__(self):
-        self.items = []           # weight gradients in GEMM layout waiting for their re-layout
-        self.gemms = []           # (problem fields, operands kept alive) of convolutions whose weight-gradient GEMMs are not launched yet
-
-
-_DW = _DwQueue()
-
-
 import os as _os
 CONVS_PER_WGRAD_LAUNCH = int(_os.environ.get("RTTS_CONVS_PER_WGRAD", "4"))   # tap problems of up to 4 convolutions are launched together
 
 
-def flush_conv_wgrad() -> None:
-    """The queued tap problems (five per convolution, dW_k = dY^T X shifted by k - 2) as ONE grouped split-K launch."""
-    q = _DW.gemms
+def flush_conv_wgrad(queue=None) -> None:
+    """The queued tap problems (five per convolution, dW_k = dY^T X shifted by k - 2) as ONE grouped split-K launch, on the
+    stream they were queued on (``queue``: an engine._Queue; None: the current device's and stream's)."""
+    queue = _engine._queue() if queue is None else queue
+    q = queue.conv_gemms
     # problems whose N and K tile by 256 go together: a group of them is large enough for the 256 x 256 ring kernel
     # (rtts_gemm_tn_grouped takes it only when EVERY problem of the group tiles); the 128-wide first / last convolution of the
     # postnet would drag its neighbours down to the 128-tile kernel
@@ -101,21 +94,22 @@ def flush_conv_wgrad() -> None:
             arr = (_lib.GemmTnProblem * len(chunk))()
             for dst, (fields, _keep) in zip(arr, chunk):
                 dst.a, dst.lda, dst.b, dst.ldb, dst.c, dst.ldc, dst.M, dst.N, dst.K, dst.accumulate = fields
-            ws = _engine._slab_ws(chunk[0][1][0].device)
-            _lib.call("rtts_gemm_tn_grouped", arr, len(chunk), ws.data_ptr(), ws.numel(), _s())
+            ws = _engine._slab_ws(chunk[0][1][0].device, queue.stream)
+            _lib.call("rtts_gemm_tn_grouped", arr, len(chunk), ws.data_ptr(), ws.numel(), queue.stream)
 
 
-def flush_conv_dw() -> None:
+def flush_conv_dw(queue=None) -> None:
     """dw[co][ci][k] += dwp[co][k][ci] for every convolution whose backward has run since the last flush (one launch)."""
-    flush_conv_wgrad()
-    pending = _DW.items
+    queue = _engine._queue() if queue is None else queue
+    flush_conv_wgrad(queue)
+    pending = queue.conv_items
     while pending:
         chunk = pending[:_lib.CONV_PERM_MAX_GROUP]
         del pending[:len(chunk)]
         jobs = (_lib.ConvPermJob * len(chunk))()
         for j, (dwp, co, ci, cp, gw) in zip(jobs, chunk):
             j.w, j.wp, j.Co, j.Ci, j.CP = dwp.data_ptr(), gw.data_ptr(), co, ci, cp
-        _lib.call("rtts_conv_dw_unperm_grouped", jobs, len(chunk), _s())
+        _lib.call("rtts_conv_dw_unperm_grouped", jobs, len(chunk), queue.stream)
 
 
 class ConvK5:
@@ -182,17 +176,18 @@ class ConvK5:
         # weight gradient of tap k = (dy)^T (x shifted by k - 2): five problems, queued so that up to three convolutions of a
         # stack share one grouped split-K launch (their operands are still in the Infinity Cache a layer or two later)
         dyb = g.body(dyh)
+        dwq = _engine._queue()
         for k in range(5):
             xs, ck = g.body(xh, k - 2), dwp[:, k * self.cp:(k + 1) * self.cp]
-            _DW.gemms.append(((dyb.data_ptr(), self.cop, xs.data_ptr(), self.cp, ck.data_ptr(), 5 * self.cp, g.mp, self.cop, self.cp, 0),
+            dwq.conv_gemms.append(((dyb.data_ptr(), self.cop, xs.data_ptr(), self.cp, ck.data_ptr(), 5 * self.cp, g.mp, self.cop, self.cp, 0),
                               (dyh, xh, dwp)))
-        if len(_DW.gemms) >= 5 * CONVS_PER_WGRAD_LAUNCH:
-            flush_conv_wgrad()
+        if len(dwq.conv_gemms) >= 5 * CONVS_PER_WGRAD_LAUNCH:
+            flush_conv_wgrad(dwq)
         # dW goes back to nn.Conv1d's (Co, Ci, 5) layout with the other deferred gradient work of the backward: one grouped
         # launch for all convolutions (engine.flush_wgrad runs the hook before anything reads the gradients)
-        _DW.items.append((dwp, self.co, self.ci, self.cp, _grad(self.conv.weight)))
-        if len(_DW.items) >= _lib.CONV_PERM_MAX_GROUP:
-            flush_conv_dw()
+        dwq.conv_items.append((dwp, self.co, self.ci, self.cp, _grad(self.conv.weight)))
+        if len(dwq.conv_items) >= _lib.CONV_PERM_MAX_GROUP:
+            flush_conv_dw(dwq)
         else:
             from .engine import _queue_final_flush
             _queue_final_flush()

@@ -114,17 +114,44 @@ def ln_fwd(x, norm):
 DEFER_COLSUM = True
 
 
-class _Queues(__import__("threading").local):
-    """Deferred gradient work of the backward pass running on THIS thread (autograd runs one backward per thread at a time and
-    the queues are drained before it returns, so two models -- or two threads -- never see each other's entries)."""
+class _Queue:
+    """Deferred gradient work queued on ONE (device, stream): whoever flushes it -- autograd's worker thread for that device
+    (where FusedStackFn.backward and the edge backwards run), the engine's end-of-backward callback, or the trainer's main
+    thread after ``loss.backward()`` -- launches the entries on the stream they were queued on, so they are ordered after
+    the kernels that produce their operands whichever thread drains them."""
 
-    def __init__(self):
-        self.colsums = []          # (partial buffer [kept alive], float offset of the block, rows, d, out tensor)
+    def __init__(self, device: int, stream: int):
+        self.device, self.stream = device, stream
+        self.colsums = []          # (partial buffer [kept alive], float offset of the block, rows, d, out tensor, ld)
         self.wgrads = []           # (grad_view, dy, x)
+        self.conv_gemms = []       # edges.py: tap problems of the convolutions' weight gradients
+        self.conv_items = []       # edges.py: (dwp, co, ci, cp, grad) re-layouts of finished convolution gradients
+        self.flush_queued = False
+
+    def __len__(self):
+        return len(self.colsums) + len(self.wgrads) + len(self.conv_gemms) + len(self.conv_items)
+
+    def clear(self):
+        del self.colsums[:], self.wgrads[:], self.conv_gemms[:], self.conv_items[:]
         self.flush_queued = False
 
 
-_Q = _Queues()
+_QUEUES = {}                      # (device index, stream handle) -> _Queue
+_QLOCK = __import__("threading").RLock()
+
+
+def _queue() -> _Queue:
+    key = (torch.cuda.current_device(), _s())
+    q = _QUEUES.get(key)
+    if q is None:
+        with _QLOCK:
+            q = _QUEUES.setdefault(key, _Queue(*key))
+    return q
+
+
+def _all_queues():
+    with _QLOCK:
+        return list(_QUEUES.values())
 
 
 def _partial_rows(m: int) -> int:
@@ -133,19 +160,21 @@ def _partial_rows(m: int) -> int:
 
 def _queue_colsum(partial: torch.Tensor, offset_floats: int, rows: int, d: int, out: torch.Tensor, ld: int = 0):
     """``ld``: row stride of the partial buffer when ``d`` columns are a block of a wider one (0: d)."""
-    _Q.colsums.append((partial, offset_floats, rows, d, out, ld))
+    _queue().colsums.append((partial, offset_floats, rows, d, out, ld))
     _queue_final_flush()
 
 
-def flush_colsum():
-    pending = _Q.colsums
-    while pending:
-        group = pending[:_lib.COLSUM_MAX_GROUP]
-        del pending[:len(group)]
-        arr = (_lib.ColsumJob * len(group))()
-        for j, (partial, off, rows, d, out, ld) in zip(arr, group):
-            j.partial, j.out, j.nrows, j.n, j.ld = partial.data_ptr() + 4 * off, out.data_ptr(), rows, d, ld
-        _lib.call("rtts_colsum_final_grouped", arr, len(group), _s())
+def flush_colsum(q: Optional[_Queue] = None):
+    for q in ([q] if q is not None else _all_queues()):
+        pending = q.colsums
+        while pending:
+            group = pending[:_lib.COLSUM_MAX_GROUP]
+            del pending[:len(group)]
+            arr = (_lib.ColsumJob * len(group))()
+            for j, (partial, off, rows, d, out, ld) in zip(arr, group):
+                j.partial, j.out, j.nrows, j.n, j.ld = partial.data_ptr() + 4 * off, out.data_ptr(), rows, d, ld
+            with torch.cuda.device(q.device):
+                _lib.call("rtts_colsum_final_grouped", arr, len(group), q.stream)
 
 
 def ln_bwd(dxn, x, mean, rstd, norm, dx_io, next_cast=None):
@@ -318,24 +347,25 @@ WGRAD_MAX_PENDING = 64
 
 
 def _final_flush():
-    _Q.flush_queued = False
     flush_wgrad()
 
 
-def _slab_ws(device):
-    key = ("slab", device, torch.cuda.current_stream(device).cuda_stream)     # launches on one stream are ordered; two streams
-    # (two trainers, a side stream) must not share partial-tile scratch
+def _slab_ws(device, stream: Optional[int] = None):
+    stream = torch.cuda.current_stream(device).cuda_stream if stream is None else stream
+    key = ("slab", torch.device(device), stream)     # launches on one stream are ordered; two streams (two trainers, a side
+    # stream) must not share partial-tile scratch
     if key not in _WS._cache:
         _WS._cache[key] = torch.empty(_SLAB_FLOATS, dtype=torch.float32, device=device)
     return _WS._cache[key]
 
 
 def _queue_final_flush():
-    if not _Q.flush_queued:
+    q = _queue()
+    if not q.flush_queued:
         # whatever is still queued when the running autograd pass ends is launched by the engine's callback
         try:
             torch.autograd.Variable._execution_engine.queue_callback(_final_flush)
-            _Q.flush_queued = True
+            q.flush_queued = True
         except RuntimeError:          # not inside a backward pass: the caller flushes
             pass
 
@@ -343,31 +373,54 @@ def _queue_final_flush():
 def flush_wgrad(colsums: bool = True):
     """Launch every queued weight gradient and (``colsums``) column-sum finalisation, grouped; release the held operands.
     ``colsums=False`` (the per-layer flush of the stack loop when nobody waits for a block's gradients): the small partial
-    buffers stay queued for fewer, fuller launches -- the end-of-backward flush takes them."""
-    _Q.flush_queued = False            # the next deferral queues a fresh end-of-backward callback (extra ones are no-ops);
-    if colsums or len(_Q.colsums) >= _lib.COLSUM_MAX_GROUP - 8:       # a backward that died half-way cannot leave the flag stuck
-        flush_colsum()
-    else:
-        _queue_final_flush()
-    pending = _Q.wgrads
-    while pending:
-        group = pending[:_lib.GEMM_TN_MAX_GROUP]
-        del pending[:len(group)]
-        arr = (_lib.GemmTnProblem * len(group))()
-        for q, (gv, dy, x) in zip(arr, group):
-            q.a, q.lda, q.b, q.ldb, q.c, q.ldc = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), gv.data_ptr(), gv.stride(0)
-            q.M, q.N, q.K, q.accumulate = dy.shape[0], dy.shape[1], x.shape[1], 1
-        ws = _slab_ws(group[0][1].device)
-        _lib.call("rtts_gemm_tn_grouped", arr, len(group), ws.data_ptr(), ws.numel(), _s())
-    for hook in FLUSH_HOOKS:           # other deferred gradient work (edges.py: the convolutions' dW re-layout)
-        hook()
+    buffers stay queued for fewer, fuller launches -- the end-of-backward flush takes them.
+    EVERY queue is drained (all devices, all streams, whichever thread filled them), each on its own stream: the trainer's
+    flush after ``loss.backward()`` on the main thread sees what autograd's worker thread queued."""
+    for q in _all_queues():
+        q.flush_queued = False         # the next deferral queues a fresh end-of-backward callback (extra ones are no-ops);
+        #                                a backward that died half-way cannot leave the flag stuck
+        if not len(q):
+            continue
+        with torch.cuda.device(q.device):
+            if colsums or len(q.colsums) >= _lib.COLSUM_MAX_GROUP - 8:
+                flush_colsum(q)
+            elif q.colsums and (q.device, q.stream) == (torch.cuda.current_device(), _s()):
+                _queue_final_flush()
+            pending = q.wgrads
+            while pending:
+                group = pending[:_lib.GEMM_TN_MAX_GROUP]
+                del pending[:len(group)]
+                arr = (_lib.GemmTnProblem * len(group))()
+                for e, (gv, dy, x) in zip(arr, group):
+                    e.a, e.lda, e.b, e.ldb, e.c, e.ldc = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), gv.data_ptr(), gv.stride(0)
+                    e.M, e.N, e.K, e.accumulate = dy.shape[0], dy.shape[1], x.shape[1], 1
+                ws = _slab_ws(group[0][1].device, q.stream)
+                _lib.call("rtts_gemm_tn_grouped", arr, len(group), ws.data_ptr(), ws.numel(), q.stream)
+            for hook in FLUSH_HOOKS:       # other deferred gradient work (edges.py: the convolutions' dW re-layout)
+                hook(q)
+
+
+def discard_pending() -> int:
+    """Drop everything queued (a backward that raised half-way must not leak its entries into the next step's gradients).
+    -> number of entries dropped."""
+    n = 0
+    for q in _all_queues():
+        n += len(q)
+        q.clear()
+    return n
 
 
 FLUSH_HOOKS = []
 
 
 def pending_wgrads() -> int:
-    return len(_Q.wgrads)
+    """Weight gradients queued on the current (device, stream) -- what the stack loop's per-layer flush counts."""
+    return len(_queue().wgrads)
+
+
+def pending_all() -> int:
+    """Every deferred entry of every queue (0 after a flush: Trainer.backward asserts it)."""
+    return sum(len(q) for q in _all_queues())
 
 
 def wgrad(grad_view: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, accumulate: bool = True):
@@ -378,7 +431,7 @@ def wgrad(grad_view: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, accumulate
     k = x.shape[1]
     if n % 128 == 0 and k % 128 == 0 and m % 64 == 0 and dy.stride(1) == 1 and x.stride(1) == 1 and grad_view.stride(1) == 1:
         if DEFER_WGRAD and accumulate:
-            _Q.wgrads.append((grad_view, dy, x))
+            _queue().wgrads.append((grad_view, dy, x))
             _queue_final_flush()
             return
         ws = _slab_ws(dy.device)

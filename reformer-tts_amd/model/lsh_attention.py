@@ -6,9 +6,24 @@ SURVEY.md Appendix B steps 2-11 in librtts_hip.so.
 MI355X-first differences from the reference's mechanism (results are the same function):
   * the two projections run as ONE (M, d) x (d, 2d) GEMM whose halves are consumed in place
     (row stride 2d) by the kernels -- no head split / merge copies;
-  * the forward keeps the sort permutation ``st`` (3 MB per decoder layer) instead of replaying
-    the RNG: the reversible recompute re-uses the buckets that the forward used, bit for bit;
-  * rotations come from a per-layer generator, so no global RNG state is captured.
+  * the forward keeps the sort permutation ``st`` (3 MB per decoder layer): the reversible
+    recompute re-uses the buckets that the forward used, bit for bit, instead of hashing the
+    reconstructed (rounding-perturbed) input again.
+
+Recompute protocol at this seam (``forward(x, input_mask=...)`` is all the reference's wrapper calls,
+``reformer.py:215-217``).  The reference re-runs the layer inside ``Deterministic.forward(set_rng=True)``
+(``reversible.py:26-41``): the device RNG state recorded before the no_grad forward is restored under
+``fork_rng`` and the layer is called again with gradients enabled.  So this layer
+  * draws its rotations from the DEFAULT device generator, as ``reformer_pytorch`` does -- the replay
+    reproduces them, and the generator is advanced by the same amount before ``post_attn_dropout``
+    draws its mask, so the mask repeats too;
+  * remembers, after a no_grad training call, the generator state it started from, the permutation and
+    a per-row signature of its input; a grad-enabled training call that starts from THE SAME generator
+    state re-uses that permutation where the signature agrees (a device-side select: no host sync) and
+    hashes afresh otherwise.  No flag from the caller is needed; ``recompute=True`` (this package's own
+    ``Deterministic``) is the same thing without the checks.
+The explicit executor (``engine.LSHExec``) keeps its permutations in per-call slots and does not come
+through ``forward``.
 """
 from __future__ import annotations
 
@@ -74,13 +89,13 @@ class LSHSelfAttention(nn.Module):
         self.post_attn_dropout = nn.Dropout(post_attn_dropout)
         self.seed = seed
         self._gen: Optional[torch.Generator] = None
-        self._saved_st: Optional[torch.Tensor] = None   # forward's permutation, re-used by the recompute
+        self._saved: Optional[tuple] = None   # (generator state, st, input signature) of the last no_grad training call
         self.forced_rotations: Optional[torch.Tensor] = None  # tests: use these instead of sampling
         self.last_st: Optional[torch.Tensor] = None
 
     rotation_pool = None       # (flat fp32 normal samples, [next offset]) while a graph-mode training forward runs, else None
 
-    def _rotations(self, x, n_buckets):
+    def _rotations(self, x, n_buckets, default_generator: bool = False):
         if self.forced_rotations is not None and hasattr(self.forced_rotations, "__next__"):
             return next(self.forced_rotations).to(device=x.device, dtype=torch.float32).contiguous()   # tests: one per call
         if self.forced_rotations is not None:
@@ -89,7 +104,7 @@ class LSHSelfAttention(nn.Module):
             return self.forced_rotations
         rows = x.shape[0] * self.heads if self.random_rotations_per_head else 1
         shape = (rows, self.dim // self.heads, self.n_hashes, n_buckets // 2)
-        if getattr(self, "use_default_generator", False):     # hipGraph capture: the default generator is graph-safe
+        if default_generator or getattr(self, "use_default_generator", False):   # graph-safe, and what Deterministic replays
             pool = LSHSelfAttention.rotation_pool             # one randn per training step for all layers (trainer.forward_loss)
             n = rows * shape[1] * shape[2] * shape[3]
             if pool is not None and pool[0].device == x.device and pool[1][0] + n <= pool[0].numel():
@@ -102,6 +117,23 @@ class LSHSelfAttention(nn.Module):
             self._gen.manual_seed(0x5EED + self.seed)
         return torch.randn(shape, device=x.device, dtype=torch.float32, generator=self._gen)
 
+    @staticmethod
+    def _generator_state(device):
+        """(seed, offset) of the default generator of ``device`` -- what ``Deterministic`` records and restores
+        (``reversible.py:21-24,36-40``); None while a hipGraph is being captured (the offset is then a graph quantity)."""
+        if device.type != "cuda":
+            return None
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        g = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+        return (g.initial_seed(), g.get_offset())
+
+    @staticmethod
+    def _signature(x):
+        """Per-row L1 norms of the layer input: equal to ~1e-6 between a forward and its reversible recompute (the
+        reconstructed stream differs by fp32 rounding), O(1) apart for any other input."""
+        return x.detach().float().abs().sum(-1)
+
     def forward(self, x, input_mask=None, recompute: bool = False, **_):
         b, t, e = x.shape
         if t <= self.full_attn_thres:
@@ -110,15 +142,25 @@ class LSHSelfAttention(nn.Module):
             raise AssertionError(f"Sequence length ({t}) needs to be divisible by target bucket size  x 2 - {self.bucket_size * 2}")
         w = torch.cat([self.toqk.weight, self.tov.weight], dim=0).to(torch.bfloat16)
         qkv = F.linear(x.to(torch.bfloat16), w)                              # (B,T,2d) = [qk | v]
-        if recompute and self._saved_st is not None:
-            st = self._saved_st
-            self._saved_st = None
-        else:
-            with torch.no_grad():
-                rot = self._rotations(x, t // self.bucket_size)
+        state = self._generator_state(x.device)
+        saved, st = self._saved, None
+        with torch.no_grad():
+            # always drawn, also when the permutation is re-used: the generator must end up where the forward left it
+            rot = self._rotations(x, t // self.bucket_size, default_generator=True)
+            replay = (self.training and torch.is_grad_enabled() and saved is not None and saved[1].shape[0] == b * self.heads
+                      and saved[1].shape[2] == t and (recompute or (state is not None and saved[0] == state)))
+            if replay and recompute:
+                st = saved[1]
+            else:
                 st, _, _ = ops.lsh_hash_sort(qkv[..., :e], rot, self.heads, self.bucket_size)
-            if self.training and not torch.is_grad_enabled():
-                self._saved_st = st          # reversible forward: keep for the recompute
+                if replay:
+                    sig = self._signature(x)
+                    same = (sig - saved[2]).abs().max() <= 1e-3 * saved[2].abs().max()
+                    st = torch.where(same, saved[1], st)
+            if replay:
+                self._saved = None
+            elif self.training and not torch.is_grad_enabled():
+                self._saved = (state, st, self._signature(x))      # reversible forward: kept for the recompute
         self.last_st = st
         mask = None if input_mask is None else input_mask.to(torch.uint8)
         out = _LSHAttnFn.apply(qkv, st, mask, self.heads, self.bucket_size, self.causal)

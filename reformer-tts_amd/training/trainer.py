@@ -241,9 +241,26 @@ class Trainer:
                 w.wait()
             self._pending.clear()
 
+    @staticmethod
+    def _run_backward(loss):
+        """``loss.backward()`` + the flush of the deferred gradient work (weight gradients, column sums, convolution
+        re-layouts are queued by the executors and launched grouped).  The executors queue from autograd's worker thread; the
+        queues are keyed by (device, stream), so this flush on the calling thread drains them.  Nothing may stay queued: a
+        leftover entry would be added to the NEXT step's gradients after ``zero_grad``.  A backward that raises drops its
+        entries."""
+        try:
+            loss.backward()
+            engine.flush_wgrad()
+        except BaseException:
+            engine.discard_pending()
+            raise
+        left = engine.pending_all()
+        if left:
+            engine.discard_pending()
+            raise RuntimeError(f"{left} deferred gradient launches were still queued after the flush")
+
     def backward(self, loss):
-        loss.backward()
-        engine.flush_wgrad()
+        self._run_backward(loss)
         self.finish_allreduce()
 
     def lr_now(self) -> float:
@@ -337,8 +354,7 @@ class Trainer:
         for i, batch in enumerate(batches):
             self._accumulating = i + 1 < n                     # all-reduce only with the last micro-batch
             loss = self.forward_loss(batch)[0]
-            (loss * (1.0 / n)).backward()
-            engine.flush_wgrad()
+            self._run_backward(loss * (1.0 / n))
             total = loss.detach() if total is None else total + loss.detach()
         self._accumulating = False
         if self.world > 1 and not self._bulk_allreduce:
@@ -467,8 +483,7 @@ class Trainer:
             self.model.train()
             self.zero_grad()
             total, raw_l, post_l, stop_l = self.forward_loss(batch, split=True)
-            total.backward()
-            engine.flush_wgrad()
+            self._run_backward(total)
             self._graph_out = (total.detach(), raw_l.detach(), post_l.detach(), stop_l.detach())
         stack_names = [n for n in enc_names if n.startswith("enc.reformer.")]
         self._stack_begin = min(self.offsets[n][0] for n in stack_names)
@@ -478,10 +493,12 @@ class Trainer:
         with self._capturing(self._graph_enc, pool=self._graph.pool()):
             self._enc_out.backward(self._enc_in.grad)
             engine.flush_wgrad()
+            assert engine.pending_all() == 0
         self._graph_pre = torch.cuda.CUDAGraph()
         with self._capturing(self._graph_pre, pool=self._graph.pool()):
             self._pre_out.backward(self._pre_in.grad)
             engine.flush_wgrad()
+            assert engine.pending_all() == 0
         self._enc_out = self._enc_in = self._pre_out = self._pre_in = None
         self._graph_opt = torch.cuda.CUDAGraph()
         with self._capturing(self._graph_opt, pool=self._graph.pool()):
