@@ -7,15 +7,20 @@ backward + gradient all-reduce + clip + AdamW) on synthetic LJSpeech-shaped batc
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement): whole-job mel-frames/s of the default (``stash``) mode -- every
-activation the backward needs is kept in HBM (about 1 GB at these shapes; the reference recomputes them because it was written
-for 16-32 GB devices; same gradients) -- plus
-  config.full_recompute_ms   the same step with the reference's pure recompute (``--recompute full``), same run
+Prints ONE JSON line on rank 0 (contract in the task statement).  WHICH MODE IS THE HEADLINE: ``value`` / ``ms_per_step`` are
+the step with the reference's reversible ACTIVATION RECOMPUTE (``--recompute full``, the default): only each stack's output
+and the LSH sort permutations survive the forward; the backward reconstructs the streams by subtraction and re-runs
+LayerNorm, projections, attention and feed-forward of every block, as ``reformer_tts/model/reversible.py:69-98`` does and as
+BASELINE.json's north_star words it.  The memory-for-time mode this package also offers (every activation the backward
+needs kept in HBM, ~1 GB of 288 GB, same gradients to 3e-4: DESIGN.md section 4) is timed in the same run and reported
+under the top-level key ``stash`` (its own value / ms_per_step / peak memory) -- never mixed into ``value``.  Also:
   roofline        the dominant kernel (LSH chunk-attention backward, MFMA-bound): algorithmic FLOP per launch / its average
-                  duration measured with HIP events on the launch stream
-  rooflines       that entry plus lsh_hash_sort (HBM-bound, SURVEY.md 8(d) bytes) and rtts_gemm_nt (every projection /
-                  feed-forward / convolution GEMM of the step, MFMA-bound), each against the spec peak AND the peak measured
-                  on this box by a stream copy / an MFMA loop (``peak_measured``)
+                  duration measured with HIP events on the launch stream; ``traffic`` = HBM bytes per launch from the
+                  committed rocprofv3 PMC passes (profiles/<round>_pmc_traffic.json) IF that file names the kernel and
+                  shape this run launches -- otherwise null and ``traffic_stale`` says why (``--strict`` raises instead)
+  rooflines       that entry plus lsh_attn_fwd (MFMA), lsh_hash_sort (HBM-bound, SURVEY.md 8(d) bytes) and rtts_gemm_nt (every
+                  projection / feed-forward / convolution GEMM of the step, MFMA-bound), each against the spec peak AND the
+                  peak measured on this box by a stream copy / an MFMA loop (``peak_measured``)
   cpu_baseline    the CPU oracle (eager fp32 PyTorch restatement of the reference's step) timed on this host's cores on a
                   bounded sample of the same workload: one warm-up pass, then up to 3 timed passes (rank 0, N=1 only)
 """
@@ -52,12 +57,14 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the full-recompute leg and the peak probes")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
-    ap.add_argument("--recompute", default="stash", choices=["stash", "projection-stash", "output-stash", "attention-stash", "full"],
+    ap.add_argument("--strict", action="store_true", help="raise when the committed PMC traffic file does not match the kernel / shape of this run")
+    ap.add_argument("--recompute", default="full", choices=["stash", "projection-stash", "output-stash", "attention-stash", "full"],
                     help="what the reversible backward recomputes: 'full' = everything, as the reference does; "
                          "'attention-stash' = attention outputs kept; 'output-stash' = block outputs f(x) kept too; 'projection-stash' = and the "
                          "projections, streams still reconstructed by subtraction; 'stash' (default) = and the streams: every "
                          "sublayer's LayerNorm input / output and projections stay in HBM (~1 GB of 288 GB), the backward "
-                         "recomputes nothing")
+                         "recomputes nothing.  The mode named here is the headline (value / ms_per_step); the other end of the "
+                         "range is timed in the same run (top-level key 'stash' or 'full_recompute')")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 12 if args.config == "baseline" else 4
@@ -150,10 +157,14 @@ def main():
     torch.cuda.set_device(dev)
 
     from reformer_tts_amd import engine, ops
-    engine.STASH_ATTENTION = args.recompute != "full"
-    engine.STASH_BLOCK_OUTPUT = args.recompute in ("stash", "projection-stash", "output-stash")
-    engine.STASH_PROJECTIONS = args.recompute in ("stash", "projection-stash")
-    engine.STASH_STREAMS = args.recompute == "stash"
+
+    def set_mode(mode):
+        engine.STASH_ATTENTION = mode != "full"
+        engine.STASH_BLOCK_OUTPUT = mode in ("stash", "projection-stash", "output-stash")
+        engine.STASH_PROJECTIONS = mode in ("stash", "projection-stash")
+        engine.STASH_STREAMS = mode == "stash"
+
+    set_mode(args.recompute)
     from reformer_tts_amd.model.config import (baseline_model_config, baseline_training_config,
                                                long_sequence_model_config)
     from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
@@ -173,7 +184,8 @@ def main():
     heads_dec = int(model_cfg.dec_reformer_kwargs.self_attn_kwargs.heads)
     n_hashes_dec = int(model_cfg.dec_reformer_kwargs.self_attn_kwargs.n_hashes)
     t_dec = -(-args.mel_len // 256) * 256
-    tags = dict(bwd=f"rtts_lsh_attn_bwd/bs{dec_bucket}", hash=f"rtts_lsh_hash_sort/nb{t_dec // dec_bucket}", gemm="rtts_gemm_nt")
+    tags = dict(bwd=f"rtts_lsh_attn_bwd/bs{dec_bucket}", fwd=f"rtts_lsh_attn_fwd/bs{dec_bucket}",
+                hash=f"rtts_lsh_hash_sort/nb{t_dec // dec_bucket}", gemm="rtts_gemm_nt")
     note(f"model built ({trainer.n_params} parameters), warming up")
     # N == 1: the whole step is one hipGraph.  N > 1: four graphs (fwd + decoder-side bwd | encoder stack bwd | encoder
     # prenet bwd | clip+AdamW) around three eager all-reduces of parts of the flat gradient buffer, so no collective is
@@ -241,21 +253,29 @@ def main():
     if not (float(loss) == float(loss)):
         raise RuntimeError("training loss is not finite")
 
-    # the same step with the reference's pure recompute, in the same run (a second capture on the same trainer)
-    full_ms = None
-    if not args.no_extra and args.recompute != "full":
-        engine.STASH_ATTENTION = engine.STASH_BLOCK_OUTPUT = engine.STASH_PROJECTIONS = False
+    # the other end of the recompute range, in the same run (a second capture on the same trainer): the memory-for-time
+    # mode when the headline is the reference's full recompute, and the other way round
+    peak_mem_gb = round(torch.cuda.max_memory_allocated(dev) / 2**30, 2)
+    other_mode = "stash" if args.recompute != "stash" else "full"
+    other = None
+    if not args.no_extra:
+        torch.cuda.reset_peak_memory_stats(dev)
+        set_mode(other_mode)
         ok = capture() if use_graph else True
         fn = trainer.replay if (use_graph and ok) else (lambda: trainer.train_step(batch))
         for _ in range(2):
             fn()
         k = max(3, min(args.steps, 10))
         dt, _ = timed(fn, k)
-        full_ms = round(1e3 * dt / k, 3)
-        engine.STASH_ATTENTION = args.recompute != "full"
-        engine.STASH_BLOCK_OUTPUT = args.recompute in ("stash", "projection-stash", "output-stash")
-        engine.STASH_PROJECTIONS = args.recompute in ("stash", "projection-stash")
-        note(f"pure recompute (reference's mode): {full_ms} ms/step")
+        other = {"ms_per_step": round(1e3 * dt / k, 3), "value": round(world * args.batch * args.mel_len * k / dt, 1),
+                 "unit": "mel-frames/s", "steps": k, "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2),
+                 "reversible_recompute": other_mode,
+                 "what": ("memory-for-time mode: every sublayer's LayerNorm input/output, projections, attention outputs and block "
+                          "outputs are kept in HBM and the backward recomputes nothing; same gradients as the headline mode to 3e-4 "
+                          "(tests/test_model_hip.py::test_attention_stash_matches_pure_recompute)") if other_mode == "stash" else
+                         "the reference's pure activation recompute (reversible.py:69-98)"}
+        set_mode(args.recompute)
+        note(f"{other_mode} mode: {other['ms_per_step']} ms/step")
     peaks = (None, None)
     if rank == 0 and not args.no_extra:
         peaks = measure_peaks(dev)
@@ -277,8 +297,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * args.batch, "parallelism": f"dp{world}",
-                       "final_loss": round(float(loss), 4), "reversible_recompute": args.recompute, "full_recompute_ms": full_ms,
-                       "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2), "launch": launch,
+                       "final_loss": round(float(loss), 4), "reversible_recompute": args.recompute,
+                       "peak_hbm_gb": peak_mem_gb, "launch": launch,
                        # what a multi-GPU record can be checked against
                        "dist": {"world_size": world, "backend": (dist.get_backend() if world > 1 else None),
                                 "backend_ranks": (dist.get_world_size() if world > 1 else 1),
@@ -286,25 +306,55 @@ def main():
                                 "collectives_per_step": (3 if (world > 1 and use_graph) else (0 if world == 1 else "per block")),
                                 "rank_seeds": "rotations and dropout seeded with seed + rank"}},
         }
+        if other is not None:
+            out["stash" if other_mode == "stash" else "full_recompute"] = other
         rooflines = []
+        from reformer_tts_amd import _lib
+        shape_key = {"BH": args.batch * heads_dec, "T": t_dec, "bucket": dec_bucket, "rounds": n_hashes_dec}
+
+        def pmc_traffic(kernel_prefix):
+            """HBM bytes per launch of ``kernel_prefix`` at ``shape_key`` from the newest committed profiles/*_pmc_traffic.json
+            (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, collected outside this process; scripts/pmc_summary.py), or
+            (None, reason) when no entry names this kernel at this shape -- a changed kernel must not inherit old counters."""
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+            if not files:
+                return None, "no profiles/*_pmc_traffic.json committed"
+            with open(files[-1]) as fh:
+                doc = json.load(fh)
+            for e in doc.get("entries", []):
+                if e["kernel"].startswith(kernel_prefix) and e.get("shape") == shape_key:
+                    return int(e["traffic_bytes"]), os.path.basename(files[-1])
+            return None, (f"{os.path.basename(files[-1])} has no entry for {kernel_prefix}* at {shape_key} "
+                          f"(it holds: {[e['kernel'] for e in doc.get('entries', [])]})")
+
+        def mfma_entry(kernel, avg_ms, launches, flops, extra=None):
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            traffic, src = pmc_traffic(kernel)
+            if traffic is None:
+                if args.strict:
+                    raise RuntimeError(f"roofline.traffic: {src}")
+                note(f"ROOFLINE TRAFFIC NOT REPORTED for {kernel}: {src}")
+            e = {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 2), "peak": BF16_DENSE_PEAK_TFLOPS,
+                 "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
+                 ("traffic_source" if traffic is not None else "traffic_stale"): src,
+                 "algorithmic_flop_per_launch": flops, "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches,
+                 "peak_measured": peaks[1], "frac_of_measured": (round(ach / peaks[1], 4) if peaks[1] else None)}
+            e.update(extra or {})
+            return e
+
         avg_ms, launches, flops = timing["bwd"]
         if launches:
-            traffic = None      # HBM bytes per launch from the committed rocprofv3 PMC passes (collected outside this process)
-            try:
-                with open(os.path.join(ROOT, "profiles", "r02b_pmc_lsh_attn_bwd.json")) as fh:
-                    traffic = json.load(fh)["traffic_bytes"] if (args.batch, args.mel_len, args.config) == (12, 1024, "baseline") else None
-            except OSError:
-                pass
-            ach = flops / (avg_ms * 1e-3) / 1e12
-            from reformer_tts_amd import _lib
             run = _lib.load().rtts_lsh_attn_bwd_run_length(args.batch, heads_dec, t_dec, n_hashes_dec, dec_bucket)
-            entry = {"kernel": "lsh_attn_bwd_walk_kernel" if run > 0 else "lsh_attn_bwd_kernel", "chunks_per_workgroup": max(run, 1),
-                     "bound": "mfma", "achieved": round(ach, 2), "peak": BF16_DENSE_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
-                     "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches, "peak_measured": peaks[1],
-                     "frac_of_measured": (round(ach / peaks[1], 4) if peaks[1] else None)}
+            entry = mfma_entry(f"lsh_attn_bwd_walk_kernel<{dec_bucket}" if run > 0 else f"lsh_attn_bwd_kernel<{dec_bucket}",
+                               avg_ms, launches, flops, {"chunks_per_workgroup": max(run, 1)})
             out["roofline"] = entry
             rooflines.append(entry)
+        avg_ms, launches, flops = timing["fwd"]
+        if launches:
+            run = _lib.load().rtts_lsh_attn_fwd_run_length(args.batch, heads_dec, t_dec, n_hashes_dec, dec_bucket)
+            rooflines.append(mfma_entry(f"lsh_attn_fwd_walk_kernel<{dec_bucket}" if run > 0 else f"lsh_attn_fwd_kernel<{dec_bucket}",
+                                        avg_ms, launches, flops, {"chunks_per_workgroup": max(run, 1)}))
         avg_ms, launches, nbytes = timing["hash"]
         if launches:
             ach = nbytes / (avg_ms * 1e-3) / 1e9

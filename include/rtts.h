@@ -58,6 +58,9 @@ int rtts_lsh_hash_sort(const void* qk, int64_t ld_qk, const float* rotations, in
 int rtts_lsh_attn_fwd(const void* qk, const void* v, int64_t ld, const int32_t* st, const uint8_t* mask,
                       int B, int H, int T, int dh, int n_hashes, int bucket_size, int causal,
                       void* o, float* lse, void* stream);
+/* how rtts_lsh_attn_fwd works a shape: 0 = one workgroup per chunk (lsh_attn_fwd_kernel), R > 0 = workgroups that walk R
+ * consecutive chunks so that every K / V row is gathered once (lsh_attn_fwd_walk_kernel); same results bit for bit */
+int rtts_lsh_attn_fwd_run_length(int B, int H, int T, int n_hashes, int bucket_size);
 
 /* ---- combine the hash rounds (step 11) and merge heads (first half of step 12) -------
  *   out     bf16 (B,T,H*dh) row stride ld_out
@@ -261,8 +264,13 @@ int rtts_tts_loss(const float* raw, const float* post, int64_t ld_mel, const flo
                   int64_t ld_stop, const float* tstop, int rows, int NM, int kind, float pos_weight, float w_raw, float w_post,
                   float w_stop, float* d_raw, float* d_post, int64_t ld_grad, float* d_stop, float* losses, float* partial_ws,
                   int padded_len, int valid_len, const float* res, int64_t ld_res, int halo, int dpost_lead, int64_t dpost_rows,
-                  int64_t tgt_batch_stride, void* stream);
+                  int64_t tgt_batch_stride, const int32_t* valid_len_dev, int64_t mask_batch_stride, int64_t tstop_batch_stride,
+                  void* stream);
 /* tgt_batch_stride: elements between two samples of tgt (0 = valid_len * NM; larger for the view frames [1, L) of the batch).
+ * valid_len_dev (may be NULL): the loss length as a device word, 1 <= *valid_len_dev <= valid_len -- a replayed hipGraph whose
+ * batch buffers are padded to a fixed length serves batches of any length up to it; valid_len is then the time length of
+ * the tgt / mask / tstop buffers only.  mask_batch_stride / tstop_batch_stride: elements between two samples of mask / tstop
+ * (0 = valid_len * NM / valid_len).
  * rtts_heads_grad scale_dev (may be NULL): the upstream gradient of the total loss, multiplied into d_raw, d_post, d_stop. */
 int rtts_heads_grad(const float* d_raw, const float* d_post, int dpost_lead, const float* dx0, int64_t ld_dx0, const float* d_stop,
                     int B, int L, int halo, int n_mels, int width, float* dheads, const float* scale_dev, void* stream);

@@ -50,6 +50,7 @@ CONV_PERM_MAX_GROUP = 8
 SIGNATURES = {
     "rtts_lsh_hash_sort": [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "rtts_lsh_attn_fwd": [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "rtts_lsh_attn_fwd_run_length": [_i32, _i32, _i32, _i32, _i32],
     "rtts_lsh_combine_fwd": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp],
     "rtts_lsh_bwd_delta": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp],
     "rtts_lsh_attn_bwd": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
@@ -84,7 +85,7 @@ SIGNATURES = {
     "rtts_bn_act_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _u32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i64, _vp],
     "rtts_bn_act_bwd": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _u32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i64, _vp, _vp, _vp, _vp],
     "rtts_tts_loss": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32,
-                      _vp, _i64, _i32, _i32, _i64, _i64, _vp],
+                      _vp, _i64, _i32, _i32, _i64, _i64, _vp, _i64, _i64, _vp],
     "rtts_pe_add": [_vp, _vp, _vp, _f32, _u32, _vp, _i32, _i64, _i32, _vp, _vp],
     "rtts_pe_dalpha": [_vp, _vp, _f32, _u32, _vp, _i32, _i64, _i32, _vp, _vp, _vp],
     "rtts_relu_drop": [_vp, _f32, _u32, _vp, _i64, _vp],

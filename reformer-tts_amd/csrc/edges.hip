@@ -384,7 +384,11 @@ __global__ __launch_bounds__(ED_THREADS) void tts_loss_kernel(const float* __res
                                                               float w_stop, float* __restrict__ d_raw, float* __restrict__ d_post,
                                                               int64_t ld_grad, float* __restrict__ d_stop, float* __restrict__ partial,
                                                               int Lp, int Lv, const float* __restrict__ res, int64_t ld_res, int hp, int dp_lead,
-                                                              long long dp_rows, long long tgt_bs) {
+                                                              long long dp_rows, long long tgt_bs, const int* __restrict__ lv_dev,
+                                                              long long mask_bs, long long tstop_bs) {
+    // lv_dev: the loss length as a DEVICE word (a replayed hipGraph serves batches of any length up to the buffers' Lv: the
+    // host value is then only the layout of tgt / mask / tstop, whose batch strides are tgt_bs / mask_bs / tstop_bs)
+    if (lv_dev) Lv = min(max(lv_dev[0], 1), Lv);
     // res != NULL: the postnet prediction is raw + res, res in halo rows (halo hp) -- the residual add of
     // reformer_tts.py:139-140 happens here; d_post is then written in the same halo rows (dp_rows rows, halo row 0 at row
     // dp_lead, zero outside the valid set): it is the output gradient of the last convolution.
@@ -406,8 +410,7 @@ __global__ __launch_bounds__(ED_THREADS) void tts_loss_kernel(const float* __res
             d_post[prow * ld_grad + c] = 0.f;
             continue;
         }
-        const size_t ti = ((row / Lp) * Lv + t) * NM + c;
-        const float mk = mask[ti], tg = tgt[(row / Lp) * (size_t)tgt_bs + (size_t)t * NM + c];   // tgt: a time-sliced view of the batch
+        const float mk = mask[(row / Lp) * (size_t)mask_bs + (size_t)t * NM + c], tg = tgt[(row / Lp) * (size_t)tgt_bs + (size_t)t * NM + c];   // tgt: a time-sliced view of the batch
         const float rv = raw[row * ld_mel + c];
         const float pv = res ? rv + res[hrow * ld_res + c] : post[row * ld_mel + c];
         const float r = rv * mk - tg, p = pv * mk - tg;
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(ED_THREADS) void tts_loss_kernel(const float* __res
             d_stop[i] = 0.f;
             continue;
         }
-        const float x = stop[i * ld_stop], t = tstop[(i / Lp) * Lv + tt];
+        const float x = stop[i * ld_stop], t = tstop[(i / Lp) * (size_t)tstop_bs + tt];
         // BCE with logits, pos_weight pw:  (1-t) x + (1 + (pw-1) t) * softplus(-x)
         const float lw = 1.f + (pos_weight - 1.f) * t;
         const float sp = fmaxf(-x, 0.f) + log1pf(expf(-fabsf(x)));      // softplus(-x)
@@ -470,7 +473,13 @@ __global__ __launch_bounds__(ED_THREADS) void tts_loss_kernel(const float* __res
 
 // losses[0..3] = total, raw, post, stop
 __global__ void tts_loss_finalize_kernel(const float* __restrict__ partial, int nblocks, float inv_el, float inv_rows, float w_raw,
-                                         float w_post, float w_stop, float* __restrict__ losses) {
+                                         float w_post, float w_stop, float* __restrict__ losses, const int* __restrict__ lv_dev, int batch,
+                                         int Lv, int NM) {
+    if (lv_dev) {
+        const float vrows = (float)batch * (float)min(max(lv_dev[0], 1), Lv);
+        inv_el = 1.f / (vrows * NM);
+        inv_rows = 1.f / vrows;
+    }
     // one wave; lane l sums blocks l, l+64, ... in order, then a fixed butterfly: deterministic
     float a = 0.f, b = 0.f, c = 0.f;
     for (int i = threadIdx.x; i < nblocks; i += 64) { a += partial[i * 3]; b += partial[i * 3 + 1]; c += partial[i * 3 + 2]; }
@@ -823,7 +832,8 @@ extern "C" int rtts_tts_loss(const float* raw, const float* post, int64_t ld_mel
                              int64_t ld_stop, const float* tstop, int rows, int NM, int kind, float pos_weight, float w_raw, float w_post,
                              float w_stop, float* d_raw, float* d_post, int64_t ld_grad, float* d_stop, float* losses, float* partial_ws,
                              int padded_len, int valid_len, const float* res, int64_t ld_res, int halo, int dpost_lead, int64_t dpost_rows,
-                             int64_t tgt_batch_stride, void* stream) {
+                             int64_t tgt_batch_stride, const int32_t* valid_len_dev, int64_t mask_batch_stride, int64_t tstop_batch_stride,
+                             void* stream) {
     RTTS_REQUIRE(raw && (post || res) && tgt && mask && stop && tstop && d_raw && d_post && d_stop && losses && partial_ws && rows > 0 && NM > 0 &&
                      ld_grad >= NM, "rtts_tts_loss: bad arguments");
     RTTS_REQUIRE(padded_len > 0 && valid_len > 0 && valid_len <= padded_len && rows % padded_len == 0,
@@ -835,13 +845,18 @@ extern "C" int rtts_tts_loss(const float* raw, const float* post, int64_t ld_mel
                  "rtts_tts_loss: res / d_post in halo rows need halo > 0 and room for B*(L+2*halo) rows; without res: halo = lead = 0");
     if (tgt_batch_stride == 0) tgt_batch_stride = (int64_t)valid_len * NM;
     RTTS_REQUIRE(tgt_batch_stride >= (int64_t)valid_len * NM, "rtts_tts_loss: tgt_batch_stride below valid_len * NM");
+    if (mask_batch_stride == 0) mask_batch_stride = (int64_t)valid_len * NM;
+    if (tstop_batch_stride == 0) tstop_batch_stride = valid_len;
+    RTTS_REQUIRE(mask_batch_stride >= (int64_t)valid_len * NM && tstop_batch_stride >= valid_len,
+                 "rtts_tts_loss: mask / tstop batch strides below valid_len rows");
     const int blocks = 512;
     hipLaunchKernelGGL(tts_loss_kernel, dim3(blocks), dim3(ED_THREADS), 0, (hipStream_t)stream, raw, post, ld_mel, tgt, mask, stop, ld_stop,
                        tstop, rows, NM, kind, pos_weight, w_raw, w_post, w_stop, d_raw, d_post, ld_grad, d_stop, partial_ws, padded_len,
-                       valid_len, res, ld_res, halo, dpost_lead, (long long)dpost_rows, (long long)tgt_batch_stride);
+                       valid_len, res, ld_res, halo, dpost_lead, (long long)dpost_rows, (long long)tgt_batch_stride, valid_len_dev,
+                       (long long)mask_batch_stride, (long long)tstop_batch_stride);
     const float vrows = (float)(rows / padded_len) * (float)valid_len;
     hipLaunchKernelGGL(tts_loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_ws, blocks, 1.f / (vrows * NM),
-                       1.f / vrows, w_raw, w_post, w_stop, losses);
+                       1.f / vrows, w_raw, w_post, w_stop, losses, valid_len_dev, rows / padded_len, valid_len, NM);
     RTTS_LAUNCH_CHECK("rtts_tts_loss");
     return 0;
 }

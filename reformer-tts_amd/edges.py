@@ -328,14 +328,16 @@ class PostnetLoss:
                   (c._bias_pad[:c.co], c.conv.bias.detach(), _lib.SEG_COPY_F32)])
         return self._wh, self._bh, c._bias_pad
 
-    def apply(self, y_dec, true_mel, true_stop, true_mask):
-        """-> (total, raw, postnet, stop) losses; only the total is differentiable (the others are reported values)."""
-        return _PostnetLossFn.apply(y_dec, true_mel, true_stop, true_mask, self)
+    def apply(self, y_dec, true_mel, true_stop, true_mask, valid_len=None):
+        """-> (total, raw, postnet, stop) losses; only the total is differentiable (the others are reported values).
+        ``valid_len``: int32 device word -- the batch's own length when the target / mask / stop tensors are buffers padded to a
+        fixed length (Trainer's per-shape graph cache); None: their time dimension is the length."""
+        return _PostnetLossFn.apply(y_dec, true_mel, true_stop, true_mask, self, valid_len)
 
 
 class _PostnetLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y_dec, true_mel, true_stop, true_mask, ex: PostnetLoss):
+    def forward(ctx, y_dec, true_mel, true_stop, true_mask, ex: PostnetLoss, valid_len=None):
         b, lp, d = y_dec.shape                      # lp = padded decoder length
         l = true_mel.shape[1]                       # loss length (cutoff)
         nm, dev = ex.nm, y_dec.device
@@ -362,12 +364,14 @@ class _PostnetLossFn(torch.autograd.Function):
         pw = torch.empty(512 * 3, dtype=torch.float32, device=dev)
         if true_mel.dtype != torch.float32 or true_mel.stride(2) != 1 or true_mel.stride(1) != nm:
             true_mel = true_mel.float().contiguous()
+        if valid_len is not None and not (valid_len.dtype == torch.int32 and valid_len.is_cuda and valid_len.numel() == 1):
+            raise ValueError("PostnetLoss: valid_len must be a one-element int32 device tensor")
         # the targets are usually the view frames [1, L) of the batch: the kernel takes its batch stride, no copy
         _lib.call("rtts_tts_loss", heads.data_ptr(), None, 128, true_mel.data_ptr(), true_mask.contiguous().data_ptr(),
                   heads[:, nm:].data_ptr(), 128, true_stop.contiguous().data_ptr(), m, nm, lm.kind, ex.pos_weight,
                   float(lm.raw_pred_loss_weight), float(lm.post_pred_loss_weight), float(lm.stop_loss_weight), d_raw.data_ptr(),
                   d_post.data_ptr(), 128, g_stop.data_ptr(), losses.data_ptr(), pw.data_ptr(), lp, l, res.data_ptr(), 128, g.H, g.LEAD,
-                  g.alloc, true_mel.stride(0), _s())
+                  g.alloc, true_mel.stride(0), None if valid_len is None else valid_len.data_ptr(), 0, 0, _s())
         ctx.ex, ctx.state = ex, (yb, wh, saved, cur, gbuf, g, d)
         ctx.set_materialize_grads(False)
         return losses[0], losses[1], losses[2], losses[3]
@@ -379,7 +383,7 @@ class _PostnetLossFn(torch.autograd.Function):
             raise NotImplementedError("PostnetLoss: only the total loss is differentiable (the parts are reported values; "
                                       "model.TTSLoss differentiates all four)")
         if g_total is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         if ctx.state is None:
             raise RuntimeError("PostnetLoss.backward: state already consumed")
         yb, wh, saved, z_last, gbuf, g, d = ctx.state
@@ -409,7 +413,7 @@ class _PostnetLossFn(torch.autograd.Function):
         wgrad(dwh, dhb, yb, accumulate=False)
         segments([(_grad(mel.weight), dwh[:nm], _lib.SEG_ADD_F32), (_grad(stop.weight), dwh[nm:nm + 1], _lib.SEG_ADD_F32)])
         dy = gemm(dhb, wh, kn=True, out_f32=True).view(b, lp, d)
-        return dy, None, None, None, None
+        return dy, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -36,7 +36,7 @@ class _LossFn(torch.autograd.Function):
         _lib.call("rtts_tts_loss", r2.data_ptr(), p2.data_ptr(), nm, tgt.data_ptr(), msk.data_ptr(), s1.data_ptr(), 1, tst.data_ptr(),
                   rows, nm, kind, float(pos_weight), float(weights[0]), float(weights[1]), float(weights[2]), d_raw.data_ptr(),
                   d_post.data_ptr(), nm, d_stop.data_ptr(), losses.data_ptr(), ws.data_ptr(), l, l, None, 0, 0, 0, 0, 0,
-                  torch.cuda.current_stream().cuda_stream)
+                  None, 0, 0, torch.cuda.current_stream().cuda_stream)
         ctx.save_for_backward(grads)
         ctx.meta = (raw.shape, stop.shape, weights, raw.dtype, post.dtype, stop.dtype)
         return losses[0], losses[1], losses[2], losses[3]

@@ -117,8 +117,11 @@ def lsh_attn_fwd(qk, v, st, heads: int, bucket_size: int, causal: bool, mask=Non
     mask = _check_mask(mask, b, t, qk.device)
     o = torch.empty(b * heads, n_hashes, t, dh, dtype=torch.bfloat16, device=qk.device)
     lse = torch.empty(b * heads, n_hashes, t, dtype=torch.float32, device=qk.device)
+    ev = TIMING.start(f"rtts_lsh_attn_fwd/bs{bucket_size}")
     _lib.call("rtts_lsh_attn_fwd", qk.data_ptr(), v.data_ptr(), ld, st.data_ptr(), _ptr(mask), b, heads, t, dh, n_hashes,
               bucket_size, int(causal), o.data_ptr(), lse.data_ptr(), _stream())
+    # two MFMA products (Q K^T and P V) of 2*bs*(2bs)*dh FLOP per chunk, n_hashes*T/bs chunks per head
+    TIMING.stop(ev, 2.0 * 2.0 * bucket_size * (2 * bucket_size) * dh * (n_hashes * t // bucket_size) * b * heads)
     return o, lse
 
 

@@ -224,7 +224,7 @@ class Trainer:
             y = self.model.decoder_hidden(batch["phonemes"], spec[:, :-1], spectrogram_mask=batch["loss_mask"].mean(dim=-1),
                                           keys_hook=self._cut_at_encoder if split else None,
                                           enc_stack_hook=self._cut_at_enc_stack if split else None)
-            losses = self._postnet_loss.apply(y, spec[:, 1:], batch["stop_tokens"], batch["loss_mask"])
+            losses = self._postnet_loss.apply(y, spec[:, 1:], batch["stop_tokens"], batch["loss_mask"], batch.get("valid_len"))
             return losses[0], losses[1], losses[2], losses[3]
         raw, post, stop, _ = self.model(batch["phonemes"], spec[:, :-1], spectrogram_mask=batch["loss_mask"].mean(dim=-1))
         return self.loss(raw, post, stop.view(stop.shape[0], -1), spec[:, 1:], batch["stop_tokens"], batch["loss_mask"])
@@ -407,26 +407,180 @@ class Trainer:
             self.refresh_mirror()                              # the bf16 mirror the GEMMs read
             engine.WEIGHT_EPOCH[0] += 1                        # cached re-layouts of weights (conv permutations) are stale
 
-    def fit(self, host_batches, log_every: int = 0):
-        """Eager training over an iterable of HOST batches (the output of ``dataset.custom_sequence_padder``; shapes may
-        vary from batch to batch, which a captured graph cannot follow): the next batch is copied to HBM on a copy stream
-        while the current step runs; ``cfg.accumulate_grad_batches`` micro-batches make one optimizer step.
-        One call = one epoch: the exponential LR schedule advances at its end (``end_epoch``).
+    def fit(self, host_batches, log_every: int = 0, graphs: Optional[bool] = None):
+        """One epoch over an iterable of HOST batches (the output of ``dataset.custom_sequence_padder``; lengths vary from
+        batch to batch): the next batch is copied to HBM on a copy stream while the current step runs;
+        ``cfg.accumulate_grad_batches`` micro-batches make one optimizer step; the exponential LR schedule advances at the
+        end (``end_epoch``).
+
+        ``graphs`` (default: on, on the GPU): every micro-batch replays a hipGraph.  The reference's loader yields few distinct
+        PADDED shapes -- the model pads text and mel to multiples of ``pad_base`` = 256 (``reformer_tts.py:119-125``) -- so one
+        forward + loss + backward graph is captured per ``(B, ceil(Lp / pad_base), ceil(Lm / pad_base))`` the first time that
+        shape is seen (``_shape_graph``) and batches are copied into its buffers, zero-padded exactly as ``pad_to_multiple``
+        would pad them; the batch's own mel length -- the loss's denominators and cut-off (``loss.py:28-53``) -- travels as a
+        device word.  Clip + AdamW is one more graph.  A shape outside the fused edges' envelope runs eagerly.
         -> list of the (mean) total loss per optimizer step (device scalars; no per-step host sync)."""
         from ..dataset import BatchPrefetcher
         losses, group = [], []
         acc = max(1, int(self.cfg.accumulate_grad_batches))
+        use_graphs = (self.device.type == "cuda" and self.use_fused_edges) if graphs is None else bool(graphs)
+
+        def step(batches):
+            if use_graphs:
+                return self._train_group_graphed(batches)
+            return self.train_step(batches[0])[0] if len(batches) == 1 else self.train_accumulated(batches)
+
         for batch in BatchPrefetcher(host_batches, self.device):
             group.append(batch)
             if len(group) == acc:
-                losses.append(self.train_step(group[0])[0] if acc == 1 else self.train_accumulated(group))
+                losses.append(step(group))
                 group = []
                 if log_every and len(losses) % log_every == 0:
                     print(f"step {self.global_step}: loss {float(losses[-1]):.4f}", flush=True)
         if group:                                              # a trailing partial group still makes a step
-            losses.append(self.train_accumulated(group))
+            losses.append(step(group))
         self.end_epoch()
         return losses
+
+    # ------------------------------------------------------------------ per-shape graph cache (real, ragged batches)
+    MAX_SHAPE_GRAPHS = 32          # LJSpeech at pad_base 256: text 1-2 x mel 1-4 multiples x (full | last) batch size
+
+    def _shape_key(self, batch):
+        pb = self.model.pad_base
+        b, lp = batch["phonemes"].shape
+        lm = batch["spectrogram"].shape[1] - 1
+        return (b, -(-lp // pb), -(-lm // pb))
+
+    def _shape_graph(self, batch):
+        """The captured forward + loss + backward of this batch's padded shape, or None when the shape has to run eagerly.
+        Entry: device buffers in the collate layout padded to multiples of pad_base + the graph that reads them."""
+        cache = self.__dict__.setdefault("_shape_graphs", {})
+        key = self._shape_key(batch)
+        if key in cache:
+            return cache[key]
+        pb, dev = self.model.pad_base, self.device
+        b, kp, km = key
+        nm = batch["spectrogram"].shape[2]
+        bufs = dict(phonemes=torch.zeros(b, kp * pb, dtype=batch["phonemes"].dtype, device=dev),
+                    spectrogram=torch.zeros(b, km * pb + 1, nm, dtype=torch.float32, device=dev),
+                    stop_tokens=torch.zeros(b, km * pb, dtype=torch.float32, device=dev),
+                    loss_mask=torch.zeros(b, km * pb, nm, dtype=torch.float32, device=dev),
+                    valid_len=torch.ones(1, dtype=torch.int32, device=dev))
+        self.model.train()
+        if len(cache) >= self.MAX_SHAPE_GRAPHS or not self._fused_edges_ok(bufs):
+            cache[key] = None
+            return None
+        from ..model.lsh_attention import LSHSelfAttention
+        for m in self.model.modules():
+            if isinstance(m, LSHSelfAttention):
+                m.use_default_generator = True
+        self._graph_rotations = True
+        if getattr(self, "_acc_scale", None) is None:
+            self._acc_scale = torch.ones((), dtype=torch.float32, device=dev)    # 1 / micro-batches of the group, a device word
+            self._valid_ring = [dict(v=torch.zeros(2, dtype=torch.float32).pin_memory(), ev=None) for _ in range(8)]
+            self._valid_next = 0
+        entry = dict(bufs=bufs, graph=None, out=None)
+        self._fill_shape_buffers(entry, batch)
+        hooks = [(seq, seq.block_done_hook) for seq in (self.model.enc.reformer.layers, self.model.dec.reformer.layers)]
+
+        def micro():
+            # caches keyed by the weight epoch (the convolutions' GEMM-layout weight copies, the decoder prenet's padded weight)
+            # are refreshed by launches the HOST decides on: the capture must contain them, a replay follows an optimizer step
+            engine.WEIGHT_EPOCH[0] += 1
+            total = self.forward_loss(bufs)[0]
+            self._run_backward(total * self._acc_scale)
+            return total.detach()
+
+        # the warm-up passes below must not leak into the running step: gradients and BatchNorm statistics are put back
+        saved_g = self.flat_g.clone()
+        saved_buffers = [(t, t.clone()) for t in self.model.buffers()]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        try:
+            for seq, _ in hooks:
+                seq.block_done_hook = None                  # no collective inside a capture: the exchange follows the last replay
+            with torch.cuda.stream(side):
+                for _ in range(2):                          # allocator, lazy attributes
+                    micro()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            pool = next((e["graph"].pool() for e in cache.values() if e is not None), None)
+            with self._capturing(graph, **({} if pool is None else {"pool": pool})):
+                entry["out"] = micro()
+            entry["graph"] = graph
+        finally:
+            for seq, h in hooks:
+                seq.block_done_hook = h
+            self.flat_g.copy_(saved_g)
+            for t, c in saved_buffers:
+                t.copy_(c)
+        cache[key] = entry
+        return entry
+
+    def _fill_shape_buffers(self, entry, batch):
+        """Device batch (its own lengths) -> the entry's padded buffers: same zeros as ``pad_to_multiple`` appends."""
+        bufs = entry["bufs"]
+        lp = batch["phonemes"].shape[1]
+        lm = batch["spectrogram"].shape[1] - 1
+        for name, src, n in (("phonemes", batch["phonemes"], lp), ("spectrogram", batch["spectrogram"], lm + 1),
+                             ("stop_tokens", batch["stop_tokens"], lm), ("loss_mask", batch["loss_mask"], lm)):
+            dst = bufs[name]
+            if dst.shape[1] > n:
+                dst[:, n:].zero_()
+            dst[:, :n].copy_(src, non_blocking=True)
+        bufs["valid_len"].fill_(lm)
+
+    def _train_group_graphed(self, batches):
+        """``train_accumulated`` with every micro-batch replayed from its shape's graph (eager for shapes without one)."""
+        from .._seeds import seed_base
+        n = len(batches)
+        self.model.train()
+        entries = [self._shape_graph(b) for b in batches]      # captures first: a capture must not see a half-built gradient
+        self.zero_grad()
+        if getattr(self, "_acc_scale", None) is not None:
+            self._acc_scale.fill_(1.0 / n)
+        if getattr(self, "_graph_opt_only", None) is None and any(e is not None for e in entries):
+            self.set_step_hyper(self.global_step)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            saved = [t.clone() for t in (self.flat_p, self.flat_m, self.flat_v, self.flat_pb)]
+            with torch.cuda.stream(side):
+                self.optimizer_step(update_hyper=False)        # warm-up of the two launches (their results are discarded)
+            torch.cuda.current_stream().wait_stream(side)
+            self.global_step -= 1
+            for t, c in zip((self.flat_p, self.flat_m, self.flat_v, self.flat_pb), saved):
+                t.copy_(c)
+            self._graph_opt_only = torch.cuda.CUDAGraph()
+            pool = next(e["graph"].pool() for e in entries if e is not None)
+            with self._capturing(self._graph_opt_only, pool=pool):
+                self.optimizer_step(update_hyper=False)
+            self.global_step -= 1
+        self.set_step_hyper(self.global_step)                  # lr, Adam step size, dropout seed of this optimizer step
+        total = None
+        for i, (batch, entry) in enumerate(zip(batches, entries)):
+            if entry is None:
+                self._accumulating = True                      # the exchange happens once, below
+                loss = self.forward_loss(batch)[0]
+                self._run_backward(loss * (1.0 / n))
+                self._accumulating = False
+                loss = loss.detach()
+            else:
+                self._fill_shape_buffers(entry, batch)
+                if i:                                          # the graph's dropout sites are frozen constants + this device word:
+                    seed_base(self.device).add_(7919)          # micro-batches of one step must not repeat each other's masks
+                entry["graph"].replay()
+                loss = entry["out"].clone()
+            total = loss if total is None else total + loss
+        if self.world > 1:
+            dist.all_reduce(self.flat_g, group=self.pg)
+        if getattr(self, "_graph_opt_only", None) is not None:
+            self.global_step += 1
+            self._graph_opt_only.replay()
+            engine.WEIGHT_EPOCH[0] += 1
+        else:
+            self.optimizer_step(update_hyper=False)
+        return total / n
 
     # ------------------------------------------------------------------ hipGraph replay of the whole step
     _bulk_allreduce = False

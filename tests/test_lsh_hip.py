@@ -119,7 +119,7 @@ def _run_fwd(ops, b, h, t, bs, nh, causal, masked, seed=0):
 @pytest.mark.parametrize("b,h,t,bs,nh,causal,masked", CASES)
 def test_attention_forward_vs_oracle(ops, b, h, t, bs, nh, causal, masked):
     """Tolerance: inputs are identical bf16 values; the kernel rounds P to bf16 (2^-9 rel) before
-    PV and o/out to bf16 on store => |err| <= ~1e-2 * max|v| on rows that see other tokens.
+    PV and o/out to bf16 on store => |err| ~ 4e-3 * max|v| on rows that see other tokens (bounds: 3x achieved).
     Rows that can only see themselves (lse ~ -5e4) sit on fp32's 4e-3 logsumexp grid, so the
     round weights legitimately differ there (see oracle/lsh_ref.py)."""
     r = _run_fwd(ops, b, h, t, bs, nh, causal, masked)
@@ -130,16 +130,22 @@ def test_attention_forward_vs_oracle(ops, b, h, t, bs, nh, causal, masked):
     m = None if r["mask"] is None else r["mask"].unsqueeze(1).expand(b, h, t).reshape(b * h, t)
     out_ref, o_ref, lse_ref = lsh_ref.lsh_attention_sorted(qk, v, sticker, undo, bs, nh, causal, m, return_parts=True)
     o, lse = r["o"].float().cpu(), r["lse"].cpu()
-    torch.testing.assert_close(lse, lse_ref, rtol=2e-3, atol=2e-2)
-    torch.testing.assert_close(o, o_ref, rtol=2e-2, atol=2e-2)
     out = _heads_first(r["out"], b, t, h, dh)
     lse_tot_ref = torch.logsumexp(lse_ref, dim=1)
     normal = lse_tot_ref > -1e4
-    torch.testing.assert_close(out[normal], out_ref[normal], rtol=2e-2, atol=2e-2)
+    vmax = v.abs().max().item()
+    e_lse = ((lse - lse_ref).abs() / (1 + lse_ref.abs())).max().item()
+    e_o = (o - o_ref).abs().max().item() / vmax
+    e_out = (out[normal] - out_ref[normal]).abs().max().item() / vmax
+    e_mean = (out[normal] - out_ref[normal]).abs().mean().item() / vmax
+    print(f"\n[lsh attention forward B={b} H={h} T={t} bs={bs} R={nh} causal={causal} masked={masked}] / max|v|: o max {e_o:.2e}, "
+          f"out max {e_out:.2e} mean {e_mean:.2e}; lse max {e_lse:.2e} of 1+|lse| (tol 1.2e-2, 1.2e-2, 8e-4, 1e-3)")
+    # bounds = ~3x the largest achieved error over all cases (o / out 3.9e-3 of max|v|, mean 2.4e-4, lse 3e-4): a regression
+    # that triples the error fails
+    torch.testing.assert_close(lse, lse_ref, rtol=1e-3, atol=1e-3)
+    assert e_o < 1.2e-2 and e_out < 1.2e-2 and e_mean < 8e-4, (e_o, e_out, e_mean)
     torch.testing.assert_close(out[~normal], out_ref[~normal], rtol=1e-1, atol=1e-1)
-    torch.testing.assert_close(r["lse_tot"].cpu(), lse_tot_ref, rtol=2e-3, atol=2e-2)
-    # mean error is far below the worst case
-    assert (out[normal] - out_ref[normal]).abs().mean() < 3e-3
+    torch.testing.assert_close(r["lse_tot"].cpu(), lse_tot_ref, rtol=1e-3, atol=1e-3)
 
 
 # ------------------------------------------------------------------ attention backward
@@ -149,7 +155,7 @@ def test_attention_backward_vs_oracle_autograd(ops, monkeypatch, b, h, t, bs, nh
     """Gradients of sum(out * dout) w.r.t. qk and v against autograd through the oracle on the same
     permutation, for both forms of the kernel (``walk``: one workgroup per chunk / workgroups walking 4 chunks --
     the library picks by shape, the small test shapes would all get the first).  bf16 partials and bf16 P/dS operands
-    bound the error at ~2% of the gradient scale."""
+    put the error at ~0.5% of the gradient scale; the bounds are 3x what is achieved."""
     if (nh * (t // bs)) % max(int(walk), 1):
         pytest.skip("the run length does not divide this ring")
     monkeypatch.setenv("RTTS_LSH_BWD_WALK", walk)
@@ -172,10 +178,12 @@ def test_attention_backward_vs_oracle_autograd(ops, monkeypatch, b, h, t, bs, nh
         scale = ref.abs().max().item()
         err = (got - ref).abs()
         msgs.append(f"{name} max {err.max().item() / scale:.2e} mean {err.mean().item() / scale:.2e} rel-L2 {float((got - ref).norm() / ref.norm()):.2e}")
-        assert err.max().item() < 4e-2 * scale + 1e-3, (name, err.max().item(), scale)
-        assert err.mean().item() < 4e-3 * scale + 1e-4, (name, err.mean().item(), scale)
+        # ~3x the largest achieved error over all cases and both kernel forms (max 5.4e-3, mean 3e-4, rel-L2 3.2e-3)
+        assert err.max().item() < 1.5e-2 * scale, (name, err.max().item(), scale)
+        assert err.mean().item() < 1e-3 * scale, (name, err.mean().item(), scale)
+        assert float((got - ref).norm() / ref.norm()) < 1e-2, (name, float((got - ref).norm() / ref.norm()))
     print(f"\n[lsh attention backward B={b} H={h} T={t} bs={bs} R={nh} causal={causal} masked={masked} walk={walk}] errors / max|ref|: " + "; ".join(msgs) +
-          " (tol max 4e-2, mean 4e-3)")
+          " (tol max 1.5e-2, mean 1e-3, rel-L2 1e-2)")
 
 
 @pytest.mark.parametrize("b,h,t,bs,nh,causal,masked", CASES)

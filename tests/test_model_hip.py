@@ -351,6 +351,38 @@ def test_training_step_path_gradients_vs_oracle(gpu):
         assert rel < (0.10 if name.startswith("enc.prenet") else 8e-2), (name, rel)
 
 
+@pytest.mark.parametrize("case", ["baseline_3+3", "long_6+6"])
+def test_full_depth_gradients_vs_oracle(gpu, case):
+    """BASELINE configs #2 and #4 at their REAL depth through the training step's own path (Trainer.forward_loss /
+    Trainer.backward): config/baseline.yml 3 + 3 layers, d = 512, B = 2 (ragged), mel 1024; config/bucket-size-64-18-06.yml
+    6 + 6 layers, buckets 64 / 64, B = 1, mel 4096 -- dropouts off so that the fp32 CPU oracle (plain autograd, the HIP
+    hash/sort's permutations) is comparable.  What this adds to the one-layer tests: every block index of the production
+    programs (kwargs routing per decoder layer, three / six cross-attention blocks summing into one encoder backward, the
+    per-layer weight-gradient flushes) carries a checked gradient."""
+    from reformer_tts_amd.model.config import as_kwargs, baseline_model_config, long_sequence_model_config
+    cfg = as_kwargs(long_sequence_model_config() if case == "long_6+6" else baseline_model_config())
+    for k in ("enc_prenet_kwargs", "dec_prenet_kwargs", "postnet_kwargs"):
+        cfg[k]["dropout"] = 0.0
+    cfg["scp_encoding_dropout"] = 0.0
+    cfg["enc_reformer_kwargs"]["attn_kwargs"]["post_attn_dropout"] = 0.0
+    cfg["dec_reformer_kwargs"]["self_attn_kwargs"]["post_attn_dropout"] = 0.0
+    cfg["dec_reformer_kwargs"]["attn_kwargs"]["dropout"] = 0.0
+    if case == "long_6+6":
+        assert cfg["enc_reformer_kwargs"]["depth"] == 6 and cfg["dec_reformer_kwargs"]["depth"] == 6
+        batch = model_ref.synthetic_batch(1, 200, 4096, seed=4)
+    else:
+        assert cfg["enc_reformer_kwargs"]["depth"] == 3 and cfg["dec_reformer_kwargs"]["depth"] == 3
+        batch = model_ref.synthetic_batch(2, 200, 1024, ragged=True, seed=3)
+    rels = _gradients_vs_oracle(gpu, cfg, batch, 7, f"grad_rel_err_full_depth_{case}.txt", through_trainer=True)
+    _report(f"full depth, {case}", rels)
+    assert len(rels) > (100 if case == "baseline_3+3" else 200)
+    # every ReLU gate between a parameter and the loss adds its bf16 sign flips (sqrt(2 f) each, ~4e-2 per feed-forward layer,
+    # test_gemm_hip.py): deeper stacks collect more of them than the one-layer tests' 8e-2.  Bounds = ~1.5x the largest
+    # achieved error of each group; a wiring mistake (a block reading another layer's mask, keys or permutation) is O(1).
+    for name, rel in rels.items():
+        assert rel < (0.20 if name.startswith("enc.") else 0.12), (name, rel)
+
+
 def test_fused_engine_matches_general_path(gpu):
     """The explicit executor (engine.py) and the nested-autograd path run the same kernels for the
     attention cores; everything around them differs in fusion only => outputs and every gradient
@@ -372,6 +404,9 @@ def test_fused_engine_matches_general_path(gpu):
         model.train()
         model.enc.reformer.layers.use_fused = fused
         model.dec.reformer.layers.use_fused = fused
+        for layer in _lsh_layers(model):              # the same hash rotations on both paths (each would draw its own)
+            layer.forced_rotations = torch.randn(1, 64, 4, layer_buckets(layer, model, batch) // 2,
+                                                 generator=torch.Generator().manual_seed(3))
         spec = batch["spectrogram"]
         raw, post, stop, _ = model(batch["phonemes"], spec[:, :-1], spectrogram_mask=batch["loss_mask"].mean(-1))
         res = TTSLoss(torch.tensor(5.0))(raw, post, stop.view(stop.shape[0], -1), spec[:, 1:], batch["stop_tokens"], batch["loss_mask"])
@@ -1129,6 +1164,64 @@ def test_fit_over_ragged_host_batches(gpu):
     losses = [float(x) for x in tr.fit(batches)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
 
+
+
+def test_fit_graph_cache_follows_the_eager_trajectory(gpu):
+    """Trainer.fit with one captured forward + loss + backward per PADDED shape (wrappers.py:213-222 yields few of them at
+    pad_base granularity) against eager fit from the same start: ragged batches of three (text, mel) lengths that fall into
+    two padded shapes -- so one graph serves two different real lengths (the loss length is a device word) -- with
+    accumulate_grad_batches = 2 (a group mixes shapes) and a trailing partial group.  Same hash rotations on both sides;
+    the per-step mean losses agree to 2e-3 relative and the parameters after the epoch point the same way."""
+    from reformer_tts_amd.dataset import custom_sequence_padder
+    from reformer_tts_amd.model.config import TTSTrainingConfig
+    from reformer_tts_amd.training import Trainer, build_model
+    g = torch.Generator().manual_seed(0)
+
+    def items(n, lp, lm):
+        return [dict(phonemes=torch.randint(1, 77, (int(lp * (0.6 + 0.4 * k / n)),), generator=g),
+                     spectrogram=(torch.randn(int(lm * (0.5 + 0.5 * k / n)), 80, generator=g) * 2 - 5).clamp(-11.5, 2.0)) for k in range(1, n + 1)]
+    a = custom_sequence_padder(items(2, 60, 200), pin_memory=True)        # text 60 -> 128, mel 200 -> 256
+    b = custom_sequence_padder(items(2, 90, 150), pin_memory=True)        # text 90 -> 128, mel 150 -> 256: the same graph
+    c = custom_sequence_padder(items(2, 150, 300), pin_memory=True)       # text 150 -> 256, mel 300 -> 384: another one
+    batches = [a, b, c, a, b, c, a]                                        # groups (a,b) (c,a) (b,c) (a)
+    runs = []
+    for graphs in (False, True):
+        from reformer_tts_amd import _seeds
+        _seeds.reset()
+        model = build_model(_hip_cfg(), gpu)
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        model.load_state_dict(synth.synth_state_dict(shapes, seed=11), strict=False)
+        for layer in _lsh_layers(model):
+            layer.forced_rotations = {nb: torch.randn(1, 64, 4, nb // 2, generator=torch.Generator().manual_seed(nb)) for nb in (2, 4, 6)}
+        tr = Trainer(model, TTSTrainingConfig(batch_size=2, learning_rate=1e-3, warmup_steps=None, accumulate_grad_batches=2), gpu)
+        model.train()
+        losses = [float(x) for x in tr.fit(batches, graphs=graphs)]
+        torch.cuda.synchronize()
+        assert tr.global_step == 4 and len(losses) == 4
+        if graphs:
+            cache = tr._shape_graphs
+            assert sorted(cache) == [(2, 1, 2), (2, 2, 3)] and all(e is not None for e in cache.values()), cache.keys()
+        runs.append((losses, tr.flat_p.clone(), {n: b_.clone() for n, b_ in model.named_buffers() if "running" in n}))
+    (l_e, p_e, bn_e), (l_g, p_g, bn_g) = runs
+    print(f"\n[fit: eager vs per-shape graphs] losses {l_e} vs {l_g}")
+    np.testing.assert_allclose(l_g, l_e, rtol=2e-3)
+    p0 = synth.synth_state_dict(shapes, seed=11)
+    cos = torch.nn.functional.cosine_similarity(p_g, p_e, dim=0).item()
+    assert cos > 0.9999, cos
+    upd_e, upd_g = p_e - _flat_like(tr, p0, gpu), p_g - _flat_like(tr, p0, gpu)
+    cos_u = torch.nn.functional.cosine_similarity(upd_e, upd_g, dim=0).item()
+    print(f"[fit: eager vs per-shape graphs] cosine of the accumulated updates {cos_u:.4f}")
+    assert cos_u > 0.97, cos_u                    # Adam divides by sqrt(v): elements with a tiny gradient take noisy +-lr steps
+    for n in bn_e:                                 # the captures' warm-up passes left no trace in the BatchNorm statistics
+        torch.testing.assert_close(bn_g[n], bn_e[n], rtol=2e-2, atol=2e-3)
+
+
+def _flat_like(tr, sd, device):
+    """A reference-named state dict laid out like the trainer's flat parameter buffer."""
+    out = torch.zeros_like(tr.flat_p)
+    for n, (s, e) in tr.offsets.items():
+        out[s:e] = sd[n].reshape(-1).to(device)
+    return out
 
 
 def test_three_training_steps_follow_the_oracle_trajectory(gpu):

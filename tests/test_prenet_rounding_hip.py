@@ -1,0 +1,105 @@
+"""Encoder prenet executor (embedding -> 3 x [Conv1d k5, BatchNorm(train), ReLU] -> Linear -> positional encoding;
+reference ``reformer_tts/model/modules.py:8-61,172-192``) against a FLOAT64 MODEL OF ITS OWN ARITHMETIC.
+
+Against the fp32 oracle the gradients of this chain sit at 6-9 % rel-L2 (tests/test_model_hip.py): three ReLU gates behind
+BatchNorm flip wherever a pre-activation lies within the bf16 error of zero, which is a property of bf16 operands, not of
+the kernels.  To separate the two, the model below computes the SAME function in float64 with a bf16 rounding at exactly
+the places where the executor stores bf16 (forward: the stack's input, every layer's activation, the conv / linear
+weights, the projection's output; backward: the gradient of every layer's activation and of every convolution's output,
+the projection's output gradient) -- the gates then agree, and what is left is kernel error: fp32 accumulation, fp32
+BatchNorm statistics, the order of the sums.  Expected and asserted: <= 1e-2 rel-L2 on every gradient (achieved is printed)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _r(x):
+    return x.to(torch.bfloat16).to(torch.float64)
+
+
+class _Round(torch.autograd.Function):
+    """bf16 rounding of the value (``fwd``) and / or of the gradient (``bwd``), computed in float64."""
+
+    @staticmethod
+    def forward(ctx, x, fwd, bwd):
+        ctx.bwd = bwd
+        return _r(x) if fwd else x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (_r(g) if ctx.bwd else g), None, None
+
+
+def _model64(sd, ids, table, eps=1e-5):
+    """float64 forward with the executor's rounding points; ``sd``: float64 leaf tensors keyed like the module."""
+    x = sd["embed.weight"][ids] * (ids != 0).unsqueeze(-1)        # (B, L, C) fp32 values, exact; padding_idx 0: zero row, no gradient
+    x = _Round.apply(x, True, False)                              # rtts_to_halo: bf16 rows; the stack's input gradient stays fp32
+    for i in (1, 2, 3):
+        w = _Round.apply(sd[f"convolutions.conv{i}.weight"], True, False)      # bf16 weight image; dW accumulates in fp32
+        y = F.conv1d(x.transpose(1, 2), w, None, padding=2)       # fp32-accumulated in the kernel; the bias is cancelled by the BatchNorm
+        y = _Round.apply(y, False, True)                          # rtts_bn_act_bwd stores dy as bf16
+        mean = y.mean(dim=(0, 2), keepdim=True)
+        var = y.var(dim=(0, 2), unbiased=False, keepdim=True)
+        z = (y - mean) / torch.sqrt(var + eps) * sd[f"convolutions.bn{i}.weight"].view(1, -1, 1) + sd[f"convolutions.bn{i}.bias"].view(1, -1, 1)
+        x = _Round.apply(torch.relu(z).transpose(1, 2), True, True)            # activation stored bf16; its gradient arrives bf16
+    w = _Round.apply(sd["projection.weight"], True, False)
+    y = _Round.apply(x @ w.t() + sd["projection.bias"], True, True)            # GEMM epilogue stores bf16; dy is cast to bf16 for dW / dx
+    return y + sd["alpha"] * table
+
+
+@pytest.mark.parametrize("b,l", [(2, 256), (12, 256)])
+def test_encoder_prenet_chain_vs_float64_model_of_its_own_roundings(gpu, b, l):
+    from reformer_tts_amd import engine
+    from reformer_tts_amd.model.modules import EncoderPreNet, ScaledPositionalEncoding
+    torch.manual_seed(21)
+    c = 512
+    prenet = EncoderPreNet(77, c, dropout=0.0).to(gpu).train()
+    pe = ScaledPositionalEncoding(c, 0.0).to(gpu).train()
+    with torch.no_grad():
+        for i in (1, 2, 3):                                       # trained-looking BatchNorm parameters, not (1, 0)
+            bn = getattr(prenet.convolutions, f"bn{i}")
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.5, 0.5)
+    ids = torch.randint(1, 77, (b, l), device=gpu)
+    ids[0, l - 56:] = 0                                            # right padding (text 200 -> 256)
+    wgt = torch.randn(b, l, c, device=gpu)
+    out = prenet(ids, pe=pe)
+    assert out.dtype == torch.float32
+    (out * wgt).sum().backward()
+    engine.flush_wgrad()
+    torch.cuda.synchronize()
+
+    names = ["embed.weight", "projection.weight", "projection.bias"] + \
+            [f"convolutions.{k}{i}.{p}" for i in (1, 2, 3) for k, p in (("conv", "weight"), ("bn", "weight"), ("bn", "bias"))]
+    mods = dict(prenet.named_parameters())
+    sd = {n: mods[n].detach().double().cpu().requires_grad_() for n in names}
+    sd["alpha"] = pe.alpha.detach().double().cpu().requires_grad_()
+    table = pe.table(l, gpu).double().cpu()
+    ref = _model64(sd, ids.cpu(), table)
+    (ref * wgt.double().cpu()).sum().backward()
+
+    def rel(a, r):
+        return float((a.double().cpu() - r).norm() / r.norm())
+
+    e_out = rel(out.detach(), ref.detach())
+    rels = {n: rel(mods[n].grad, sd[n].grad) for n in names}
+    # the scalar alpha gradient is a sum of B*L*C signed terms that may cancel: measured against the size of those terms
+    terms = (wgt.double().cpu() * table).norm()
+    rels["alpha"] = float((pe.alpha.grad.double().cpu() - sd["alpha"].grad).abs() / terms)
+    top = sorted(rels.items(), key=lambda kv: -kv[1])
+    print(f"\n[encoder prenet vs float64 model of its roundings, B={b} L={l}] output rel-L2 {e_out:.2e}; gradients: " +
+          ", ".join(f"{k} {v:.2e}" for k, v in top[:6]) + f"; median {sorted(rels.values())[len(rels) // 2]:.2e}")
+    assert e_out < 4e-3, e_out                    # one bf16 rounding of the result is 1.7e-3 rel-L2
+    for n, v in rels.items():
+        assert v < 1e-2, (n, v)
+    # padding_idx row: no gradient
+    assert float(mods["embed.weight"].grad[0].abs().max()) == 0.0
