@@ -14,6 +14,16 @@
  *   - the library never allocates, frees or synchronises: outputs and
  *     workspaces are caller-owned, launches go to the `stream` argument
  *     (a hipStream_t passed as void*), so calls are graph-capturable;
+ *   - DEVICE of a call: the stream's.  A forward is called from the Python main
+ *     thread, a backward from PyTorch's autograd worker thread for the device
+ *     (nested inside the reversible function's backward), and HIP's current
+ *     device is per thread -- so every launching entry point first binds the
+ *     calling thread to the device its `stream` belongs to (hipStreamGetDevice +
+ *     hipSetDevice when it differs): the explicit device ordinal SURVEY.md 8(b)
+ *     asks for travels inside the stream handle and cannot disagree with it.
+ *     A NULL stream (the legacy default stream) means the thread's current
+ *     device.  Every pointer of a call must belong to that device; return -3 =
+ *     the stream handle is not a stream of this process;
  *   - `bf16` buffers hold IEEE bfloat16 (uint16_t storage);
  *   - activations of width d = H*dh are row-major with an explicit row stride
  *     `ld` in ELEMENTS (so qk and v may be the two halves of one (B*T, 2d) GEMM
@@ -366,7 +376,11 @@ int rtts_peak_mfma(float* sink, int workgroups, int iters, void* stream);
  *   rtts_sw_gate          fused_add_tanh_sigmoid_multiply (:10-24) of the pointwise output pw (B*L, 2C) and the layer's
  *                         slice [cond_offset, +2C) of the conditioning (B*Lm, ld_cond), nearest-upsampled by `upsample`
  *                         (nn.Upsample, :216-219) -> acts bf16 (B*L, C)
- *   rtts_sw_coupling_inv  a1 = (a1 - b) / exp(s) on channels [half, 2*half) of audio (rows, ld_audio), wn_out = [s | b] (:353-359) */
+ *   rtts_sw_coupling_inv  a1 = (a1 - b) / exp(s) on channels [half, 2*half) of audio (rows, ld_audio), wn_out = [s | b] (:353-359)
+ *   rtts_sw_coupling_inv1x1  the same coupling followed by the inverse invertible 1x1 convolution (:57-85, :360-361) in one
+ *                         launch: out (rows, n) fp32 = [a0 | (a1 - b) / exp(s)] @ winv^T, winv (n, n) fp32 row-major = W^-1,
+ *                         wn_out = [s | b] with row stride ld_wn (the WN block's end_conv GEMM output, consumed in place);
+ *                         n even, <= 128; NOT in place; fp32 FMA arithmetic (the audio path never drops to bf16) */
 int rtts_sw_depthwise_k3(const float* x, const float* w, const float* bias, int B, int L, int C, void* y,
                          const float* edge_lo, const float* edge_hi, void* stream);
 /* edge_lo / edge_hi (C floats, may be NULL) are subtracted at l = 0 / l = L-1: the share of a folded BatchNorm constant
@@ -374,6 +388,8 @@ int rtts_sw_depthwise_k3(const float* x, const float* w, const float* bias, int 
 int rtts_sw_gate(const void* pw, const void* cond, int64_t ld_cond, int cond_offset, int upsample, int B, int L, int Lm, int C,
                  void* acts, void* stream);
 int rtts_sw_coupling_inv(float* audio, int64_t ld_audio, const float* wn_out, int64_t rows, int half, void* stream);
+int rtts_sw_coupling_inv1x1(const float* audio, int64_t ld_audio, const float* wn_out, int64_t ld_wn, const float* winv, int n,
+                            int64_t rows, float* out, int64_t ld_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -102,6 +102,7 @@ SIGNATURES = {
     "rtts_sw_depthwise_k3": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "rtts_sw_gate": [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "rtts_sw_coupling_inv": [_vp, _i64, _vp, _i64, _i32, _vp],
+    "rtts_sw_coupling_inv1x1": [_vp, _i64, _vp, _i64, _vp, _i32, _i64, _vp, _i64, _vp],
     "rtts_adamw_step": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _vp],
 }
 

@@ -691,6 +691,7 @@ static inline uint32_t ed_thresh(float p) { return p <= 0.f ? 0u : (uint32_t)((d
 
 extern "C" int rtts_to_halo(const void* src, int64_t ld_src, int64_t src_batch_stride, int C_src, int src_f32, int B, int L, int halo, int C,
                             void* dst, int lead, int64_t rows, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(src && dst && B > 0 && L > 0 && halo >= 0 && C > 0 && C % 8 == 0 && C_src > 0 && C_src % 8 == 0 && C_src <= C && ld_src >= C_src &&
                      ld_src % (src_f32 ? 4 : 8) == 0, "rtts_to_halo: bad arguments");
     if (src_batch_stride == 0) src_batch_stride = (int64_t)L * ld_src;
@@ -711,6 +712,7 @@ extern "C" int rtts_to_halo(const void* src, int64_t ld_src, int64_t src_batch_s
 
 extern "C" int rtts_heads_grad(const float* d_raw, const float* d_post, int dpost_lead, const float* dx0, int64_t ld_dx0, const float* d_stop,
                                int B, int L, int halo, int n_mels, int width, float* dheads, const float* scale_dev, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(d_raw && d_post && dx0 && d_stop && dheads && B > 0 && L > 0 && halo >= 0 && width % 4 == 0 && n_mels < width && dpost_lead >= 0,
                  "rtts_heads_grad: bad arguments");
     hipLaunchKernelGGL(heads_grad_kernel, dim3(ed_grid((size_t)B * L * (width / 4))), dim3(ED_THREADS), 0, (hipStream_t)stream, d_raw, d_post,
@@ -720,6 +722,7 @@ extern "C" int rtts_heads_grad(const float* d_raw, const float* d_post, int dpos
 }
 
 extern "C" int rtts_conv_w_perm(const float* w, int Co, int Ci, int CP, void* wp, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(w && wp && Co > 0 && Ci > 0 && CP >= Ci, "rtts_conv_w_perm: bad arguments");
     hipLaunchKernelGGL(conv_w_perm_kernel, dim3(ed_grid((size_t)Co * 5 * CP)), dim3(ED_THREADS), 0, (hipStream_t)stream, w, Co, Ci, CP, (bf16_t*)wp);
     RTTS_LAUNCH_CHECK("rtts_conv_w_perm");
@@ -727,6 +730,7 @@ extern "C" int rtts_conv_w_perm(const float* w, int Co, int Ci, int CP, void* wp
 }
 
 extern "C" int rtts_conv_w_perm_grouped(const rtts_conv_perm_job* jobs, int n, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(jobs && n > 0 && n <= RTTS_CONV_PERM_MAX_GROUP, "rtts_conv_w_perm_grouped: 1..%d jobs", RTTS_CONV_PERM_MAX_GROUP);
     CwGroup g;
     g.n = n;
@@ -744,6 +748,7 @@ extern "C" int rtts_conv_w_perm_grouped(const rtts_conv_perm_job* jobs, int n, v
 }
 
 extern "C" int rtts_conv_dw_unperm_grouped(const rtts_conv_perm_job* jobs, int n, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(jobs && n > 0 && n <= RTTS_CONV_PERM_MAX_GROUP, "rtts_conv_dw_unperm_grouped: 1..%d jobs", RTTS_CONV_PERM_MAX_GROUP);
     CwGroup g;
     g.n = n;
@@ -761,6 +766,7 @@ extern "C" int rtts_conv_dw_unperm_grouped(const rtts_conv_perm_job* jobs, int n
 }
 
 extern "C" int rtts_conv_dw_unperm(const float* dwp, int Co, int Ci, int CP, float* dw, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(dwp && dw && Co > 0 && Ci > 0 && CP >= Ci, "rtts_conv_dw_unperm: bad arguments");
     hipLaunchKernelGGL(conv_dw_unperm_kernel, dim3(ed_grid((size_t)Co * Ci * 5)), dim3(ED_THREADS), 0, (hipStream_t)stream, dwp, Co, Ci, CP, dw);
     RTTS_LAUNCH_CHECK("rtts_conv_dw_unperm");
@@ -775,6 +781,7 @@ static inline dim3 ed_col_grid(int M, int C) {
 
 extern "C" int rtts_bn_stats(const float* y, int B, int L, int halo, int C, float* mean, float* rstd, float* run_mean, float* run_var,
                              const float* mean_shift, int64_t* num_batches, float* partial_ws, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(y && mean && rstd && partial_ws && B > 0 && L > 0 && halo >= 0 && C > 0 && C % 4 == 0, "rtts_bn_stats: bad arguments");
     const EdHalo g = ed_halo(B, L, halo);
     const dim3 grid = ed_col_grid(B * g.P, C);
@@ -790,6 +797,7 @@ extern "C" int rtts_bn_stats(const float* y, int B, int L, int halo, int C, floa
 extern "C" int rtts_bn_act_fwd(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
                                float drop_p, uint32_t seed, const uint32_t* seed_dev, int B, int L, int halo, int C, void* z, int z_halo,
                                int z_lead, int64_t z_rows, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(y && mean && rstd && gamma && beta && z && B > 0 && L > 0 && halo >= 0 && C % 4 == 0 && (act == 1 || act == 2) && drop_p >= 0.f &&
                      drop_p < 1.f, "rtts_bn_act_fwd: bad arguments");
     const EdHalo g = ed_halo(B, L, halo);
@@ -806,6 +814,7 @@ extern "C" int rtts_bn_act_fwd(const float* y, const float* mean, const float* r
 extern "C" int rtts_bn_act_bwd(const float* y, const void* dz, int dz_halo, const float* mean, const float* rstd, const float* gamma,
                                const float* beta, int act, float drop_p, uint32_t seed, const uint32_t* seed_dev, int B, int L, int halo, int C,
                                void* dy, int dy_lead, int64_t dy_rows, float* dgamma, float* dbeta, float* partial_ws, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(y && dz && mean && rstd && gamma && beta && dy && dgamma && dbeta && partial_ws && B > 0 && L > 0 && halo >= 0 && C % 4 == 0 &&
                      (act == 1 || act == 2), "rtts_bn_act_bwd: bad arguments");
     const EdHalo g = ed_halo(B, L, halo);
@@ -834,6 +843,7 @@ extern "C" int rtts_tts_loss(const float* raw, const float* post, int64_t ld_mel
                              int padded_len, int valid_len, const float* res, int64_t ld_res, int halo, int dpost_lead, int64_t dpost_rows,
                              int64_t tgt_batch_stride, const int32_t* valid_len_dev, int64_t mask_batch_stride, int64_t tstop_batch_stride,
                              void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(raw && (post || res) && tgt && mask && stop && tstop && d_raw && d_post && d_stop && losses && partial_ws && rows > 0 && NM > 0 &&
                      ld_grad >= NM, "rtts_tts_loss: bad arguments");
     RTTS_REQUIRE(padded_len > 0 && valid_len > 0 && valid_len <= padded_len && rows % padded_len == 0,
@@ -863,6 +873,7 @@ extern "C" int rtts_tts_loss(const float* raw, const float* post, int64_t ld_mel
 
 extern "C" int rtts_embedding_bwd(const int64_t* ids, const float* dx, int rows, int C, int n_embeddings, int padding_idx, float* dE,
                                   float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(ids && dx && dE && rows > 0 && C > 0 && n_embeddings > 0 && drop_p >= 0.f && drop_p < 1.f, "rtts_embedding_bwd: bad arguments");
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3(n_embeddings, (C + 63) / 64), dim3(ED_THREADS), 0, (hipStream_t)stream,
                        ids, dx, rows, C, padding_idx, dE, seed, seed_dev, ed_thresh(drop_p), 1.f / (1.f - drop_p));
@@ -872,6 +883,7 @@ extern "C" int rtts_embedding_bwd(const int64_t* ids, const float* dx, int rows,
 
 extern "C" int rtts_embedding_fwd(const int64_t* ids, const float* E, int rows, int C, int n_embeddings, float drop_p, uint32_t seed,
                                   const uint32_t* seed_dev, float* out, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(ids && E && out && rows > 0 && C > 0 && C % 4 == 0 && n_embeddings > 0 && drop_p >= 0.f && drop_p < 1.f,
                  "rtts_embedding_fwd: bad arguments");
     const size_t n4 = (size_t)rows * C / 4;
@@ -882,6 +894,7 @@ extern "C" int rtts_embedding_fwd(const int64_t* ids, const float* E, int rows, 
 }
 
 extern "C" int rtts_segments(const rtts_segment* jobs, int n, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(jobs && n > 0 && n <= RTTS_SEGMENTS_MAX, "rtts_segments: 1..%d jobs", RTTS_SEGMENTS_MAX);
     SgGroup g;
     g.n = n;
@@ -904,6 +917,7 @@ extern "C" int rtts_segments(const rtts_segment* jobs, int n, void* stream) {
 
 extern "C" int rtts_pe_add(const void* y, const float* table, const float* alpha, float drop_p, uint32_t seed, const uint32_t* seed_dev,
                            int T, int64_t M, int d, float* out, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(y && table && alpha && out && T > 0 && M > 0 && d > 0 && d % 4 == 0 && M % T == 0 && drop_p >= 0.f && drop_p < 1.f,
                  "rtts_pe_add: bad arguments");
     const size_t n4 = (size_t)M * d / 4;
@@ -915,6 +929,7 @@ extern "C" int rtts_pe_add(const void* y, const float* table, const float* alpha
 
 extern "C" int rtts_pe_dalpha(const float* dy, const float* table, float drop_p, uint32_t seed, const uint32_t* seed_dev, int T, int64_t M,
                               int d, float* dalpha, float* partial_ws, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(dy && table && dalpha && partial_ws && T > 0 && M > 0 && d % 4 == 0 && M % T == 0, "rtts_pe_dalpha: bad arguments");
     const size_t n4 = (size_t)M * d / 4;
     const int blocks = 512;
@@ -926,6 +941,7 @@ extern "C" int rtts_pe_dalpha(const float* dy, const float* table, float drop_p,
 }
 
 extern "C" int rtts_relu_drop(void* h, float drop_p, uint32_t seed, const uint32_t* seed_dev, int64_t n, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(h && n > 0 && n % 8 == 0 && drop_p >= 0.f && drop_p < 1.f, "rtts_relu_drop: bad arguments");
     hipLaunchKernelGGL(relu_drop_kernel, dim3(ed_grid((size_t)n / 8)), dim3(ED_THREADS), 0, (hipStream_t)stream, (bf16_t*)h, seed, seed_dev,
                        ed_thresh(drop_p), 1.f / (1.f - drop_p), (size_t)n / 8);

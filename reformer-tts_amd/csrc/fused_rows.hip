@@ -467,6 +467,7 @@ static inline unsigned stream_grid(size_t work_items) {
 
 extern "C" int rtts_ln_fwd(const float* x, const float* gamma, const float* beta, void* xn, float* mean, float* rstd, int M, int d,
                            void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(x && gamma && beta && xn && mean && rstd && M > 0, "rtts_ln_fwd: bad arguments");
     const dim3 grid((M + FR_WAVES - 1) / FR_WAVES);
 #define CALL(EPL, VEC) hipLaunchKernelGGL((ln_fwd_kernel<EPL, VEC>), grid, dim3(FR_THREADS), 0, (hipStream_t)stream, x, gamma, beta, (bf16_t*)xn, mean, rstd, M)
@@ -479,6 +480,7 @@ extern "C" int rtts_ln_fwd(const float* x, const float* gamma, const float* beta
 extern "C" int rtts_ln_bwd(const void* dxn, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx_io,
                            float* dgamma, float* dbeta, float* partial_ws, int M, int d, void* dyb_next, float* partial_next,
                            float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(!dyb_next || partial_next, "rtts_ln_bwd: dyb_next needs partial_next");
     RTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "rtts_ln_bwd: bad drop_p");
     RTTS_REQUIRE(dxn && x && mean && rstd && gamma && dx_io && partial_ws && M > 0 && (!dgamma == !dbeta), "rtts_ln_bwd: bad arguments");
@@ -500,6 +502,7 @@ extern "C" int rtts_ln_bwd(const void* dxn, const float* x, const float* mean, c
 
 extern "C" int rtts_cast_colsum(const float* dy, void* dyb, float* dbias, float* partial_ws, int M, int d, float drop_p, uint32_t seed,
                                 const uint32_t* seed_dev, const float* scale_dev, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(dy && dyb && partial_ws && M > 0 && drop_p >= 0.f && drop_p < 1.f, "rtts_cast_colsum: bad arguments");
     int blocks = (M + FR_WAVES - 1) / FR_WAVES;
     if (blocks > FR_PARTIAL_BLOCKS) blocks = FR_PARTIAL_BLOCKS;
@@ -516,6 +519,7 @@ extern "C" int rtts_cast_colsum(const float* dy, void* dyb, float* dbias, float*
 
 extern "C" int rtts_colsum_bf16(void* dh, const void* h, int64_t ld, float* dbias, float* partial_ws, int M, int d, int relu_gate,
                                 float gate_scale, void* gated_out, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(dh && partial_ws && M > 0 && (!relu_gate || h), "rtts_colsum_bf16: bad arguments");
     bf16_t* dst = (bf16_t*)(gated_out ? gated_out : dh);
     RTTS_REQUIRE(ld >= d && ld % 8 == 0, "rtts_colsum_bf16: bad row stride");
@@ -551,6 +555,7 @@ __global__ __launch_bounds__(FR_THREADS) void sum_streams_kernel(const float* __
 }
 
 extern "C" int rtts_sum_streams(const float* a, const float* b, int64_t n, float* out, void* out_bf16, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(a && b && (out || out_bf16) && n > 0 && n % 4 == 0, "rtts_sum_streams: bad arguments");
     hipLaunchKernelGGL(sum_streams_kernel, dim3(stream_grid((size_t)n / 4)), dim3(FR_THREADS), 0, (hipStream_t)stream, a, b, (size_t)n / 4, out,
                        (bf16_t*)out_bf16);
@@ -564,6 +569,7 @@ extern "C" int rtts_colsum_partial_rows(int M) {
 }
 
 extern "C" int rtts_colsum_final_grouped(const rtts_colsum_job* jobs, int n, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(jobs && n > 0 && n <= RTTS_COLSUM_MAX_GROUP, "rtts_colsum_final_grouped: 1..%d jobs", RTTS_COLSUM_MAX_GROUP);
     CsGroup grp;
     grp.n = n;
@@ -586,6 +592,7 @@ extern "C" int rtts_colsum_final_grouped(const rtts_colsum_job* jobs, int n, voi
 
 extern "C" int rtts_residual_epilogue(const float* x, const void* g, const float* bias, float sign, float* y, int64_t M, int d,
                                       float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(x && g && y && M > 0 && d > 0 && d % 4 == 0 && drop_p >= 0.f && drop_p < 1.f, "rtts_residual_epilogue: bad arguments");
     const size_t n4 = (size_t)M * d / 4;
     hipLaunchKernelGGL(residual_epilogue_kernel, dim3(stream_grid(n4)), dim3(FR_THREADS), 0, (hipStream_t)stream, x, (const bf16_t*)g,
@@ -597,6 +604,7 @@ extern "C" int rtts_residual_epilogue(const float* x, const void* g, const float
 extern "C" int rtts_residual_ln(float* x, const void* g, const float* bias, float sign, const float* gamma, const float* beta,
                                 void* xn, float* mean, float* rstd, int M, int d, float drop_p, uint32_t seed,
                                 const uint32_t* seed_dev, float* y, void* stream) {
+    RTTS_ENTER(stream);
     if (!y) y = x;
     RTTS_REQUIRE(x && g && gamma && beta && xn && mean && rstd && M > 0 && drop_p >= 0.f && drop_p < 1.f, "rtts_residual_ln: bad arguments");
     const dim3 grid((M + FR_WAVES - 1) / FR_WAVES);
@@ -608,6 +616,7 @@ extern "C" int rtts_residual_ln(float* x, const void* g, const float* bias, floa
 }
 
 extern "C" int rtts_bias_act(void* h, const float* bias, int64_t M, int d, int relu, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(h && bias && M > 0 && d > 0 && d % 8 == 0, "rtts_bias_act: bad arguments");
     const size_t n8 = (size_t)M * d / 8;
     hipLaunchKernelGGL(bias_act_kernel, dim3(stream_grid(n8)), dim3(FR_THREADS), 0, (hipStream_t)stream, (bf16_t*)h, bias, n8, d, relu);
@@ -616,6 +625,7 @@ extern "C" int rtts_bias_act(void* h, const float* bias, int64_t M, int d, int r
 }
 
 extern "C" int rtts_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(src && dst && n > 0 && n % 4 == 0, "rtts_cast_f32_bf16: n must be a positive multiple of 4");
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(stream_grid((size_t)n / 4)), dim3(FR_THREADS), 0, (hipStream_t)stream, src,
                        (bf16_t*)dst, (size_t)n / 4);

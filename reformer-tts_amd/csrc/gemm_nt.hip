@@ -559,6 +559,7 @@ static int gn_run(const void* a, int64_t lda, const void* w, int64_t ldw, int w_
 extern "C" int rtts_gemm_nt(const void* a, int64_t lda, const void* w, int64_t ldw, int w_is_kn, int M, int N, int K, void* c,
                             int64_t ldc, const float* bias, int epilogue, const void* gate, int64_t ldg, float* colsum_partial,
                             void* stream) {
+    RTTS_ENTER(stream);
     return gn_run(a, lda, w, ldw, w_is_kn, M, N, K, c, ldc, bias, epilogue, gate, ldg, colsum_partial, 0, 0, 0, stream);
 }
 
@@ -570,6 +571,7 @@ extern "C" int64_t rtts_gemm_nt_gate_words(int M, int N) {
 
 extern "C" int rtts_gemm_nt_gated(const void* a, int64_t lda, const void* w, int64_t ldw, int w_is_kn, int M, int N, int K, void* c,
                                   int64_t ldc, const float* bias, int epilogue, uint64_t* gate_words, float* colsum_partial, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(gate_words && (epilogue == 2 || epilogue == 3), "rtts_gemm_nt_gated: epilogue 2 (bias + ReLU, writes the words) or 3 (reads them)");
     return gn_run(a, lda, w, ldw, w_is_kn, M, N, K, c, ldc, bias, epilogue, nullptr, 0, colsum_partial, 0, 0, 0, stream,
                   (unsigned long long*)gate_words);
@@ -577,6 +579,7 @@ extern "C" int rtts_gemm_nt_gated(const void* a, int64_t lda, const void* w, int
 
 extern "C" int rtts_conv1d_k5(const void* x, int64_t ldx, const void* wp, int64_t ldw, int transposed, int M, int C_out, int C_in,
                               void* y, int64_t ldy, const float* bias, int out_f32, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(C_in > 0 && C_in % GN_BK == 0 && C_out > 0, "rtts_conv1d_k5: channel counts must be multiples of 64 (got %d -> %d)", C_in, C_out);
     RTTS_REQUIRE(!bias || out_f32, "rtts_conv1d_k5: a bias rides in the fp32 epilogue only");
     // forward:    y[m][co] = sum_{tap, ci} x[m + tap - 2][ci] * wp[co][tap * C_in + ci]              (wp (C_out, 5 C_in), NT)

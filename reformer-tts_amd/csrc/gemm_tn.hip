@@ -422,6 +422,7 @@ static int gt_launch(const GtGroup& grp, int wg, hipStream_t s) {
 }
 
 extern "C" int rtts_gemm_tn_grouped(const rtts_gemm_tn_problem* problems, int n, float* slab_ws, int64_t slab_ws_floats, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(problems && n > 0 && n <= RTTS_GEMM_TN_MAX_GROUP, "rtts_gemm_tn_grouped: 1..%d problems", RTTS_GEMM_TN_MAX_GROUP);
     GtGroup grp;
     grp.n = n;
@@ -497,6 +498,7 @@ extern "C" int rtts_gemm_tn_grouped(const rtts_gemm_tn_problem* problems, int n,
 
 extern "C" int rtts_gemm_tn(const void* a, int64_t lda, const void* b, int64_t ldb, int M, int N, int K, float* c, int64_t ldc,
                             int accumulate, float* slab_ws, int64_t slab_ws_floats, void* stream) {
+    RTTS_ENTER(stream);
     rtts_gemm_tn_problem q;
     q.a = a; q.lda = lda; q.b = b; q.ldb = ldb; q.c = c; q.ldc = ldc;
     q.M = M; q.N = N; q.K = K; q.accumulate = accumulate;

@@ -1094,6 +1094,7 @@ extern "C" int rtts_lsh_attn_bwd(const void* qk, const void* v, int64_t ld, cons
                                  const void* dout, int64_t ld_dout, const float* lse_tot, const float* delta, int B, int H,
                                  int T, int dh, int n_hashes, int bucket_size, int causal, void* dqk_part, void* dv_part,
                                  uint8_t* row_flags, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(qk && v && st && dout && lse_tot && delta && dqk_part && dv_part, "rtts_lsh_attn_bwd: null pointer");
     RTTS_REQUIRE(dh == AB_DH, "rtts_lsh_attn_bwd: dh=%d unsupported (this build: 64)", dh);
     RTTS_REQUIRE(bucket_size == 64 || bucket_size == 128, "rtts_lsh_attn_bwd: bucket_size=%d unsupported (64 or 128)", bucket_size);

@@ -328,6 +328,7 @@ extern "C" int rtts_lsh_attn_fwd_run_length(int B, int H, int T, int n_hashes, i
 extern "C" int rtts_lsh_attn_fwd(const void* qk, const void* v, int64_t ld, const int32_t* st, const uint8_t* mask, int B,
                                  int H, int T, int dh, int n_hashes, int bucket_size, int causal, void* o, float* lse,
                                  void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(qk && v && st && o && lse, "rtts_lsh_attn_fwd: null pointer");
     RTTS_REQUIRE(dh == AF_DH, "rtts_lsh_attn_fwd: dh=%d unsupported (this build: 64)", dh);
     RTTS_REQUIRE(bucket_size == 64 || bucket_size == 128, "rtts_lsh_attn_fwd: bucket_size=%d unsupported (64 or 128)", bucket_size);

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void lsh_bwd_reduce_kernel(const bf16_t* __res
 
 extern "C" int rtts_lsh_combine_fwd(const void* o, const float* lse, int B, int H, int T, int dh, int n_hashes, void* out,
                                     int64_t ld_out, float* lse_tot, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(o && lse && out && lse_tot, "rtts_lsh_combine_fwd: null pointer");
     RTTS_REQUIRE(dh == CB_DH && n_hashes > 0 && n_hashes <= CB_MAXR, "rtts_lsh_combine_fwd: need dh == 64, n_hashes <= 16");
     RTTS_REQUIRE(B > 0 && H > 0 && T > 0 && ld_out >= (int64_t)H * dh && ld_out % 8 == 0, "rtts_lsh_combine_fwd: bad shape/stride");
@@ -127,6 +128,7 @@ extern "C" int rtts_lsh_combine_fwd(const void* o, const float* lse, int B, int 
 
 extern "C" int rtts_lsh_bwd_delta(const void* out, int64_t ld_out, const void* dout, int64_t ld_dout, int B, int H, int T, int dh,
                                   float* delta, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(out && dout && delta, "rtts_lsh_bwd_delta: null pointer");
     RTTS_REQUIRE(dh == CB_DH && B > 0 && H > 0 && T > 0, "rtts_lsh_bwd_delta: need dh == 64");
     RTTS_REQUIRE(ld_out >= (int64_t)H * dh && ld_out % 8 == 0 && ld_dout >= (int64_t)H * dh && ld_dout % 8 == 0,
@@ -142,6 +144,7 @@ extern "C" int rtts_lsh_bwd_delta(const void* out, int64_t ld_out, const void* d
 
 extern "C" int rtts_lsh_bwd_reduce(const void* dqk_part, const void* dv_part, int B, int H, int T, int dh, int n_hashes, void* dqk,
                                    void* dv, int64_t ld_d, const uint8_t* row_flags, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(dqk_part && dv_part && dqk && dv, "rtts_lsh_bwd_reduce: null pointer");
     RTTS_REQUIRE(dh == CB_DH && B > 0 && H > 0 && T > 0 && n_hashes > 0, "rtts_lsh_bwd_reduce: need dh == 64");
     RTTS_REQUIRE(ld_d >= (int64_t)H * dh && ld_d % 8 == 0, "rtts_lsh_bwd_reduce: bad stride");

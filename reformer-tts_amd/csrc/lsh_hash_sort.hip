@@ -283,6 +283,7 @@ static int launch_hash_sort(const bf16_t* qk, int64_t ld, const float* rot, int 
 extern "C" int rtts_lsh_hash_sort(const void* qk, int64_t ld_qk, const float* rotations, int rot_rows, int B, int H,
                                   int T, int dh, int n_hashes, int bucket_size, int32_t* buckets, int32_t* st,
                                   int32_t* undo, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(qk && rotations && st, "rtts_lsh_hash_sort: null pointer");
     RTTS_REQUIRE(dh == HS_DH, "rtts_lsh_hash_sort: dh=%d unsupported (this build: 64)", dh);
     RTTS_REQUIRE(bucket_size > 0 && T > 0 && T % (2 * bucket_size) == 0,

@@ -96,6 +96,7 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(float* __restrict__ 
 
 extern "C" int rtts_grad_clip_scale(const float* grads, int64_t n, float grad_mult, float max_norm, float* partial_ws,
                                     float* scale_out, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(grads && partial_ws && scale_out && n > 0, "rtts_grad_clip_scale: bad arguments");
     RTTS_REQUIRE(((uintptr_t)grads & 15) == 0, "rtts_grad_clip_scale: grads must be 16-byte aligned");
     int blocks = (int)((n / 4 + OPT_THREADS - 1) / OPT_THREADS);
@@ -111,6 +112,7 @@ extern "C" int rtts_grad_clip_scale(const float* grads, int64_t n, float grad_mu
 extern "C" int rtts_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* decay_mask,
                                int64_t n, const float* scale, const float* hyper, float beta1, float beta2, float eps,
                                float weight_decay, void* bf16_mirror, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(params && grads && exp_avg && exp_avg_sq && decay_mask && hyper && n > 0, "rtts_adamw_step: bad arguments");
     RTTS_REQUIRE(n % 4 == 0, "rtts_adamw_step: n must be a multiple of 4 (pad the flat buffers)");
     RTTS_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0 &&

@@ -35,6 +35,7 @@ __global__ __launch_bounds__(512) void peak_mfma_kernel(float* __restrict__ sink
 }
 
 extern "C" int rtts_peak_copy(const void* src, void* dst, int64_t bytes, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(src && dst && bytes > 0 && bytes % 16 == 0, "rtts_peak_copy: bytes must be a positive multiple of 16");
     hipLaunchKernelGGL(peak_copy_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, (size_t)bytes / 16);
     RTTS_LAUNCH_CHECK("rtts_peak_copy");
@@ -43,6 +44,7 @@ extern "C" int rtts_peak_copy(const void* src, void* dst, int64_t bytes, void* s
 
 // FLOP of one launch: workgroups * 8 waves * iters * 8 MFMAs * (16*16*32*2)
 extern "C" int rtts_peak_mfma(float* sink, int workgroups, int iters, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(sink && workgroups > 0 && iters > 0, "rtts_peak_mfma: bad arguments");
     hipLaunchKernelGGL(peak_mfma_kernel, dim3(workgroups), dim3(512), 0, (hipStream_t)stream, sink, iters);
     RTTS_LAUNCH_CHECK("rtts_peak_mfma");

@@ -38,6 +38,34 @@ extern "C" void rtts_set_error(const char* fmt, ...);
         }                                                                    \
     } while (0)
 
+// DEVICE OF A CALL.  An entry point is called from the Python main thread in a forward and from PyTorch's
+// autograd worker thread in a backward; HIP's current device is per thread.  Every launching entry point therefore binds the
+// calling thread to the device its stream belongs to before it touches the runtime: the explicit `int device` of the ABI is
+// carried by the stream handle (hipStreamGetDevice), so a caller cannot pass a stream of one device and the ordinal of another.
+// The null stream has no device of its own: the thread's current device is used, as everywhere in HIP.
+static inline int rtts_bind_device(void* stream) {
+    if (!stream) return 0;
+    hipDevice_t dev = -1;
+    if (hipStreamGetDevice((hipStream_t)stream, &dev) != hipSuccess) {
+        (void)hipGetLastError();
+        rtts_set_error("the stream handle %p does not belong to any device of this process", stream);
+        return -3;
+    }
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == (int)dev) return 0;
+    if (hipSetDevice((int)dev) != hipSuccess) {
+        (void)hipGetLastError();
+        rtts_set_error("cannot bind the calling thread to device %d (the device of the stream)", (int)dev);
+        return -3;
+    }
+    return 0;
+}
+#define RTTS_ENTER(stream)                              \
+    do {                                                \
+        const int rc_enter_ = rtts_bind_device(stream); \
+        if (rc_enter_) return rc_enter_;                \
+    } while (0)
+
 // The dynamic-LDS limit is an attribute of a LOADED function, i.e. per device: raise it once per (function, device), again when
 // a later call needs more, and report a failure at the call that caused it instead of at some later launch.
 struct RttsLdsState { size_t set[64]; };

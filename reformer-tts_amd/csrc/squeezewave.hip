@@ -90,6 +90,7 @@ __global__ __launch_bounds__(SW_THREADS) void sw_coupling_inv_kernel(float* __re
 
 extern "C" int rtts_sw_depthwise_k3(const float* x, const float* w, const float* bias, int B, int L, int C, void* y, const float* edge_lo,
                                     const float* edge_hi, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(x && w && bias && y && B > 0 && L > 0 && C > 0 && C % 4 == 0, "rtts_sw_depthwise_k3: bad arguments (C %% 4 == 0)");
     const size_t n4 = (size_t)B * L * C / 4;
     hipLaunchKernelGGL(sw_depthwise_k3_kernel, dim3(sw_grid(n4)), dim3(SW_THREADS), 0, (hipStream_t)stream, x, w, bias, L, C, n4, (bf16_t*)y, edge_lo, edge_hi);
@@ -99,6 +100,7 @@ extern "C" int rtts_sw_depthwise_k3(const float* x, const float* w, const float*
 
 extern "C" int rtts_sw_gate(const void* pw, const void* cond, int64_t ld_cond, int cond_offset, int upsample, int B, int L, int Lm, int C,
                             void* acts, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(pw && cond && acts && B > 0 && L > 0 && Lm > 0 && C > 0 && C % 8 == 0 && cond_offset % 8 == 0 && ld_cond % 8 == 0 &&
                      upsample >= 1 && (int64_t)Lm * upsample == L && ld_cond >= cond_offset + 2 * C,
                  "rtts_sw_gate: bad arguments (C %% 8 == 0, L == Lm * upsample)");
@@ -110,9 +112,84 @@ extern "C" int rtts_sw_gate(const void* pw, const void* cond, int64_t ld_cond, i
 }
 
 extern "C" int rtts_sw_coupling_inv(float* audio, int64_t ld_audio, const float* wn_out, int64_t rows, int half, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(audio && wn_out && rows > 0 && half > 0 && ld_audio >= 2 * half, "rtts_sw_coupling_inv: bad arguments");
     const size_t n = (size_t)rows * half;
     hipLaunchKernelGGL(sw_coupling_inv_kernel, dim3(sw_grid(n)), dim3(SW_THREADS), 0, (hipStream_t)stream, audio, ld_audio, wn_out, half, n);
     RTTS_LAUNCH_CHECK("rtts_sw_coupling_inv");
+    return 0;
+}
+
+// ------------------------------------------------------------------ inverse coupling + inverse invertible 1x1 convolution
+// out (rows, n) fp32 = [a0 | (a1 - b) * exp(-s)] @ Winv^T  -- the tail of one flow of SqueezeWave.infer
+// (/root/reference/reformer_tts/squeeze_wave/modules.py:353-361: the affine coupling undone, then InvertibleConv1d's
+// W_inverse, :57-85).  The audio path stays fp32 end to end (twelve chained matrix products: bf16 operands would leave ~3
+// digits), so this is an fp32 FMA kernel, not an MFMA one: n <= 128 channels, 2*n*n FLOP per row -- 0.4 GFLOP for a
+// 2-second utterance.  One workgroup = 32 rows; Winv^T (n x n) and the 32 coupled rows sit in LDS, thread (row, g) owns
+// the output columns g, g + 8, ... of its row: the W reads of 8 neighbouring lanes are 8 consecutive words, the x reads
+// broadcast.
+#define SWI_ROWS 32
+#define SWI_MAXN 128
+__global__ __launch_bounds__(SW_THREADS) void sw_coupling_inv1x1_kernel(const float* __restrict__ audio, int64_t ld_audio,
+                                                                        const float* __restrict__ wn, int64_t ld_wn,
+                                                                        const float* __restrict__ winv, int n, int half, long long rows,
+                                                                        float* __restrict__ out, int64_t ld_out) {
+    extern __shared__ __attribute__((aligned(16))) float swi_smem[];
+    float* Wt = swi_smem;                     // [n][n]: Wt[k][c] = Winv[c][k]
+    float* X = Wt + n * n;                    // [SWI_ROWS][n + 1]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n * n; i += SW_THREADS) {
+        const int c = i / n, k = i % n;       // coalesced read of Winv's rows; the transposed store is n-strided (once per block)
+        Wt[k * n + c] = winv[i];
+    }
+    const long long r0 = (long long)blockIdx.x * SWI_ROWS;
+    for (int i = tid; i < SWI_ROWS * n; i += SW_THREADS) {
+        const int rr = i / n, k = i % n;
+        const long long row = r0 + rr;
+        float v = 0.f;
+        if (row < rows) {
+            v = audio[row * ld_audio + k];
+            if (k >= half) {
+                const float s = wn[row * ld_wn + (k - half)], b = wn[row * ld_wn + k];
+                v = (v - b) * __expf(-s);
+            }
+        }
+        X[rr * (n + 1) + k] = v;
+    }
+    __syncthreads();
+    const int rr = tid >> 3, g = tid & 7;
+    float acc[SWI_MAXN / 8];
+#pragma unroll
+    for (int j = 0; j < SWI_MAXN / 8; ++j) acc[j] = 0.f;
+    const float* xr = X + rr * (n + 1);
+    for (int k = 0; k < n; ++k) {
+        const float xv = xr[k];
+        const float* wk = Wt + k * n + g;
+#pragma unroll
+        for (int j = 0; j < SWI_MAXN / 8; ++j)
+            if (g + 8 * j < n) acc[j] = __builtin_fmaf(xv, wk[8 * j], acc[j]);
+    }
+    const long long row = r0 + rr;
+    if (row < rows) {
+#pragma unroll
+        for (int j = 0; j < SWI_MAXN / 8; ++j)
+            if (g + 8 * j < n) out[row * ld_out + g + 8 * j] = acc[j];
+    }
+}
+
+static RttsLdsState g_swi_lds;
+
+extern "C" int rtts_sw_coupling_inv1x1(const float* audio, int64_t ld_audio, const float* wn_out, int64_t ld_wn, const float* winv, int n,
+                                       int64_t rows, float* out, int64_t ld_out, void* stream) {
+    RTTS_ENTER(stream);
+    RTTS_REQUIRE(audio && wn_out && winv && out && rows > 0 && n >= 2 && n % 2 == 0 && n <= SWI_MAXN && ld_audio >= n && ld_wn >= n && ld_out >= n,
+                 "rtts_sw_coupling_inv1x1: n must be even and <= %d, leading dimensions >= n (got n=%d)", SWI_MAXN, n);
+    RTTS_REQUIRE(out != audio, "rtts_sw_coupling_inv1x1: not in place (a block reads rows of audio that another may have rewritten)");
+    const size_t lds = ((size_t)n * n + (size_t)SWI_ROWS * (n + 1)) * sizeof(float);
+    RTTS_ENSURE_LDS("rtts_sw_coupling_inv1x1", sw_coupling_inv1x1_kernel, lds, g_swi_lds);
+    const unsigned blocks = (unsigned)((rows + SWI_ROWS - 1) / SWI_ROWS);
+    hipLaunchKernelGGL(sw_coupling_inv1x1_kernel, dim3(blocks), dim3(SW_THREADS), lds, (hipStream_t)stream, audio, ld_audio, wn_out, ld_wn, winv,
+                       n, n / 2, (long long)rows, out, ld_out);
+    RTTS_LAUNCH_CHECK("rtts_sw_coupling_inv1x1");
     return 0;
 }

@@ -447,6 +447,7 @@ extern "C" int rtts_xattn_key_chunks(int Tk) { return (Tk >= 128 && Tk % 128 == 
 extern "C" int rtts_xattn_fwd(const void* q, int64_t ld_q, const void* kv, int64_t ld_kv, const uint8_t* kvalid, int B, int H, int Tq,
                               int Tk, int dh, void* o, int64_t ld_o, float* lse, float drop_p, uint32_t seed, const uint32_t* seed_dev,
                               void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(q && kv && o && lse && drop_p >= 0.f && drop_p < 1.f, "rtts_xattn_fwd: bad arguments");
     if (xa_check("rtts_xattn_fwd", B, H, Tq, Tk, dh, ld_q, ld_kv)) return -1;
     RTTS_REQUIRE(ld_o >= (int64_t)H * dh && ld_o % 8 == 0, "rtts_xattn_fwd: bad ld_o");
@@ -471,6 +472,7 @@ extern "C" int rtts_xattn_bwd(const void* q, int64_t ld_q, const void* kv, int64
                               int64_t ld_dout, const float* lse, const float* delta, int B, int H, int Tq, int Tk, int dh, void* dq,
                               int64_t ld_dq, void* dkv_part, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* dq_chunks,
                               void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(q && kv && dout && lse && delta && dq && dkv_part && drop_p >= 0.f && drop_p < 1.f, "rtts_xattn_bwd: bad arguments");
     if (xa_check("rtts_xattn_bwd", B, H, Tq, Tk, dh, ld_q, ld_kv)) return -1;
     RTTS_REQUIRE(ld_dout >= (int64_t)H * dh && ld_dout % 8 == 0 && ld_dq >= (int64_t)H * dh && ld_dq % 8 == 0,
@@ -503,6 +505,7 @@ extern "C" int rtts_xattn_bwd(const void* q, int64_t ld_q, const void* kv, int64
 }
 
 extern "C" int rtts_sum_slabs(const void* part, int nslabs, int64_t n, void* out, void* stream) {
+    RTTS_ENTER(stream);
     RTTS_REQUIRE(part && out && nslabs > 0 && n > 0 && n % 8 == 0, "rtts_sum_slabs: n must be a positive multiple of 8");
     size_t blocks = ((size_t)n / 8 + 255) / 256;
     if (blocks > 4096) blocks = 4096;

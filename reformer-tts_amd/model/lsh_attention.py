@@ -99,7 +99,10 @@ class LSHSelfAttention(nn.Module):
         if self.forced_rotations is not None and hasattr(self.forced_rotations, "__next__"):
             return next(self.forced_rotations).to(device=x.device, dtype=torch.float32).contiguous()   # tests: one per call
         if isinstance(self.forced_rotations, dict):            # tests: one tensor per bucket count (batches of several padded lengths)
-            return self.forced_rotations[n_buckets].to(device=x.device, dtype=torch.float32).contiguous()
+            r = self.forced_rotations[n_buckets]
+            if r.device != x.device or r.dtype != torch.float32 or not r.is_contiguous():     # moved once (never inside a capture)
+                r = self.forced_rotations[n_buckets] = r.to(device=x.device, dtype=torch.float32).contiguous()
+            return r
         if self.forced_rotations is not None:
             if self.forced_rotations.device != x.device or self.forced_rotations.dtype != torch.float32:
                 self.forced_rotations = self.forced_rotations.to(device=x.device, dtype=torch.float32).contiguous()

@@ -5,15 +5,17 @@ Module tree, constructor arguments and ``state_dict`` names follow
 ``DepthwiseSeparableConv1d`` :88-122, ``InvertibleConv1d`` :27-85) so that the reference's checkpoints load; the
 modules here only HOLD parameters.  ``infer`` (:334-376) runs through an explicit executor:
 
-* activations are channels-last rows ``(B*L, C)``: every 1x1 ``Conv1d`` is one GEMM over rows (hipBLASLt, bf16
-  operands, fp32 accumulate), the WN residual stream and the audio stay fp32;
+* activations are channels-last rows ``(B*L, C)``: every 1x1 ``Conv1d`` is one ``rtts_gemm_nt`` launch over rows (the
+  hand-written MFMA kernel of csrc/gemm_nt.hip: bf16 operands, fp32 accumulate, bias / fp32 store in its epilogue), the WN
+  residual stream and the audio stay fp32;
 * weight norm and the eval-mode BatchNorm in front of each depthwise convolution are folded into plain weights once
   per parameter version (what ``remove_norms`` :237-248,378-419 does destructively);
 * the mel conditioning of all ``n_layers`` layers of a flow is one GEMM (``cond_layer``), consumed in place by the gate
   kernel with nearest-neighbour upsampling done by indexing;
 * depthwise k3 + folded BatchNorm, tanh*sigmoid gate and inverse affine coupling are the kernels of
   ``csrc/squeezewave.hip``; the residual add is the TTS path's ``rtts_residual_epilogue``;
-* the inverse of each invertible 1x1 convolution is cached (fp32) like the reference's ``W_inverse``.
+* the inverse of each invertible 1x1 convolution is cached (fp32) like the reference's ``W_inverse`` and applied, with the
+  inverse coupling in front of it, by the fp32 kernel ``rtts_sw_coupling_inv1x1``.
 
 There is no CPU fallback: ``infer`` raises off the GPU."""
 from __future__ import annotations
@@ -77,20 +79,49 @@ def _normed(conv) -> torch.Tensor:
     return w.squeeze(-1)
 
 
+def _pad(n: int, q: int) -> int:
+    return -(-n // q) * q
+
+
 class _FoldedWN:
     """Inference weights of one WN block: bf16 GEMM operands (row-major (Cout, Cin)), fp32 biases, depthwise taps with
     the eval-mode BatchNorm folded in:  dw(bn(x)) = sum_k (w_k * a) x_{l+k-1} + [b + (sum_k w_k) * c],
     a = gamma / sqrt(var + eps), c = beta - mean * a.  (Zero padding pads bn(x), i.e. the constant c is NOT added at the
-    borders by the reference; the border rows get the exact correction below.)"""
+    borders by the reference; the border rows get the exact correction below.)
+
+    Every 1x1 convolution (``start``, ``cond_layer``, the pointwise half of ``in_layers``, ``res_skip_layers``, ``end``;
+    reference ``modules.py:203-235``) is ``rtts_gemm_nt`` (csrc/gemm_nt.hip) over channels-last rows: operands are padded ONCE
+    here to the kernel's granules -- input widths to multiples of 64 (audio halves 64, 56, ... and the 80 mel channels: zero
+    columns), the ``end`` projection's 2 * n_half outputs to a multiple of 64 (zero rows; its consumer takes a row stride) --
+    and the row count of an utterance is rounded up to 128 in the activation buffers (rows are independent: the extra rows
+    are never read back).  ``in_tree`` is False for toy widths the MFMA kernel does not tile (n_channels % 64, n_half % 8 or
+    n_mel % 8 != 0): those run the same arithmetic through the library GEMM and say so once."""
 
     def __init__(self, wn: WN):
         bf = torch.bfloat16
         self.c, self.nl, self.up = wn.n_channels, wn.n_layers, wn.upsample_scale
         if wn.kernel_size != 3:
             raise NotImplementedError("the HIP depthwise kernel is built for conv_kernel_size == 3")
-        self.w_start, self.b_start = _normed(wn.start_conv).to(bf).contiguous(), wn.start_conv.bias.detach().float()
-        self.w_cond, self.b_cond = _normed(wn.cond_layer).to(bf).contiguous(), wn.cond_layer.bias.detach().to(bf)
-        self.w_end, self.b_end = wn.end_conv.weight.detach().float().squeeze(-1).to(bf).contiguous(), wn.end_conv.bias.detach().float()
+        w_start, w_cond = _normed(wn.start_conv), _normed(wn.cond_layer)
+        w_end = wn.end_conv.weight.detach().float().squeeze(-1)
+        self.n_half, self.n_mel = w_start.shape[1], w_cond.shape[1]
+        self.in_tree = self.c % 64 == 0 and self.n_half % 8 == 0 and self.n_mel % 8 == 0
+        dev = w_start.device
+
+        def kpad(w):            # (N, K) -> (N, K rounded up to 64) bf16, zero columns
+            if not self.in_tree:
+                return w.to(bf).contiguous()
+            out = torch.zeros(w.shape[0], _pad(w.shape[1], 64), dtype=bf, device=dev)
+            out[:, :w.shape[1]] = w.to(bf)
+            return out
+
+        self.w_start, self.b_start = kpad(w_start), wn.start_conv.bias.detach().float().contiguous()
+        self.w_cond, self.b_cond = kpad(w_cond), wn.cond_layer.bias.detach().float().contiguous()
+        self.n_end = _pad(w_end.shape[0], 64) if self.in_tree else w_end.shape[0]
+        self.w_end = torch.zeros(self.n_end, self.c, dtype=bf, device=dev)
+        self.w_end[:w_end.shape[0]] = w_end.to(bf)
+        self.b_end = torch.zeros(self.n_end, dtype=torch.float32, device=dev)
+        self.b_end[:w_end.shape[0]] = wn.end_conv.bias.detach().float()
         self.dw_w, self.dw_b, self.dw_edge, self.w_pw, self.b_pw, self.w_rs, self.b_rs = [], [], [], [], [], [], []
         for i in range(wn.n_layers):
             bn, dw, pw = wn.in_layers[i].layer
@@ -102,31 +133,58 @@ class _FoldedWN:
             # at l = 0 the tap k = 0 sees the zero padding of bn(x), not c; at l = L-1 the tap k = 2 likewise
             self.dw_edge.append(((w[:, 0] * cst).contiguous(), (w[:, 2] * cst).contiguous()))
             self.w_pw.append(pw.weight.detach().float().squeeze(-1).to(bf).contiguous())
-            self.b_pw.append(pw.bias.detach().to(bf))
+            self.b_pw.append(pw.bias.detach().float().contiguous())
             self.w_rs.append(_normed(wn.res_skip_layers[i]).to(bf).contiguous())
             self.b_rs.append(wn.res_skip_layers[i].bias.detach().float().contiguous())
 
-    def forward(self, a0: torch.Tensor, mel_rows: torch.Tensor, b: int, length: int, mel_len: int) -> torch.Tensor:
-        """a0 fp32 (B*L, n_half) rows, mel_rows bf16 (B*Lm, n_mel) -> fp32 (B*L, 2*n_half) = [s | b]."""
-        dev, c = a0.device, self.c
+    def condition(self, mel: torch.Tensor, b: int, mel_len: int) -> torch.Tensor:
+        """mel fp32 (B*Lm, n_mel) rows -> (rows, 2c * n_layers) bf16: the conditioning of all layers in one GEMM."""
+        if not self.in_tree:
+            return torch.addmm(self.b_cond.to(torch.bfloat16), mel.to(torch.bfloat16), self.w_cond.t())
+        from ..engine import gemm
+        mp, kp = _pad(b * mel_len, 128), self.w_cond.shape[1]
+        x = torch.empty(mp, kp, dtype=torch.bfloat16, device=mel.device)
+        _lib.call("rtts_to_halo", mel.data_ptr(), mel.stride(0), 0, self.n_mel, 1, b, mel_len, 0, kp, x.data_ptr(), 0, mp, _s())
+        return gemm(x, self.w_cond, bias=self.b_cond)
+
+    def forward(self, audio: torch.Tensor, mel: torch.Tensor, b: int, length: int, mel_len: int) -> torch.Tensor:
+        """audio fp32 (B*L, n_rem) rows (the first n_half channels condition the block), mel fp32 (B*Lm, n_mel) rows
+        -> fp32 (rows >= B*L, n_end >= 2*n_half) = [s | b | zero columns]."""
+        dev, c = audio.device, self.c
         m = b * length
-        if a0.shape[1] % 8:      # odd channel counts (tiny test configurations): plain fp32 GEMM
-            h = torch.addmm(self.b_start, a0, self.w_start.float().t())
-        else:
-            h = torch.mm(a0.to(torch.bfloat16), self.w_start.t(), out_dtype=torch.float32) + self.b_start
-        cond = torch.addmm(self.b_cond, mel_rows, self.w_cond.t())                 # (B*Lm, 2c*nl) bf16, all layers at once
         up = length // mel_len
+        cond = self.condition(mel, b, mel_len)
+        if self.in_tree:
+            from ..engine import gemm
+            mp, kp = _pad(m, 128), self.w_start.shape[1]
+            a0 = torch.empty(mp, kp, dtype=torch.bfloat16, device=dev)        # bf16 copy of the conditioning half, zero padded
+            _lib.call("rtts_to_halo", audio.data_ptr(), audio.stride(0), 0, self.n_half, 1, b, length, 0, kp, a0.data_ptr(), 0, mp, _s())
+            h = gemm(a0, self.w_start, bias=self.b_start, out_f32=True)        # (mp, c) fp32: the WN residual stream
+            mm = lambda x, w, bias=None, f32=False: gemm(x, w, bias=bias, out_f32=f32)     # noqa: E731
+        else:
+            _lib.note_general_path("SqueezeWave WN block", f"widths (n_channels {c}, n_half {self.n_half}, n_mel {self.n_mel}) the MFMA GEMM "
+                                   "does not tile (n_channels % 64, n_half % 8, n_mel % 8): library GEMM")
+            mp = m
+            a0 = audio[:, :self.n_half].contiguous()
+            h = torch.addmm(self.b_start, a0, self.w_start.float().t())
+
+            def mm(x, w, bias=None, f32=False):
+                y = torch.mm(x, w.t(), out_dtype=torch.float32)
+                y = y if bias is None else y + bias
+                return y if f32 else y.to(torch.bfloat16)
         for i in range(self.nl):
-            dw = torch.empty(m, c, dtype=torch.bfloat16, device=dev)
+            dw = torch.empty(mp, c, dtype=torch.bfloat16, device=dev)
             lo, hi = self.dw_edge[i]                                             # zero padding pads bn(x): no folded constant there
             _lib.call("rtts_sw_depthwise_k3", h.data_ptr(), self.dw_w[i].data_ptr(), self.dw_b[i].data_ptr(), b, length, c, dw.data_ptr(),
                       lo.data_ptr(), hi.data_ptr(), _s())
-            pw = torch.addmm(self.b_pw[i], dw, self.w_pw[i].t())                   # (M, 2c) bf16
-            acts = torch.empty(m, c, dtype=torch.bfloat16, device=dev)
+            pw = mm(dw, self.w_pw[i], self.b_pw[i])                                # (mp, 2c) bf16
+            acts = torch.empty(mp, c, dtype=torch.bfloat16, device=dev)
             _lib.call("rtts_sw_gate", pw.data_ptr(), cond.data_ptr(), cond.stride(0), i * 2 * c, up, b, length, mel_len, c, acts.data_ptr(), _s())
-            rs = torch.mm(acts, self.w_rs[i].t())
+            rs = mm(acts, self.w_rs[i])
             _lib.call("rtts_residual_epilogue", h.data_ptr(), rs.data_ptr(), self.b_rs[i].data_ptr(), 1.0, h.data_ptr(), m, c, 0.0, 0, None, _s())
-        return torch.mm(h.to(torch.bfloat16), self.w_end.t(), out_dtype=torch.float32) + self.b_end
+        hb = torch.empty(mp, c, dtype=torch.bfloat16, device=dev)
+        _lib.call("rtts_cast_f32_bf16", h.data_ptr(), hb.data_ptr(), m * c, _s())
+        return mm(hb, self.w_end, self.b_end, True)
 
 
 class SqueezeWave(nn.Module):
@@ -188,14 +246,16 @@ class SqueezeWave(nn.Module):
         assert [tuple(z.shape) for z in noise] == shapes, "noise tensors do not match noise_shapes()"
         rows = lambda z: z.to(dev, torch.float32).permute(0, 2, 1).reshape(b * length, -1).contiguous()    # noqa: E731
         draws = iter(noise)
-        mel_rows = mel.permute(0, 2, 1).reshape(b * mel_len, n_mel).to(torch.bfloat16).contiguous()
+        mel_rows = mel.to(torch.float32).permute(0, 2, 1).reshape(b * mel_len, n_mel).contiguous()
         audio = rows(next(draws))                                                  # (B*L, n_remaining) fp32
         for k in reversed(range(self.n_flows)):
-            half = audio.shape[1] // 2
-            a0 = audio[:, :half].contiguous()
-            wn_out = folded[k].forward(a0, mel_rows, b, length, mel_len)            # [s | b]
-            _lib.call("rtts_sw_coupling_inv", audio.data_ptr(), audio.stride(0), wn_out.data_ptr(), audio.shape[0], half, _s())
-            audio = torch.mm(audio, self._winv[k].t())                             # inverse 1x1 convolution, fp32
+            n = audio.shape[1]
+            wn_out = folded[k].forward(audio, mel_rows, b, length, mel_len)        # [s | b | padding], row stride n_end
+            nxt = torch.empty_like(audio)
+            # inverse coupling + inverse 1x1 convolution in one fp32 launch (modules.py:353-361)
+            _lib.call("rtts_sw_coupling_inv1x1", audio.data_ptr(), audio.stride(0), wn_out.data_ptr(), wn_out.stride(0),
+                      self._winv[k].data_ptr(), n, audio.shape[0], nxt.data_ptr(), nxt.stride(0), _s())
+            audio = nxt
             if self.return_early(k):
                 audio = torch.cat((sigma * rows(next(draws)), audio), dim=1)
         return torch.clamp(audio.view(b, length * audio.shape[1]), -1, 1)

@@ -380,7 +380,7 @@ def test_full_depth_gradients_vs_oracle(gpu, case):
     # test_gemm_hip.py): deeper stacks collect more of them than the one-layer tests' 8e-2.  Bounds = ~1.5x the largest
     # achieved error of each group; a wiring mistake (a block reading another layer's mask, keys or permutation) is O(1).
     for name, rel in rels.items():
-        assert rel < (0.20 if name.startswith("enc.") else 0.12), (name, rel)
+        assert rel < (0.15 if name.startswith("enc.") else 0.12), (name, rel)
 
 
 def test_fused_engine_matches_general_path(gpu):
@@ -405,8 +405,7 @@ def test_fused_engine_matches_general_path(gpu):
         model.enc.reformer.layers.use_fused = fused
         model.dec.reformer.layers.use_fused = fused
         for layer in _lsh_layers(model):              # the same hash rotations on both paths (each would draw its own)
-            layer.forced_rotations = torch.randn(1, 64, 4, layer_buckets(layer, model, batch) // 2,
-                                                 generator=torch.Generator().manual_seed(3))
+            layer.forced_rotations = {nb: torch.randn(1, 64, 4, nb // 2, generator=torch.Generator().manual_seed(3)) for nb in (2, 4, 6, 8)}
         spec = batch["spectrogram"]
         raw, post, stop, _ = model(batch["phonemes"], spec[:, :-1], spectrogram_mask=batch["loss_mask"].mean(-1))
         res = TTSLoss(torch.tensor(5.0))(raw, post, stop.view(stop.shape[0], -1), spec[:, 1:], batch["stop_tokens"], batch["loss_mask"])
