@@ -538,4 +538,119 @@ def decoder_prenet_pe(prenet, pe, spec):
     return proj_pe(h.view(b, l, -1), lyr.projection, pe)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# Inference (no-grad) forms of the edges: ``ReformerTTS.infer`` / ``Trainer.validate`` (reference reformer_tts.py:145-221,
+# training/wrappers.py:107-140) run the prenets, the heads and the postnet in eval mode.  Same kernels as the training
+# executors above -- rtts_gemm_nt for every Linear, the implicit-GEMM Conv1d on halo rows, rtts_bn_act_fwd with the RUNNING
+# statistics in place of the batch statistics -- no autograd state, no library GEMM.
+# ------------------------------------------------------------------------------------------------------------------
+def _padded_linear(lin) -> tuple:
+    """(weight (N rounded up to 64, K rounded up to 64) bf16 zero padded, bias (N padded) fp32 | None), cached on the module and
+    rebuilt when the master weight changed."""
+    w = lin.weight
+    ver = (w._version, WEIGHT_EPOCH[0], w.data_ptr(), None if lin.bias is None else lin.bias._version)
+    cache = getattr(lin, "_rtts_padded", None)
+    if cache is None or cache[0] != ver or cache[1].device != w.device:
+        n, k = w.shape
+        npad, kpad = -(-n // 64) * 64, -(-k // 64) * 64
+        wb = w.detach().to(torch.bfloat16)
+        if (npad, kpad) != (n, k):
+            buf = torch.zeros(npad, kpad, dtype=torch.bfloat16, device=w.device)
+            buf[:n, :k].copy_(wb)
+            wb = buf
+        bias = None
+        if lin.bias is not None:
+            bias = torch.zeros(npad, dtype=torch.float32, device=w.device)
+            bias[:n].copy_(lin.bias.detach())
+        lin._rtts_padded = cache = (ver, wb.contiguous(), bias)
+    return cache[1], cache[2]
+
+
+def linear_nograd(x: torch.Tensor, lin, relu: bool = False, out_f32: bool = False) -> torch.Tensor:
+    """y (..., N) = [relu](x W^T + b) on rtts_gemm_nt for a tensor that needs no gradient: rows are rounded up to 128 and the
+    input width to 64 in one cast launch (rtts_to_halo with halo 0), the weight's output rows to 64.  bf16 (or fp32) result."""
+    shape = x.shape
+    k = shape[-1]
+    x2 = x.detach().reshape(-1, k)
+    m = x2.shape[0]
+    wb, bias = _padded_linear(lin)
+    n = lin.weight.shape[0]
+    mp, kp = -(-m // 128) * 128, wb.shape[1]
+    if x2.dtype == torch.bfloat16 and mp == m and kp == k and x2.stride(1) == 1 and x2.stride(0) % 8 == 0:
+        a = x2
+    else:
+        if x2.dtype not in (torch.float32, torch.bfloat16) or x2.stride(1) != 1 or k % 8 != 0 or \
+                x2.stride(0) % (4 if x2.dtype == torch.float32 else 8) != 0:
+            x2 = torch.nn.functional.pad(x2.float(), (0, -k % 8)).contiguous()         # odd widths: align once (tiny inputs only)
+        a = torch.empty(mp, kp, dtype=torch.bfloat16, device=x.device)
+        _lib.call("rtts_to_halo", x2.data_ptr(), x2.stride(0), 0, x2.shape[1], int(x2.dtype == torch.float32), 1, m, 0, kp, a.data_ptr(), 0, mp, _s())
+    if relu and bias is None:
+        bias = torch.zeros(wb.shape[0], dtype=torch.float32, device=x.device)
+    y = gemm(a, wb, bias=bias, relu=relu, out_f32=out_f32)
+    return y[:m, :n].view(*shape[:-1], n)
+
+
+def conv_stack_nograd(x: torch.Tensor, layers, convend=None) -> torch.Tensor:
+    """Eval-mode convolution stack on halo rows: ``layers`` = [(conv, bn, act)] with act 1 = ReLU, 2 = tanh (BatchNorm on its
+    running statistics, dropout off), optionally followed by ``convend`` (a bare Conv1d with bias).  x (B, L, C) fp32 | bf16
+    -> (B, L, C_out): bf16 after the last activation, fp32 after ``convend``."""
+    b, l, c = x.shape
+    dev = x.device
+    g = Halo(b, l)
+    x2 = x.detach().reshape(b * l, c)
+    if x2.dtype not in (torch.float32, torch.bfloat16) or x2.stride(1) != 1 or c % 8 != 0:
+        x2 = torch.nn.functional.pad(x2.float(), (0, -c % 8)).contiguous()
+    first = layers[0][0] if layers else convend
+    ex0 = _conv_exec(first)
+    cur = g.new(ex0.cp, dev)
+    _lib.call("rtts_to_halo", x2.data_ptr(), x2.stride(0), 0, x2.shape[1], int(x2.dtype == torch.float32), b, l, g.H, ex0.cp, cur.data_ptr(),
+              g.LEAD, g.alloc, _s())
+    for i, (conv, bn, act) in enumerate(layers):
+        ex = _conv_exec(conv)
+        y = ex.forward(cur, g)                                    # (mp, cop) fp32, bias not added
+        # eval: act(gamma * (y + bias - running_mean) * rsqrt(running_var + eps) + beta): the kernel's "mean" is running_mean - bias
+        cop = ex.cop
+        mean = torch.zeros(cop, dtype=torch.float32, device=dev)
+        rstd = torch.zeros(cop, dtype=torch.float32, device=dev)
+        mean[:ex.co] = bn.running_mean - conv.bias.detach()
+        rstd[:ex.co] = torch.rsqrt(bn.running_var + bn.eps)
+        gamma, beta = _pad_vec(bn.weight.detach(), cop), _pad_vec(bn.bias.detach(), cop)
+        last = convend is None and i == len(layers) - 1
+        if last:
+            z = torch.empty(b * l, cop, dtype=torch.bfloat16, device=dev)
+            zargs = (0, 0, b * l)
+        else:
+            z = g.new(cop, dev)
+            zargs = (1, g.LEAD, g.alloc)
+        _lib.call("rtts_bn_act_fwd", y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act, 0.0, 0,
+                  seed_base(dev).data_ptr(), b, l, g.H, cop, z.data_ptr(), *zargs, _s())
+        if last:
+            return z.view(b, l, cop)[..., :ex.co]
+        cur = z
+    ex = _conv_exec(convend)
+    bias = _pad_vec(convend.bias.detach(), ex.cop)
+    y = ex.forward(cur, g, bias=bias)                              # (mp, cop) fp32 halo rows
+    return g.valid(y)[..., :ex.co]
+
+
+def _conv_exec(conv) -> "ConvK5":
+    ex = getattr(conv, "_rtts_k5", None)
+    if ex is None:
+        ex = conv._rtts_k5 = ConvK5(conv)
+    return ex
+
+
+def _pad_vec(v: torch.Tensor, n: int) -> torch.Tensor:
+    if v.shape[0] == n and v.dtype == torch.float32:
+        return v.contiguous()
+    out = torch.zeros(n, dtype=torch.float32, device=v.device)
+    out[:v.shape[0]].copy_(v)
+    return out
+
+
+def nograd_ok(x: torch.Tensor) -> bool:
+    """The inference forms apply: a CUDA tensor, no gradient being recorded."""
+    return x.is_cuda and not torch.is_grad_enabled()
+
+
 _engine.FLUSH_HOOKS.append(flush_conv_dw)

@@ -128,6 +128,12 @@ class EncoderPreNet(nn.Module):
                 from ..edges import proj_pe
                 return proj_pe(z, self.projection, pe)               # projection + positional encoding fused
             return _bf16_linear(z, self.projection).float()
+        if not self.training and self.use_fused and x.is_cuda and not torch.is_grad_enabled():
+            # inference: the same kernels on the running BatchNorm statistics (edges.conv_stack_nograd), no library GEMM
+            from ..edges import conv_stack_nograd, linear_nograd
+            z = conv_stack_nograd(x, [(c.conv1, c.bn1, 1), (c.conv2, c.bn2, 1), (c.conv3, c.bn3, 1)])
+            y = linear_nograd(z, self.projection).float()
+            return y if pe is None else pe(y)
         if self.training and x.is_cuda:
             from .._lib import note_general_path
             note_general_path("encoder prenet", "use_fused is off" if not self.use_fused else
@@ -152,6 +158,10 @@ class DecoderPreNet(nn.Module):
 
     def forward(self, input_):
         l = self.layer
+        if not self.training and input_.is_cuda and not torch.is_grad_enabled():
+            from ..edges import linear_nograd            # inference: bias + ReLU in the GEMM epilogue, dropout is off
+            x = linear_nograd(linear_nograd(input_, l.fc1, relu=True), l.fc2, relu=True)
+            return linear_nograd(x, l.projection).float()
         x = l.dropout1(F.relu(_bf16_linear(input_, l.fc1)))
         x = l.dropout2(F.relu(_bf16_linear(x, l.fc2)))
         return _bf16_linear(x, l.projection).float()
@@ -173,6 +183,10 @@ class PostConvNet(nn.Module):
     def forward(self, input_):
         x = input_                                              # (B, L, mel) channels-last throughout
         depth = (len(self.layers) - 1) // 4
+        if not self.training and x.is_cuda and not torch.is_grad_enabled():
+            from ..edges import conv_stack_nograd          # inference: implicit-GEMM convolutions, running BatchNorm statistics
+            stack = [(getattr(self.layers, f"conv{i}"), getattr(self.layers, f"bn{i}"), 2) for i in range(depth)]
+            return conv_stack_nograd(x, stack, convend=self.layers.convend).float()
         for i in range(depth):
             conv, bn, drop = getattr(self.layers, f"conv{i}"), getattr(self.layers, f"bn{i}"), getattr(self.layers, f"dropout{i}")
             x = drop(torch.tanh(batch_norm_rows(conv1d_k5_rows(x, conv), bn)))

@@ -48,6 +48,9 @@ class Decoder(nn.Module):
 
     def forward(self, input_, keys, key_padding_mask=None, input_mask=None):
         x, attention_matrices = self.hidden(input_, keys, key_padding_mask=key_padding_mask, input_mask=input_mask)
+        if not self.training and x.is_cuda and not torch.is_grad_enabled():
+            from ..edges import linear_nograd            # inference: the heads on rtts_gemm_nt (fp32 epilogue), as in the training step
+            return linear_nograd(x, self.mel_linear, out_f32=True), linear_nograd(x, self.stop_linear, out_f32=True), attention_matrices
         return self.mel_linear(x), self.stop_linear(x), attention_matrices
 
 
@@ -149,6 +152,11 @@ class ReformerTTS(nn.Module):
             return self._infer_graphed(phonemes, max_len, stop_threshold, stop_at_stop_token, cache_encoder, check_every)
         was_training = self.training
         self.eval()
+        stacks = (self.enc.reformer.layers, self.dec.reformer.layers)
+        was_fused = [st_.fused_in_eval for st_ in stacks]
+        for st_ in stacks:
+            st_.fused_in_eval = True         # the stacks' forward through the explicit executor: with the no-grad edges
+            #                                  (edges.py) a generation step runs no library GEMM at all
         try:
             dev = self.dec.mel_linear.weight.device
             phonemes = phonemes.to(dev)
@@ -203,6 +211,8 @@ class ReformerTTS(nn.Module):
             stop = torch.where(stop == 0, torch.full_like(stop, max_len), stop)
             return buf[:, 1:cur].transpose(1, 2).contiguous(), stop
         finally:
+            for st_, f in zip(stacks, was_fused):
+                st_.fused_in_eval = f
             self.train(was_training)
 
     @torch.no_grad()

@@ -178,9 +178,19 @@ class Trainer:
     # ------------------------------------------------------------------ step pieces
     use_fused_edges = True
 
-    def _fused_edges_ok(self, batch) -> bool:
+    @staticmethod
+    def _frames(batch):
+        """(input frames [0, L-1), target frames [1, L)) of a batch (``wrappers.py:57-63``): views of ``spectrogram``, or the
+        two padded buffers of a per-shape graph entry -- the input must be ZERO behind the batch's own length, like the tail
+        ``pad_to_multiple`` appends, while the target still holds the last frame, so one padded array cannot serve both."""
+        if "spectrogram_input" in batch:
+            return batch["spectrogram_input"], batch["spectrogram_target"]
         spec = batch["spectrogram"]
-        lm = spec.shape[1] - 1
+        return spec[:, :-1], spec[:, 1:]
+
+    def _fused_edges_ok(self, batch) -> bool:
+        spec = self._frames(batch)[0]
+        lm = spec.shape[1]
         lp = -(-lm // self.model.pad_base) * self.model.pad_base      # the decoder runs on the padded length
         ok = self.use_fused_edges and self.device.type == "cuda" and self.model.training and (spec.shape[0] * lp) % 64 == 0
         if not ok and self.use_fused_edges and self.device.type == "cuda" and self.model.training:
@@ -201,7 +211,7 @@ class Trainer:
 
     def forward_loss(self, batch, split: bool = False):
         """``wrappers.py:53-72``: input frames [0, L-1), targets [1, L), mask = loss_mask.mean(-1)."""
-        spec = batch["spectrogram"]
+        spec = self._frames(batch)[0]
         from ..model.lsh_attention import LSHSelfAttention
         if getattr(self, "_graph_rotations", False):
             # graph mode: the hash rotations of every LSH layer of this forward are slices of ONE sample (one launch, not one
@@ -216,18 +226,18 @@ class Trainer:
             LSHSelfAttention.rotation_pool = None
 
     def _forward_loss(self, batch, split: bool = False):
-        spec = batch["spectrogram"]
+        spec_in, spec_tgt = self._frames(batch)
         if self._fused_edges_ok(batch):
             from ..edges import PostnetLoss
             if getattr(self, "_postnet_loss", None) is None:
                 self._postnet_loss = PostnetLoss(self.model, self.loss)
-            y = self.model.decoder_hidden(batch["phonemes"], spec[:, :-1], spectrogram_mask=batch["loss_mask"].mean(dim=-1),
+            y = self.model.decoder_hidden(batch["phonemes"], spec_in, spectrogram_mask=batch["loss_mask"].mean(dim=-1),
                                           keys_hook=self._cut_at_encoder if split else None,
                                           enc_stack_hook=self._cut_at_enc_stack if split else None)
-            losses = self._postnet_loss.apply(y, spec[:, 1:], batch["stop_tokens"], batch["loss_mask"], batch.get("valid_len"))
+            losses = self._postnet_loss.apply(y, spec_tgt, batch["stop_tokens"], batch["loss_mask"], batch.get("valid_len"))
             return losses[0], losses[1], losses[2], losses[3]
-        raw, post, stop, _ = self.model(batch["phonemes"], spec[:, :-1], spectrogram_mask=batch["loss_mask"].mean(dim=-1))
-        return self.loss(raw, post, stop.view(stop.shape[0], -1), spec[:, 1:], batch["stop_tokens"], batch["loss_mask"])
+        raw, post, stop, _ = self.model(batch["phonemes"], spec_in, spectrogram_mask=batch["loss_mask"].mean(dim=-1))
+        return self.loss(raw, post, stop.view(stop.shape[0], -1), spec_tgt, batch["stop_tokens"], batch["loss_mask"])
 
     def zero_grad(self):
         self.flat_g.zero_()
@@ -462,7 +472,8 @@ class Trainer:
         b, kp, km = key
         nm = batch["spectrogram"].shape[2]
         bufs = dict(phonemes=torch.zeros(b, kp * pb, dtype=batch["phonemes"].dtype, device=dev),
-                    spectrogram=torch.zeros(b, km * pb + 1, nm, dtype=torch.float32, device=dev),
+                    spectrogram_input=torch.zeros(b, km * pb, nm, dtype=torch.float32, device=dev),
+                    spectrogram_target=torch.zeros(b, km * pb, nm, dtype=torch.float32, device=dev),
                     stop_tokens=torch.zeros(b, km * pb, dtype=torch.float32, device=dev),
                     loss_mask=torch.zeros(b, km * pb, nm, dtype=torch.float32, device=dev),
                     valid_len=torch.ones(1, dtype=torch.int32, device=dev))
@@ -523,7 +534,8 @@ class Trainer:
         bufs = entry["bufs"]
         lp = batch["phonemes"].shape[1]
         lm = batch["spectrogram"].shape[1] - 1
-        for name, src, n in (("phonemes", batch["phonemes"], lp), ("spectrogram", batch["spectrogram"], lm + 1),
+        spec = batch["spectrogram"]
+        for name, src, n in (("phonemes", batch["phonemes"], lp), ("spectrogram_input", spec[:, :-1], lm), ("spectrogram_target", spec[:, 1:], lm),
                              ("stop_tokens", batch["stop_tokens"], lm), ("loss_mask", batch["loss_mask"], lm)):
             dst = bufs[name]
             if dst.shape[1] > n:

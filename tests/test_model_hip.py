@@ -1084,6 +1084,43 @@ def test_infer_matches_reference_golden(golden_dir, gpu, case):
         assert float((spec.cpu() - ref).abs().mean()) < 0.1 * scale
 
 
+@pytest.mark.parametrize("what", ["infer", "infer_graph", "validate"])
+def test_eval_mode_paths_run_no_library_gemm(golden_dir, gpu, what):
+    """Generation (reformer_tts.py:145-221) and validation (training/wrappers.py:107-140) run the model in eval mode: prenets
+    (running BatchNorm statistics), heads, postnet and both stacks go through the in-tree kernels -- an ATen census of the
+    call shows no matrix product, convolution, linear or scaled-dot-product operator, and nothing reports a general path."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from reformer_tts_amd import _lib
+    from reformer_tts_amd.model.config import TTSTrainingConfig
+    from reformer_tts_amd.training import Trainer, synthetic_batch
+    zi, model = _load_infer(golden_dir, gpu, "concat_stop")
+    for layer in _lsh_layers(model):
+        layer.forced_rotations = None                  # the fixture's recorded rotations are per call: draw fresh ones here
+    ph = torch.from_numpy(zi["phonemes"])
+    seen = []
+
+    class Census(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            seen.append(str(func))
+            return func(*args, **(kwargs or {}))
+
+    if what == "validate":
+        tr = Trainer(model, TTSTrainingConfig(batch_size=2), gpu)
+        batch = synthetic_batch(2, 100, 200, device=gpu)
+        run = lambda: tr.validate(batch)                                             # noqa: E731
+    else:
+        run = lambda: model.infer(ph, max_len=86, stop_at_stop_token=False, use_graph=(what == "infer_graph"))   # noqa: E731
+    run()                                             # warm-up: padded weight copies, tables, graph captures
+    before = len(_lib.PATHS_LEFT)
+    with Census():
+        out = run()
+    assert all(torch.isfinite(o).all() for o in out if torch.is_tensor(o) and o.is_floating_point())
+    bad = sorted({f for f in seen if any(k in f for k in ("aten.mm", "aten.addmm", "aten.bmm", "aten.matmul", "aten.convolution", "aten.linear",
+                                                          "scaled_dot_product", "aten.baddbmm"))})
+    assert not bad, bad
+    assert len(_lib.PATHS_LEFT) == before, _lib.PATHS_LEFT[before:]
+
+
 def test_infer_cached_encoder_and_check_interval(golden_dir, gpu):
     """check_every only moves the host's look at the stop flags: identical output for 1 and 8.  cache_encoder runs the
     encoder once; with rotations held fixed per layer (what makes the two runs comparable) the frames agree closely."""
