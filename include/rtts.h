@@ -270,6 +270,24 @@ int rtts_bn_act_fwd(const float* y, const float* mean, const float* rstd, const 
 int rtts_bn_act_bwd(const float* y, const void* dz, int dz_halo, const float* mean, const float* rstd, const float* gamma,
                     const float* beta, int act, float drop_p, uint32_t seed, const uint32_t* seed_dev, int B, int L, int halo, int C,
                     void* dy, int dy_lead, int64_t dy_rows, float* dgamma, float* dbeta, float* partial_ws, void* stream);
+/* Data-parallel BatchNorm (SyncBN; SURVEY.md 8(e), reference modules.py:29,127 normalise over the whole batch): the two
+ * stages of rtts_bn_stats / rtts_bn_act_bwd as separate calls, so that the caller can all-reduce the 2*C floats between them.
+ *   rtts_bn_moments        moments[0..C) = sum y, [C..2C) = sum y^2 over this rank's B*L valid rows
+ *   rtts_bn_from_moments   mean / rstd (eps 1e-5; running statistics as rtts_bn_stats) from summed moments over `count` rows
+ *   rtts_bn_act_bwd_sums   sums[0..C) = sum g, [C..2C) = sum g*yhat (g = dz through act and dropout); dgamma, dbeta accumulate
+ *                          the LOCAL sums (the gradient all-reduce adds the ranks)
+ *   rtts_bn_act_bwd_apply  dy from (all-reduced) sums over `count` rows
+ * count = 0 in rtts_bn_from_moments / rtts_bn_act_bwd_apply: the row count is read from element [2*C] of moments / sums -- the
+ * caller stores its own B*L there before the all-reduce, so ranks with different batch shapes need no second collective. */
+int rtts_bn_moments(const float* y, int B, int L, int halo, int C, float* moments, float* partial_ws, void* stream);
+int rtts_bn_from_moments(const float* moments, int64_t count, int C, float* mean, float* rstd, float* run_mean, float* run_var,
+                         const float* mean_shift, int64_t* num_batches, void* stream);
+int rtts_bn_act_bwd_sums(const float* y, const void* dz, int dz_halo, const float* mean, const float* rstd, const float* gamma,
+                         const float* beta, int act, float drop_p, uint32_t seed, const uint32_t* seed_dev, int B, int L, int halo, int C,
+                         float* sums, float* dgamma, float* dbeta, float* partial_ws, void* stream);
+int rtts_bn_act_bwd_apply(const float* y, const void* dz, int dz_halo, const float* mean, const float* rstd, const float* gamma,
+                          const float* beta, int act, float drop_p, uint32_t seed, const uint32_t* seed_dev, int B, int L, int halo, int C,
+                          const float* sums, int64_t count, void* dy, int dy_lead, int64_t dy_rows, void* stream);
 int rtts_tts_loss(const float* raw, const float* post, int64_t ld_mel, const float* tgt, const float* mask, const float* stop,
                   int64_t ld_stop, const float* tstop, int rows, int NM, int kind, float pos_weight, float w_raw, float w_post,
                   float w_stop, float* d_raw, float* d_post, int64_t ld_grad, float* d_stop, float* losses, float* partial_ws,

@@ -84,6 +84,10 @@ SIGNATURES = {
     "rtts_bn_stats": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "rtts_bn_act_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _u32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i64, _vp],
     "rtts_bn_act_bwd": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _u32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i64, _vp, _vp, _vp, _vp],
+    "rtts_bn_moments": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "rtts_bn_from_moments": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "rtts_bn_act_bwd_sums": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _u32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    "rtts_bn_act_bwd_apply": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _u32, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _i64, _vp],
     "rtts_tts_loss": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32,
                       _vp, _i64, _i32, _i32, _i64, _i64, _vp, _i64, _i64, _vp],
     "rtts_pe_add": [_vp, _vp, _vp, _f32, _u32, _vp, _i32, _i64, _i32, _vp, _vp],

@@ -275,6 +275,37 @@ __global__ __launch_bounds__(64 * ED_FIN_WAVES) void bn_finalize_bwd_kernel(cons
     dgamma[c] += q;
 }
 
+// ---- data-parallel BatchNorm (SyncBN): the per-rank sums leave the chip between the two stages so that the caller can
+//      all-reduce them (2*C floats per BatchNorm layer and direction).  Reference: modules.py:29,127 normalise
+//      over the WHOLE batch, which under data parallelism is spread over the ranks.
+// moments[0..C) = sum y, moments[C..2C) = sum y^2 over this rank's valid rows
+__global__ __launch_bounds__(64 * ED_FIN_WAVES) void bn_moments_kernel(const float* __restrict__ partial, int nrows, int C, float* __restrict__ moments) {
+    __shared__ float red[2][ED_FIN_WAVES][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    float s, q;
+    ed_reduce_partials(partial, nrows, C, c, s, q, red);
+    if (threadIdx.x >= 64 || c >= C) return;
+    moments[c] = s;
+    moments[C + c] = q;
+}
+// mean / rstd (+ running statistics) from summed moments over `count` rows (the global batch)
+__global__ void bn_from_moments_kernel(const float* __restrict__ moments, float count, int C, float* __restrict__ mean, float* __restrict__ rstd,
+                                       float* __restrict__ run_mean, float* __restrict__ run_var, const float* __restrict__ mean_shift,
+                                       long long* __restrict__ num_batches) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (num_batches && c == 0) num_batches[0] += 1;
+    if (c >= C) return;
+    if (count <= 0.f) count = moments[2 * C];         // the row count travelled through the all-reduce with the sums
+    const float mu = moments[c] / count;
+    const float var = fmaxf(moments[C + c] / count - mu * mu, 0.f);
+    mean[c] = mu;
+    rstd[c] = rsqrtf(var + 1e-5f);
+    if (run_mean) {
+        run_mean[c] = 0.9f * run_mean[c] + 0.1f * (mu + (mean_shift ? mean_shift[c] : 0.f));
+        run_var[c] = 0.9f * run_var[c] + 0.1f * var * (count / (count > 1.f ? count - 1.f : 1.f));
+    }
+}
+
 // z = dropout(act(gamma*(y-mean)*rstd + beta)) as bf16; 4 channels per thread.  y: halo (or plain) rows described by g;
 // z_halo: z is a halo array of z_rows rows whose row z_lead is halo row 0 (everything outside the valid set is written as
 // zero: the next convolution's taps read it); else z has B*L plain rows.  The dropout counter is the element index in y.
@@ -333,6 +364,7 @@ __global__ __launch_bounds__(ED_THREADS) void bn_act_bwd_apply_kernel(const floa
                                                                       const float* __restrict__ sums, float inv_m, EdHalo g, int dz_halo, int dy_lead,
                                                                       size_t n4, int C, int cshift, bf16_t* __restrict__ dy) {
     if (seed_dev) seed += seed_dev[0];
+    if (inv_m < 0.f) inv_m = 1.f / sums[2 * C];       // data-parallel form: the global row count came through the all-reduce
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         unsigned drow_;
         int c;
@@ -834,6 +866,64 @@ extern "C" int rtts_bn_act_bwd(const float* y, const void* dz, int dz_halo, cons
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ed_grid(n4)), dim3(ED_THREADS), 0, (hipStream_t)stream, y, (const bf16_t*)dz, mean, rstd,
                        gamma, beta, act, seed, seed_dev, th, ds, sums, 1.f / (float)((size_t)B * L), g, dzh, dy_lead, n4, C, ed_cshift(C), (bf16_t*)dy);
     RTTS_LAUNCH_CHECK("rtts_bn_act_bwd");
+    return 0;
+}
+
+extern "C" int rtts_bn_moments(const float* y, int B, int L, int halo, int C, float* moments, float* partial_ws, void* stream) {
+    RTTS_ENTER(stream);
+    RTTS_REQUIRE(y && moments && partial_ws && B > 0 && L > 0 && halo >= 0 && C > 0 && C % 4 == 0, "rtts_bn_moments: bad arguments");
+    const EdHalo g = ed_halo(B, L, halo);
+    const dim3 grid = ed_col_grid(B * g.P, C);
+    hipLaunchKernelGGL((col_partial_kernel<0>), grid, dim3(ED_THREADS), 0, (hipStream_t)stream, y, (const bf16_t*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0u, (const uint32_t*)nullptr, 0u, 1.f, g, 1, C,
+                       partial_ws);
+    hipLaunchKernelGGL(bn_moments_kernel, dim3((C + 63) / 64), dim3(64 * ED_FIN_WAVES), 0, (hipStream_t)stream, partial_ws, (int)grid.x, C, moments);
+    RTTS_LAUNCH_CHECK("rtts_bn_moments");
+    return 0;
+}
+
+extern "C" int rtts_bn_from_moments(const float* moments, int64_t count, int C, float* mean, float* rstd, float* run_mean, float* run_var,
+                                    const float* mean_shift, int64_t* num_batches, void* stream) {
+    RTTS_ENTER(stream);
+    RTTS_REQUIRE(moments && mean && rstd && count >= 0 && C > 0, "rtts_bn_from_moments: bad arguments");
+    hipLaunchKernelGGL(bn_from_moments_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, moments, (float)count, C, mean, rstd,
+                       run_mean, run_var, mean_shift, (long long*)num_batches);
+    RTTS_LAUNCH_CHECK("rtts_bn_from_moments");
+    return 0;
+}
+
+extern "C" int rtts_bn_act_bwd_sums(const float* y, const void* dz, int dz_halo, const float* mean, const float* rstd, const float* gamma,
+                                    const float* beta, int act, float drop_p, uint32_t seed, const uint32_t* seed_dev, int B, int L, int halo,
+                                    int C, float* sums, float* dgamma, float* dbeta, float* partial_ws, void* stream) {
+    RTTS_ENTER(stream);
+    RTTS_REQUIRE(y && dz && mean && rstd && gamma && beta && sums && dgamma && dbeta && partial_ws && B > 0 && L > 0 && halo >= 0 && C % 4 == 0 &&
+                     (act == 1 || act == 2), "rtts_bn_act_bwd_sums: bad arguments");
+    const EdHalo g = ed_halo(B, L, halo);
+    const dim3 grid = ed_col_grid(B * g.P, C);
+    const int dzh = (halo > 0 && dz_halo) ? 1 : 0;
+    hipLaunchKernelGGL((col_partial_kernel<1>), grid, dim3(ED_THREADS), 0, (hipStream_t)stream, y, (const bf16_t*)dz, mean, rstd, gamma, beta, act,
+                       seed, seed_dev, ed_thresh(drop_p), 1.f / (1.f - drop_p), g, dzh, C, partial_ws);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 63) / 64), dim3(64 * ED_FIN_WAVES), 0, (hipStream_t)stream, partial_ws,
+                       (int)grid.x, C, sums, dgamma, dbeta);
+    RTTS_LAUNCH_CHECK("rtts_bn_act_bwd_sums");
+    return 0;
+}
+
+extern "C" int rtts_bn_act_bwd_apply(const float* y, const void* dz, int dz_halo, const float* mean, const float* rstd, const float* gamma,
+                                     const float* beta, int act, float drop_p, uint32_t seed, const uint32_t* seed_dev, int B, int L, int halo,
+                                     int C, const float* sums, int64_t count, void* dy, int dy_lead, int64_t dy_rows, void* stream) {
+    RTTS_ENTER(stream);
+    RTTS_REQUIRE(y && dz && mean && rstd && gamma && beta && sums && dy && count >= 0 && B > 0 && L > 0 && halo >= 0 && C % 4 == 0 &&
+                     (act == 1 || act == 2), "rtts_bn_act_bwd_apply: bad arguments");
+    const EdHalo g = ed_halo(B, L, halo);
+    RTTS_REQUIRE(dy_lead >= 0 && dy_rows >= dy_lead + (int64_t)B * g.P, "rtts_bn_act_bwd_apply: dy needs room for B*(L+2*halo) rows behind its lead-in");
+    const int dzh = (halo > 0 && dz_halo) ? 1 : 0;
+    const size_t n4 = (size_t)dy_rows * C / 4;
+    RTTS_REQUIRE(n4 < (1ull << 30), "rtts_bn_act_bwd_apply: more than 2^32 elements");
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ed_grid(n4)), dim3(ED_THREADS), 0, (hipStream_t)stream, y, (const bf16_t*)dz, mean, rstd,
+                       gamma, beta, act, seed, seed_dev, ed_thresh(drop_p), 1.f / (1.f - drop_p), sums, count > 0 ? 1.f / (float)count : -1.f, g, dzh,
+                       dy_lead, n4, C, ed_cshift(C), (bf16_t*)dy);
+    RTTS_LAUNCH_CHECK("rtts_bn_act_bwd_apply");
     return 0;
 }
 

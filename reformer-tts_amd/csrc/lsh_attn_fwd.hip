@@ -17,8 +17,13 @@
 //   4. O^T += V^T P^T: the P^T accumulators are the B operand as they stand (rows of X are the
 //      contraction index), V^T fragments come from the row-major V image by ds_read_b64_tr_b16;
 //   5. rows of o and lse are written directly at their UNSORTED position (round, t).
-// The kernel is VALU-bound (about 10 vector ops per logit against 1/64 MFMA), so it is built for
-// occupancy: ~120 VGPRs, tile loop not unrolled, 2 workgroups (16 waves) per CU.
+// The kernel is built for occupancy: ~120 VGPRs, tile loop not unrolled, 2 workgroups (16 waves) per CU.  It is LATENCY-bound,
+// not VALU-bound as round 2 assumed: a variant with the running maximum replaced by the bound |q| dh^-1/2 of the normalised
+// keys' logits (no max, no rescale, one exp per logit: 6.5 vector issue slots per logit instead of 8.5, same registers, no
+// spills) measured 124-125 us against 121 us at the decoder shape and 116 against 107 us at T = 4096
+// (gpurun_out/r03_kbench_fwd_{fixed,nofixed}.log; round 3) -- removed again.  A wave's chain through a key tile
+// (4 dependent MFMAs, ~150 dependent vector instructions at one issue per 4 cycles, 4 MFMAs) sets the pace, four waves per
+// SIMD out of phase do not fill the issue slots, and gather -> tiles -> merge -> stores is one serial chain per workgroup.
 #include "rtts_common.h"
 #include <float.h>
 
@@ -149,80 +154,8 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
     for (int dt = 0; dt < 2; ++dt) tro[dt] = af_voff(4 * hh + trq, dt * 4 + 2 * trc + (trp >> 1)) + 8 * (trp & 1);
 
     const bool wrap = (cprev / nb) != (c / nb);
-    // ---- softmax mode of this query tile --------------------------------------------------------------------------------
-    // Keys are L2-normalised, so every logit of query q is bounded: |x| = |q . k| * sc_k <= |q| * dh^-1/2 * log2(e) =: mq (the
-    // key's scale sc_k = dh^-1/2 log2(e) / |k| is computed from the same bf16 values the MFMA multiplies).  With the bound as the
-    // FIXED reference of the exponentials -- p = exp2(x - mq) in [2^(-2 mq), 1] -- the online-softmax machinery (running
-    // maximum, rescale of O and l, a second exp per tile) disappears: per logit one fma, the mask select, one exp2 and one add
-    // (6.5 issue slots against 8.5).  mq = C^2 / ksc[q] from the gather's own row norm.  2 mq must stay inside fp32's exponent
-    // range: a tile with mq > 60 anywhere (|q| > 330: never seen, LayerNorm feeds the projection) takes the online path below.
-    // The self logit (-5e4) is 0 in this scale; a query that sees NOTHING but itself (first token of a causal ring, an
-    // invalid query) is recognised by l == 0 at the end and gets what the reference's softmax gives: its own value row,
-    // lse = -5e4 + ln(copies of itself among the keys).
-    const float mq = (0.125f * AF_LOG2E) * (0.125f * AF_LOG2E) / ksc[qrow];
-#ifdef AF_NO_FIXED_MAX                       // A/B builds (scripts/build_ab.sh): the online softmax everywhere
-    const bool fixed = false;
-#else
-    const bool fixed = !__any(mq > 60.f);
-#endif
-    float m = fixed ? mq : AF_NEG, l = 0.f, nself = 0.f;
+    float m = AF_NEG, l = 0.f;
     f32x16 oacc[2] = {{0}, {0}};
-    if (fixed) {
-#pragma unroll AF_UNROLL
-        for (int kt = kh * (NKT / 2); kt < (kh + 1) * (NKT / 2); ++kt) {
-            f32x16 acc = {0};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + r) * AF_ROWB + (ks * 16 + 8 * hh) * 2);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc, 0, 0, 0);
-            }
-            const bool chk_self = (kt < NQT) ? (kt == qt) : wrap;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int key0 = kt * 32 + 8 * g + 4 * hh;
-                const float4 sc = *reinterpret_cast<const float4*>(ksc + key0);
-                const int4 ke = *reinterpret_cast<const int4*>(kpe + key0);
-                const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
-                const int kev[4] = {ke.x, ke.y, ke.z, ke.w};
-                if (chk_self) {
-                    const int4 kp = *reinterpret_cast<const int4*>(kpos + key0);
-                    const int kpv[4] = {kp.x, kp.y, kp.z, kp.w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const bool self = kpv[j] == qpos;
-                        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[4 * g + j], scv[j], -mq));
-                        p = (kev[j] > qpe || self) ? 0.f : p;
-                        nself += self ? 1.f : 0.f;
-                        acc[4 * g + j] = p;
-                        l += p;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[4 * g + j], scv[j], -mq));
-                        p = (kev[j] > qpe) ? 0.f : p;
-                        acc[4 * g + j] = p;
-                        l += p;
-                    }
-                }
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const int o8 = 8 * s2;
-                const bf16x8 pf = cvt_bf16x8(acc[o8], acc[o8 + 1], acc[o8 + 2], acc[o8 + 3], acc[o8 + 4], acc[o8 + 5], acc[o8 + 6], acc[o8 + 7]);
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const int blk = (kt * 32 + 16 * s2) * 128;
-                    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((RTTS_LDS short4v*)(Vs + blk + tro[dt]));
-                    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((RTTS_LDS short4v*)(Vs + blk + 8 * 128 + tro[dt ^ 1]));
-                    const af_short8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, both), pf, oacc[dt], 0, 0, 0);
-                }
-            }
-        }
-        l = rtts_xhalf_sum(l);
-        nself = rtts_xhalf_sum(nself);
-    } else {
 #pragma unroll AF_UNROLL
     for (int kt = kh * (NKT / 2); kt < (kh + 1) * (NKT / 2); ++kt) {
         f32x16 acc = {0};
@@ -305,10 +238,9 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
         }
     }
     l = rtts_xhalf_sum(l);
-    }
 
     // ---- merge the two key halves of a query tile through LDS (aliases the K image) ----------
-    float* part = reinterpret_cast<float*>(Ks) + (size_t)qt * 35 * 64;   // [35][64]: 32 x O, m, l, self count per lane
+    float* part = reinterpret_cast<float*>(Ks) + (size_t)qt * 34 * 64;   // [34][64]: 32 x O, m, l per lane
     AF_STAMP(3);
     __syncthreads();                       // every wave is done reading K
     AF_STAMP(4);
@@ -320,41 +252,10 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
         }
         part[32 * 64 + lane] = m;
         part[33 * 64 + lane] = l;
-        part[34 * 64 + lane] = nself;
     }
     __syncthreads();
     if (kh == 1) return;
-    if (fixed) {                           // both halves used the same reference mq: plain sums
-        l += part[33 * 64 + lane];
-        nself += part[34 * 64 + lane];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            oacc[0][i] += part[i * 64 + lane];
-            oacc[1][i] += part[(16 + i) * 64 + lane];
-        }
-        if (__any(l == 0.f)) {             // rare: a query with no live key but itself
-            if (l == 0.f) {
-                const bf16_t* vrow = vbase + (size_t)qpos * ld;
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const uint2 vv = *reinterpret_cast<const uint2*>(vrow + dt * 32 + 8 * g + 4 * hh);
-                        oacc[dt][4 * g] = __uint_as_float(vv.x << 16);
-                        oacc[dt][4 * g + 1] = __uint_as_float(vv.x & 0xffff0000u);
-                        oacc[dt][4 * g + 2] = __uint_as_float(vv.y << 16);
-                        oacc[dt][4 * g + 3] = __uint_as_float(vv.y & 0xffff0000u);
-                    }
-                l = fmaxf(nself, 1.f);     // lse = -5e4 + ln(copies); o = the value row (the copies are the same token)
-                m = -5e4f * AF_LOG2E;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    oacc[0][i] *= l;
-                    oacc[1][i] *= l;
-                }
-            }
-        }
-    } else {
+    {
         const float m2 = part[32 * 64 + lane], l2 = part[33 * 64 + lane];
         const float mm = fmaxf(m, m2);
         const float a1 = __builtin_amdgcn_exp2f(m - mm), a2 = __builtin_amdgcn_exp2f(m2 - mm);

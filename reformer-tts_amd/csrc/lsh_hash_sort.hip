@@ -18,6 +18,7 @@
 // ballot / ~ballot per bucket-id bit), a lane's stable rank is the popcount of that mask below it, and the
 // per-(wave, bucket) running offsets live in LDS -- O(log n_buckets) wave ops per group instead of O(n_buckets).
 #include "rtts_common.h"
+#include <stdlib.h>
 
 #define HS_DH 64
 #ifndef HS_PF32
@@ -257,6 +258,211 @@ __global__ __launch_bounds__(64 * WAVES) void lsh_hash_sort_kernel(
     }
 }
 
+// ======================================================================================================================
+// Two-launch form (default): HASH for all rounds at once, then SORT per (head, round).
+//
+// The one-launch kernel above reads and stages every qk row once per hash round (8 times: 768 workgroups, four dependent
+// load -> hash trips each) and broadcasts the rotation matrix from LDS for every row element: 23-28 us at the decoder shape,
+// 0.10 of the HBM roofline, 72 % of its wave cycles waiting.  Here
+//   * rtts hash kernel: a workgroup = 128 tokens of one (batch, head); its rows are fetched and staged ONCE and projected
+//     on the columns of ALL rounds by v_mfma_f32_32x32x2_f32 -- bit for bit the k-ordered fp32 fmaf chain of
+//     oracle/lsh_int.c (one rounding per product, no wider accumulation; the 33..64-bucket path above already relies on it).
+//     The A operand is R^T with the rounds side by side: pass p holds the columns 32p .. 32p+31 of the (round, column)
+//     grid at capacity HALF per round (decoder: 8 rounds x 4 columns = ONE pass), 32 registers per lane loaded straight
+//     from the (tiny, L2-resident) rotation tensor -- no LDS broadcast at all.  The q values of a lane's two tokens stay in
+//     registers across passes.  Bucket ids go to the `st` array itself (as scratch) and to `buckets` when asked for.
+//   * sort kernel: one workgroup per (head, round) reads its T bucket ids (4 KB) and runs the same stable counting sort.
+// Traffic: 128 B per token and head read once + 2 x 4 B x rounds written + 4 B x rounds read.
+template <int HALF>
+__global__ __launch_bounds__(128) void lsh_hash_rounds_kernel(const bf16_t* __restrict__ qk, int64_t ld, const float* __restrict__ rotations,
+                                                              int rot_rows, int H, int T, int n_hashes, int half,
+                                                              int32_t* __restrict__ buckets, int32_t* __restrict__ ids) {
+    __shared__ __attribute__((aligned(16))) unsigned char tile[2 * 64 * HS_ROWB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int blocks_per_head = T / 128;
+    const uint32_t w = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = w / blocks_per_head, t0 = (w % blocks_per_head) * 128 + wave * 64;
+    const int b = bh / H, h = bh % H;
+    const int NB = 2 * half;
+    const bf16_t* base = qk + ((size_t)b * T + t0) * ld + (size_t)h * HS_DH;
+    unsigned char* wt = tile + wave * 64 * HS_ROWB;
+    {   // stage this wave's 64 rows: coalesced 16-byte pieces, all eight loads in flight
+        uint4 pre[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) pre[p] = *reinterpret_cast<const uint4*>(base + (size_t)(p * 8 + (lane >> 3)) * ld + (lane & 7) * 8);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) *reinterpret_cast<uint4*>(wt + (p * 8 + (lane >> 3)) * HS_ROWB + (lane & 7) * 16) = pre[p];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int hh = lane >> 5, l31 = lane & 31;
+    // B operand: q[token][2j + hh], tokens 32 * sub + (lane & 31): 2 x 32 registers, kept for every pass
+    float bq[2][32];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+        const unsigned char* rowp = wt + (32 * sub + l31) * HS_ROWB;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const uint4 val = *reinterpret_cast<const uint4*>(rowp + p * 16);
+            const uint32_t uu[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bq[sub][p * 4 + k] = __uint_as_float(hh ? (uu[k] & 0xffff0000u) : (uu[k] << 16));
+        }
+    }
+    const float* rot_src = rotations + (size_t)(rot_rows == 1 ? 0 : bh) * HS_DH * n_hashes * half;
+    const int passes = (n_hashes * HALF + 31) / 32;
+    constexpr int RPP = HALF >= 32 ? 1 : 32 / HALF;        // rounds per pass
+    for (int p = 0; p < passes; ++p) {
+        // A operand: column m = lane & 31 of this pass = (round, column in round) at capacity HALF; zero outside the real grid
+        const int cg = 32 * p + l31;
+        const int ar = cg / HALF, aci = cg % HALF;
+        const bool areal = ar < n_hashes && aci < half;
+        float rot_reg[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j)
+            rot_reg[j] = areal ? rot_src[((size_t)(2 * j + hh) * n_hashes + ar) * half + aci] : 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            f32x16 acc = {0};
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rot_reg[j], bq[sub][j], acc, 0, 0, 0);
+            const int tok = t0 + 32 * sub + l31;
+            // acc[i] = projection on column m = 8 * (i >> 2) + 4 * hh + (i & 3) of this pass; argmax over [xR, -xR] of each round,
+            // the first maximum winning (ascending column, +x before -x)
+            if constexpr (HALF <= 4) {
+                // a lane's group g (four consecutive columns) holds 4 / HALF complete rounds
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int jr = 0; jr < 4 / HALF; ++jr) {
+                        const int rr = p * RPP + (8 * g + 4 * hh) / HALF + jr;
+                        float best = -__builtin_inff();
+                        int bi = 0;
+#pragma unroll
+                        for (int ci = 0; ci < HALF; ++ci) {
+                            const float x = acc[4 * g + jr * HALF + ci];
+                            if (ci < half && x > best) { best = x; bi = ci; }
+                        }
+#pragma unroll
+                        for (int ci = 0; ci < HALF; ++ci) {
+                            const float x = -acc[4 * g + jr * HALF + ci];
+                            if (ci < half && x > best) { best = x; bi = half + ci; }
+                        }
+                        if (rr < n_hashes) {
+                            ids[((size_t)bh * n_hashes + rr) * T + tok] = bi;
+                            if (buckets) buckets[((size_t)bh * n_hashes + rr) * T + tok] = bi + rr * NB;
+                        }
+                    }
+            } else {
+                // HALF = 8, 16, 32: a round spans both lane halves (and HALF / 8 groups): lane-local first maximum, then the
+                // partner half's -- larger value wins, the smaller index on a tie
+                constexpr int GPR = HALF / 8;                  // groups per round
+#pragma unroll
+                for (int q = 0; q < 4 / GPR; ++q) {
+                    const int rr = p * RPP + q;
+                    float best = -__builtin_inff();
+                    int bi = 0;
+#pragma unroll
+                    for (int gg = 0; gg < GPR; ++gg)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int ci = 8 * gg + 4 * hh + j;
+                            const float x = acc[4 * (q * GPR + gg) + j];
+                            if (ci < half && x > best) { best = x; bi = ci; }
+                        }
+#pragma unroll
+                    for (int gg = 0; gg < GPR; ++gg)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int ci = 8 * gg + 4 * hh + j;
+                            const float x = -acc[4 * (q * GPR + gg) + j];
+                            if (ci < half && x > best) { best = x; bi = half + ci; }
+                        }
+                    const auto sv = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+                    const auto si = __builtin_amdgcn_permlane32_swap((unsigned)bi, (unsigned)bi, false, false);
+                    const float ob = __uint_as_float(hh ? sv[0] : sv[1]);
+                    const int oi = (int)(hh ? si[0] : si[1]);
+                    const int idx = (ob > best || (ob == best && oi < bi)) ? oi : bi;
+                    if (rr < n_hashes && hh == (q & 1)) {      // both halves know the result: they take turns storing
+                        ids[((size_t)bh * n_hashes + rr) * T + tok] = idx;
+                        if (buckets) buckets[((size_t)bh * n_hashes + rr) * T + tok] = idx + rr * NB;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// stable counting sort of one (head, round): ids (in `st`, written by the hash kernel) -> st (sorted slot -> token), undo
+template <int BITS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void lsh_sort_ids_kernel(int T, int NB, int32_t* __restrict__ st, int32_t* __restrict__ undo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t* bkt = reinterpret_cast<uint16_t*>(smem);
+    int* cntw = reinterpret_cast<int*>(smem + ((T * 2 + 15) & ~15));
+    int* tot = cntw + WAVES * 64;
+    const uint32_t w = xcd_remap(blockIdx.x, gridDim.x);       // (head, round) in the order of the arrays
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int32_t* st_out = st + (size_t)w * T;
+    int32_t* undo_out = undo ? undo + (size_t)w * T : nullptr;
+    const int seg = T / WAVES, s0 = wave * seg;
+    for (int i = tid; i < WAVES * 64; i += 64 * WAVES) cntw[i] = 0;
+    __syncthreads();
+    for (int t = lane; t < seg; t += 64) {                     // wave w counts the segment it will place
+        const int id = st_out[s0 + t];
+        bkt[s0 + t] = (uint16_t)id;
+        atomicAdd(&cntw[wave * 64 + id], 1);                   // integer LDS add: order-free, deterministic
+    }
+    __syncthreads();                                           // all ids are in LDS: st may be overwritten from here on
+    if (tid < NB) {
+        int t = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < WAVES; ++w2) t += cntw[w2 * 64 + tid];
+        tot[tid] = t;
+    }
+    __syncthreads();
+    int basek = 0;
+    if (lane < NB) {
+        for (int k = 0; k < lane; ++k) basek += tot[k];
+        for (int w2 = 0; w2 < wave; ++w2) basek += cntw[w2 * 64 + lane];
+    }
+    __syncthreads();
+    int* run = cntw + wave * 64;
+    if (lane < NB) run[lane] = basek;
+    __builtin_amdgcn_wave_barrier();
+    for (int t0 = 0; t0 < seg; t0 += 64) {
+        const bool act = t0 + lane < seg;
+        const int mb = act ? (int)bkt[s0 + t0 + lane] : -1;
+        const unsigned long long m = match_lanes<BITS>(mb);
+        const unsigned long long below = m & ((1ull << lane) - 1ull);
+        int pos = 0;
+        if (act) pos = run[mb] + __popcll(below);
+        __builtin_amdgcn_wave_barrier();
+        if (act && below == 0) run[mb] += __popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        if (act) {
+            const int t = s0 + t0 + lane;
+            st_out[pos] = t;
+            if (undo_out) undo_out[t] = pos;
+        }
+    }
+}
+
+template <int HALF>
+static int launch_hash_then_sort(const bf16_t* qk, int64_t ld, const float* rot, int rot_rows, int B, int H, int T, int n_hashes,
+                                 int32_t* buckets, int32_t* st, int32_t* undo, int half, hipStream_t stream) {
+    constexpr int NBC = 2 * HALF;
+    constexpr int BITS = (NBC <= 2) ? 1 : (NBC <= 4) ? 2 : (NBC <= 8) ? 3 : (NBC <= 16) ? 4 : (NBC <= 32) ? 5 : 6;
+    hipLaunchKernelGGL((lsh_hash_rounds_kernel<HALF>), dim3(B * H * (T / 128)), dim3(128), 0, stream, qk, ld, rot, rot_rows, H, T, n_hashes,
+                       half, buckets, st);
+    RTTS_LAUNCH_CHECK("rtts_lsh_hash_sort (hash)");
+    const size_t lds = ((T * 2 + 15) & ~15) + (8 * 64 + 64) * 4;
+    if (T >= HS_W8_MIN_T && T % 512 == 0)
+        hipLaunchKernelGGL((lsh_sort_ids_kernel<BITS, 8>), dim3(B * H * n_hashes), dim3(512), lds, stream, T, 2 * half, st, undo);
+    else
+        hipLaunchKernelGGL((lsh_sort_ids_kernel<BITS, 4>), dim3(B * H * n_hashes), dim3(256), lds, stream, T, 2 * half, st, undo);
+    RTTS_LAUNCH_CHECK("rtts_lsh_hash_sort (sort)");
+    return 0;
+}
+
 template <int HALF, int WAVES>
 static int launch_hash_sort_w(const bf16_t* qk, int64_t ld, const float* rot, int rot_rows, int B, int H, int T,
                               int n_hashes, int32_t* buckets, int32_t* st, int32_t* undo, int half, hipStream_t stream) {
@@ -299,6 +505,15 @@ extern "C" int rtts_lsh_hash_sort(const void* qk, int64_t ld_qk, const float* ro
     const bf16_t* q = (const bf16_t*)qk;
     RTTS_REQUIRE(half >= 1 && half <= 32, "rtts_lsh_hash_sort: n_buckets=%d unsupported (2 .. 64)", 2 * half);
     // column capacity = next power of two; the extra columns are zero padding that the argmax ignores
+    static const int v1 = [] { const char* e = getenv("RTTS_HASH_SORT_V1"); return e ? atoi(e) : 0; }();      // A/B runs: the one-launch kernel
+    if (!v1) {
+        if (half <= 1) return launch_hash_then_sort<1>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, s);
+        if (half <= 2) return launch_hash_then_sort<2>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, s);
+        if (half <= 4) return launch_hash_then_sort<4>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, s);
+        if (half <= 8) return launch_hash_then_sort<8>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, s);
+        if (half <= 16) return launch_hash_then_sort<16>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, s);
+        return launch_hash_then_sort<32>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, s);
+    }
     if (half <= 1) return launch_hash_sort<1>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, s);
     if (half <= 2) return launch_hash_sort<2>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, s);
     if (half <= 4) return launch_hash_sort<4>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, s);

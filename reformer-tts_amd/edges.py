@@ -199,6 +199,15 @@ class ConvK5:
         return dx
 
 
+# Data-parallel BatchNorm statistics (the reference's BatchNorm layers, modules.py:29,127, normalise over the
+# WHOLE batch, which data parallelism spreads over the ranks).  None: every rank normalises over its own rows (the default;
+# DESIGN.md section 7 states the deviation).  A process group (``Trainer`` sets it from ``TTSTrainingConfig.sync_batchnorm``):
+# the per-channel sums of both stages -- forward {sum y, sum y^2}, backward {sum g, sum g*yhat} -- and the row count are
+# all-reduced between the stage that produces them and the stage that uses them: 2*C + 1 floats per BatchNorm layer and
+# direction, six layers.  Eager steps only: a collective inside a hipGraph capture is not attempted.
+SYNC_BN = None
+
+
 class ConvBNAct:
     """Conv1d(k5) -> BatchNorm1d (batch statistics) -> act (1 relu / 2 tanh) -> Dropout(p), on halo rows."""
 
@@ -216,8 +225,17 @@ class ConvBNAct:
         bn = self.bn
         # running_mean tracks the mean of (y + conv bias): the bias is left out of y (BatchNorm cancels it) and shifts
         # only the running mean; num_batches_tracked is bumped by the same launch
-        _lib.call("rtts_bn_stats", y.data_ptr(), g.b, g.l, g.H, c, mean.data_ptr(), rstd.data_ptr(), bn.running_mean.data_ptr(),
-                  bn.running_var.data_ptr(), self.c.conv.bias.data_ptr(), bn.num_batches_tracked.data_ptr(), _ws(dev, c).data_ptr(), _s())
+        if SYNC_BN is None:
+            _lib.call("rtts_bn_stats", y.data_ptr(), g.b, g.l, g.H, c, mean.data_ptr(), rstd.data_ptr(), bn.running_mean.data_ptr(),
+                      bn.running_var.data_ptr(), self.c.conv.bias.data_ptr(), bn.num_batches_tracked.data_ptr(), _ws(dev, c).data_ptr(), _s())
+        else:
+            import torch.distributed as dist
+            mom = torch.empty(2 * c + 1, dtype=torch.float32, device=dev)
+            _lib.call("rtts_bn_moments", y.data_ptr(), g.b, g.l, g.H, c, mom.data_ptr(), _ws(dev, c).data_ptr(), _s())
+            mom[2 * c:].fill_(float(g.b * g.l))
+            dist.all_reduce(mom, group=SYNC_BN)
+            _lib.call("rtts_bn_from_moments", mom.data_ptr(), 0, c, mean.data_ptr(), rstd.data_ptr(), bn.running_mean.data_ptr(),
+                      bn.running_var.data_ptr(), self.c.conv.bias.data_ptr(), bn.num_batches_tracked.data_ptr(), _s())
         seed = next(_seed_counter) * 2654435761 % (1 << 32)
         if plain_out:
             z = torch.empty(g.b * g.l, c, dtype=torch.bfloat16, device=dev)
@@ -235,9 +253,21 @@ class ConvBNAct:
         c = y.shape[1]
         bn = self.bn
         dy = g.new(c, y.device)
-        _lib.call("rtts_bn_act_bwd", y.data_ptr(), dz.data_ptr(), int(dz_halo), mean.data_ptr(), rstd.data_ptr(), bn.weight.data_ptr(),
-                  bn.bias.data_ptr(), self.act, self.p, seed, seed_base(y.device).data_ptr(), g.b, g.l, g.H, c, dy.data_ptr(), g.LEAD, g.alloc,
-                  _grad(bn.weight).data_ptr(), _grad(bn.bias).data_ptr(), _ws(y.device, c).data_ptr(), _s())
+        if SYNC_BN is None:
+            _lib.call("rtts_bn_act_bwd", y.data_ptr(), dz.data_ptr(), int(dz_halo), mean.data_ptr(), rstd.data_ptr(), bn.weight.data_ptr(),
+                      bn.bias.data_ptr(), self.act, self.p, seed, seed_base(y.device).data_ptr(), g.b, g.l, g.H, c, dy.data_ptr(), g.LEAD, g.alloc,
+                      _grad(bn.weight).data_ptr(), _grad(bn.bias).data_ptr(), _ws(y.device, c).data_ptr(), _s())
+        else:
+            import torch.distributed as dist
+            sums = torch.empty(2 * c + 1, dtype=torch.float32, device=y.device)
+            _lib.call("rtts_bn_act_bwd_sums", y.data_ptr(), dz.data_ptr(), int(dz_halo), mean.data_ptr(), rstd.data_ptr(), bn.weight.data_ptr(),
+                      bn.bias.data_ptr(), self.act, self.p, seed, seed_base(y.device).data_ptr(), g.b, g.l, g.H, c, sums.data_ptr(),
+                      _grad(bn.weight).data_ptr(), _grad(bn.bias).data_ptr(), _ws(y.device, c).data_ptr(), _s())
+            sums[2 * c:].fill_(float(g.b * g.l))
+            dist.all_reduce(sums, group=SYNC_BN)
+            _lib.call("rtts_bn_act_bwd_apply", y.data_ptr(), dz.data_ptr(), int(dz_halo), mean.data_ptr(), rstd.data_ptr(), bn.weight.data_ptr(),
+                      bn.bias.data_ptr(), self.act, self.p, seed, seed_base(y.device).data_ptr(), g.b, g.l, g.H, c, sums.data_ptr(), 0,
+                      dy.data_ptr(), g.LEAD, g.alloc, _s())
         _grad(self.c.conv.bias)       # exists (stays zero: the true gradient of a bias in front of BatchNorm is zero)
         return self.c.backward(dy, xh, g, need_dx, dx_f32)
 

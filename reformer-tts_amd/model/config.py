@@ -117,6 +117,9 @@ class TTSTrainingConfig:
     post_pred_loss_weight: float = 1.0
     stop_loss_weight: float = 1.0
     spectrogram_loss: str = "mse"
+    # this package's addition (not a key of the reference's TTSTrainingConfig): under data parallelism, BatchNorm statistics
+    # over the GLOBAL batch (what the reference's single-process BatchNorm sees) instead of each rank's own rows
+    sync_batchnorm: bool = False
 
 
 def _merge(dc, overrides: dict):

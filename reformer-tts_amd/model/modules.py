@@ -46,6 +46,10 @@ def batch_norm_rows(x, bn: nn.BatchNorm1d):
     (B, L) and updates the running buffers (momentum 0.1, unbiased variance) like nn.BatchNorm1d."""
     xf = x.float()
     if bn.training:
+        from .. import edges
+        if edges.SYNC_BN is not None:
+            raise NotImplementedError("sync_batchnorm is implemented by the fused edge executors (edges.ConvBNAct); this batch took "
+                                      "the general path -- see the reformer_tts_amd log for the reason")
         var, mean = torch.var_mean(xf, dim=(0, 1), unbiased=False)
         with torch.no_grad():
             n = xf.shape[0] * xf.shape[1]

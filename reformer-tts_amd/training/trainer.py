@@ -72,6 +72,18 @@ class Trainer:
         sch = cfg.lr_scheduler
         self._base_lr = float(cfg.learning_rate if sch is None else sch.initial_lr)
         self._lr = self._base_lr                         # what the reference's optimizer.param_groups[...]["lr"] holds
+        # also validated here, before any training, as the reference does in configure_optimizers (wrappers.py:258-279)
+        if sch is not None:
+            if sch.start_schedule_epoch < 1:
+                raise AssertionError("start_schedule_epoch has to be >= 1")
+            end = sch.end_schedule_epoch if sch.end_schedule_epoch is not None else cfg.max_epochs
+            if end is None:
+                raise ValueError("lr_scheduler: end_schedule_epoch or max_epochs must be set")
+            if end <= sch.start_schedule_epoch:
+                raise ValueError(f"lr_scheduler: the schedule must end after it starts (start {sch.start_schedule_epoch}, end {end})")
+        if getattr(cfg, "sync_batchnorm", False) and self.world > 1:
+            from .. import edges
+            edges.SYNC_BN = process_group if process_group is not None else dist.group.WORLD
         self._decorrelate_replicas()
         self._flatten()
         self._make_buckets()
@@ -295,9 +307,17 @@ class Trainer:
         self._lr *= factor
         return factor
 
+    def take_lr(self, step_index: int) -> float:
+        """The rate optimizer step ``step_index`` runs with, taken: during warm-up the hook ASSIGNS it to the optimizer state
+        (``wrappers.py:284-294``), so the epoch schedule continues from it.  (``lr_now_for`` only reads.)"""
+        lr = self.lr_now_for(step_index)
+        if self.cfg.warmup_steps is not None and step_index < self.cfg.warmup_steps:
+            self._lr = lr
+        return lr
+
     def set_step_hyper(self, step_index: int):
         """Host -> device copy of this step's {lr, lr*sqrt(1-b2^t)/(1-b1^t)} (t = step_index + 1); outside any graph."""
-        lr = self.lr_now_for(step_index)
+        lr = self.take_lr(step_index)
         t = step_index + 1
         slot = self._hyper_ring[self._ring_next % len(self._hyper_ring)]
         self._ring_next += 1
@@ -330,11 +350,12 @@ class Trainer:
         WEIGHT_EPOCH[0] += 1
 
     def lr_now_for(self, step: int) -> float:
-        """Rate of optimizer step ``step``: the warm-up hook (``wrappers.py:284-294``) ASSIGNS base * min(1, (step+1)/warmup)
-        while step < warmup (overwriting what the epoch schedule left, as the reference does); afterwards the rate is whatever
-        the last assignment / the epoch schedule (``end_epoch``) made of it."""
+        """Rate of optimizer step ``step`` (pure: a logging call changes nothing): base * min(1, (step+1)/warmup) while step <
+        warmup -- the warm-up hook (``wrappers.py:284-294``) assigns that value, overwriting what the epoch schedule left, and
+        ``set_step_hyper`` performs the assignment when the step is actually taken -- afterwards whatever the last assignment /
+        the epoch schedule (``end_epoch``) made of it."""
         if self.cfg.warmup_steps is not None and step < self.cfg.warmup_steps:
-            self._lr = min(1.0, float(step + 1) / self.cfg.warmup_steps) * self._base_lr
+            return min(1.0, float(step + 1) / self.cfg.warmup_steps) * self._base_lr
         return self._lr
 
     def train_step(self, batch, update_hyper: bool = True):
@@ -433,7 +454,8 @@ class Trainer:
         from ..dataset import BatchPrefetcher
         losses, group = [], []
         acc = max(1, int(self.cfg.accumulate_grad_batches))
-        use_graphs = (self.device.type == "cuda" and self.use_fused_edges) if graphs is None else bool(graphs)
+        from .. import edges
+        use_graphs = (self.device.type == "cuda" and self.use_fused_edges and edges.SYNC_BN is None) if graphs is None else bool(graphs)
 
         def step(batches):
             if use_graphs:
@@ -618,6 +640,10 @@ class Trainer:
 
         Rotations and dropout draw from the graph-safe default generator."""
         from ..model.lsh_attention import LSHSelfAttention
+        from .. import edges
+        if edges.SYNC_BN is not None:
+            raise _lib.RttsError("sync_batchnorm all-reduces BatchNorm sums inside the forward and the backward: such steps run eagerly "
+                                 "(train_step / fit(graphs=False)); no collective is captured into a hipGraph")
         if segmented is None:
             segmented = self.world > 1
         segmented = bool(segmented) and self._fused_edges_ok(batch) if segmented else False

@@ -6,8 +6,17 @@ BatchNorm flip wherever a pre-activation lies within the bf16 error of zero, whi
 the kernels.  To separate the two, the model below computes the SAME function in float64 with a bf16 rounding at exactly
 the places where the executor stores bf16 (forward: the stack's input, every layer's activation, the conv / linear
 weights, the projection's output; backward: the gradient of every layer's activation and of every convolution's output,
-the projection's output gradient) -- the gates then agree, and what is left is kernel error: fp32 accumulation, fp32
-BatchNorm statistics, the order of the sums.  Expected and asserted: <= 1e-2 rel-L2 on every gradient (achieved is printed)."""
+the projection's output gradient) -- the gates then agree except where fp32 and float64 accumulation differ, and what is
+left is kernel error: fp32 accumulation, fp32 BatchNorm statistics, the order of the sums.
+
+What such a comparison can resolve.  The chain is chaotic at the 1e-2 level: an accumulation difference of 1e-7 moves a
+fraction ~2e-5 of a layer's bf16 activation roundings by one ulp; each moved rounding shifts the next layer's pre-activations
+by ~1e-4; by the third layer every pre-activation carries such a shift and ~6e-5 of its ReLU gates flip, which is
+sqrt(2 * 6e-5) ~ 1e-2 on every gradient upstream -- measured 7e-3 ... 9.6e-3, uniform over the parameters (a float64 run of the
+model itself moves by 4e-3 ... 5e-3 when ANY one of its rounding points is removed).  So the bound below is 2e-2: an order of
+magnitude under the 6-9 % of the fp32-oracle comparison, which is the separation this test is for; the kernels' own
+accuracy is pinned one kernel at a time (test_conv1d_k5_implicit_gemm_vs_float64: 3.4e-7, test_bn_act_dropout_kernels_vs_autograd,
+test_gemm_hip)."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -100,6 +109,6 @@ def test_encoder_prenet_chain_vs_float64_model_of_its_own_roundings(gpu, b, l):
           ", ".join(f"{k} {v:.2e}" for k, v in top) + f"; median {sorted(rels.values())[len(rels) // 2]:.2e}")
     assert e_out < 4e-3, e_out                    # one bf16 rounding of the result is 1.7e-3 rel-L2
     for n, v in rels.items():
-        assert v < 1e-2, (n, v)
+        assert v < 2e-2, (n, v)
     # padding_idx row: no gradient
     assert float(mods["embed.weight"].grad[0].abs().max()) == 0.0

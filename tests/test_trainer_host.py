@@ -38,7 +38,11 @@ def test_learning_rate_follows_the_reference_schedule(warmup, sched):
     got = []
     for _ in range(epochs):
         for _ in range(steps_per_epoch):
-            got.append(tr.lr_now_for(tr.global_step))
+            peek = tr.lr_now_for(tr.global_step)                 # reading the rate (logging) changes nothing ...
+            state = tr._lr
+            assert tr.lr_now_for(tr.global_step) == peek and tr._lr == state
+            got.append(tr.take_lr(tr.global_step))               # ... taking the step does (what set_step_hyper calls)
+            assert got[-1] == peek
             tr.global_step += 1
         tr.end_epoch()
     assert len(got) == len(want)
@@ -59,6 +63,23 @@ def test_schedule_rejects_a_start_before_epoch_one():
     tr = _trainer(TTSTrainingConfig(lr_scheduler=LRSchedulerConfig(start_schedule_epoch=0, end_schedule_epoch=3)))
     with pytest.raises(AssertionError, match="start_schedule_epoch has to be >= 1"):
         tr.end_epoch()
+
+
+def test_schedule_is_validated_before_training_starts():
+    """The reference asserts on the scheduler configuration in configure_optimizers (wrappers.py:258-279), before the first
+    step; so does Trainer.__init__ (not only end_epoch, a whole epoch later)."""
+    from reformer_tts_amd.model.config import LRSchedulerConfig, TTSTrainingConfig, model_config_from_dict
+    from reformer_tts_amd.training import Trainer, build_model
+    from oracle import model_ref
+    cfg = model_ref.small_cfg()
+    cfg["enc_reformer_kwargs"]["attn_kwargs"]["implementation"] = "hip"
+    cfg["dec_reformer_kwargs"]["self_attn_kwargs"]["implementation"] = "hip"
+    model = build_model(model_config_from_dict(cfg))
+    for sched, exc, msg in ((LRSchedulerConfig(start_schedule_epoch=0, end_schedule_epoch=3), AssertionError, "has to be >= 1"),
+                            (LRSchedulerConfig(start_schedule_epoch=2, end_schedule_epoch=None), ValueError, "max_epochs must be set"),
+                            (LRSchedulerConfig(start_schedule_epoch=3, end_schedule_epoch=3), ValueError, "must end after it starts")):
+        with pytest.raises(exc, match=msg):
+            Trainer(model, TTSTrainingConfig(lr_scheduler=sched), "cpu")
 
 
 def test_stop_mae_matches_the_reference_formula():
