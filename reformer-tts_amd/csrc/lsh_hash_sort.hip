@@ -506,7 +506,11 @@ extern "C" int rtts_lsh_hash_sort(const void* qk, int64_t ld_qk, const float* ro
     RTTS_REQUIRE(half >= 1 && half <= 32, "rtts_lsh_hash_sort: n_buckets=%d unsupported (2 .. 64)", 2 * half);
     // column capacity = next power of two; the extra columns are zero padding that the argmax ignores
     static const int v1 = [] { const char* e = getenv("RTTS_HASH_SORT_V1"); return e ? atoi(e) : 0; }();      // A/B runs: the one-launch kernel
-    if (!v1) {
+    // short sequences keep the one-launch kernel: at T = 256 (encoder shape) the two launches measure 9.2 us against 6.7 us --
+    // the second kernel boundary costs more than the staging it saves; from T = 1024 on: 14.8 against 18.4 us (decoder shape, the
+    // same box: gpurun_out/r03_kbench_hash_v{1,2}.log), 61.7 against 66.1 us at T = 4096 with 64 buckets (f32-MFMA-bound there:
+    // 4.3 GFLOP of exact fp32 projections at the 155 TF f32 matrix rate = 28 us)
+    if (!v1 && T >= 1024) {
         if (half <= 1) return launch_hash_then_sort<1>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, s);
         if (half <= 2) return launch_hash_then_sort<2>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, s);
         if (half <= 4) return launch_hash_then_sort<4>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, s);

@@ -113,20 +113,21 @@ def main():
             dv_part = torch.empty(2, b * h, nh, t, dh, dtype=torch.bfloat16, device=dev)
             flags = torch.ones(b * h, nh, t, dtype=torch.uint8, device=dev)
             walks = _lib.load().rtts_lsh_attn_bwd_run_length(b, h, t, nh, bs) > 0
-            s = torch.cuda.current_stream().cuda_stream
             ld = qkv.stride(1)
 
             def bwd():
+                s = torch.cuda.current_stream().cuda_stream      # inside: under --graph the capture stream is current
                 _lib.call("rtts_lsh_attn_bwd", qk.data_ptr(), v.data_ptr(), ld, st.data_ptr(), mask.data_ptr(), dout.data_ptr(),
                           dout.stride(1), lse_tot.data_ptr(), delta.data_ptr(), b, h, t, dh, nh, bs, int(causal),
                           dqk_part.data_ptr(), dv_part.data_ptr(), flags.data_ptr(), s)
             _lib.call("rtts_lsh_bwd_delta", out.data_ptr(), out.stride(1), dout.data_ptr(), dout.stride(1), b, h, t, dh,
-                      delta.data_ptr(), s)
+                      delta.data_ptr(), torch.cuda.current_stream().cuda_stream)
             us = timeit(bwd, args.iters)
             res["attn_bwd"] = (us, f"{5 * pair_flops / us / 1e6:8.1f} TFLOP/s")
             dqk, dv = torch.empty_like(qk.contiguous()), torch.empty_like(qk.contiguous())
 
             def red():
+                s = torch.cuda.current_stream().cuda_stream
                 _lib.call("rtts_lsh_bwd_reduce", dqk_part.data_ptr(), dv_part.data_ptr(), b, h, t, dh, nh, dqk.data_ptr(),
                           dv.data_ptr(), dqk.stride(1), flags.data_ptr() if walks else None, s)
             us = timeit(red, args.iters)
