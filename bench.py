@@ -187,9 +187,9 @@ def main():
     tags = dict(bwd=f"rtts_lsh_attn_bwd/bs{dec_bucket}", fwd=f"rtts_lsh_attn_fwd/bs{dec_bucket}",
                 hash=f"rtts_lsh_hash_sort/nb{t_dec // dec_bucket}", gemm="rtts_gemm_nt")
     note(f"model built ({trainer.n_params} parameters), warming up")
-    # N == 1: the whole step is one hipGraph.  N > 1: four graphs (fwd + decoder-side bwd | encoder stack bwd | encoder
-    # prenet bwd | clip+AdamW) around three eager all-reduces of parts of the flat gradient buffer, so no collective is
-    # ever captured.
+    # N == 1: the whole step is one hipGraph.  N > 1: a chain of graphs (fwd + heads/postnet bwd | one per decoder layer |
+    # encoder stack bwd | encoder prenet bwd | clip+AdamW) with the all-reduce of each graph's slice of the flat gradient
+    # buffer issued between them, so no collective is ever captured.
     use_graph = not args.no_graph
     one_graph = world == 1
 
@@ -225,11 +225,31 @@ def main():
             dt = float(t.item())
         return dt, last
 
+    def graph_timed(fn, calls, replays):
+        """-> (average ms per call, calls timed): ``calls`` invocations of ``fn`` captured into one hipGraph, replayed."""
+        from reformer_tts_amd._graphs import capturing
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with capturing(g):
+            for _ in range(calls):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(replays):
+            g.replay()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / (calls * replays), calls * replays
+
     if use_graph:
         use_graph = capture()
     if use_graph:
         step_fn = trainer.replay
-        note("step captured into " + ("one hipGraph" if one_graph else "four hipGraphs around the three gradient all-reduces"))
+        note("step captured into " + ("one hipGraph" if one_graph else f"{len(trainer._segments) + 1} hipGraphs around {len(trainer._segments)} gradient all-reduces"))
     else:
         trainer._bulk_allreduce = False               # eager: per-block all-reduce overlapped with the backward
         step_fn = lambda: trainer.train_step(batch)   # noqa: E731
@@ -285,7 +305,8 @@ def main():
         frames = world * args.batch * args.mel_len * args.steps
         n_par = trainer.n_params
         launch = ("hipGraph replay" if one_graph else
-                  "hipGraph replay (fwd+dec bwd | all-reduce | enc stack bwd | all-reduce | enc prenet bwd | all-reduce | optimizer)") \
+                  "hipGraph replay (fwd + heads/postnet bwd | one graph per decoder layer bwd | enc stack bwd | enc prenet bwd | optimizer; the "
+                  "all-reduce of a graph's gradient range runs while the next graph replays: config.dist.schedule)") \
             if use_graph else "eager"
         workload = (f"config/baseline.yml full Reformer-TTS training step (enc 3 / dec 3 layers, d=512, LSH 8 rounds, buckets 64/128), "
                     f"per-GPU batch {args.batch}, text {args.text_len}->256, mel {args.mel_len}x80" if args.config == "baseline" else
@@ -303,7 +324,8 @@ def main():
                        "dist": {"world_size": world, "backend": (dist.get_backend() if world > 1 else None),
                                 "backend_ranks": (dist.get_world_size() if world > 1 else 1),
                                 "allreduce_bytes_per_step": (4 * n_par if world > 1 else 0),
-                                "collectives_per_step": (3 if (world > 1 and use_graph) else (0 if world == 1 else "per block")),
+                                "collectives_per_step": (len(trainer._segments) if (world > 1 and use_graph) else (0 if world == 1 else "per block")),
+                                "schedule": (trainer.segment_plan() if (world > 1 and use_graph) else None),
                                 "rank_seeds": "rotations and dropout seeded with seed + rank"}},
         }
         if other is not None:
@@ -357,13 +379,22 @@ def main():
                                         avg_ms, launches, flops, {"chunks_per_workgroup": max(run, 1)}))
         avg_ms, launches, nbytes = timing["hash"]
         if launches:
+            # a 10-15 us launch is host-bound when launched eagerly (Python + ctypes per call): its device time comes from a
+            # hipGraph of 20 calls at the same shape, replayed, with HIP events on the replay stream
+            qk_probe = torch.randn(args.batch, t_dec, heads_dec * 64, device=dev).bfloat16()
+            rot_probe = torch.randn(1, 64, n_hashes_dec, t_dec // dec_bucket // 2, device=dev)
+            avg_ms, launches = graph_timed(lambda: ops.lsh_hash_sort(qk_probe, rot_probe, heads_dec, dec_bucket), 20, 10)
+            two = _lib.load().rtts_lsh_hash_sort_launches(t_dec) == 2
             ach = nbytes / (avg_ms * 1e-3) / 1e9
-            rooflines.append({"kernel": "lsh_hash_sort_kernel", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            rooflines.append({"kernel": "lsh_hash_rounds_kernel + lsh_sort_ids_kernel" if two else "lsh_hash_sort_kernel", "bound": "hbm",
+                              "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
-                              "launches_timed": launches, "peak_measured": peaks[0],
+                              "launches_timed": launches, "timed": "hipGraph of 20 calls, replayed 10 times (device time; eager launches of a "
+                              "kernel this short are host-bound)", "peak_measured": peaks[0],
                               "frac_of_measured": (round(ach / peaks[0], 4) if peaks[0] else None),
                               "algorithmic_bytes_per_launch": int(nbytes),
-                              "note": "SURVEY.md 8(d): 224 B per token and head (hash 128 + 32, sort 64); decoder-shape launches"})
+                              "note": "SURVEY.md 8(d): 224 B per token and head (hash 128 + 32, sort 64); decoder shape; one rtts_lsh_hash_sort "
+                                      "call = " + ("two launches (hash of all rounds, then the sorts)" if two else "one launch")})
         avg_ms, launches, flops = timing["gemm"]
         if launches:
             ach = flops / (avg_ms * 1e-3) / 1e12

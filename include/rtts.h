@@ -59,6 +59,10 @@ const char* rtts_last_error(void);
 int rtts_lsh_hash_sort(const void* qk, int64_t ld_qk, const float* rotations, int rot_rows,
                        int B, int H, int T, int dh, int n_hashes, int bucket_size,
                        int32_t* buckets, int32_t* st, int32_t* undo, void* stream);
+/* how the call is worked: 2 = lsh_hash_rounds_kernel (the projections of ALL rounds through the f32 MFMA, every row staged
+ * once; bucket ids pass through `st`) + lsh_sort_ids_kernel, from T = 1024 on; 1 = lsh_hash_sort_kernel (one launch, a
+ * workgroup per (head, round)) for short sequences.  Same results bit for bit. */
+int rtts_lsh_hash_sort_launches(int T);
 
 /* ---- LSH attention: chunked attention forward (Appendix B steps 4-10) ----------------
  *   qk, v  bf16 rows as above (common stride ld)
@@ -68,8 +72,9 @@ int rtts_lsh_hash_sort(const void* qk, int64_t ld_qk, const float* rotations, in
 int rtts_lsh_attn_fwd(const void* qk, const void* v, int64_t ld, const int32_t* st, const uint8_t* mask,
                       int B, int H, int T, int dh, int n_hashes, int bucket_size, int causal,
                       void* o, float* lse, void* stream);
-/* how rtts_lsh_attn_fwd works a shape: 0 = one workgroup per chunk (lsh_attn_fwd_kernel), R > 0 = workgroups that walk R
- * consecutive chunks so that every K / V row is gathered once (lsh_attn_fwd_walk_kernel); same results bit for bit */
+/* how rtts_lsh_attn_fwd works a shape: 0 = one workgroup per chunk (lsh_attn_fwd_kernel), the only form this build has.
+ * (A form that walks consecutive chunks like the backward's was priced in round 3 and not built: the forward is
+ * latency-bound at two workgroups per CU, and a ring of three chunk slots leaves room for one -- DESIGN.md section 5.) */
 int rtts_lsh_attn_fwd_run_length(int B, int H, int T, int n_hashes, int bucket_size);
 
 /* ---- combine the hash rounds (step 11) and merge heads (first half of step 12) -------

@@ -50,6 +50,7 @@ CONV_PERM_MAX_GROUP = 8
 SIGNATURES = {
     "rtts_lsh_hash_sort": [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "rtts_lsh_attn_fwd": [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "rtts_lsh_hash_sort_launches": [_i32],
     "rtts_lsh_attn_fwd_run_length": [_i32, _i32, _i32, _i32, _i32],
     "rtts_lsh_combine_fwd": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp],
     "rtts_lsh_bwd_delta": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp],

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64 * WAVES) void lsh_hash_sort_kernel(
 // The one-launch kernel above reads and stages every qk row once per hash round (8 times: 768 workgroups, four dependent
 // load -> hash trips each) and broadcasts the rotation matrix from LDS for every row element: 23-28 us at the decoder shape,
 // 0.10 of the HBM roofline, 72 % of its wave cycles waiting.  Here
-//   * rtts hash kernel: a workgroup = 128 tokens of one (batch, head); its rows are fetched and staged ONCE and projected
+//   * hash kernel: a workgroup = 128 tokens of one (batch, head), 32 per wave; its rows are fetched and staged ONCE and projected
 //     on the columns of ALL rounds by v_mfma_f32_32x32x2_f32 -- bit for bit the k-ordered fp32 fmaf chain of
 //     oracle/lsh_int.c (one rounding per product, no wider accumulation; the 33..64-bucket path above already relies on it).
 //     The A operand is R^T with the rounds side by side: pass p holds the columns 32p .. 32p+31 of the (round, column)
@@ -274,38 +274,40 @@ __global__ __launch_bounds__(64 * WAVES) void lsh_hash_sort_kernel(
 //   * sort kernel: one workgroup per (head, round) reads its T bucket ids (4 KB) and runs the same stable counting sort.
 // Traffic: 128 B per token and head read once + 2 x 4 B x rounds written + 4 B x rounds read.
 template <int HALF>
-__global__ __launch_bounds__(128) void lsh_hash_rounds_kernel(const bf16_t* __restrict__ qk, int64_t ld, const float* __restrict__ rotations,
+__global__ __launch_bounds__(256) void lsh_hash_rounds_kernel(const bf16_t* __restrict__ qk, int64_t ld, const float* __restrict__ rotations,
                                                               int rot_rows, int H, int T, int n_hashes, int half,
                                                               int32_t* __restrict__ buckets, int32_t* __restrict__ ids) {
-    __shared__ __attribute__((aligned(16))) unsigned char tile[2 * 64 * HS_ROWB];
+    // 4 waves x 32 tokens: a wave's chain (rows -> LDS -> 32 registers, rotation columns -> 32 registers, 32 dependent
+    // f32 MFMAs per pass, argmax, stores) is short and ~100 registers, so four waves per SIMD overlap each other's latencies
+    // (two 64-token waves per workgroup measured 11.7 us at the decoder shape)
+    __shared__ __attribute__((aligned(16))) unsigned char tile[4 * 32 * HS_ROWB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int blocks_per_head = T / 128;
     const uint32_t w = xcd_remap(blockIdx.x, gridDim.x);
-    const int bh = w / blocks_per_head, t0 = (w % blocks_per_head) * 128 + wave * 64;
+    const int bh = w / blocks_per_head, t0 = (w % blocks_per_head) * 128 + wave * 32;
     const int b = bh / H, h = bh % H;
     const int NB = 2 * half;
     const bf16_t* base = qk + ((size_t)b * T + t0) * ld + (size_t)h * HS_DH;
-    unsigned char* wt = tile + wave * 64 * HS_ROWB;
-    {   // stage this wave's 64 rows: coalesced 16-byte pieces, all eight loads in flight
-        uint4 pre[8];
+    unsigned char* wt = tile + wave * 32 * HS_ROWB;
+    {   // stage this wave's 32 rows: coalesced 16-byte pieces, all four loads in flight
+        uint4 pre[4];
 #pragma unroll
-        for (int p = 0; p < 8; ++p) pre[p] = *reinterpret_cast<const uint4*>(base + (size_t)(p * 8 + (lane >> 3)) * ld + (lane & 7) * 8);
+        for (int p = 0; p < 4; ++p) pre[p] = *reinterpret_cast<const uint4*>(base + (size_t)(p * 8 + (lane >> 3)) * ld + (lane & 7) * 8);
 #pragma unroll
-        for (int p = 0; p < 8; ++p) *reinterpret_cast<uint4*>(wt + (p * 8 + (lane >> 3)) * HS_ROWB + (lane & 7) * 16) = pre[p];
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(wt + (p * 8 + (lane >> 3)) * HS_ROWB + (lane & 7) * 16) = pre[p];
     }
     __builtin_amdgcn_wave_barrier();
     const int hh = lane >> 5, l31 = lane & 31;
-    // B operand: q[token][2j + hh], tokens 32 * sub + (lane & 31): 2 x 32 registers, kept for every pass
-    float bq[2][32];
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-        const unsigned char* rowp = wt + (32 * sub + l31) * HS_ROWB;
+    // B operand: q[token][2j + hh], token = lane & 31: 32 registers, kept for every pass
+    float bq[1][32];
+    {
+        const unsigned char* rowp = wt + l31 * HS_ROWB;
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const uint4 val = *reinterpret_cast<const uint4*>(rowp + p * 16);
             const uint32_t uu[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) bq[sub][p * 4 + k] = __uint_as_float(hh ? (uu[k] & 0xffff0000u) : (uu[k] << 16));
+            for (int k = 0; k < 4; ++k) bq[0][p * 4 + k] = __uint_as_float(hh ? (uu[k] & 0xffff0000u) : (uu[k] << 16));
         }
     }
     const float* rot_src = rotations + (size_t)(rot_rows == 1 ? 0 : bh) * HS_DH * n_hashes * half;
@@ -320,12 +322,12 @@ __global__ __launch_bounds__(128) void lsh_hash_rounds_kernel(const bf16_t* __re
 #pragma unroll
         for (int j = 0; j < 32; ++j)
             rot_reg[j] = areal ? rot_src[((size_t)(2 * j + hh) * n_hashes + ar) * half + aci] : 0.f;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
+        {
+            constexpr int sub = 0;
             f32x16 acc = {0};
 #pragma unroll
             for (int j = 0; j < 32; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rot_reg[j], bq[sub][j], acc, 0, 0, 0);
-            const int tok = t0 + 32 * sub + l31;
+            const int tok = t0 + l31;
             // acc[i] = projection on column m = 8 * (i >> 2) + 4 * hh + (i & 3) of this pass; argmax over [xR, -xR] of each round,
             // the first maximum winning (ascending column, +x before -x)
             if constexpr (HALF <= 4) {
@@ -451,7 +453,7 @@ static int launch_hash_then_sort(const bf16_t* qk, int64_t ld, const float* rot,
                                  int32_t* buckets, int32_t* st, int32_t* undo, int half, hipStream_t stream) {
     constexpr int NBC = 2 * HALF;
     constexpr int BITS = (NBC <= 2) ? 1 : (NBC <= 4) ? 2 : (NBC <= 8) ? 3 : (NBC <= 16) ? 4 : (NBC <= 32) ? 5 : 6;
-    hipLaunchKernelGGL((lsh_hash_rounds_kernel<HALF>), dim3(B * H * (T / 128)), dim3(128), 0, stream, qk, ld, rot, rot_rows, H, T, n_hashes,
+    hipLaunchKernelGGL((lsh_hash_rounds_kernel<HALF>), dim3(B * H * (T / 128)), dim3(256), 0, stream, qk, ld, rot, rot_rows, H, T, n_hashes,
                        half, buckets, st);
     RTTS_LAUNCH_CHECK("rtts_lsh_hash_sort (hash)");
     const size_t lds = ((T * 2 + 15) & ~15) + (8 * 64 + 64) * 4;
@@ -486,6 +488,14 @@ static int launch_hash_sort(const bf16_t* qk, int64_t ld, const float* rot, int 
     return launch_hash_sort_w<HALF, 4>(qk, ld, rot, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, stream);
 }
 
+static int hs_use_v1() {
+    static const int v1 = [] { const char* e = getenv("RTTS_HASH_SORT_V1"); return e ? atoi(e) : 0; }();      // A/B runs: the one-launch kernel
+    return v1;
+}
+
+// how rtts_lsh_hash_sort works a sequence length: 2 = lsh_hash_rounds_kernel + lsh_sort_ids_kernel, 1 = lsh_hash_sort_kernel
+extern "C" int rtts_lsh_hash_sort_launches(int T) { return (!hs_use_v1() && T >= 1024) ? 2 : 1; }
+
 extern "C" int rtts_lsh_hash_sort(const void* qk, int64_t ld_qk, const float* rotations, int rot_rows, int B, int H,
                                   int T, int dh, int n_hashes, int bucket_size, int32_t* buckets, int32_t* st,
                                   int32_t* undo, void* stream) {
@@ -505,12 +515,11 @@ extern "C" int rtts_lsh_hash_sort(const void* qk, int64_t ld_qk, const float* ro
     const bf16_t* q = (const bf16_t*)qk;
     RTTS_REQUIRE(half >= 1 && half <= 32, "rtts_lsh_hash_sort: n_buckets=%d unsupported (2 .. 64)", 2 * half);
     // column capacity = next power of two; the extra columns are zero padding that the argmax ignores
-    static const int v1 = [] { const char* e = getenv("RTTS_HASH_SORT_V1"); return e ? atoi(e) : 0; }();      // A/B runs: the one-launch kernel
     // short sequences keep the one-launch kernel: at T = 256 (encoder shape) the two launches measure 9.2 us against 6.7 us --
     // the second kernel boundary costs more than the staging it saves; from T = 1024 on: 14.8 against 18.4 us (decoder shape, the
     // same box: gpurun_out/r03_kbench_hash_v{1,2}.log), 61.7 against 66.1 us at T = 4096 with 64 buckets (f32-MFMA-bound there:
     // 4.3 GFLOP of exact fp32 projections at the 155 TF f32 matrix rate = 28 us)
-    if (!v1 && T >= 1024) {
+    if (rtts_lsh_hash_sort_launches(T) == 2) {
         if (half <= 1) return launch_hash_then_sort<1>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, s);
         if (half <= 2) return launch_hash_then_sort<2>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, s);
         if (half <= 4) return launch_hash_then_sort<4>(q, ld_qk, rotations, rot_rows, B, H, T, n_hashes, buckets, st, undo, half, s);

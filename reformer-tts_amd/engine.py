@@ -879,55 +879,80 @@ class FusedStackFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        if ctx.state is None:
-            raise RuntimeError("FusedStackFn.backward: this forward's state was already consumed (the streams are rebuilt in "
-                               "place; a second backward through the same stack call is not possible)")
-        s1, s2, steps, extra, b, t, d, has_ctx, seq, slots = ctx.state
-        ctx.state = None
         with torch.no_grad():
-            gboth = torch.empty(2, b * t, d, dtype=torch.float32, device=dout.device)
-            gboth.copy_(dout.detach().reshape(1, b * t, d).expand(2, -1, -1))
-            g1, g2 = gboth[0], gboth[1]
-            dkeys = None
-            if has_ctx:
-                dkeys = torch.zeros(extra["keys_bf16"].shape, dtype=torch.float32, device=dout.device)
-                extra = dict(extra, dkeys=dkeys)
-            done = []
-            chain = _Chain(_flat_calls(steps), reverse=True, slots=slots)
-            for i in range(len(steps) - 1, -1, -1):
-                kind, f, g, kw = steps[i]
-                if kind == "swap":
-                    s1, s2, g1, g2 = s2, s1, g2, g1
-                elif kind == "half":
-                    if "keys_bf16" in kw:
-                        kw = dict(kw, dkeys=dkeys)
-                    post, nxt = f.backward(s1, s2, g1, g2, b, t, slot=slots[(i, "f")], **kw, **chain.args(i, "f", s2),
-                                           **chain.grad_args(i, "f", g1))
-                    chain.done(post, s1)
-                    chain.grad_done(nxt, g2)
-                else:
-                    post, nxt = g.backward(s2, s1, g2, g1, b, t, slot=slots[(i, "g")], **chain.args(i, "g", s1),
-                                           **chain.grad_args(i, "g", g2))
-                    chain.done(post, s2)
-                    chain.grad_done(nxt, g1)
-                    post, nxt = f.backward(s1, s2, g1, g2, b, t, slot=slots[(i, "f")], **kw, **chain.args(i, "f", s2),
-                                           **chain.grad_args(i, "f", g1))
-                    chain.done(post, s1)
-                    chain.grad_done(nxt, g2)
-                done.append(i)
-                hook = seq.block_done_hook
-                waited_for = hook is not None and getattr(hook, "active", lambda: True)()
-                if WGRAD_FLUSH_PER_LAYER or waited_for:
-                    if pending_wgrads() >= 7 or i == 0:
-                        # one grouped launch per layer's worth of weight gradients; only then are the finished blocks'
-                        # gradient slices final, so their all-reduce hooks run here
-                        flush_wgrad(colsums=waited_for)
-                        if seq.block_done_hook is not None:
-                            for j in done:
-                                seq.block_done_hook(seq, j)
-                        done.clear()
-                elif pending_wgrads() >= WGRAD_MAX_PENDING:
-                    flush_wgrad()      # nobody waits for a block's gradients (one GPU): they go out in a few large groups at the
-                    #                    end of the backward; this only bounds the operands held
-            dx = (g1 + g2).view(b, t, d)
-        return dx, (None if dkeys is None else dkeys.view(b, -1, d)), None, None
+            gen = stack_backward_steps(ctx, dout)
+            try:
+                while True:
+                    seq, done = next(gen)
+                    if seq.block_done_hook is not None:
+                        for j in done:
+                            seq.block_done_hook(seq, j)
+            except StopIteration as fin:
+                dx, dkeys = fin.value
+        return dx, dkeys, None, None
+
+
+def stack_backward_steps(ctx, dout, complete_layers: Optional[bool] = None):
+    """The backward of one FusedStackFn.forward as a GENERATOR: runs the blocks in reverse and yields ``(seq, [block indices])``
+    every time a layer's worth of weight gradients has been flushed -- from that point the listed blocks' slices of the flat
+    gradient buffer are final -- and returns ``(dx, dkeys)`` through StopIteration.  FusedStackFn.backward drives it to the end
+    and calls the block-done hooks at every stop; the data-parallel trainer's segmented capture (Trainer.capture) drives it
+    itself, on the calling thread, and closes one hipGraph / opens the next at every stop, so that a decoder layer's
+    gradient all-reduce can be issued while the next layer's backward replays.  Call under ``torch.no_grad()``.
+    ``complete_layers``: also finalise the deferred column sums (bias / LayerNorm gradients) at every stop (default: only
+    when a block-done hook is waiting for the gradients)."""
+    if ctx.state is None:
+        raise RuntimeError("FusedStackFn.backward: this forward's state was already consumed (the streams are rebuilt in "
+                           "place; a second backward through the same stack call is not possible)")
+    s1, s2, steps, extra, b, t, d, has_ctx, seq, slots = ctx.state
+    ctx.state = None
+    gboth = torch.empty(2, b * t, d, dtype=torch.float32, device=dout.device)
+    gboth.copy_(dout.detach().reshape(1, b * t, d).expand(2, -1, -1))
+    g1, g2 = gboth[0], gboth[1]
+    dkeys = None
+    if has_ctx:
+        dkeys = torch.zeros(extra["keys_bf16"].shape, dtype=torch.float32, device=dout.device)
+        extra = dict(extra, dkeys=dkeys)
+    done = []
+    chain = _Chain(_flat_calls(steps), reverse=True, slots=slots)
+    for i in range(len(steps) - 1, -1, -1):
+        kind, f, g, kw = steps[i]
+        if kind == "swap":
+            s1, s2, g1, g2 = s2, s1, g2, g1
+        elif kind == "half":
+            if "keys_bf16" in kw:
+                kw = dict(kw, dkeys=dkeys)
+            post, nxt = f.backward(s1, s2, g1, g2, b, t, slot=slots[(i, "f")], **kw, **chain.args(i, "f", s2),
+                                   **chain.grad_args(i, "f", g1))
+            chain.done(post, s1)
+            chain.grad_done(nxt, g2)
+        else:
+            post, nxt = g.backward(s2, s1, g2, g1, b, t, slot=slots[(i, "g")], **chain.args(i, "g", s1),
+                                   **chain.grad_args(i, "g", g2))
+            chain.done(post, s2)
+            chain.grad_done(nxt, g1)
+            post, nxt = f.backward(s1, s2, g1, g2, b, t, slot=slots[(i, "f")], **kw, **chain.args(i, "f", s2),
+                                   **chain.grad_args(i, "f", g1))
+            chain.done(post, s1)
+            chain.grad_done(nxt, g2)
+        done.append(i)
+        hook = seq.block_done_hook
+        waited_for = (hook is not None and getattr(hook, "active", lambda: True)()) if complete_layers is None else bool(complete_layers)
+        if WGRAD_FLUSH_PER_LAYER or waited_for:
+            if pending_wgrads() >= 7 or i == 0:
+                # one grouped launch per layer's worth of weight gradients; only then are the finished blocks'
+                # gradient slices final, so their all-reduce hooks run here
+                flush_wgrad(colsums=waited_for)
+                yield seq, list(done)
+                done.clear()
+        elif pending_wgrads() >= WGRAD_MAX_PENDING:
+            flush_wgrad()      # nobody waits for a block's gradients (one GPU): they go out in a few large groups at the
+            #                    end of the backward; this only bounds the operands held
+    dx = (g1 + g2).view(b, t, d)
+    return dx, (None if dkeys is None else dkeys.view(b, -1, d))
+
+
+class _ManualCtx:
+    """Stands in for autograd's ctx when a stack's forward / backward are driven by hand (Trainer's segmented capture)."""
+    state = None
+

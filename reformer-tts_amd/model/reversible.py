@@ -186,6 +186,7 @@ class ReversibleSequence(nn.Module):
         self.fused_in_eval = False  # generation: the executor's forward in eval mode too (half the launches of the general path)
         self._program = None
         self._program_built = False
+        self.manual = None          # dict while the trainer drives the backward by hand (see forward_sum), else None
 
     def forward_sum(self, x, kwargs_list=None, context=None):
         """Both streams start as ``x``; returns their sum after the stack (``reformer.py:81-93,139-158``)."""
@@ -199,6 +200,17 @@ class ReversibleSequence(nn.Module):
                 self._program, self._program_built = build_program(self), True
             if self._program is not None:
                 from ..engine import FusedStackFn
+                if self.manual is not None and self.training and torch.is_grad_enabled():
+                    # the data-parallel trainer drives this stack's backward itself (engine.stack_backward_steps), one
+                    # hipGraph per layer: the forward runs outside autograd and leaves (ctx, input, context, output) behind;
+                    # the output is a leaf whose .grad the loss's backward fills
+                    from ..engine import _ManualCtx
+                    ctx = _ManualCtx()
+                    with torch.no_grad():
+                        out = FusedStackFn.forward(ctx, x, context, self, kwargs_list)
+                    out.requires_grad_(True)
+                    self.manual["call"] = (ctx, x, context, out)
+                    return out
                 return FusedStackFn.apply(x, context, self, kwargs_list)
             from .._lib import note_general_path
             note_general_path("reversible stack", "a block is outside the executors' envelope (e.g. feed-forward dropout > 0)")

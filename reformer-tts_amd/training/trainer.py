@@ -627,16 +627,17 @@ class Trainer:
 
         * one process (or ``segmented=False``): ONE graph = forward + backward (+ per-block all-reduce) + clip + AdamW +
           mirror refresh;
-        * data parallel (default when world > 1): FOUR graphs with the gradient exchange between them, no collective
-          inside any capture (nothing is asked of RCCL beyond plain all-reduces):
-              A   zero + forward + loss + backward of postnet, heads, decoder, decoder prenet
-                  -> all-reduce of the decoder-side part of the flat gradient buffer (~59 MB), asynchronous
-              B   backward of the encoder stack, from d(loss)/d(encoder output)         (overlaps that all-reduce)
-                  -> all-reduce of the encoder stack's part (~35 MB), asynchronous
-              B'  backward of the encoder prenet + positional encoding               (overlaps that all-reduce)
-                  -> all-reduce of the prenet's part (~17 MB): the only exposed one
-              C   clip + AdamW + mirror refresh
-          Three large collectives (what xGMI's per-link-bound ring likes); ~85 % of the bytes hidden.
+        * data parallel (default when world > 1): a CHAIN of graphs with the gradient exchange between them, no collective
+          inside any capture (nothing is asked of RCCL beyond plain all-reduces of slices of the flat gradient buffer):
+              A    zero + forward + loss + backward of heads and postnet       -> all-reduce of their part (~7 MB)
+              D_l  backward of decoder layer l = L-1 .. 0, one graph each (the stack's backward is driven by hand through
+                   engine.stack_backward_steps, on this thread, so that a capture can end at a layer boundary); the bottom
+                   layer's graph also holds the decoder prenet's backward     -> all-reduce of that layer (~17 MB each)
+              B    backward of the encoder stack, from d(loss)/d(encoder output) -> all-reduce of the stack's part (~35 MB)
+              B'   backward of the encoder prenet + positional encoding       -> all-reduce of the prenet's part (~17 MB)
+              C    clip + AdamW + mirror refresh
+          Every all-reduce is issued the moment its graph has been enqueued and runs while the NEXT graph replays; only the
+          last one (17 MB of 108) has nothing to hide behind.  Messages of 7-35 MB: xGMI's ring is per-link bound.
 
         Rotations and dropout draw from the graph-safe default generator."""
         from ..model.lsh_attention import LSHSelfAttention
@@ -660,43 +661,102 @@ class Trainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
-        self._graph_enc = self._graph_pre = self._graph_opt = None
+        self._graph_opt = None
+        self._segments = []
         self.set_step_hyper(self.global_step)
         if not segmented:
             with self._capturing(self._graph):
                 self._graph_out = self.train_step(batch, update_hyper=False)
             self.global_step -= 1                        # capturing does not execute: the captured step has not run yet
             return self._graph_out
+        # ---- segmented capture: [(graph, gradient range that is final when it ends)] in replay order
         enc_names = [n for n in self.offsets if n.startswith("enc.")]
-        self._enc_end = max(self.offsets[n][1] for n in enc_names)
-        if min(self.offsets[n][0] for n in self.offsets if not n.startswith("enc.")) < self._enc_end:
+        enc_end = max(self.offsets[n][1] for n in enc_names)
+        if min(self.offsets[n][0] for n in self.offsets if not n.startswith("enc.")) < enc_end:
             raise RuntimeError("flat buffer: encoder parameters are expected to come first")
-        with self._capturing(self._graph):
-            self.model.train()
-            self.zero_grad()
-            total, raw_l, post_l, stop_l = self.forward_loss(batch, split=True)
-            self._run_backward(total)
-            self._graph_out = (total.detach(), raw_l.detach(), post_l.detach(), stop_l.detach())
         stack_names = [n for n in enc_names if n.startswith("enc.reformer.")]
-        self._stack_begin = min(self.offsets[n][0] for n in stack_names)
-        if any(self.offsets[n][0] >= self._stack_begin for n in enc_names if n not in stack_names):
+        stack_begin = min(self.offsets[n][0] for n in stack_names)
+        if any(self.offsets[n][0] >= stack_begin for n in enc_names if n not in stack_names):
             raise RuntimeError("flat buffer: the encoder prenet is expected in front of the encoder stack")
-        self._graph_enc = torch.cuda.CUDAGraph()
-        with self._capturing(self._graph_enc, pool=self._graph.pool()):
+        dec_stack = [n for n in self.offsets if n.startswith("dec.reformer.")]
+        dec_stack_end = max(self.offsets[n][1] for n in dec_stack)
+        tail = [n for n in self.offsets if not n.startswith("enc.") and self.offsets[n][0] >= dec_stack_end]
+        if any(n.startswith(("dec.prenet", "dec.positional_encoding", "dec.reformer")) for n in tail) or not tail:
+            raise RuntimeError("flat buffer: heads and postnet are expected behind the decoder stack")
+        dec_seq = self.model.dec.reformer.layers
+        segs = []
+        dec_seq.manual = {}
+        try:
+            with self._capturing(self._graph):
+                self.model.train()
+                self.zero_grad()
+                total, raw_l, post_l, stop_l = self.forward_loss(batch, split=True)
+                self._run_backward(total)            # heads + postnet; stops at the decoder stack's output (a leaf: driven by hand)
+                self._graph_out = (total.detach(), raw_l.detach(), post_l.detach(), stop_l.detach())
+            segs.append((self._graph, (dec_stack_end, self.n_params)))
+            if "call" not in dec_seq.manual:
+                raise RuntimeError("the decoder stack did not take the explicit executor: the segmented capture needs it")
+            ctx, dec_x, _, dec_out = dec_seq.manual["call"]
+            gen = engine.stack_backward_steps(ctx, dec_out.grad, complete_layers=True)
+            finished = False
+            while not finished:
+                g = torch.cuda.CUDAGraph()
+                with self._capturing(g, pool=self._graph.pool()):
+                    with torch.no_grad():
+                        _, done = next(gen)      # one decoder layer's backward + its weight gradients and column sums
+                    rng = [self.block_bucket[("dec", j)] for j in done if ("dec", j) in self.block_bucket]
+                    lo, hi = min(r[0] for r in rng), max(r[1] for r in rng)
+                    if 0 in done:                # the bottom layer: the generator ends; the decoder prenet's backward joins this graph
+                        try:
+                            with torch.no_grad():
+                                next(gen)
+                            raise RuntimeError("stack_backward_steps yielded after block 0")
+                        except StopIteration as fin:
+                            dx, dkeys = fin.value
+                        dec_x.backward(dx)
+                        self._enc_in.grad = dkeys
+                        engine.flush_wgrad()
+                        assert engine.pending_all() == 0
+                        lo = enc_end             # decoder prenet + positional encoding sit between the encoder and the stack
+                        finished = True
+                segs.append((g, (lo, hi)))
+        finally:
+            dec_seq.manual = None
+        g = torch.cuda.CUDAGraph()
+        with self._capturing(g, pool=self._graph.pool()):
             self._enc_out.backward(self._enc_in.grad)
             engine.flush_wgrad()
             assert engine.pending_all() == 0
-        self._graph_pre = torch.cuda.CUDAGraph()
-        with self._capturing(self._graph_pre, pool=self._graph.pool()):
+        segs.append((g, (stack_begin, enc_end)))
+        g = torch.cuda.CUDAGraph()
+        with self._capturing(g, pool=self._graph.pool()):
             self._pre_out.backward(self._pre_in.grad)
             engine.flush_wgrad()
             assert engine.pending_all() == 0
+        segs.append((g, (0, stack_begin)))
         self._enc_out = self._enc_in = self._pre_out = self._pre_in = None
+        cover = sorted(r for _, r in segs)
+        if cover[0][0] != 0 or cover[-1][1] != self.n_params or any(a[1] != b[0] for a, b in zip(cover, cover[1:])):
+            raise RuntimeError(f"segmented capture: the gradient ranges do not tile the flat buffer: {cover}")
+        self._segments = segs
         self._graph_opt = torch.cuda.CUDAGraph()
         with self._capturing(self._graph_opt, pool=self._graph.pool()):
             self.optimizer_step(update_hyper=False)
         self.global_step -= 1
         return self._graph_out
+
+    def segment_plan(self):
+        """[(bytes of the gradient range all-reduced after segment k, launches-free description)] of the captured data-parallel
+        schedule (bench.py prints it): which collective overlaps which graph."""
+        n_dec = len(self._segments) - 3
+        names = ["forward + loss + heads/postnet backward"] + [f"decoder layer {k} backward" for k in range(n_dec - 1, -1, -1)] + \
+                ["encoder stack backward", "encoder prenet backward"]
+        names[n_dec] += " + decoder prenet backward"
+        out = []
+        for k, ((_, (s, e)), nm) in enumerate(zip(self._segments, names)):
+            nxt = names[k + 1] if k + 1 < len(names) else "nothing (exposed)"
+            out.append(dict(after=nm, allreduce_bytes=4 * (e - s), overlaps=nxt))
+        return out
 
     def bulk_allreduce(self):
         if self.world > 1:
@@ -705,18 +765,17 @@ class Trainer:
     def replay(self):
         self.set_step_hyper(self.global_step)
         self.global_step += 1
-        self._graph.replay()
-        if self._graph_opt is not None:
-            works = []
+        if self._graph_opt is None:
+            self._graph.replay()
+            return self._graph_out
+        # data parallel: every segment's gradient range is final when its graph ends -- its all-reduce is issued at once and
+        # runs while the next segment replays; only the last (the encoder prenet's 17 MB) has nothing to hide behind
+        works = []
+        for g, (s, e) in self._segments:
+            g.replay()
             if self.world > 1:
-                works.append(dist.all_reduce(self.flat_g[self._enc_end:], group=self.pg, async_op=True))
-            self._graph_enc.replay()
-            if self.world > 1:
-                works.append(dist.all_reduce(self.flat_g[self._stack_begin:self._enc_end], group=self.pg, async_op=True))
-            self._graph_pre.replay()
-            if self.world > 1:
-                works.append(dist.all_reduce(self.flat_g[:self._stack_begin], group=self.pg, async_op=True))
-            for w in works:
-                w.wait()
-            self._graph_opt.replay()
+                works.append(dist.all_reduce(self.flat_g[s:e], group=self.pg, async_op=True))
+        for w in works:
+            w.wait()
+        self._graph_opt.replay()
         return self._graph_out

@@ -1,7 +1,8 @@
 """Worker of tests/test_dp_gpu.py: one rank of a 2-process gloo job sharing cuda:0.  Runs three training steps of the small
 model in the two data-parallel modes of the trainer and checks (a) replicas stay identical, (b) the modes agree:
     eager      per-block all-reduce issued from the block-done hooks, overlapped with the backward
-    graphs     four hipGraphs (fwd + decoder-side bwd | encoder stack bwd | encoder prenet bwd | clip + AdamW) around three eager all-reduces
+    graphs     a chain of hipGraphs (fwd + heads/postnet bwd | one per decoder layer | encoder stack bwd | encoder prenet bwd | clip + AdamW)
+               with the all-reduce of each graph's gradient range issued while the next one replays
 (parameters after three steps, loss of the third step)."""
 import os
 import sys
@@ -35,7 +36,10 @@ def run(mode, rank, dev):
             losses.append(float(tr.train_step(batch)[0]))
     else:
         tr.capture(batch)                      # two eager steps (bulk all-reduce), then the graphs are captured
-        assert tr._graph_enc is not None and tr._graph_pre is not None and tr._graph_opt is not None
+        # forward+loss+heads | one graph per decoder layer (depth 1 here) | encoder stack | encoder prenet, then the optimizer
+        assert len(tr._segments) == 4 and tr._graph_opt is not None, len(tr._segments)
+        plan = tr.segment_plan()
+        assert sum(p["allreduce_bytes"] for p in plan) == 4 * tr.n_params and plan[-1]["overlaps"].startswith("nothing")
         losses = [None, None, float(tr.replay()[0])]
     torch.cuda.synchronize()
     return tr, losses
