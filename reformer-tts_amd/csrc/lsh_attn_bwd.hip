@@ -630,11 +630,8 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
     float ksc = 0.f, sdq = 0.f;
     int myvalid = 1, mypos = 0, kpk = 0;
     f32x16 dvacc[2], gacc[2];   // [dh tile]: rows = dh, lane = key
-#ifdef AB_PRIO
-    // static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md, two waves per SIMD, item 4): waves
-    // 4..7 lose the issue arbitration against their older SIMD partners in every segment; one s_setprio for the whole kernel
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= NW / 2) __builtin_amdgcn_s_setprio(AB_PRIO);
-#endif
+    // (A static s_setprio 1 for the second-dispatched half of the workgroup -- MI355X_MICROARCH.md, two waves per SIMD, item 4 --
+    //  measured null here: 220.9 against 221.3 / 220.4 us, profiles/r03_lsh_attn_bwd_prio_ab.log.)
 #pragma unroll 1
     for (int j = 0; j < R; ++j) {
         // nothing else but scalars is carried from one step to the next: the lane id goes through an opaque move so that no address
