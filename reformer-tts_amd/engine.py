@@ -487,7 +487,9 @@ class LSHExec:
 
     @staticmethod
     def supported(withnorm) -> bool:
-        return True      # post_attn_dropout rides in the residual epilogue (counter-hash mask, reproduced by the backward)
+        # post_attn_dropout rides in the residual epilogue (counter-hash mask, reproduced by the backward); the projections are
+        # rtts_gemm_nt launches: K = d and N = d, 2d must be multiples of its 64-wide stages / tiles
+        return withnorm.fn.layer.dim % 64 == 0
 
     def _wqkv(self):
         lyr = self.layer
@@ -580,7 +582,9 @@ class FFNExec:
     @staticmethod
     def supported(mod) -> bool:
         wn = mod.fn if hasattr(mod, "chunks") else mod
-        return wn.fn.net[2].p == 0.0
+        lin1, lin2 = wn.fn.net[0], wn.fn.net[3]
+        # both layers are rtts_gemm_nt launches: every width a multiple of its 64-wide stages / tiles
+        return wn.fn.net[2].p == 0.0 and all(v % 64 == 0 for v in (lin1.in_features, lin1.out_features, lin2.out_features))
 
     def _internals(self, inp, g=None, pre=None, h=None):
         """h: (activation, gate words | None) kept from the forward, or None: computed here."""
@@ -632,7 +636,8 @@ class XAttnExec:
     @staticmethod
     def supported(withnorm) -> bool:
         m = withnorm.fn.layer      # dropout on the attention probabilities runs inside the kernels (counter-hash mask)
-        return m.bias_k is None and not m.add_zero_attn and m._qkv_same_embed_dim
+        return m.bias_k is None and not m.add_zero_attn and m._qkv_same_embed_dim and m.embed_dim % 64 == 0 and \
+            m.embed_dim // m.num_heads == 64
 
     def _internals(self, inp, b, t, keys_bf16, kvalid, stash=None, g=None, pre=None, drop=None, proj=None):
         m = self.mha
@@ -875,6 +880,9 @@ class FusedStackFn(torch.autograd.Function):
             else:
                 out = (s1 + s2).view(b, t, d)
         ctx.state = (s1, s2, steps, extra, b, t, d, context is not None, seq, slots)
+        # with the streams kept, the first sublayer's saved input IS the caller's x (no copy): an in-place write to x between this
+        # forward and its backward would silently change the gradients -- remember the version, check it in the backward
+        ctx.x_guard = (x, x._version) if kept else None
         return out
 
     @staticmethod
@@ -906,6 +914,10 @@ def stack_backward_steps(ctx, dout, complete_layers: Optional[bool] = None):
                            "place; a second backward through the same stack call is not possible)")
     s1, s2, steps, extra, b, t, d, has_ctx, seq, slots = ctx.state
     ctx.state = None
+    guard = getattr(ctx, "x_guard", None)
+    if guard is not None and guard[0]._version != guard[1]:
+        raise RuntimeError("the input of a reversible stack was modified in place between its forward and its backward: with the streams "
+                           "kept (engine.STASH_STREAMS) the first sublayer reads it again -- clone it before writing to it")
     gboth = torch.empty(2, b * t, d, dtype=torch.float32, device=dout.device)
     gboth.copy_(dout.detach().reshape(1, b * t, d).expand(2, -1, -1))
     g1, g2 = gboth[0], gboth[1]

@@ -207,6 +207,15 @@ class Trainer:
         ok = self.use_fused_edges and self.device.type == "cuda" and self.model.training and (spec.shape[0] * lp) % 64 == 0
         if not ok and self.use_fused_edges and self.device.type == "cuda" and self.model.training:
             _lib.note_general_path("heads / postnet / loss", f"batch x padded length = {spec.shape[0]} x {lp} is not a multiple of 64")
+        if ok:
+            # the BatchNorm kernels run over the convolutions' 128-padded width and read / write their per-channel vectors at that
+            # width; the [mel | stop] heads share one 128-wide GEMM
+            pn = self.model.postnet.layers
+            width = pn.conv0.out_channels
+            if width % 128 != 0 or self.model.num_mel_coeffs + 1 > 128 or self.model.num_mel_coeffs % 8 != 0:
+                _lib.note_general_path("heads / postnet / loss", f"postnet width {width} (needs a multiple of 128) / {self.model.num_mel_coeffs} "
+                                       "mel channels (a multiple of 8, at most 127)")
+                ok = False
         return ok
 
     def _cut_at_encoder(self, keys):

@@ -1202,6 +1202,56 @@ def test_fit_over_ragged_host_batches(gpu):
 
 
 
+def test_deferred_gradient_queues_are_drained_whichever_thread_ends_the_backward(gpu):
+    """The executors queue weight gradients / column sums from autograd's WORKER thread; the trainer flushes from the calling
+    thread.  The queues are keyed by (device, stream), so that flush sees them: (a) a backward whose graph also has a CPU leaf
+    (its last node runs on another thread) leaves nothing queued and gives the same gradients as the plain backward, bit for
+    bit; (b) entries queued by a backward that RAISES are dropped, not added to the next step's gradients."""
+    from reformer_tts_amd import engine
+    from reformer_tts_amd.model.config import TTSTrainingConfig
+    from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
+    model = build_model(_hip_cfg(), gpu)
+    batch = synthetic_batch(2, 100, 256, device=gpu)
+    for layer in _lsh_layers(model):
+        layer.forced_rotations = {nb: torch.randn(1, 64, 4, nb // 2, generator=torch.Generator().manual_seed(nb)) for nb in (2, 4)}
+    tr = Trainer(model, TTSTrainingConfig(batch_size=2), gpu)
+    model.train()
+
+    def grads(extra):
+        from reformer_tts_amd import _seeds
+        _seeds.reset()
+        tr.zero_grad()
+        loss = tr.forward_loss(batch)[0]
+        tr._run_backward(loss if extra is None else loss + extra().to(gpu))
+        torch.cuda.synchronize()
+        assert engine.pending_all() == 0
+        return tr.flat_g.clone()
+
+    plain = grads(None)
+    cpu_leaf = torch.ones(5, requires_grad=True)
+    mixed = grads(lambda: (cpu_leaf * 3.0).sum())
+    assert torch.equal(plain, mixed) and float(cpu_leaf.grad.sum()) == 15.0
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+
+    tr.zero_grad()
+    a = torch.randn(256, 128, device=gpu).bfloat16()
+    engine.wgrad(torch.zeros(128, 128, device=gpu), a, a)            # something queued, as a half-finished backward leaves it
+    assert engine.pending_all() == 1
+    with pytest.raises(RuntimeError, match="boom"):
+        tr._run_backward(Boom.apply(torch.ones(1, device=gpu, requires_grad=True)).sum())
+    assert engine.pending_all() == 0
+    again = grads(None)
+    assert torch.equal(plain, again)
+
+
 def test_fit_graph_cache_follows_the_eager_trajectory(gpu):
     """Trainer.fit with one captured forward + loss + backward per PADDED shape (wrappers.py:213-222 yields few of them at
     pad_base granularity) against eager fit from the same start: ragged batches of three (text, mel) lengths that fall into
