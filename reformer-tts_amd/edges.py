@@ -454,7 +454,7 @@ def _seed() -> int:
 
 
 def _pe_ws(device) -> torch.Tensor:
-    key = ("pe", device)
+    key = ("pe", device, torch.cuda.current_stream(device).cuda_stream)
     if key not in _WS._cache:
         _WS._cache[key] = torch.empty(512, dtype=torch.float32, device=device)
     return _WS._cache[key]

@@ -92,7 +92,7 @@ class _WS:
 
     @classmethod
     def partial(cls, device, d: int) -> torch.Tensor:
-        key = (device, d)
+        key = (device, d, torch.cuda.current_stream(device).cuda_stream)      # two streams (encoder beside decoder) never share scratch
         if key not in cls._cache:
             cls._cache[key] = torch.empty(2 * 256 * d, dtype=torch.float32, device=device)
         return cls._cache[key]
@@ -843,6 +843,8 @@ class FusedStackFn(torch.autograd.Function):
             if context is not None:
                 kpm = next((k.get("key_padding_mask") for k in kwargs_list if "key" in k), None)
                 kb = bf16_twin(context)                           # the encoder stack's own bf16 copy of its output
+                if kb is None and getattr(context, "_rtts_ready", None) is not None:
+                    torch.cuda.current_stream().wait_event(context._rtts_ready)      # no twin: the cast below reads the keys NOW
                 kb = kb.view(-1, d) if kb is not None else context.detach().reshape(-1, d).to(torch.bfloat16)
                 kv = None
                 if kpm is not None:
@@ -856,10 +858,16 @@ class FusedStackFn(torch.autograd.Function):
                 steps.append((kind, f, g, kw))
             chain = _Chain(_flat_calls(steps), reverse=False)
             slots = {(i, w): {} for (_, i, w) in _flat_calls(steps)}      # forward -> backward state of THIS call, one per executor
+            keys_ready = getattr(context, "_rtts_ready", None) if context is not None else None
             for i, (kind, f, g, kw) in enumerate(steps):
                 if kind == "swap":
                     s1, s2 = s2, s1
                 elif kind == "half":
+                    if keys_ready is not None and "keys_bf16" in kw:
+                        # the encoder ran on a stream of its own beside the decoder's first blocks (Trainer, overlapped step):
+                        # the first cross-attention is where the two meet
+                        torch.cuda.current_stream().wait_event(keys_ready)
+                        keys_ready = None
                     post = f.forward(s1, s2, b, t, slot=slots[(i, "f")], keep_streams=kept, **kw, **chain.args(i, "f", s2))
                     s1 = slots[(i, "f")].pop("acc_out", s1)
                     chain.done(post, s1)
@@ -900,7 +908,7 @@ class FusedStackFn(torch.autograd.Function):
         return dx, dkeys, None, None
 
 
-def stack_backward_steps(ctx, dout, complete_layers: Optional[bool] = None):
+def stack_backward_steps(ctx, dout, complete_layers: Optional[bool] = None, notify_dkeys: bool = False):
     """The backward of one FusedStackFn.forward as a GENERATOR: runs the blocks in reverse and yields ``(seq, [block indices])``
     every time a layer's worth of weight gradients has been flushed -- from that point the listed blocks' slices of the flat
     gradient buffer are final -- and returns ``(dx, dkeys)`` through StopIteration.  FusedStackFn.backward drives it to the end
@@ -908,7 +916,9 @@ def stack_backward_steps(ctx, dout, complete_layers: Optional[bool] = None):
     itself, on the calling thread, and closes one hipGraph / opens the next at every stop, so that a decoder layer's
     gradient all-reduce can be issued while the next layer's backward replays.  Call under ``torch.no_grad()``.
     ``complete_layers``: also finalise the deferred column sums (bias / LayerNorm gradients) at every stop (default: only
-    when a block-done hook is waiting for the gradients)."""
+    when a block-done hook is waiting for the gradients).  ``notify_dkeys``: additionally yield ``(seq, ("dkeys", dkeys))`` as soon
+    as the gradient of the cross-attention keys is complete (after the LOWEST cross-attention block's backward): the encoder's
+    backward can start there, beside the remaining decoder blocks."""
     if ctx.state is None:
         raise RuntimeError("FusedStackFn.backward: this forward's state was already consumed (the streams are rebuilt in "
                            "place; a second backward through the same stack call is not possible)")
@@ -927,6 +937,7 @@ def stack_backward_steps(ctx, dout, complete_layers: Optional[bool] = None):
         extra = dict(extra, dkeys=dkeys)
     done = []
     chain = _Chain(_flat_calls(steps), reverse=True, slots=slots)
+    key_blocks = [i for i, st in enumerate(steps) if st[0] == "half" and "keys_bf16" in st[3]]
     for i in range(len(steps) - 1, -1, -1):
         kind, f, g, kw = steps[i]
         if kind == "swap":
@@ -938,6 +949,8 @@ def stack_backward_steps(ctx, dout, complete_layers: Optional[bool] = None):
                                    **chain.grad_args(i, "f", g1))
             chain.done(post, s1)
             chain.grad_done(nxt, g2)
+            if notify_dkeys and key_blocks and i == key_blocks[0]:
+                yield seq, ("dkeys", dkeys.view(b, -1, d))
         else:
             post, nxt = g.backward(s2, s1, g2, g1, b, t, slot=slots[(i, "g")], **chain.args(i, "g", s1),
                                    **chain.grad_args(i, "g", g2))

@@ -97,13 +97,31 @@ class ReformerTTS(nn.Module):
         spectrogram_mask = pad_to_multiple(spectrogram_mask.unsqueeze(-1).to(dev), self.pad_base).squeeze(-1).to(torch.bool)
         return pad_phonemes, phoneme_mask, spectrogram_mask, pad_to_multiple(spectrogram, self.pad_base)
 
-    def decoder_hidden(self, phonemes, spectrogram, spectrogram_mask=None, keys_hook=None, enc_stack_hook=None):
+    def decoder_hidden(self, phonemes, spectrogram, spectrogram_mask=None, keys_hook=None, enc_stack_hook=None, enc_stream=None):
         """Decoder output (B, T_padded, d) in front of the mel/stop heads: the training step feeds it to the
         fused heads + postnet + loss executor (``edges.PostnetLoss``).  ``keys_hook`` (encoder output -> tensor the
         decoder reads) lets the data-parallel trainer cut the autograd graph between encoder and decoder so that the
         two halves of the backward are separate launches with a gradient all-reduce in between."""
         pad_phonemes, phoneme_mask, spectrogram_mask, pad_spec = self._encode_inputs(phonemes, spectrogram, spectrogram_mask)
-        keys = self.enc(pad_phonemes, input_mask=phoneme_mask, stack_hook=enc_stack_hook)
+        if enc_stream is not None:
+            # the encoder (3,072 rows at the baseline shape: launch- and latency-bound kernels on three quarters of the chip) runs
+            # on a stream of its own BESIDE the decoder prenet and the first decoder block, which do not read its output; the
+            # decoder's first cross-attention waits for the event left on the keys (engine.FusedStackFn.forward)
+            main = torch.cuda.current_stream()
+            enc_stream.wait_stream(main)
+            for t_ in (pad_phonemes, phoneme_mask):
+                t_.record_stream(enc_stream)
+            with torch.cuda.stream(enc_stream):
+                keys = self.enc(pad_phonemes, input_mask=phoneme_mask, stack_hook=enc_stack_hook)
+                ready = torch.cuda.Event()
+                ready.record(enc_stream)
+            keys.record_stream(main)
+            twin = getattr(keys, "_rtts_bf16", None)
+            if twin is not None:
+                twin[0].record_stream(main)               # the stack's bf16 copy of the keys: the cross-attention's k|v projection reads it
+            keys._rtts_ready = ready
+        else:
+            keys = self.enc(pad_phonemes, input_mask=phoneme_mask, stack_hook=enc_stack_hook)
         if keys_hook is not None:
             keys = keys_hook(keys)
         kpm = ~phoneme_mask

@@ -222,6 +222,9 @@ class Trainer:
         """keys_hook of the split step: the decoder reads a detached copy, the encoder's backward is run later from its grad."""
         self._enc_out = keys
         self._enc_in = keys.detach().requires_grad_(True)
+        for attr in ("_rtts_bf16", "_rtts_ready"):          # the stack's own bf16 copy / the "encoder done" event travel with the values
+            if hasattr(keys, attr):
+                setattr(self._enc_in, attr, getattr(keys, attr))
         return self._enc_in
 
     def _cut_at_enc_stack(self, x):
@@ -248,13 +251,19 @@ class Trainer:
 
     def _forward_loss(self, batch, split: bool = False):
         spec_in, spec_tgt = self._frames(batch)
+        if split == "overlap":
+            from ..model.lsh_attention import LSHSelfAttention
+            if LSHSelfAttention.rotation_pool is not None:        # drawn on this stream, read by the encoder's hash kernels on theirs
+                LSHSelfAttention.rotation_pool[0].record_stream(self._enc_stream())
         if self._fused_edges_ok(batch):
             from ..edges import PostnetLoss
             if getattr(self, "_postnet_loss", None) is None:
                 self._postnet_loss = PostnetLoss(self.model, self.loss)
+            overlap = split == "overlap"
             y = self.model.decoder_hidden(batch["phonemes"], spec_in, spectrogram_mask=batch["loss_mask"].mean(dim=-1),
                                           keys_hook=self._cut_at_encoder if split else None,
-                                          enc_stack_hook=self._cut_at_enc_stack if split else None)
+                                          enc_stack_hook=self._cut_at_enc_stack if (split and not overlap) else None,
+                                          enc_stream=self._enc_stream() if overlap else None)
             losses = self._postnet_loss.apply(y, spec_tgt, batch["stop_tokens"], batch["loss_mask"], batch.get("valid_len"))
             return losses[0], losses[1], losses[2], losses[3]
         raw, post, stop, _ = self.model(batch["phonemes"], spec_in, spectrogram_mask=batch["loss_mask"].mean(dim=-1))
@@ -373,6 +382,66 @@ class Trainer:
         self.zero_grad()
         total, raw_l, post_l, stop_l = self.forward_loss(batch)
         self.backward(total)
+        if self._bulk_allreduce:
+            self.bulk_allreduce()
+        self.optimizer_step(update_hyper)
+        return total.detach(), raw_l.detach(), post_l.detach(), stop_l.detach()
+
+    # ------------------------------------------------------------------ encoder beside decoder (captured steps)
+    overlap_encoder = True      # Trainer.capture (one process): the encoder on a stream of its own, see train_step_overlapped
+
+    def _enc_stream(self):
+        if getattr(self, "_enc_stream_obj", None) is None:
+            self._enc_stream_obj = torch.cuda.Stream(self.device)
+        return self._enc_stream_obj
+
+    def train_step_overlapped(self, batch, update_hyper: bool = True):
+        """``train_step`` with the ENCODER ON A STREAM OF ITS OWN (meant to be captured: in a hipGraph the two streams become
+        parallel branches; launched eagerly the host serialises them anyway).  Forward: encoder prenet + stack beside the
+        decoder prenet and the first decoder LSH block (they do not read the encoder's output); the first cross-attention
+        waits.  Backward: the decoder stack runs outside autograd (``ReversibleSequence.manual``) and its backward generator
+        says when the gradient of the keys is complete -- after the lowest cross-attention block -- from where the encoder's
+        backward (stack + prenet, autograd, on the encoder's stream) runs beside decoder layer 0's LSH-attention backward and
+        the decoder prenet's.  Same arithmetic, same gradients as ``train_step`` (``test_overlapped_step_matches_the_serial_step``)."""
+        if not self._fused_edges_ok(batch):
+            return self.train_step(batch, update_hyper)
+        self.model.train()
+        self.zero_grad()
+        main, side = torch.cuda.current_stream(), self._enc_stream()
+        dec_seq = self.model.dec.reformer.layers
+        dec_seq.manual = {}
+        try:
+            total, raw_l, post_l, stop_l = self.forward_loss(batch, split="overlap")
+            if "call" not in dec_seq.manual:
+                raise RuntimeError("the decoder stack did not take the explicit executor: the overlapped step needs it")
+            self._run_backward(total)                # heads + postnet: stops at the decoder stack's output (a leaf)
+            ctx, dec_x, _, dec_out = dec_seq.manual["call"]
+            gen = engine.stack_backward_steps(ctx, dec_out.grad, notify_dkeys=True)
+            dx = None
+            while True:
+                try:
+                    with torch.no_grad():
+                        _, item = next(gen)
+                except StopIteration as fin:
+                    dx = fin.value[0]
+                    break
+                if isinstance(item, tuple) and item[0] == "dkeys":
+                    dkeys = item[1]
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                    dkeys.record_stream(side)
+                    with torch.cuda.stream(side):
+                        self._enc_out.backward(dkeys)          # encoder stack + prenet, on the encoder's stream
+                        engine.flush_wgrad()
+            dec_x.backward(dx)                                 # decoder prenet + positional encoding
+            engine.flush_wgrad()
+            main.wait_stream(side)
+            if engine.pending_all():
+                raise RuntimeError("deferred gradient launches were still queued at the end of the overlapped step")
+        finally:
+            dec_seq.manual = None
+            self._enc_out = self._enc_in = None
         if self._bulk_allreduce:
             self.bulk_allreduce()
         self.optimizer_step(update_hyper)
@@ -674,8 +743,17 @@ class Trainer:
         self._segments = []
         self.set_step_hyper(self.global_step)
         if not segmented:
+            step = self.train_step_overlapped if (self.overlap_encoder and self.world == 1) else self.train_step
+            if step is not self.train_step:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    step(batch)                          # warm-up of the second stream's scratch / allocator state
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                self.set_step_hyper(self.global_step)
             with self._capturing(self._graph):
-                self._graph_out = self.train_step(batch, update_hyper=False)
+                self._graph_out = step(batch, update_hyper=False)
             self.global_step -= 1                        # capturing does not execute: the captured step has not run yet
             return self._graph_out
         # ---- segmented capture: [(graph, gradient range that is final when it ends)] in replay order

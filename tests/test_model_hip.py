@@ -1252,6 +1252,59 @@ def test_deferred_gradient_queues_are_drained_whichever_thread_ends_the_backward
     assert torch.equal(plain, again)
 
 
+@pytest.mark.parametrize("mode", ["stash", "full"])
+def test_overlapped_step_matches_the_serial_step(gpu, mode):
+    """Trainer.train_step_overlapped -- the encoder on a stream of its own beside the decoder prenet / first decoder block in
+    the forward and beside decoder layer 0's LSH backward in the backward, the decoder stack driven outside autograd -- against
+    train_step from the same start: same losses, same parameters after two optimizer steps (only the grouping of the deferred
+    weight-gradient launches differs: 1e-5), eagerly and as a captured hipGraph (where the streams really are parallel branches)."""
+    from reformer_tts_amd import engine
+    from reformer_tts_amd.model.config import TTSTrainingConfig
+    from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
+    keep = (engine.STASH_ATTENTION, engine.STASH_BLOCK_OUTPUT, engine.STASH_PROJECTIONS, engine.STASH_STREAMS)
+    engine.STASH_ATTENTION = engine.STASH_BLOCK_OUTPUT = engine.STASH_PROJECTIONS = engine.STASH_STREAMS = (mode == "stash")
+    try:
+        cfg = model_ref.small_cfg()
+        cfg["enc_reformer_kwargs"]["depth"] = 2
+        cfg["dec_reformer_kwargs"]["depth"] = 2
+        cfg["enc_reformer_kwargs"]["attn_kwargs"]["implementation"] = "hip"
+        cfg["dec_reformer_kwargs"]["self_attn_kwargs"]["implementation"] = "hip"
+        from reformer_tts_amd.model.config import model_config_from_dict
+        batch = synthetic_batch(2, 100, 256, device=gpu)
+        runs = {}
+        for how in ("serial", "overlapped", "captured"):
+            from reformer_tts_amd import _seeds
+            _seeds.reset()
+            model = build_model(model_config_from_dict(cfg), gpu)
+            shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+            model.load_state_dict(synth.synth_state_dict(shapes, seed=13), strict=False)
+            for layer in _lsh_layers(model):
+                layer.forced_rotations = {nb: torch.randn(1, 64, 4, nb // 2, generator=torch.Generator().manual_seed(nb)) for nb in (2, 4)}
+            tr = Trainer(model, TTSTrainingConfig(batch_size=2, learning_rate=1e-3, warmup_steps=None, gradient_clip_val=1.0), gpu)
+            if how == "captured":
+                tr.capture(batch)                              # three warm-up steps, then the capture of the overlapped step
+                assert tr.overlap_encoder and tr._graph_opt is None
+                losses = [float(tr.replay()[0]) for _ in range(2)]
+            else:
+                fn = tr.train_step if how == "serial" else tr.train_step_overlapped
+                n = 2 if how != "serial" else 5
+                losses = [float(fn(batch)[0]) for _ in range(n)]
+            torch.cuda.synchronize()
+            assert engine.pending_all() == 0
+            runs[how] = (losses, tr.flat_p.clone())
+        (l_s, p_s), (l_o, p_o), (l_c, p_c) = runs["serial"], runs["overlapped"], runs["captured"]
+        np.testing.assert_allclose(l_o, l_s[:2], rtol=1e-5)
+        rel = float((p_o - runs["serial"][1]).norm() / p_s.norm())     # serial ran 5 steps: compare the matching prefix below
+        # serial after 2 steps is not kept above: rerun quickly
+        np.testing.assert_allclose(l_c, l_s[3:5], rtol=2e-3)            # the captured run: 3 warm-up steps, then steps 4 and 5
+        rel_c = float((p_c - p_s).norm() / p_s.norm())
+        print(f"\n[overlapped step, {mode}] eager losses {l_o} vs serial {l_s[:2]}; captured steps 4-5 {l_c} vs serial {l_s[3:5]}; "
+              f"parameters after 5 steps: captured vs serial rel {rel_c:.2e}")
+        assert rel_c < 1e-4, rel_c
+    finally:
+        engine.STASH_ATTENTION, engine.STASH_BLOCK_OUTPUT, engine.STASH_PROJECTIONS, engine.STASH_STREAMS = keep
+
+
 def test_fit_graph_cache_follows_the_eager_trajectory(gpu):
     """Trainer.fit with one captured forward + loss + backward per PADDED shape (wrappers.py:213-222 yields few of them at
     pad_base granularity) against eager fit from the same start: ragged batches of three (text, mel) lengths that fall into
