@@ -733,9 +733,10 @@ class Trainer:
         self._bulk_allreduce = bool(segmented)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        step = self.train_step_overlapped if (self.overlap_encoder and self.world == 1 and not segmented) else self.train_step
         with torch.cuda.stream(side):
-            for _ in range(2):                           # warm-up on a side stream (allocator, lazy attributes)
-                self.train_step(batch)
+            for k in range(2):                           # warm-up on a side stream (allocator, lazy attributes); the second one in
+                (step if k else self.train_step)(batch)  # the form that is captured (its second stream's scratch)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
@@ -743,15 +744,6 @@ class Trainer:
         self._segments = []
         self.set_step_hyper(self.global_step)
         if not segmented:
-            step = self.train_step_overlapped if (self.overlap_encoder and self.world == 1) else self.train_step
-            if step is not self.train_step:
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    step(batch)                          # warm-up of the second stream's scratch / allocator state
-                torch.cuda.current_stream().wait_stream(side)
-                torch.cuda.synchronize()
-                self.set_step_hyper(self.global_step)
             with self._capturing(self._graph):
                 self._graph_out = step(batch, update_hyper=False)
             self.global_step -= 1                        # capturing does not execute: the captured step has not run yet
