@@ -304,7 +304,7 @@ def main():
     if rank == 0:
         frames = world * args.batch * args.mel_len * args.steps
         n_par = trainer.n_params
-        launch = ("hipGraph replay" if one_graph else
+        launch = ("hipGraph replay (one graph; the encoder is a parallel branch beside the decoder: Trainer.train_step_overlapped)" if one_graph else
                   "hipGraph replay (fwd + heads/postnet bwd | one graph per decoder layer bwd | enc stack bwd | enc prenet bwd | optimizer; the "
                   "all-reduce of a graph's gradient range runs while the next graph replays: config.dist.schedule)") \
             if use_graph else "eager"
