@@ -122,7 +122,6 @@ class _Queue:
 
     def __init__(self, device: int, stream: int):
         self.device, self.stream = device, stream
-        self.stream_obj = torch.cuda.current_stream(device)     # the torch stream the handle belongs to (events for side launches)
         self.colsums = []          # (partial buffer [kept alive], float offset of the block, rows, d, out tensor, ld)
         self.wgrads = []           # (grad_view, dy, x)
         self.conv_gemms = []       # edges.py: tap problems of the convolutions' weight gradients
@@ -388,17 +387,6 @@ def flush_wgrad(colsums: bool = True):
             elif q.colsums and (q.device, q.stream) == (torch.cuda.current_device(), _s()):
                 _queue_final_flush()
             pending = q.wgrads
-            # WGRAD_SIDE (the overlapped step sets it): the weight gradients are leaves of the backward -- launched on a second
-            # stream they become a parallel branch of the captured step and fill the drain / ramp bubbles of the main chain's
-            # kernel boundaries.  The side stream waits for everything queued so far on the entries' own stream; the operands are
-            # marked as used there so that the allocator does not hand them out again before the branch is joined.
-            side = WGRAD_SIDE[0] if (WGRAD_SIDE[0] is not None and pending and q.stream != WGRAD_SIDE[0].cuda_stream) else None
-            launch_stream = q.stream
-            if side is not None:
-                ev = torch.cuda.Event()
-                ev.record(q.stream_obj)
-                side.wait_event(ev)
-                launch_stream = side.cuda_stream
             while pending:
                 group = pending[:_lib.GEMM_TN_MAX_GROUP]
                 del pending[:len(group)]
@@ -406,16 +394,10 @@ def flush_wgrad(colsums: bool = True):
                 for e, (gv, dy, x) in zip(arr, group):
                     e.a, e.lda, e.b, e.ldb, e.c, e.ldc = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), gv.data_ptr(), gv.stride(0)
                     e.M, e.N, e.K, e.accumulate = dy.shape[0], dy.shape[1], x.shape[1], 1
-                    if side is not None:
-                        dy.record_stream(side)
-                        x.record_stream(side)
-                ws = _slab_ws(group[0][1].device, launch_stream)
-                _lib.call("rtts_gemm_tn_grouped", arr, len(group), ws.data_ptr(), ws.numel(), launch_stream)
+                ws = _slab_ws(group[0][1].device, q.stream)
+                _lib.call("rtts_gemm_tn_grouped", arr, len(group), ws.data_ptr(), ws.numel(), q.stream)
             for hook in FLUSH_HOOKS:       # other deferred gradient work (edges.py: the convolutions' dW re-layout)
                 hook(q)
-
-
-WGRAD_SIDE = [None]     # a torch.cuda.Stream while an overlapped step wants its weight gradients on a second stream, else None
 
 
 def discard_pending() -> int:

@@ -395,11 +395,6 @@ class Trainer:
             self._enc_stream_obj = torch.cuda.Stream(self.device)
         return self._enc_stream_obj
 
-    def _wgrad_stream(self):
-        if getattr(self, "_wgrad_stream_obj", None) is None:
-            self._wgrad_stream_obj = torch.cuda.Stream(self.device)
-        return self._wgrad_stream_obj
-
     def train_step_overlapped(self, batch, update_hyper: bool = True):
         """``train_step`` with the ENCODER ON A STREAM OF ITS OWN (meant to be captured: in a hipGraph the two streams become
         parallel branches; launched eagerly the host serialises them anyway).  Forward: encoder prenet + stack beside the
@@ -415,10 +410,7 @@ class Trainer:
         main, side = torch.cuda.current_stream(), self._enc_stream()
         dec_seq = self.model.dec.reformer.layers
         dec_seq.manual = {}
-        wgrad_side = __import__("os").environ.get("RTTS_WGRAD_SIDE", "0") == "1"
         try:
-            if wgrad_side:
-                engine.WGRAD_SIDE[0] = self._wgrad_stream()
             total, raw_l, post_l, stop_l = self.forward_loss(batch, split="overlap")
             if "call" not in dec_seq.manual:
                 raise RuntimeError("the decoder stack did not take the explicit executor: the overlapped step needs it")
@@ -445,14 +437,11 @@ class Trainer:
             dec_x.backward(dx)                                 # decoder prenet + positional encoding
             engine.flush_wgrad()
             main.wait_stream(side)
-            if wgrad_side:
-                main.wait_stream(self._wgrad_stream())
             if engine.pending_all():
                 raise RuntimeError("deferred gradient launches were still queued at the end of the overlapped step")
         finally:
             dec_seq.manual = None
             self._enc_out = self._enc_in = None
-            engine.WGRAD_SIDE[0] = None
         if self._bulk_allreduce:
             self.bulk_allreduce()
         self.optimizer_step(update_hyper)
