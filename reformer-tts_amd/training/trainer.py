@@ -251,7 +251,11 @@ class Trainer:
 
     def _forward_loss(self, batch, split: bool = False):
         spec_in, spec_tgt = self._frames(batch)
-        if split == "overlap":
+        # the encoder on a stream of its own beside the decoder's first blocks: the overlapped one-process step, and the forward
+        # of the data-parallel chain of graphs (there the encoder's backward keeps its own graphs: its gradient ranges are
+        # exchanged while the next graph replays)
+        side_enc = bool(split) and self.overlap_encoder and self.device.type == "cuda" and self._fused_edges_ok(batch)
+        if side_enc:
             from ..model.lsh_attention import LSHSelfAttention
             if LSHSelfAttention.rotation_pool is not None:        # drawn on this stream, read by the encoder's hash kernels on theirs
                 LSHSelfAttention.rotation_pool[0].record_stream(self._enc_stream())
@@ -263,7 +267,7 @@ class Trainer:
             y = self.model.decoder_hidden(batch["phonemes"], spec_in, spectrogram_mask=batch["loss_mask"].mean(dim=-1),
                                           keys_hook=self._cut_at_encoder if split else None,
                                           enc_stack_hook=self._cut_at_enc_stack if (split and not overlap) else None,
-                                          enc_stream=self._enc_stream() if overlap else None)
+                                          enc_stream=self._enc_stream() if side_enc else None)
             losses = self._postnet_loss.apply(y, spec_tgt, batch["stop_tokens"], batch["loss_mask"], batch.get("valid_len"))
             return losses[0], losses[1], losses[2], losses[3]
         raw, post, stop, _ = self.model(batch["phonemes"], spec_in, spectrogram_mask=batch["loss_mask"].mean(dim=-1))
