@@ -810,12 +810,16 @@ class Trainer:
             self._enc_out.backward(self._enc_in.grad)
             engine.flush_wgrad()
             assert engine.pending_all() == 0
+            if self.overlap_encoder:             # the encoder's nodes (and its deferred launches) ran on the encoder's stream: join
+                torch.cuda.current_stream().wait_stream(self._enc_stream())
         segs.append((g, (stack_begin, enc_end)))
         g = torch.cuda.CUDAGraph()
         with self._capturing(g, pool=self._graph.pool()):
             self._pre_out.backward(self._pre_in.grad)
             engine.flush_wgrad()
             assert engine.pending_all() == 0
+            if self.overlap_encoder:
+                torch.cuda.current_stream().wait_stream(self._enc_stream())
         segs.append((g, (0, stack_begin)))
         self._enc_out = self._enc_in = self._pre_out = self._pre_in = None
         cover = sorted(r for _, r in segs)
