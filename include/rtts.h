@@ -71,7 +71,12 @@ int rtts_lsh_hash_sort_launches(int T);
  *   lse    f32  (B*H, n_hashes, T)      per-round logsumexp of the masked logits */
 int rtts_lsh_attn_fwd(const void* qk, const void* v, int64_t ld, const int32_t* st, const uint8_t* mask,
                       int B, int H, int T, int dh, int n_hashes, int bucket_size, int causal,
-                      void* o, float* lse, void* stream);
+                      void* o, float* lse, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev, void* stream);
+/* drop_p > 0: dropout on the attention probabilities (the layer's `dropout` knob, reference reformer_tts/model/config.py:27):
+ * the chunk's softmax output is multiplied by keep = 0 | 1/(1-p) before it meets the values; lse is that of the undropped
+ * probabilities.  keep is a counter hash of (drop_seed + *seed_dev, pair), pair = ((head * chunks + chunk) * bucket_size +
+ * query row of the chunk) * 2*bucket_size + key row (own chunk's keys first): no mask is stored, rtts_lsh_attn_bwd called with
+ * the same (drop_p, drop_seed, seed_dev) -- and the reversible recompute's forward -- redraw the same one.  seed_dev may be NULL. */
 /* how rtts_lsh_attn_fwd works a shape: 0 = one workgroup per chunk (lsh_attn_fwd_kernel), the only form this build has.
  * (A form that walks consecutive chunks like the backward's was priced in round 3 and not built: the forward is
  * latency-bound at two workgroups per CU, and a ring of three chunk slots leaves room for one -- DESIGN.md section 5.) */
@@ -107,7 +112,8 @@ int rtts_lsh_bwd_delta(const void* out, int64_t ld_out, const void* dout, int64_
 int rtts_lsh_attn_bwd(const void* qk, const void* v, int64_t ld, const int32_t* st, const uint8_t* mask,
                       const void* dout, int64_t ld_dout, const float* lse_tot, const float* delta,
                       int B, int H, int T, int dh, int n_hashes, int bucket_size, int causal,
-                      void* dqk_part, void* dv_part, uint8_t* row_flags, void* stream);
+                      void* dqk_part, void* dv_part, uint8_t* row_flags, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev,
+                      void* stream);
 int rtts_lsh_bwd_reduce(const void* dqk_part, const void* dv_part, int B, int H, int T, int dh, int n_hashes,
                         void* dqk, void* dv, int64_t ld_d, const uint8_t* row_flags, void* stream);
 

@@ -75,8 +75,11 @@ def lsh_attention_sorted(
     causal: bool,
     input_mask: Optional[torch.Tensor] = None,
     return_parts: bool = False,
+    keep: Optional[torch.Tensor] = None,
 ):
-    """Steps 4-11 given the sort permutation.  qk, v: (BH,T,dh); mask (BH,T) bool."""
+    """Steps 4-11 given the sort permutation.  qk, v: (BH,T,dh); mask (BH,T) bool.  ``keep`` (BH, chunks, bucket_size,
+    2 * bucket_size): the dropout of step 9 as explicit keep-scales (0 or 1/(1-p)) on the chunk's probabilities, own chunk's
+    keys first -- nn.Dropout's arithmetic with the mask given instead of drawn."""
     bh, t, dh = qk.shape
     n_chunks = n_hashes * (t // bucket_size)
     st = sticker % t                                            # step 4
@@ -100,6 +103,8 @@ def lsh_attention_sorted(
     dots = dots.masked_fill(bq_t[:, :, :, None] == bkv_t[:, :, None, :], SELF_VALUE)  # (iii)
     lse = torch.logsumexp(dots, dim=-1, keepdim=True)           # step 9
     probs = torch.exp(dots - lse)
+    if keep is not None:
+        probs = probs * keep
     bo = torch.einsum("bcij,bcje->bcie", probs, bv)
     so = bo.reshape(bh, n_hashes * t, dh)
     slse = lse.reshape(bh, n_hashes * t)

@@ -37,3 +37,34 @@ def synth_state_dict(shapes: Mapping[str, Sequence[int]], seed: int = 0) -> Dict
     (BatchNorm running statistics are not part of the training forward and are skipped)."""
     return {k: synth_tensor(k, s, seed) for k, s in shapes.items()
             if not (k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"))}
+
+
+def drop_hash(seed: int, idx):
+    """numpy twin of the kernels' counter hash (csrc/rtts_common.h ``rtts_drop_hash``): uint32 arithmetic, element-wise over idx."""
+    import numpy as np
+    m = np.uint64(0xFFFFFFFF)
+
+    def u32(x):
+        return np.asarray(x, dtype=np.uint64) & m
+
+    s = u32(seed)
+    s ^= s >> np.uint64(16); s = u32(s * np.uint64(0x85ebca6b)); s ^= s >> np.uint64(13); s = u32(s * np.uint64(0xc2b2ae35)); s ^= s >> np.uint64(16)
+    x = u32(u32(idx) * np.uint64(0x9E3779B1) + s)
+    x ^= x >> np.uint64(16); x = u32(x * np.uint64(0x7feb352d))
+    x ^= u32((s << np.uint64(13)) | (s >> np.uint64(19)))
+    x ^= x >> np.uint64(15); x = u32(x * np.uint64(0x846ca68b)); x ^= x >> np.uint64(16)
+    return x.astype(np.uint64)
+
+
+def attention_keep_scales(seed: int, p: float, heads: int, chunks: int, bucket_size: int):
+    """(heads, chunks, bucket_size, 2 * bucket_size) float32 keep-scales of the LSH attention's probability dropout as the
+    kernels draw them: pair = ((head * chunks + chunk) * bucket_size + query row) * 2 * bucket_size + key row, kept iff
+    hash(seed, pair) >= p * 2^32."""
+    import numpy as np
+    import torch
+    n = heads * chunks * bucket_size * 2 * bucket_size
+    assert n < 2 ** 32
+    h = drop_hash(seed, np.arange(n, dtype=np.uint64))
+    thresh = np.uint64(int(float(np.float32(p)) * 4294967296.0))
+    keep = (h >= thresh).astype(np.float32) / np.float32(1.0 - np.float32(p))
+    return torch.from_numpy(keep.reshape(heads, chunks, bucket_size, 2 * bucket_size))

@@ -76,12 +76,21 @@ __device__ __forceinline__ int ab_ds_off(int key, int gran) {
 #define AB_KT2 1
 #endif
 
-template <int BS, bool CAUSAL, bool MASKED>
+// DROP: dropout on the attention probabilities (lsh_attn_fwd.hip): with keep = 0 | 1/(1-p) from the same counter hash of the
+// pair index, dV += (keep P')^T dout and dS = P' (keep dP - delta); delta = out . dout already contains the mask.
+struct AbDrop {
+    uint32_t seed;
+    const uint32_t* seed_dev;
+    uint32_t thresh;
+    float scale;
+};
+
+template <int BS, bool CAUSAL, bool MASKED, bool DROP>
 __global__ __launch_bounds__(BS * 4 / AB_KT2, AB_KT2 == 2 ? 1 : 2) void lsh_attn_bwd_kernel(
     const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v, int64_t ld, const int32_t* __restrict__ st,
     const uint8_t* __restrict__ mask, const bf16_t* __restrict__ dout, int64_t ld_do, const float* __restrict__ lse_tot,
     const float* __restrict__ delta, int H, int T, int n_hashes, bf16_t* __restrict__ dqk_part, bf16_t* __restrict__ dv_part,
-    size_t slot_stride) {
+    size_t slot_stride, AbDrop dr) {
     constexpr int KT2 = AB_KT2;
     constexpr int NK = 2 * BS;
     constexpr int NQT = BS / 32;
@@ -306,6 +315,20 @@ __global__ __launch_bounds__(BS * 4 / AB_KT2, AB_KT2 == 2 ? 1 : 2) void lsh_attn
             }
             // P' = exp2(s*ksc*log2e - lse*log2e); dS' = P' (dP - delta) ksc  (0 at the self logit: it was a constant).
             // ksc multiplies dS' once here: G' = dS'^T Q then gives dK = G' - k^ (k^ . G'), and dQ^T = K^T dS'^T.
+            uint32_t kbits = 0u;          // DROP: bit i = pair i of this tile is kept
+            if constexpr (DROP) {
+                // with dropout the softmax's backward sees keep * dP: pacc = dP - delta and pinit = -delta, so the masked
+                // value is keep * (pacc - pinit) + pinit; the arithmetic below then runs unchanged, and P' gets its keep-scale
+                // (for dV) after it
+                const uint32_t seed = dr.seed + (dr.seed_dev ? dr.seed_dev[0] : 0u);
+                const uint32_t pair0 = ((uint32_t)wi * BS + (uint32_t)(qt * 32 + 4 * hh)) * (uint32_t)NK + (uint32_t)myrow[k2];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const bool kept = rtts_drop_hash(seed, pair0 + (uint32_t)(8 * (i >> 2) + (i & 3)) * (uint32_t)NK) >= dr.thresh;
+                    kbits |= kept ? (1u << i) : 0u;
+                    pacc[i] = kept ? __builtin_fmaf(dr.scale, pacc[i] - pinit[i], pinit[i]) : pinit[i];
+                }
+            }
             float pp[16], ds[16];
             const float ksc2 = ksc[k2] * 1.4426950408889634f;
             if (chk_self) {
@@ -341,6 +364,10 @@ __global__ __launch_bounds__(BS * 4 / AB_KT2, AB_KT2 == 2 ? 1 : 2) void lsh_attn
                         ds[i] = p * pacc[i] * ksc[k2];
                     }
                 }
+            }
+            if constexpr (DROP) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pp[i] = ((kbits >> i) & 1u) ? pp[i] * dr.scale : 0.f;
             }
             if (KT2 == 1) {   // read only now, so that their registers are free during the softmax arithmetic above
 #pragma unroll
@@ -538,12 +565,12 @@ __device__ __forceinline__ void ab_dma16(const void* gptr, RTTS_LDS void* lds_ds
 // j + 1 by plain loads that are stored to LDS late in the step.  After the first chunk of a run a step starts with its
 // operands already on chip, and only half the K rows are fetched at all.  Same arithmetic, same outputs, same partial-row
 // layout as the kernel above (the row staging reuses the dS'^T image, so dV leaves after the dQ product, not before it).
-template <int BS, bool CAUSAL, bool MASKED>
+template <int BS, bool CAUSAL, bool MASKED, bool DROP>
 __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
     const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v, int64_t ld, const int32_t* __restrict__ st,
     const uint8_t* __restrict__ mask, const bf16_t* __restrict__ dout, int64_t ld_do, const float* __restrict__ lse_tot,
     const float* __restrict__ delta, int H, int T, int n_hashes, bf16_t* __restrict__ dqk_part, bf16_t* __restrict__ dv_part,
-    size_t slot_stride, int R, uint8_t* __restrict__ row_flags) {
+    size_t slot_stride, int R, uint8_t* __restrict__ row_flags, AbDrop dr) {
     constexpr int NK = 2 * BS;
     constexpr int NQT = BS / 32;
     constexpr int NW = NK / 32;
@@ -783,6 +810,17 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[ks], sacc, 0, 0, 0);    // S[q][key]
                 pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof[ks], vf[ks], pacc, 0, 0, 0);   // dP[q][key] - delta[q]
             }
+            uint32_t kbits = 0u;          // DROP: bit i = pair i of this tile is kept
+            if constexpr (DROP) {
+                const uint32_t seed = dr.seed + (dr.seed_dev ? dr.seed_dev[0] : 0u);
+                const uint32_t pair0 = (((uint32_t)bh * C + (uint32_t)c) * BS + (uint32_t)(qt * 32 + 4 * hh)) * (uint32_t)NK + (uint32_t)myrow;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const bool kept = rtts_drop_hash(seed, pair0 + (uint32_t)(8 * (i >> 2) + (i & 3)) * (uint32_t)NK) >= dr.thresh;
+                    kbits |= kept ? (1u << i) : 0u;
+                    pacc[i] = kept ? __builtin_fmaf(dr.scale, pacc[i] - pinit[i], pinit[i]) : pinit[i];
+                }
+            }
             float pp[16], ds[16];
             const float ksc2 = ksc * 1.4426950408889634f;
             if (chk_self) {
@@ -818,6 +856,10 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
                         ds[i] = p * pacc[i] * ksc;
                     }
                 }
+            }
+            if constexpr (DROP) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pp[i] = ((kbits >> i) & 1u) ? pp[i] * dr.scale : 0.f;
             }
             bf16x8 qtf[2][2], dotf[2][2];   // [s2][dh tile]
 #pragma unroll
@@ -1030,10 +1072,13 @@ extern "C" int rtts_lsh_attn_bwd_run_length(int B, int H, int T, int n_hashes, i
 template <int BS>
 static int launch_attn_bwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const int32_t* st, const uint8_t* mask,
                            const bf16_t* dout, int64_t ld_do, const float* lse_tot, const float* delta, int B, int H, int T,
-                           int n_hashes, int causal, bf16_t* dqk_part, bf16_t* dv_part, uint8_t* row_flags, hipStream_t stream) {
+                           int n_hashes, int causal, bf16_t* dqk_part, bf16_t* dv_part, uint8_t* row_flags, float drop_p,
+                           uint32_t drop_seed, const uint32_t* seed_dev, hipStream_t stream) {
     constexpr int NK = 2 * BS;
     const size_t slot_stride = (size_t)B * H * n_hashes * T * AB_DH;
-    const int vi = (causal ? 2 : 0) + (mask ? 1 : 0);
+    const bool drop = drop_p > 0.f;
+    const int vi = (drop ? 4 : 0) + (causal ? 2 : 0) + (mask ? 1 : 0);
+    const AbDrop dr{drop_seed, seed_dev, rtts_drop_thresh(drop_p), 1.f / (1.f - drop_p)};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     const int C = n_hashes * (T / BS);
@@ -1044,50 +1089,52 @@ static int launch_attn_bwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const 
                                 "row_flags (B*H*n_hashes*T bytes) is required", R);
         const size_t ds_bytes = (size_t)NK * (BS * 2), stg_bytes = (size_t)(NK / 32) * 32 * AB_ROWB;
         const size_t wlds = (size_t)BS * 40 + 5 * (size_t)BS * 128 + (ds_bytes > stg_bytes ? ds_bytes : stg_bytes);
-        static bool wattr[64][4] = {};
+        static bool wattr[64][8] = {};
         const dim3 wgrid((unsigned)(chunks / R)), wblock(BS * 4);
-#define AB_WGO(C_, M_)                                                                                                     \
+#define AB_WGO(C_, M_, D_)                                                                                                 \
     do {                                                                                                                   \
-        auto kern = lsh_attn_bwd_walk_kernel<BS, C_, M_>;                                                                  \
+        auto kern = lsh_attn_bwd_walk_kernel<BS, C_, M_, D_>;                                                              \
         if (!wattr[dev][vi]) {                                                                                             \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds); \
             RTTS_REQUIRE(e == hipSuccess, "rtts_lsh_attn_bwd: cannot raise the dynamic LDS limit to %zu bytes", wlds);     \
             wattr[dev][vi] = true;                                                                                         \
         }                                                                                                                  \
         hipLaunchKernelGGL(kern, wgrid, wblock, wlds, stream, qk, v, ld, st, mask, dout, ld_do, lse_tot, delta, H, T, n_hashes, \
-                           dqk_part, dv_part, slot_stride, R, row_flags);                                                  \
+                           dqk_part, dv_part, slot_stride, R, row_flags, dr);                                              \
     } while (0)
+#define AB_WGO2(C_, M_) do { if (drop) AB_WGO(C_, M_, true); else AB_WGO(C_, M_, false); } while (0)
         if (causal) {
-            if (mask) AB_WGO(true, true); else AB_WGO(true, false);
+            if (mask) AB_WGO2(true, true); else AB_WGO2(true, false);
         } else {
-            if (mask) AB_WGO(false, true); else AB_WGO(false, false);
+            if (mask) AB_WGO2(false, true); else AB_WGO2(false, false);
         }
+#undef AB_WGO2
 #undef AB_WGO
         RTTS_LAUNCH_CHECK("rtts_lsh_attn_bwd");
         return 0;
     }
     const size_t lds = NK * 128 + BS * 128 + NK * (BS * 2) + (NK / 32) * 32 * AB_ROWB + NK * 12 + BS * 12;
     const dim3 grid(B * H * n_hashes * (T / BS)), block(BS * 4 / AB_KT2);
-    static bool attr[64][4] = {};                // per device: the dynamic-LDS limit is an attribute of the loaded function
-#define AB_KERN(C_, M_) lsh_attn_bwd_kernel<BS, C_, M_>
-#define AB_GO(C_, M_)                                                                                                      \
+    static bool attr[64][8] = {};                // per device: the dynamic-LDS limit is an attribute of the loaded function
+#define AB_GO(C_, M_, D_)                                                                                                  \
     do {                                                                                                                   \
-        auto kern = AB_KERN(C_, M_);                                                                                       \
+        auto kern = lsh_attn_bwd_kernel<BS, C_, M_, D_>;                                                                   \
         if (!attr[dev][vi]) {                                                                                              \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             RTTS_REQUIRE(e == hipSuccess, "rtts_lsh_attn_bwd: cannot raise the dynamic LDS limit to %zu bytes", lds);      \
             attr[dev][vi] = true;                                                                                          \
         }                                                                                                                  \
         hipLaunchKernelGGL(kern, grid, block, lds, stream, qk, v, ld, st, mask, dout, ld_do, lse_tot, delta, H, T, n_hashes, \
-                           dqk_part, dv_part, slot_stride);                                                                \
+                           dqk_part, dv_part, slot_stride, dr);                                                            \
     } while (0)
+#define AB_GO2(C_, M_) do { if (drop) AB_GO(C_, M_, true); else AB_GO(C_, M_, false); } while (0)
     if (causal) {
-        if (mask) AB_GO(true, true); else AB_GO(true, false);
+        if (mask) AB_GO2(true, true); else AB_GO2(true, false);
     } else {
-        if (mask) AB_GO(false, true); else AB_GO(false, false);
+        if (mask) AB_GO2(false, true); else AB_GO2(false, false);
     }
+#undef AB_GO2
 #undef AB_GO
-#undef AB_KERN
     RTTS_LAUNCH_CHECK("rtts_lsh_attn_bwd");
     return 0;
 }
@@ -1095,7 +1142,7 @@ static int launch_attn_bwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const 
 extern "C" int rtts_lsh_attn_bwd(const void* qk, const void* v, int64_t ld, const int32_t* st, const uint8_t* mask,
                                  const void* dout, int64_t ld_dout, const float* lse_tot, const float* delta, int B, int H,
                                  int T, int dh, int n_hashes, int bucket_size, int causal, void* dqk_part, void* dv_part,
-                                 uint8_t* row_flags, void* stream) {
+                                 uint8_t* row_flags, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev, void* stream) {
     RTTS_ENTER(stream);
     RTTS_REQUIRE(qk && v && st && dout && lse_tot && delta && dqk_part && dv_part, "rtts_lsh_attn_bwd: null pointer");
     RTTS_REQUIRE(dh == AB_DH, "rtts_lsh_attn_bwd: dh=%d unsupported (this build: 64)", dh);
@@ -1107,10 +1154,11 @@ extern "C" int rtts_lsh_attn_bwd(const void* qk, const void* v, int64_t ld, cons
                  "rtts_lsh_attn_bwd: row strides must be >= H*dh and multiples of 8");
     RTTS_REQUIRE((((uintptr_t)qk | (uintptr_t)v | (uintptr_t)dout | (uintptr_t)dqk_part | (uintptr_t)dv_part) & 15) == 0,
                  "rtts_lsh_attn_bwd: buffers must be 16-byte aligned");
+    RTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "rtts_lsh_attn_bwd: drop_p must be in [0, 1)");
     hipStream_t s = (hipStream_t)stream;
     if (bucket_size == 64)
         return launch_attn_bwd<64>((const bf16_t*)qk, (const bf16_t*)v, ld, st, mask, (const bf16_t*)dout, ld_dout, lse_tot, delta,
-                                   B, H, T, n_hashes, causal, (bf16_t*)dqk_part, (bf16_t*)dv_part, row_flags, s);
+                                   B, H, T, n_hashes, causal, (bf16_t*)dqk_part, (bf16_t*)dv_part, row_flags, drop_p, drop_seed, seed_dev, s);
     return launch_attn_bwd<128>((const bf16_t*)qk, (const bf16_t*)v, ld, st, mask, (const bf16_t*)dout, ld_dout, lse_tot, delta, B,
-                                H, T, n_hashes, causal, (bf16_t*)dqk_part, (bf16_t*)dv_part, row_flags, s);
+                                H, T, n_hashes, causal, (bf16_t*)dqk_part, (bf16_t*)dv_part, row_flags, drop_p, drop_seed, seed_dev, s);
 }

@@ -57,11 +57,17 @@ extern "C" int rtts_debug_af_phases(void* dst) { return (int)hipMemcpyFromSymbol
 __device__ __forceinline__ int af_sw(int row) { return ((row >> 1) & 3) | ((((row >> 3) ^ (row >> 1)) & 1) << 2); }
 __device__ __forceinline__ int af_voff(int row, int piece) { return row * 128 + ((piece ^ af_sw(row)) << 4); }
 
-template <int BS, bool CAUSAL, bool MASKED>
+// DROP: dropout on the attention probabilities (the reference layer's `dropout` knob, reformer_tts/model/config.py:27: the
+// per-chunk softmax output is dropped before it multiplies the values; lse -- hence the round weights -- sees the undropped
+// probabilities).  Counter-hash mask keyed by (seed, pair index): pair = ((head * chunks + chunk) * BS + query row) * 2BS +
+// key row, the same index in the backward kernels, so no mask is stored and the reversible recompute redraws the same one.
+template <int BS, bool CAUSAL, bool MASKED, bool DROP>
 __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v,
                                                                  int64_t ld, const int32_t* __restrict__ st,
                                                                  const uint8_t* __restrict__ mask, int H, int T, int n_hashes,
-                                                                 bf16_t* __restrict__ o, float* __restrict__ lse) {
+                                                                 bf16_t* __restrict__ o, float* __restrict__ lse, uint32_t drop_seed,
+                                                                 const uint32_t* __restrict__ seed_dev, uint32_t drop_thresh,
+                                                                 float drop_scale) {
     constexpr int NK = 2 * BS;
     constexpr int NKT = NK / 32;
     constexpr int NTHR = BS * 4;          // two waves per 32-query tile: each walks one half of the keys
@@ -222,6 +228,12 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
             acc[i] = p;
             l += p;
         }
+        if constexpr (DROP) {
+            const uint32_t seed = drop_seed + (seed_dev ? seed_dev[0] : 0u);
+            const uint32_t pair0 = ((uint32_t)wi * BS + (uint32_t)qrow) * (uint32_t)NK + (uint32_t)(kt * 32 + 4 * hh);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] *= rtts_drop_keep(seed, pair0 + 8 * (i >> 2) + (i & 3), drop_thresh, drop_scale);
+        }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const int o8 = 8 * s2;
@@ -300,26 +312,32 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
     AF_STAMP(5);
 }
 
-static RttsLdsState g_fwd_lds[2][4];
+static RttsLdsState g_fwd_lds[2][8];
 
 template <int BS>
 static int launch_attn_fwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const int32_t* st, const uint8_t* mask, int B, int H,
-                           int T, int n_hashes, int causal, bf16_t* o, float* lse, hipStream_t stream) {
+                           int T, int n_hashes, int causal, bf16_t* o, float* lse, float drop_p, uint32_t seed,
+                           const uint32_t* seed_dev, hipStream_t stream) {
     constexpr int NK = 2 * BS;
     const size_t lds = 2 * NK * AF_ROWB + NK * 12;
     const dim3 grid(B * H * n_hashes * (T / BS)), block(BS * 4);
-    const int vi = (causal ? 2 : 0) + (mask ? 1 : 0);
-#define AF_GO(C_, M_)                                                                                                      \
+    const bool drop = drop_p > 0.f;
+    const int vi = (drop ? 4 : 0) + (causal ? 2 : 0) + (mask ? 1 : 0);
+    const uint32_t th = rtts_drop_thresh(drop_p);
+    const float sc = 1.f / (1.f - drop_p);
+#define AF_GO(C_, M_, D_)                                                                                                  \
     do {                                                                                                                   \
-        auto kern = lsh_attn_fwd_kernel<BS, C_, M_>;                                                                       \
+        auto kern = lsh_attn_fwd_kernel<BS, C_, M_, D_>;                                                                   \
         RTTS_ENSURE_LDS("rtts_lsh_attn_fwd", kern, lds, g_fwd_lds[BS == 128][vi]);                                         \
-        hipLaunchKernelGGL(kern, grid, block, lds, stream, qk, v, ld, st, mask, H, T, n_hashes, o, lse);                   \
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, qk, v, ld, st, mask, H, T, n_hashes, o, lse, seed, seed_dev, th, sc); \
     } while (0)
+#define AF_GO2(C_, M_) do { if (drop) AF_GO(C_, M_, true); else AF_GO(C_, M_, false); } while (0)
     if (causal) {
-        if (mask) AF_GO(true, true); else AF_GO(true, false);
+        if (mask) AF_GO2(true, true); else AF_GO2(true, false);
     } else {
-        if (mask) AF_GO(false, true); else AF_GO(false, false);
+        if (mask) AF_GO2(false, true); else AF_GO2(false, false);
     }
+#undef AF_GO2
 #undef AF_GO
     RTTS_LAUNCH_CHECK("rtts_lsh_attn_fwd");
     return 0;
@@ -332,7 +350,7 @@ extern "C" int rtts_lsh_attn_fwd_run_length(int B, int H, int T, int n_hashes, i
 
 extern "C" int rtts_lsh_attn_fwd(const void* qk, const void* v, int64_t ld, const int32_t* st, const uint8_t* mask, int B,
                                  int H, int T, int dh, int n_hashes, int bucket_size, int causal, void* o, float* lse,
-                                 void* stream) {
+                                 float drop_p, uint32_t drop_seed, const uint32_t* seed_dev, void* stream) {
     RTTS_ENTER(stream);
     RTTS_REQUIRE(qk && v && st && o && lse, "rtts_lsh_attn_fwd: null pointer");
     RTTS_REQUIRE(dh == AF_DH, "rtts_lsh_attn_fwd: dh=%d unsupported (this build: 64)", dh);
@@ -342,8 +360,12 @@ extern "C" int rtts_lsh_attn_fwd(const void* qk, const void* v, int64_t ld, cons
     RTTS_REQUIRE(B > 0 && H > 0 && n_hashes > 0, "rtts_lsh_attn_fwd: bad B/H/n_hashes");
     RTTS_REQUIRE(ld >= (int64_t)H * dh && ld % 8 == 0, "rtts_lsh_attn_fwd: ld must be >= H*dh and a multiple of 8");
     RTTS_REQUIRE((((uintptr_t)qk | (uintptr_t)v | (uintptr_t)o) & 15) == 0, "rtts_lsh_attn_fwd: qk, v, o must be 16-byte aligned");
+    RTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "rtts_lsh_attn_fwd: drop_p must be in [0, 1)");
+    RTTS_REQUIRE((uint64_t)B * H * n_hashes * T * 2 * bucket_size < (1ull << 32), "rtts_lsh_attn_fwd: more than 2^32 query-key pairs");
     hipStream_t s = (hipStream_t)stream;
     if (bucket_size == 64)
-        return launch_attn_fwd<64>((const bf16_t*)qk, (const bf16_t*)v, ld, st, mask, B, H, T, n_hashes, causal, (bf16_t*)o, lse, s);
-    return launch_attn_fwd<128>((const bf16_t*)qk, (const bf16_t*)v, ld, st, mask, B, H, T, n_hashes, causal, (bf16_t*)o, lse, s);
+        return launch_attn_fwd<64>((const bf16_t*)qk, (const bf16_t*)v, ld, st, mask, B, H, T, n_hashes, causal, (bf16_t*)o, lse, drop_p,
+                                   drop_seed, seed_dev, s);
+    return launch_attn_fwd<128>((const bf16_t*)qk, (const bf16_t*)v, ld, st, mask, B, H, T, n_hashes, causal, (bf16_t*)o, lse, drop_p,
+                                drop_seed, seed_dev, s);
 }

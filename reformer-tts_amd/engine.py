@@ -505,7 +505,7 @@ class LSHExec:
             return torch.as_strided(ga, (2 * ga.shape[0], ga.shape[1]), (ga.shape[1], 1)), None
         return None, (ga, gb)
 
-    def _internals(self, inp, b, t, mask, st, stash=None, g=None, pre=None, qkv=None):
+    def _internals(self, inp, b, t, mask, st, stash=None, g=None, pre=None, qkv=None, adrop=None):
         lyr = self.layer
         e = lyr.dim
         if t <= lyr.full_attn_thres:
@@ -521,7 +521,7 @@ class LSHExec:
         if stash is not None:
             out, lse_tot = stash
         else:
-            o, lse = ops.lsh_attn_fwd(qkv[..., :e], qkv[..., e:], st, lyr.heads, lyr.bucket_size, lyr.causal, mask)
+            o, lse = ops.lsh_attn_fwd(qkv[..., :e], qkv[..., e:], st, lyr.heads, lyr.bucket_size, lyr.causal, mask, adrop)
             out, lse_tot = ops.lsh_combine_fwd(o, lse, b, lyr.heads)
         if g is None:
             g = gemm(out.view(b * t, e), _bf16(lyr.to_out.weight))
@@ -529,11 +529,14 @@ class LSHExec:
 
     def forward(self, acc, inp, b, t, mask=None, pre=None, next_norm=None, slot=None, keep_streams=False, **_):
         slot = self._own_slot if slot is None else slot
-        xn, mean, rstd, _, qkv, st, out, lse_tot, g = self._internals(inp, b, t, mask, None, pre=pre)
+        # dropout on the attention probabilities (the layer's `dropout` knob): a (p, seed) pair the recompute and the backward reuse
+        pa = getattr(self.layer, "dropout", 0.0) if self.layer.training else 0.0
+        adrop = (pa, next_seed()) if pa > 0.0 else None
+        xn, mean, rstd, _, qkv, st, out, lse_tot, g = self._internals(inp, b, t, mask, None, pre=pre, adrop=adrop)
         p = self.layer.post_attn_dropout.p if self.layer.training else 0.0
         slot.clear()
         slot.update(st=st, stash=(out, lse_tot) if STASH_ATTENTION else None, g=g if STASH_BLOCK_OUTPUT else None,
-                    qkv=qkv if STASH_PROJECTIONS else None, drop=(p, next_seed()) if p > 0.0 else None)
+                    qkv=qkv if STASH_PROJECTIONS else None, drop=(p, next_seed()) if p > 0.0 else None, adrop=adrop)
         return residual(acc, g, self.layer.to_out.bias, 1.0, next_norm, slot["drop"], out=_keep_streams(keep_streams, slot, acc, inp, xn, mean, rstd))
 
     def backward(self, acc, inp, d_acc, d_inp, b, t, mask=None, pre=None, next_norm=None, pre_cast=None, next_cast=None, slot=None, **_):
@@ -545,8 +548,9 @@ class LSHExec:
         kept = "inp" in slot                       # STASH_STREAMS: the forward's own LayerNorm input / output, nothing reconstructed
         if kept:
             inp, pre = slot["inp"], slot["pre"]
+        adrop = slot.get("adrop")
         xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g = self._internals(inp, b, t, mask, slot["st"], slot["stash"],
-                                                                         _NO_G if kept else slot["g"], pre, slot["qkv"])
+                                                                         _NO_G if kept else slot["g"], pre, slot["qkv"], adrop)
         drop = slot["drop"]
         slot.clear()
         post = None if kept else residual(acc, g, lyr.to_out.bias, -1.0, next_norm, drop)   # reconstruct the stream (same dropout mask)
@@ -556,7 +560,7 @@ class LSHExec:
         dout = gemm(dyb, _bf16(lyr.to_out.weight), kn=True).view(b, t, e)
         dqkv = torch.empty_like(qkv)
         ops.lsh_attn_bwd(qkv[..., :e], qkv[..., e:], st, out, dout, lse_tot, lyr.heads, lyr.bucket_size, lyr.causal, mask,
-                         dqkv=(dqkv[..., :e], dqkv[..., e:]))
+                         dqkv=(dqkv[..., :e], dqkv[..., e:]), drop=adrop)
         dqkv2 = dqkv.view(b * t, 2 * e)
         gview, pair = self._wqkv_grad()
         if gview is not None:

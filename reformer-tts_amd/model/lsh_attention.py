@@ -34,32 +34,33 @@ from torch import nn
 import torch.nn.functional as F
 
 from .. import ops
+from .._seeds import next_seed
 
 
 class _LSHAttnFn(torch.autograd.Function):
     """qkv (B,T,2d) bf16 [qk | v], st (B*H,R,T) -> out (B,T,d) bf16 (heads merged)."""
 
     @staticmethod
-    def forward(ctx, qkv, st, mask, heads, bucket_size, causal):
+    def forward(ctx, qkv, st, mask, heads, bucket_size, causal, drop=None):
         d = qkv.shape[-1] // 2
         qk, v = qkv[..., :d], qkv[..., d:]
-        o, lse = ops.lsh_attn_fwd(qk, v, st, heads, bucket_size, causal, mask)
+        o, lse = ops.lsh_attn_fwd(qk, v, st, heads, bucket_size, causal, mask, drop)
         out, lse_tot = ops.lsh_combine_fwd(o, lse, qkv.shape[0], heads)
         ctx.save_for_backward(qkv, st, out, lse_tot, mask)
-        ctx.cfg = (heads, bucket_size, causal)
+        ctx.cfg = (heads, bucket_size, causal, drop)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, st, out, lse_tot, mask = ctx.saved_tensors
-        heads, bucket_size, causal = ctx.cfg
+        heads, bucket_size, causal, drop = ctx.cfg
         d = qkv.shape[-1] // 2
         dqkv = torch.empty_like(qkv)
         if dout.dtype != torch.bfloat16 or dout.stride(2) != 1:
             dout = dout.to(torch.bfloat16).contiguous()
         ops.lsh_attn_bwd(qkv[..., :d], qkv[..., d:], st, out, dout, lse_tot, heads, bucket_size, causal, mask,
-                         dqkv=(dqkv[..., :d], dqkv[..., d:]))
-        return dqkv, None, None, None, None, None
+                         dqkv=(dqkv[..., :d], dqkv[..., d:]), drop=drop)
+        return dqkv, None, None, None, None, None, None
 
 
 class LSHSelfAttention(nn.Module):
@@ -72,8 +73,9 @@ class LSHSelfAttention(nn.Module):
             raise AssertionError("dimensions must be divisible by number of heads")
         unsupported = dict(add_local_attn_hash=add_local_attn_hash, attend_across_buckets=not attend_across_buckets,
                            allow_duplicate_attention=not allow_duplicate_attention, num_mem_kv=num_mem_kv,
-                           one_value_head=one_value_head, use_full_attn=use_full_attn, return_attn=return_attn,
-                           dropout=dropout)
+                           one_value_head=one_value_head, use_full_attn=use_full_attn, return_attn=return_attn)
+        if not 0.0 <= dropout < 1.0:
+            raise ValueError(f"dropout must be in [0, 1), got {dropout}")
         bad = [k for k, v in unsupported.items() if v]
         if bad:
             raise NotImplementedError(f"implementation='hip' supports the default value of {bad} only")
@@ -87,6 +89,8 @@ class LSHSelfAttention(nn.Module):
         self.tov = nn.Linear(dim, dim, bias=False)
         self.to_out = nn.Linear(dim, dim)
         self.post_attn_dropout = nn.Dropout(post_attn_dropout)
+        self.dropout = float(dropout)        # on the attention probabilities (config.py:27): a counter-hash mask inside the kernels
+        self._attn_drop = None               # (p, seed) of the last no_grad training call: the recompute redraws the same mask
         self.seed = seed
         self._gen: Optional[torch.Generator] = None
         self._saved: Optional[tuple] = None   # (generator state, st, input signature) of the last no_grad training call
@@ -162,12 +166,17 @@ class LSHSelfAttention(nn.Module):
                     sig = self._signature(x)
                     same = (sig - saved[2]).abs().max() <= 1e-3 * saved[2].abs().max()
                     st = torch.where(same, saved[1], st)
+            drop = None
+            if self.training and self.dropout > 0.0:
+                # the mask is a function of (seed, pair): a replayed call takes the seed of the call it replays
+                drop = self._attn_drop if (replay and self._attn_drop is not None) else (self.dropout, next_seed())
             if replay:
                 self._saved = None
             elif self.training and not torch.is_grad_enabled():
                 self._saved = (state, st, self._signature(x))      # reversible forward: kept for the recompute
+                self._attn_drop = drop
         self.last_st = st
         mask = None if input_mask is None else input_mask.to(torch.uint8)
-        out = _LSHAttnFn.apply(qkv, st, mask, self.heads, self.bucket_size, self.causal)
+        out = _LSHAttnFn.apply(qkv, st, mask, self.heads, self.bucket_size, self.causal, drop)
         y = F.linear(out, self.to_out.weight.to(torch.bfloat16), self.to_out.bias.to(torch.bfloat16))
         return self.post_attn_dropout(y.float())

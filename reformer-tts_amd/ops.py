@@ -104,8 +104,17 @@ def _check_mask(mask: Optional[torch.Tensor], b: int, t: int, device) -> Optiona
     return mask.to(device=device, dtype=torch.uint8).contiguous()
 
 
-def lsh_attn_fwd(qk, v, st, heads: int, bucket_size: int, causal: bool, mask=None):
-    """-> o (B*H,R,T,dh) bf16, lse (B*H,R,T) f32; rows already at unsorted positions."""
+def _drop_args(drop, device):
+    """(p, seed) | None -> (p, seed, device seed word) of a counter-hash dropout site."""
+    if not drop or drop[0] <= 0.0:
+        return 0.0, 0, None
+    from ._seeds import seed_base
+    return float(drop[0]), int(drop[1]) & 0xFFFFFFFF, seed_base(device).data_ptr()
+
+
+def lsh_attn_fwd(qk, v, st, heads: int, bucket_size: int, causal: bool, mask=None, drop=None):
+    """-> o (B*H,R,T,dh) bf16, lse (B*H,R,T) f32; rows already at unsorted positions.  ``drop`` = (p, seed): dropout on the
+    attention probabilities (the layer's ``dropout`` knob); pass the same pair to ``lsh_attn_bwd``."""
     ld = _check_rows(qk, "qk")
     if _check_rows(v, "v") != ld or v.shape != qk.shape:
         raise ValueError("qk and v must share shape and row stride")
@@ -119,7 +128,7 @@ def lsh_attn_fwd(qk, v, st, heads: int, bucket_size: int, causal: bool, mask=Non
     lse = torch.empty(b * heads, n_hashes, t, dtype=torch.float32, device=qk.device)
     ev = TIMING.start(f"rtts_lsh_attn_fwd/bs{bucket_size}")
     _lib.call("rtts_lsh_attn_fwd", qk.data_ptr(), v.data_ptr(), ld, st.data_ptr(), _ptr(mask), b, heads, t, dh, n_hashes,
-              bucket_size, int(causal), o.data_ptr(), lse.data_ptr(), _stream())
+              bucket_size, int(causal), o.data_ptr(), lse.data_ptr(), *_drop_args(drop, qk.device), _stream())
     # two MFMA products (Q K^T and P V) of 2*bs*(2bs)*dh FLOP per chunk, n_hashes*T/bs chunks per head
     TIMING.stop(ev, 2.0 * 2.0 * bucket_size * (2 * bucket_size) * dh * (n_hashes * t // bucket_size) * b * heads)
     return o, lse
@@ -138,7 +147,7 @@ def lsh_combine_fwd(o, lse, batch: int, heads: int, out: Optional[torch.Tensor] 
 
 
 def lsh_attn_bwd(qk, v, st, out, dout, lse_tot, heads: int, bucket_size: int, causal: bool, mask=None,
-                 dqkv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+                 dqkv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, drop=None):
     """Backward of hash-sorted attention + round combine.  -> dqk, dv (B,T,H*dh) bf16."""
     ld = _check_rows(qk, "qk")
     if _check_rows(v, "v") != ld:
@@ -159,7 +168,7 @@ def lsh_attn_bwd(qk, v, st, out, dout, lse_tot, heads: int, bucket_size: int, ca
     ev = TIMING.start(f"rtts_lsh_attn_bwd/bs{bucket_size}")
     _lib.call("rtts_lsh_attn_bwd", qk.data_ptr(), v.data_ptr(), ld, st.data_ptr(), _ptr(mask), dout.data_ptr(), ld_do,
               lse_tot.data_ptr(), delta.data_ptr(), b, heads, t, dh, n_hashes, bucket_size, int(causal), dqk_part.data_ptr(),
-              dv_part.data_ptr(), _ptr(flags), _stream())
+              dv_part.data_ptr(), _ptr(flags), *_drop_args(drop, dev), _stream())
     # five MFMA products of 2*bs*(2bs)*dh FLOP per chunk, n_hashes*T/bs chunks per head
     TIMING.stop(ev, 5.0 * 2.0 * bucket_size * (2 * bucket_size) * dh * (n_hashes * t // bucket_size) * b * heads)
     if dqkv is None:

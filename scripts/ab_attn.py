@@ -75,12 +75,12 @@ def main():
                 def run():
                     if KERNEL == "fwd":
                         rc = lib.rtts_lsh_attn_fwd(qk.data_ptr(), v.data_ptr(), qkv.stride(1), st.data_ptr(), mask.data_ptr(), b, h, t, dh,
-                                                   nh, bs, int(causal), dqk.data_ptr(), dv.data_ptr(), s)
+                                                   nh, bs, int(causal), dqk.data_ptr(), dv.data_ptr(), 0.0, 0, None, s)
                         assert rc == 0
                         return
                     rc = lib.rtts_lsh_attn_bwd(qk.data_ptr(), v.data_ptr(), qkv.stride(1), st.data_ptr(), mask.data_ptr(),
                                                dout.data_ptr(), dout.stride(1), lse_tot.data_ptr(), delta.data_ptr(), b, h, t, dh, nh,
-                                               bs, int(causal), dqk.data_ptr(), dv.data_ptr(), s)
+                                               bs, int(causal), dqk.data_ptr(), dv.data_ptr(), None, 0.0, 0, None, s)
                     assert rc == 0
                 run()
                 torch.cuda.synchronize()

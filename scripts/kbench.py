@@ -119,7 +119,7 @@ def main():
                 s = torch.cuda.current_stream().cuda_stream      # inside: under --graph the capture stream is current
                 _lib.call("rtts_lsh_attn_bwd", qk.data_ptr(), v.data_ptr(), ld, st.data_ptr(), mask.data_ptr(), dout.data_ptr(),
                           dout.stride(1), lse_tot.data_ptr(), delta.data_ptr(), b, h, t, dh, nh, bs, int(causal),
-                          dqk_part.data_ptr(), dv_part.data_ptr(), flags.data_ptr(), s)
+                          dqk_part.data_ptr(), dv_part.data_ptr(), flags.data_ptr(), 0.0, 0, None, s)
             _lib.call("rtts_lsh_bwd_delta", out.data_ptr(), out.stride(1), dout.data_ptr(), dout.stride(1), b, h, t, dh,
                       delta.data_ptr(), torch.cuda.current_stream().cuda_stream)
             us = timeit(bwd, args.iters)

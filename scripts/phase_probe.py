@@ -56,7 +56,7 @@ def main_fwd():
     s = torch.cuda.current_stream().cuda_stream
     for _ in range(5):
         rc = lib.rtts_lsh_attn_fwd(qk.data_ptr(), v.data_ptr(), qkv.stride(1), st.data_ptr(), mask.data_ptr(), b, h, t, dh, nh, bs,
-                                   int(causal), o.data_ptr(), lse.data_ptr(), s)
+                                   int(causal), o.data_ptr(), lse.data_ptr(), 0.0, 0, None, s)
         assert rc == 0
     torch.cuda.synchronize()
     buf = np.zeros(16 * 8192, dtype=np.uint64)
@@ -115,7 +115,7 @@ def main():
     def run():
         rc = lib.rtts_lsh_attn_bwd(qk.data_ptr(), v.data_ptr(), qkv.stride(1), st.data_ptr(), mask.data_ptr(), dout.data_ptr(),
                                    dout.stride(1), lse_tot.data_ptr(), delta.data_ptr(), b, h, t, dh, nh, bs, int(causal),
-                                   dqk_part.data_ptr(), dv_part.data_ptr(), flags.data_ptr(), s)
+                                   dqk_part.data_ptr(), dv_part.data_ptr(), flags.data_ptr(), 0.0, 0, None, s)
         assert rc == 0
     for _ in range(3):
         run()

@@ -186,6 +186,58 @@ def test_attention_backward_vs_oracle_autograd(ops, monkeypatch, b, h, t, bs, nh
           " (tol max 1.5e-2, mean 1e-3, rel-L2 1e-2)")
 
 
+@pytest.mark.parametrize("walk", ["0", "4"])
+@pytest.mark.parametrize("b,h,t,bs,nh,causal,masked", [CASES[0], CASES[2], CASES[5]])
+def test_attention_probability_dropout_vs_oracle(ops, monkeypatch, b, h, t, bs, nh, causal, masked, walk):
+    """The layer's `dropout` knob (reference reformer_tts/model/config.py:27): the chunk's softmax output
+    is dropped before it meets the values, lse is that of the undropped probabilities.  The kernels draw the mask from a
+    counter hash of (seed, pair index); the oracle gets the SAME mask as explicit keep-scales (oracle/synth.py rebuilds the
+    hash in numpy), so forward and backward are compared like the dropout-free case: lse identical to the run without
+    dropout, o / out / dqk / dv within the same bounds, and the mask really drops ~p of the pairs."""
+    from oracle import synth
+    from reformer_tts_amd._seeds import seed_base
+    if (nh * (t // bs)) % max(int(walk), 1):
+        pytest.skip("the run length does not divide this ring")
+    monkeypatch.setenv("RTTS_LSH_BWD_WALK", walk)
+    p_drop, seed = 0.25, 0x1234567
+    r = _run_fwd(ops, b, h, t, bs, nh, causal, masked, seed=9)
+    dh = r["dh"]
+    m_d = None if r["mask"] is None else r["mask"].cuda()
+    o_d, lse_d = ops.lsh_attn_fwd(r["qk_d"], r["v_d"], r["st"], h, bs, causal, m_d, drop=(p_drop, seed))
+    out_d, lse_tot_d = ops.lsh_combine_fwd(o_d, lse_d, b, h)
+    torch.cuda.synchronize()
+    assert torch.equal(lse_d, r["lse"]) and torch.equal(lse_tot_d, r["lse_tot"])          # dropout does not touch the normaliser
+    eff_seed = (seed + int(seed_base(r["qk_d"].device).item())) & 0xFFFFFFFF
+    keep = synth.attention_keep_scales(eff_seed, p_drop, b * h, nh * (t // bs), bs)
+    assert abs(float((keep > 0).float().mean()) - (1 - p_drop)) < 2e-2
+    qk = _heads_first(r["qkv"][..., :h * dh], b, t, h, dh).requires_grad_()
+    v = _heads_first(r["qkv"][..., h * dh:], b, t, h, dh).requires_grad_()
+    sticker, undo = _flat_perm(r["st"].cpu())
+    m = None if r["mask"] is None else r["mask"].unsqueeze(1).expand(b, h, t).reshape(b * h, t)
+    out_ref, o_ref, _ = lsh_ref.lsh_attention_sorted(qk, v, sticker, undo, bs, nh, causal, m, return_parts=True, keep=keep)
+    vmax = v.abs().max().item()
+    e_o = (o_d.float().cpu() - o_ref.detach()).abs().max().item() / vmax
+    normal = torch.logsumexp(r["lse"].cpu(), dim=1) > -1e4
+    e_out = (_heads_first(out_d, b, t, h, dh)[normal] - out_ref.detach()[normal]).abs().max().item() / vmax
+    assert e_o < 1.6e-2 and e_out < 1.6e-2, (e_o, e_out)           # 1/(1-p) = 1.33 x the dropout-free bound
+    # the mask did something: the dropped output differs from the plain one
+    assert (o_d.float() - r["o"].float()).abs().max().item() > 0.05 * vmax
+    g = torch.Generator().manual_seed(11)
+    dout = torch.randn(b, t, h * dh, generator=g).bfloat16()
+    dqk, dv = ops.lsh_attn_bwd(r["qk_d"], r["v_d"], r["st"], out_d, dout.cuda(), lse_tot_d, h, bs, causal, m_d, drop=(p_drop, seed))
+    torch.cuda.synchronize()
+    out_ref.backward(_heads_first(dout, b, t, h, dh))
+    msgs = []
+    for got, ref, name in ((_heads_first(dv, b, t, h, dh), v.grad, "dv"), (_heads_first(dqk, b, t, h, dh), qk.grad, "dqk")):
+        scale = ref.abs().max().item()
+        err = (got - ref).abs()
+        rel = float((got - ref).norm() / ref.norm())
+        msgs.append(f"{name} max {err.max().item() / scale:.2e} mean {err.mean().item() / scale:.2e} rel-L2 {rel:.2e}")
+        assert err.max().item() < 2e-2 * scale and err.mean().item() < 1.4e-3 * scale and rel < 1.4e-2, (name, msgs[-1])
+    print(f"\n[lsh attention with probability dropout {p_drop} B={b} H={h} T={t} bs={bs} R={nh} causal={causal} masked={masked} walk={walk}] "
+          f"o max {e_o:.2e}, out max {e_out:.2e} of max|v|; " + "; ".join(msgs))
+
+
 @pytest.mark.parametrize("b,h,t,bs,nh,causal,masked", CASES)
 def test_walking_backward_matches_the_one_chunk_kernel(ops, monkeypatch, b, h, t, bs, nh, causal, masked):
     """lsh_attn_bwd as workgroups that walk R consecutive chunks of a ring (operands of the next chunk prefetched by

@@ -612,8 +612,11 @@ def test_conv1d_k5_implicit_gemm_vs_float64(gpu, b, l, ci, co):
         assert float(y[:, co:].abs().max()) == 0.0          # padded output channels: zero weight rows
 
 
-def test_attention_stash_matches_pure_recompute(gpu):
-    """STASH_ATTENTION / STASH_BLOCK_OUTPUT / STASH_PROJECTIONS keep the attention outputs / the block outputs f(x) / the
+@pytest.mark.parametrize("attn_dropout", [0.0, 0.2])
+def test_attention_stash_matches_pure_recompute(gpu, attn_dropout):
+    """(attn_dropout > 0: the LSH layers' `dropout` knob -- probability dropout inside the attention kernels; the recomputing
+    modes must redraw the forward's mask from the kept (p, seed), else the reconstruction and the gradients drift apart.)
+    STASH_ATTENTION / STASH_BLOCK_OUTPUT / STASH_PROJECTIONS keep the attention outputs / the block outputs f(x) / the
     projections (qk|v, q, k|v, the feed-forward hidden activation) of the forward for the
     backward instead of recomputing them from the RECONSTRUCTED stream (which differs from the forward's stream in the
     last fp32 bits, so the modes are not bitwise equal): gradients agree to rounding with the reference's pure recompute."""
@@ -623,6 +626,8 @@ def test_attention_stash_matches_pure_recompute(gpu):
     cfg = model_ref.small_cfg()
     cfg["enc_reformer_kwargs"]["attn_kwargs"]["implementation"] = "hip"
     cfg["dec_reformer_kwargs"]["self_attn_kwargs"]["implementation"] = "hip"
+    cfg["enc_reformer_kwargs"]["attn_kwargs"]["dropout"] = attn_dropout
+    cfg["dec_reformer_kwargs"]["self_attn_kwargs"]["dropout"] = attn_dropout
     batch = synthetic_batch(2, 100, 256, device=gpu)
     grads = []
     old = engine.STASH_ATTENTION, engine.STASH_BLOCK_OUTPUT, engine.STASH_PROJECTIONS, engine.STASH_STREAMS
@@ -630,6 +635,8 @@ def test_attention_stash_matches_pure_recompute(gpu):
         for stash, stash_out, stash_proj, streams in ((True, True, True, True), (True, True, True, False), (True, True, False, False),
                                                       (True, False, False, False), (False, False, False, False)):
             engine.STASH_ATTENTION, engine.STASH_BLOCK_OUTPUT, engine.STASH_PROJECTIONS, engine.STASH_STREAMS = stash, stash_out, stash_proj, streams
+            from reformer_tts_amd import _seeds
+            _seeds.reset()                              # every mode draws the same dropout seeds
             model = build_model(model_config_from_dict(cfg), gpu)
             tr = Trainer(model, TTSTrainingConfig(batch_size=2), gpu)
             model.train()
