@@ -393,7 +393,9 @@ def test_c_abi_rejects_bad_arguments_with_a_message(ops):
         # row stride not a multiple of 8
         (("rtts_lsh_hash_sort", qk.data_ptr(), 130, rot.data_ptr(), 1, 1, 2, 256, 64, 2, 64, None, st.data_ptr(), None, s), "ld_qk"),
         # unsupported bucket size in the attention kernels
-        (("rtts_lsh_attn_fwd", qk.data_ptr(), qk.data_ptr(), 128, st.data_ptr(), None, 1, 2, 256, 64, 2, 32, 0, qk.data_ptr(), st.data_ptr(), s), "bucket_size=32"),
+        (("rtts_lsh_attn_fwd", qk.data_ptr(), qk.data_ptr(), 128, st.data_ptr(), None, 1, 2, 256, 64, 2, 32, 0, qk.data_ptr(), st.data_ptr(), 0.0, 0, None, s), "bucket_size=32"),
+        # dropout probability out of range
+        (("rtts_lsh_attn_fwd", qk.data_ptr(), qk.data_ptr(), 128, st.data_ptr(), None, 1, 2, 256, 64, 2, 64, 0, qk.data_ptr(), st.data_ptr(), 1.0, 0, None, s), "drop_p"),
         # weight-gradient GEMM: N not a multiple of 128
         (("rtts_gemm_tn", qk.data_ptr(), 96, qk.data_ptr(), 128, 256, 96, 128, st.data_ptr(), 128, 1, st.data_ptr(), 1 << 20, s), "128"),
         # AdamW: n not a multiple of 4
