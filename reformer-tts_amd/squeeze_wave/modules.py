@@ -216,7 +216,11 @@ class SqueezeWave(nn.Module):
         if self._folded is None or self._folded_key != key:
             with torch.no_grad():
                 self._folded = [_FoldedWN(wn) for wn in self.wn_layers]
-                self._winv = [conv.conv.weight.detach().float().squeeze(-1).inverse().contiguous() for conv in self.inv_conv_layers]
+                # twelve matrices of at most 128 x 128, once per parameter version: inverted on the host in float64 (LAPACK) -- no
+                # device library (rocSOLVER / hipBLAS) call anywhere in the vocoder
+                dev = self.inv_conv_layers[0].conv.weight.device
+                self._winv = [conv.conv.weight.detach().squeeze(-1).double().cpu().inverse().float().contiguous().to(dev)
+                              for conv in self.inv_conv_layers]
             self._folded_key = key
         return self._folded
 
