@@ -411,6 +411,16 @@ class Trainer:
             return self.train_step(batch, update_hyper)
         self.model.train()
         self.zero_grad()
+        total, raw_l, post_l, stop_l = self.forward_backward_overlapped(batch)
+        if self._bulk_allreduce:
+            self.bulk_allreduce()
+        self.optimizer_step(update_hyper)
+        return total.detach(), raw_l.detach(), post_l.detach(), stop_l.detach()
+
+    def forward_backward_overlapped(self, batch, loss_scale=None):
+        """Forward + loss + backward of one (micro-)batch in the two-stream schedule of ``train_step_overlapped``; gradients
+        accumulate into the flat buffer.  ``loss_scale``: a device scalar multiplied into the loss before the backward (1 / number
+        of micro-batches under ``accumulate_grad_batches``).  -> the four losses."""
         main, side = torch.cuda.current_stream(), self._enc_stream()
         dec_seq = self.model.dec.reformer.layers
         dec_seq.manual = {}
@@ -418,7 +428,7 @@ class Trainer:
             total, raw_l, post_l, stop_l = self.forward_loss(batch, split="overlap")
             if "call" not in dec_seq.manual:
                 raise RuntimeError("the decoder stack did not take the explicit executor: the overlapped step needs it")
-            self._run_backward(total)                # heads + postnet: stops at the decoder stack's output (a leaf)
+            self._run_backward(total if loss_scale is None else total * loss_scale)     # heads + postnet: stops at the decoder stack's output (a leaf)
             ctx, dec_x, _, dec_out = dec_seq.manual["call"]
             gen = engine.stack_backward_steps(ctx, dec_out.grad, notify_dkeys=True)
             dx = None
@@ -446,10 +456,7 @@ class Trainer:
         finally:
             dec_seq.manual = None
             self._enc_out = self._enc_in = None
-        if self._bulk_allreduce:
-            self.bulk_allreduce()
-        self.optimizer_step(update_hyper)
-        return total.detach(), raw_l.detach(), post_l.detach(), stop_l.detach()
+        return total, raw_l, post_l, stop_l
 
     _accumulating = False
 
@@ -602,6 +609,8 @@ class Trainer:
             # caches keyed by the weight epoch (the convolutions' GEMM-layout weight copies, the decoder prenet's padded weight)
             # are refreshed by launches the HOST decides on: the capture must contain them, a replay follows an optimizer step
             engine.WEIGHT_EPOCH[0] += 1
+            if self.overlap_encoder:                     # the encoder as a parallel branch of the graph (train_step_overlapped)
+                return self.forward_backward_overlapped(bufs, self._acc_scale)[0].detach()
             total = self.forward_loss(bufs)[0]
             self._run_backward(total * self._acc_scale)
             return total.detach()
