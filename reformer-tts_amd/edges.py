@@ -575,25 +575,38 @@ def decoder_prenet_pe(prenet, pe, spec):
 # statistics in place of the batch statistics -- no autograd state, no library GEMM.
 # ------------------------------------------------------------------------------------------------------------------
 def _padded_linear(lin) -> tuple:
-    """(weight (N rounded up to 64, K rounded up to 64) bf16 zero padded, bias (N padded) fp32 | None), cached on the module and
-    rebuilt when the master weight changed."""
+    """(weight (N rounded up to 64, K rounded up to 64) bf16 zero padded, bias (N padded) fp32 | None): PERSISTENT buffers on the
+    module, refreshed IN PLACE when the master weight changed -- a captured hipGraph (``ReformerTTS.infer(use_graph=True)``) holds
+    their addresses and must see the values of the current parameters (``refresh_eval_operands`` runs the refresh eagerly
+    before replays)."""
     w = lin.weight
     ver = (w._version, WEIGHT_EPOCH[0], w.data_ptr(), None if lin.bias is None else lin.bias._version)
     cache = getattr(lin, "_rtts_padded", None)
-    if cache is None or cache[0] != ver or cache[1].device != w.device:
+    if cache is None or cache[1].device != w.device:
         n, k = w.shape
         npad, kpad = -(-n // 64) * 64, -(-k // 64) * 64
-        wb = w.detach().to(torch.bfloat16)
-        if (npad, kpad) != (n, k):
-            buf = torch.zeros(npad, kpad, dtype=torch.bfloat16, device=w.device)
-            buf[:n, :k].copy_(wb)
-            wb = buf
-        bias = None
+        wb = torch.zeros(npad, kpad, dtype=torch.bfloat16, device=w.device)
+        bias = None if lin.bias is None else torch.zeros(npad, dtype=torch.float32, device=w.device)
+        lin._rtts_padded = cache = [None, wb, bias]
+    if cache[0] != ver:
+        n, k = w.shape
+        cache[1][:n, :k].copy_(w.detach())
         if lin.bias is not None:
-            bias = torch.zeros(npad, dtype=torch.float32, device=w.device)
-            bias[:n].copy_(lin.bias.detach())
-        lin._rtts_padded = cache = (ver, wb.contiguous(), bias)
+            cache[2][:n].copy_(lin.bias.detach())
+        cache[0] = ver
     return cache[1], cache[2]
+
+
+def refresh_eval_operands(model) -> None:
+    """Bring every cached inference operand of ``model`` (padded Linear weights, GEMM-layout convolution weights) up to date
+    with the current parameters, eagerly: called at the start of ``ReformerTTS.infer`` so that graphs captured by an earlier
+    call replay with today's weights."""
+    for m in model.modules():
+        if isinstance(m, torch.nn.Linear) and getattr(m, "_rtts_padded", None) is not None:
+            _padded_linear(m)
+        ex = getattr(m, "_rtts_k5", None)
+        if ex is not None:
+            ex.weight_perm()
 
 
 def linear_nograd(x: torch.Tensor, lin, relu: bool = False, out_f32: bool = False) -> torch.Tensor:

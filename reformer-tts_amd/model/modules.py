@@ -211,9 +211,15 @@ class ScaledPositionalEncoding(nn.Module):
 
     def table(self, length: int, device):
         if self._table is None or self._table.shape[0] < length or self._table.device != device:
-            pos = torch.arange(length, device=device, dtype=self.inv_freq.dtype)
+            # a captured hipGraph holds the ADDRESS of the table it was captured with: a table that is outgrown stays alive (and
+            # unchanged) for as long as the module does, and the new one is sized generously so that this happens rarely
+            if self._table is not None:
+                self.__dict__.setdefault("_old_tables", []).append(self._table)
+            rows = max(length, 1024)
+            rows = 1 << (rows - 1).bit_length()
+            pos = torch.arange(rows, device=device, dtype=self.inv_freq.dtype)
             ang = pos[:, None] * self.inv_freq.to(device)[None, :]
-            self._table = torch.stack([ang.sin(), ang.cos()], dim=-1).reshape(length, -1)
+            self._table = torch.stack([ang.sin(), ang.cos()], dim=-1).reshape(rows, -1)
         return self._table[:length]
 
     def forward(self, input_):

@@ -166,6 +166,9 @@ class ReformerTTS(nn.Module):
         * ``use_graph=True`` ("concat" only): one frame = one hipGraph replay (see ``_infer_graphed``)."""
         assert combine_strategy in {"concat", "replace"}
         assert -1. < stop_threshold < 1.
+        if self.dec.mel_linear.weight.is_cuda:
+            from ..edges import refresh_eval_operands
+            refresh_eval_operands(self)               # cached padded / re-laid-out weights follow the parameters (graphs hold addresses)
         if use_graph and combine_strategy == "concat":
             return self._infer_graphed(phonemes, max_len, stop_threshold, stop_at_stop_token, cache_encoder, check_every)
         was_training = self.training
