@@ -153,10 +153,11 @@ class LSHSelfAttention(nn.Module):
         qkv = F.linear(x.to(torch.bfloat16), w)                              # (B,T,2d) = [qk | v]
         state = self._generator_state(x.device)
         saved, st = self._saved, None
+        grad_on = torch.is_grad_enabled()        # read here: the block below runs under no_grad
         with torch.no_grad():
             # always drawn, also when the permutation is re-used: the generator must end up where the forward left it
             rot = self._rotations(x, t // self.bucket_size, default_generator=True)
-            replay = (self.training and torch.is_grad_enabled() and saved is not None and saved[1].shape[0] == b * self.heads
+            replay = (self.training and grad_on and saved is not None and saved[1].shape[0] == b * self.heads
                       and saved[1].shape[2] == t and (recompute or (state is not None and saved[0] == state)))
             if replay and recompute:
                 st = saved[1]
@@ -172,7 +173,7 @@ class LSHSelfAttention(nn.Module):
                 drop = self._attn_drop if (replay and self._attn_drop is not None) else (self.dropout, next_seed())
             if replay:
                 self._saved = None
-            elif self.training and not torch.is_grad_enabled():
+            elif self.training and not grad_on:
                 self._saved = (state, st, self._signature(x))      # reversible forward: kept for the recompute
                 self._attn_drop = drop
         self.last_st = st

@@ -135,13 +135,15 @@ def _mask(b, t, dev):
     return m
 
 
-@pytest.mark.parametrize("p_drop", [0.0, 0.15])
+@pytest.mark.parametrize("p_drop,attn_p", [(0.0, 0.0), (0.15, 0.0), (0.0, 0.2), (0.15, 0.2)])
 @pytest.mark.parametrize("perturbed", [False, True])
-def test_grad_enabled_call_under_restored_rng_repeats_the_no_grad_call(dev, p_drop, perturbed):
+def test_grad_enabled_call_under_restored_rng_repeats_the_no_grad_call(dev, p_drop, attn_p, perturbed):
     """record RNG -> layer(x, input_mask=m) under no_grad -> (other work draws random numbers) -> fork_rng + restore ->
     layer(x', input_mask=m) with gradients: same buckets, same output, same dropout mask.  ``perturbed``: x' differs
-    from x by fp32 rounding noise, as the reconstructed stream of a reversible backward does."""
-    layer = _layer(dev, p=p_drop)
+    from x by fp32 rounding noise, as the reconstructed stream of a reversible backward does.  ``attn_p``: dropout on the
+    attention probabilities, whose mask is a function of a per-call seed the replay has to take over (a fresh seed moves the
+    output by O(1))."""
+    layer = _layer(dev, p=p_drop, attn_p=attn_p)
     wrapped = RngReplay(layer)
     b, t = 2, 512
     x = torch.randn(b, t, 128, device=dev)
@@ -164,6 +166,23 @@ def test_grad_enabled_call_under_restored_rng_repeats_the_no_grad_call(dev, p_dr
         assert torch.equal(y1, y0), "same input, same RNG state: the replay must be bit-identical"
     y1.sum().backward()
     assert torch.isfinite(x1.grad).all() and x1.grad.abs().max() > 0
+
+
+def test_replay_takes_the_remembered_permutation_rather_than_hashing_again(dev):
+    """The recompute must USE what the forward left behind (re-hashing a reconstructed input can flip near-tied buckets):
+    the remembered permutation is swapped for a marked one between the two calls and has to come back out."""
+    layer = _layer(dev)
+    wrapped = RngReplay(layer)
+    x = torch.randn(2, 512, 128, device=dev)
+    with torch.no_grad():
+        wrapped(x, record_rng=True)
+    state, st, sig = layer._saved
+    marked = torch.flip(st, dims=[-1]).contiguous()          # still one permutation of the positions per (head, round)
+    assert not torch.equal(marked, st)
+    layer._saved = (state, marked, sig)
+    wrapped(x.clone().requires_grad_(), set_rng=True)
+    assert torch.equal(layer.last_st, marked)
+    assert layer._saved is None, "a remembered permutation serves one recompute"
 
 
 def test_without_the_rng_restore_the_layer_draws_new_rotations(dev):
@@ -247,8 +266,9 @@ def test_two_block_stack_under_the_reference_protocol_matches_plain_autograd(dev
     y_r, dx_r, g_r = run(lambda xi: _StackFn.apply(xi, list(rev), kw))
     st_rev = [f.fn.last_st.clone() for f in fs]
     y_p, dx_p, g_p = run(plain_fn)
-    for a, c in zip(st_rev, (f.fn.last_st for f in fs)):
-        assert torch.equal(a, c), "reversible recompute and plain forward hashed differently"
+    for i, (a, c) in enumerate(zip(st_rev, (f.fn.last_st for f in fs))):
+        assert torch.equal(a, c), (f"block {i}: reversible recompute and plain forward hashed differently at {int((a != c).sum())} "
+                                   f"of {a.numel()} slots; outputs differ by {float((y_r - y_p).abs().max()):.3e}")
     assert torch.equal(y_r, y_p)
 
     def rel(a, c):
