@@ -32,8 +32,10 @@
 #define AF_LOG2E 1.4426950408889634f
 #define AF_NEG (-1.0e30f)
 #define AF_BIGPOS 0x40000000
+#define AF_SLACK 8.0f   // see the tile loop: the running maximum may lag the true one by this many log2 units
 
 typedef __attribute__((ext_vector_type(8))) short af_short8;
+typedef __attribute__((ext_vector_type(2))) __bf16 af_bf2;
 
 // Phase probe (scripts/phase_probe.py --fwd builds a private copy with -DAF_PHASE_TIMING): waves 0 and NQT (the two key
 // halves of query tile 0) stamp the shader clock at the phase boundaries.  Never defined in the product build.
@@ -73,11 +75,13 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
     constexpr int NTHR = BS * 4;          // two waves per 32-query tile: each walks one half of the keys
     constexpr int NQT = BS / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* Ks = smem;
-    unsigned char* Vs = Ks + NK * AF_ROWB;                       // [NK][128] swizzled (the output staging reuses it, padded)
-    float* ksc = reinterpret_cast<float*>(Vs + NK * AF_ROWB);   // dh^-1/2 / |k| * log2(e)
+    // the three per-key word arrays come FIRST: the tile loop reads them at (one base register + immediate), and a DS
+    // immediate offset is 16 bits -- behind the 72 KB of images every one of those reads needed its own address add
+    float* ksc = reinterpret_cast<float*>(smem);                 // dh^-1/2 / |k| * log2(e)
     int* kpos = reinterpret_cast<int*>(ksc + NK);                // original position (self test)
     int* kpe = kpos + NK;                                        // effective position for the `dead` compare
+    unsigned char* Ks = smem + NK * 12;
+    unsigned char* Vs = Ks + NK * AF_ROWB;                       // [NK][128] swizzled (the output staging reuses it, padded)
 
     const int nb = T / BS;
     const int C = n_hashes * nb;
@@ -122,14 +126,12 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
         for (int it = 0; it < ITERS; ++it) {
             const int row = (it * NTHR + tid) >> 3, piece = tid & 7;
             *reinterpret_cast<uint4*>(Ks + row * AF_ROWB + piece * 16) = kreg[it];
-            const uint32_t u[4] = {kreg[it].x, kreg[it].y, kreg[it].z, kreg[it].w};
+            // |row piece|^2 straight from the packed pairs: v_dot2c_f32_bf16, 4 instructions per 16 bytes (unpack + fma: 16)
             float ss = 0.f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float a = __uint_as_float(u[k] << 16), bq = __uint_as_float(u[k] & 0xffff0000u);
-                ss = __builtin_fmaf(a, a, ss);
-                ss = __builtin_fmaf(bq, bq, ss);
-            }
+            ss = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(af_bf2, kreg[it].x), __builtin_bit_cast(af_bf2, kreg[it].x), ss, false);
+            ss = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(af_bf2, kreg[it].y), __builtin_bit_cast(af_bf2, kreg[it].y), ss, false);
+            ss = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(af_bf2, kreg[it].z), __builtin_bit_cast(af_bf2, kreg[it].z), ss, false);
+            ss = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(af_bf2, kreg[it].w), __builtin_bit_cast(af_bf2, kreg[it].w), ss, false);
             ss = rtts_sum8(ss);
             // the row's three words leave in one ds_write_b32: lane `piece` stores word `piece`
             int w = __float_as_int((0.125f * AF_LOG2E) * __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f)));   // 1 / max(|k|, 1e-12)
@@ -171,6 +173,10 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc, 0, 0, 0);
         }
         float tmax = AF_NEG;
+#if defined(AF_ABLATE) && AF_ABLATE == 3
+        // timing experiment only: no scale, no masks, no max, no exp
+        tmax = 0.f;
+#else
         // can a key of this tile BE the query itself?  own keys: only the diagonal tile; looked-back keys: only when the
         // previous chunk belongs to another hash round.  Wave-uniform: the common path skips the test.
         const bool chk_self = (kt < NQT) ? (kt == qt) : wrap;
@@ -204,36 +210,52 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float x = acc[4 * g + j] * scv[j];
+#if !defined(AF_ABLATE) || AF_ABLATE != 2
                     x = (kev[j] > qpe) ? AF_NEG : x;
+#endif
                     acc[4 * g + j] = x;
                     tmax = fmaxf(tmax, x);
                 }
             }
         }
         tmax = rtts_xhalf_max(tmax);
-        const float mnew = fmaxf(m, tmax);
-        const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-        m = mnew;
-        if (__any(alpha != 1.f)) {
+#endif
+        // LAZY reference: m follows the running maximum only when a tile exceeds it by more than AF_SLACK (log2 units), so
+        // probabilities stay below 2^AF_SLACK (exact in fp32, and bf16 keeps its relative precision) and the rescale of O
+        // and l -- 34 multiplies and an exp per tile -- runs for the first live tile of a wave and then almost never
+        // (wave-uniform branch).  (m, l, O) stay a consistent triple, so the merge and lse = m + log2 l need no change.
+        if (__any(tmax > m + AF_SLACK)) {
+            const float mnew = fmaxf(m, tmax);
+            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+            m = mnew;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 oacc[0][i] *= alpha;
                 oacc[1][i] *= alpha;
             }
+            l *= alpha;
         }
-        l *= alpha;
+#if defined(AF_ABLATE) && AF_ABLATE == 3
+#pragma unroll
+        for (int i = 0; i < 16; ++i) l += acc[i];
+#else
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float p = __builtin_amdgcn_exp2f(acc[i] - mnew);
+            const float p = __builtin_amdgcn_exp2f(acc[i] - m);
             acc[i] = p;
             l += p;
         }
+#endif
         if constexpr (DROP) {
             const uint32_t seed = drop_seed + (seed_dev ? seed_dev[0] : 0u);
             const uint32_t pair0 = ((uint32_t)wi * BS + (uint32_t)qrow) * (uint32_t)NK + (uint32_t)(kt * 32 + 4 * hh);
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] *= rtts_drop_keep(seed, pair0 + 8 * (i >> 2) + (i & 3), drop_thresh, drop_scale);
         }
+#if defined(AF_ABLATE) && AF_ABLATE == 4
+        oacc[0][0] += acc[0] + acc[5] + acc[10] + acc[15];      // timing experiment only: no P V product
+        if (false)
+#endif
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const int o8 = 8 * s2;
@@ -270,9 +292,12 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
     {
         const float m2 = part[32 * 64 + lane], l2 = part[33 * 64 + lane];
         const float mm = fmaxf(m, m2);
-        const float a1 = __builtin_amdgcn_exp2f(m - mm), a2 = __builtin_amdgcn_exp2f(m2 - mm);
+        float a1 = __builtin_amdgcn_exp2f(m - mm), a2 = __builtin_amdgcn_exp2f(m2 - mm);
         l = l * a1 + l2 * a2;
         m = mm;
+        const float inv_l = 1.f / l;         // the normalisation rides in the merge coefficients
+        a1 *= inv_l;
+        a2 *= inv_l;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             oacc[0][i] = oacc[0][i] * a1 + part[i * 64 + lane] * a2;
@@ -284,7 +309,6 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
     // The accumulator holds a query per lane and dh down the registers; the tile goes through a [32][144 B] LDS
     // staging (the V image is dead by now) so that a row leaves as eight 16-byte pieces = one full 128-byte line.
     const int round = c / nb;
-    const float inv_l = 1.f / l;
     const size_t obase = ((size_t)bh * n_hashes + round) * T;
     unsigned char* stg = Vs + qt * (32 * AF_ROWB);
 #pragma unroll
@@ -292,8 +316,8 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             uint2 pk;
-            pk.x = pack_bf16x2(oacc[dt][4 * g] * inv_l, oacc[dt][4 * g + 1] * inv_l);
-            pk.y = pack_bf16x2(oacc[dt][4 * g + 2] * inv_l, oacc[dt][4 * g + 3] * inv_l);
+            pk.x = pack_bf16x2(oacc[dt][4 * g], oacc[dt][4 * g + 1]);
+            pk.y = pack_bf16x2(oacc[dt][4 * g + 2], oacc[dt][4 * g + 3]);
             *reinterpret_cast<uint2*>(stg + r * AF_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2) = pk;
         }
     }
