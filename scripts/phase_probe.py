@@ -62,6 +62,23 @@ def main_fwd():
     buf = np.zeros(16 * 8192, dtype=np.uint64)
     assert lib.rtts_debug_af_phases(buf.ctypes.data) == 0
     allp = buf.reshape(8192, 16)[: b * h * nh * (t // bs)].astype(np.int64)
+    run = lib.rtts_lsh_attn_fwd_run_length(b, h, t, nh, bs)
+    if run > 0:
+        # walking form: stamps of step AF_WSTEP (default 1) of every run, wave 0 (own keys) and wave NQT (looked-back keys)
+        allw = buf.reshape(8192, 16)[: b * h * nh * (t // bs) // run].astype(np.int64)
+        own = ["Q fragments + 4 key tiles", "wait barrier 1 (tiles of all waves)", "(nothing)", "wait barrier 2 (partials written)",
+               "merge + stage + row stores issued", "wait barrier 3", "wait barrier 4 (next chunk placed)"]
+        back = ["Q fragments + 4 key tiles", "wait barrier 1 (tiles of all waves)", "partials -> LDS, next rows requested",
+                "wait barrier 2", "wait barrier 3 (own waves merged + stored)", "next rows -> LDS (waits for the loads)", "wait barrier 4"]
+        for half, off, names in (("own waves (wave 0)", 0, own), ("back waves (wave NQT)", 8, back)):
+            ph = allw[:, off:off + 8]
+            ph = ph[ph[:, 7] > 0]
+            d = np.diff(ph, axis=1)
+            print(f"{half}: run length {run}, workgroups {len(ph)}")
+            for i, nm in enumerate(names):
+                print(f"  {nm:44s} median {np.median(d[:, i]):8.0f}  p10 {np.percentile(d[:, i], 10):8.0f}  p90 {np.percentile(d[:, i], 90):8.0f}")
+            print(f"  one step                                     median {np.median(ph[:, 7] - ph[:, 0]):8.0f}")
+        return
     names = ["gather (positions -> rows -> LDS image)", "wait barrier 1", "Q fragments + 4 key tiles (online softmax)",
              "wait merge barrier", "merge + stage + row stores issued"]
     for half, off in (("own keys (wave 0)", 0), ("looked-back keys (wave NQT)", 8)):

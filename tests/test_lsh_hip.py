@@ -238,6 +238,33 @@ def test_attention_probability_dropout_vs_oracle(ops, monkeypatch, b, h, t, bs, 
           f"o max {e_o:.2e}, out max {e_out:.2e} of max|v|; " + "; ".join(msgs))
 
 
+@pytest.mark.parametrize("drop", [None, (0.25, 77)])
+@pytest.mark.parametrize("b,h,t,bs,nh,causal,masked", CASES)
+def test_walking_forward_matches_the_one_chunk_kernel(ops, monkeypatch, b, h, t, bs, nh, causal, masked, drop):
+    """lsh_attn_fwd as workgroups that walk a run of consecutive chunks (every K / V row gathered once, the next chunk's
+    rows fetched while the current one is merged and stored) against the one-chunk kernel: the arithmetic of a chunk is the
+    same instruction sequence in both, so o and lse must agree BIT FOR BIT for every run length that divides the ring --
+    including runs that start at chunk 0 (the looked-back chunk wraps to the end of the ring), runs that cross a hash round,
+    and dropout on the probabilities (same pair index)."""
+    from reformer_tts_amd import _lib
+    r = _run_fwd(ops, b, h, t, bs, nh, causal, masked, seed=3)
+    m = None if r["mask"] is None else r["mask"].cuda()
+    ring = nh * (t // bs)
+    outs = {}
+    for run in (0, 1, 2, 4, 8):
+        if run and ring % run:
+            continue
+        monkeypatch.setenv("RTTS_LSH_FWD_WALK", str(run))
+        assert _lib.load().rtts_lsh_attn_fwd_run_length(b, h, t, nh, bs) == run
+        o, lse = ops.lsh_attn_fwd(r["qk_d"], r["v_d"], r["st"], h, bs, causal, m, drop)
+        torch.cuda.synchronize()
+        outs[run] = (o.clone(), lse.clone())
+    assert len(outs) >= 3
+    for run, (o, lse) in outs.items():
+        assert torch.equal(o, outs[0][0]), f"run length {run}: o differs from the one-chunk kernel"
+        assert torch.equal(lse, outs[0][1]), f"run length {run}: lse differs from the one-chunk kernel"
+
+
 @pytest.mark.parametrize("b,h,t,bs,nh,causal,masked", CASES)
 def test_walking_backward_matches_the_one_chunk_kernel(ops, monkeypatch, b, h, t, bs, nh, causal, masked):
     """lsh_attn_bwd as workgroups that walk R consecutive chunks of a ring (operands of the next chunk prefetched by
