@@ -386,9 +386,15 @@ def main():
             avg_ms, launches = graph_timed(lambda: ops.lsh_hash_sort(qk_probe, rot_probe, heads_dec, dec_bucket), 20, 10)
             two = _lib.load().rtts_lsh_hash_sort_launches(t_dec) == 2
             ach = nbytes / (avg_ms * 1e-3) / 1e9
+            # counters of the launch(es) one call makes (the hash of all rounds and the sorts are two kernels from T = 1024 on)
+            parts = [pmc_traffic(k) for k in (("lsh_hash_rounds_kernel", "lsh_sort_ids_kernel") if two else ("lsh_hash_sort_kernel",))]
+            h_traffic = sum(p[0] for p in parts) if all(p[0] is not None for p in parts) else None
             rooflines.append({"kernel": "lsh_hash_rounds_kernel + lsh_sort_ids_kernel" if two else "lsh_hash_sort_kernel", "bound": "hbm",
                               "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                              "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": h_traffic,
+                              ("traffic_source" if h_traffic is not None else "traffic_stale"): parts[0][1] if h_traffic is not None
+                              else next(p[1] for p in parts if p[0] is None),
+                              "avg_launch_ms": round(avg_ms, 4),
                               "launches_timed": launches, "timed": "hipGraph of 20 calls, replayed 10 times (device time; eager launches of a "
                               "kernel this short are host-bound)", "peak_measured": peaks[0],
                               "frac_of_measured": (round(ach / peaks[0], 4) if peaks[0] else None),
