@@ -77,9 +77,10 @@ int rtts_lsh_attn_fwd(const void* qk, const void* v, int64_t ld, const int32_t* 
  * probabilities.  keep is a counter hash of (drop_seed + *seed_dev, pair), pair = ((head * chunks + chunk) * bucket_size +
  * query row of the chunk) * 2*bucket_size + key row (own chunk's keys first): no mask is stored, rtts_lsh_attn_bwd called with
  * the same (drop_p, drop_seed, seed_dev) -- and the reversible recompute's forward -- redraw the same one.  seed_dev may be NULL. */
-/* how rtts_lsh_attn_fwd works a shape: 0 = one workgroup per chunk (lsh_attn_fwd_kernel), the only form this build has.
- * (A form that walks consecutive chunks like the backward's was priced in round 3 and not built: the forward is
- * latency-bound at two workgroups per CU, and a ring of three chunk slots leaves room for one -- DESIGN.md section 5.) */
+/* how rtts_lsh_attn_fwd works a shape: 0 = one workgroup per chunk (lsh_attn_fwd_kernel; small grids), R > 0 = workgroups
+ * that walk runs of R consecutive chunks of a (batch, head) ring (lsh_attn_fwd_walk_kernel: every K / V row gathered once,
+ * the next chunk's rows fetched while the current one is merged and stored; same results bit for bit).  -1: bad arguments.
+ * RTTS_LSH_FWD_WALK=<R> in the environment forces a run length (0: the one-chunk kernel) for tests and A/B runs. */
 int rtts_lsh_attn_fwd_run_length(int B, int H, int T, int n_hashes, int bucket_size);
 
 /* ---- combine the hash rounds (step 11) and merge heads (first half of step 12) -------
