@@ -78,6 +78,24 @@ __device__ __forceinline__ int ab_ds_off(int key, int gran) {
 
 // DROP: dropout on the attention probabilities (lsh_attn_fwd.hip): with keep = 0 | 1/(1-p) from the same counter hash of the
 // pair index, dV += (keep P')^T dout and dS = P' (keep dP - delta); delta = out . dout already contains the mask.
+// |half a key row|^2 from its four fragments: v_dot2c_f32_bf16 on the packed pairs (16 instructions in four chains of four;
+// unpack + fma was 64 in one chain of 32 dependent fmas) -- the same arithmetic as the forward kernel's norms.
+typedef __attribute__((ext_vector_type(2))) __bf16 ab_bf2;
+__device__ __forceinline__ float ab_frags_sumsq(const bf16x8 (&f)[4]) {
+    float part[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const uint4 u = __builtin_bit_cast(uint4, f[ks]);
+        float a = 0.f;
+        a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(ab_bf2, u.x), __builtin_bit_cast(ab_bf2, u.x), a, false);
+        a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(ab_bf2, u.y), __builtin_bit_cast(ab_bf2, u.y), a, false);
+        a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(ab_bf2, u.z), __builtin_bit_cast(ab_bf2, u.z), a, false);
+        a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(ab_bf2, u.w), __builtin_bit_cast(ab_bf2, u.w), a, false);
+        part[ks] = a;
+    }
+    return (part[0] + part[1]) + (part[2] + part[3]);
+}
+
 struct AbDrop {
     uint32_t seed;
     const uint32_t* seed_dev;
@@ -214,18 +232,7 @@ __global__ __launch_bounds__(BS * 4 / AB_KT2, AB_KT2 == 2 ? 1 : 2) void lsh_attn
     for (int k2 = 0; k2 < KT2; ++k2) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) kf[k2][ks] = *reinterpret_cast<const bf16x8*>(Ks + (wave * KT2 + k2) * (32 * 128) + fro[ks]);
-        float ss = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const uint4 u4 = __builtin_bit_cast(uint4, kf[k2][ks]);
-            const uint32_t u[4] = {u4.x, u4.y, u4.z, u4.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float a = __uint_as_float(u[k] << 16), bq = __uint_as_float(u[k] & 0xffff0000u);
-                ss = __builtin_fmaf(a, a, ss);
-                ss = __builtin_fmaf(bq, bq, ss);
-            }
-        }
+        float ss = ab_frags_sumsq(kf[k2]);
         ss = rtts_xhalf_sum(ss);
         ksc[k2] = 0.125f * __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));   // dh^-1/2 / max(|k|, 1e-12)
         kpk[k2] = myvalid[k2] ? (CAUSAL ? mypos[k2] : 0) : 0x40000000;
@@ -719,18 +726,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
             mypos = pos_now;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(Kt + fro[ks]);
-            float ss = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const uint4 u4 = __builtin_bit_cast(uint4, kf[ks]);
-                const uint32_t u[4] = {u4.x, u4.y, u4.z, u4.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float a = __uint_as_float(u[k] << 16), bq = __uint_as_float(u[k] & 0xffff0000u);
-                    ss = __builtin_fmaf(a, a, ss);
-                    ss = __builtin_fmaf(bq, bq, ss);
-                }
-            }
+            float ss = ab_frags_sumsq(kf);
             ss = rtts_xhalf_sum(ss);
             ksc = 0.125f * __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));   // dh^-1/2 / max(|k|, 1e-12)
             kpk = myvalid ? (CAUSAL ? mypos : 0) : 0x40000000;
@@ -960,7 +956,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
                 kraw[dt][4 * g + 3] = __uint_as_float(kk.y & 0xffff0000u);
             }
         if (own_tile) {
-            float sd = 0.f;
+            float sd4[4] = {0.f, 0.f, 0.f, 0.f};        // four chains of 8, not one of 32 dependent fmas
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -971,10 +967,10 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
                         gacc[dt][4 * g + jj] += dqf[jj];
-                        sd = __builtin_fmaf(kraw[dt][4 * g + jj], dqf[jj], sd);
+                        sd4[jj] = __builtin_fmaf(kraw[dt][4 * g + jj], dqf[jj], sd4[jj]);
                     }
                 }
-            sdq = rtts_xhalf_sum(sd);
+            sdq = rtts_xhalf_sum((sd4[0] + sd4[1]) + (sd4[2] + sd4[3]));
         }
         if (!own_tile || j == R - 1) {
             const int slot = (!own_tile && j == 0) ? 1 : 0;
@@ -1005,11 +1001,12 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
             }
             {
                 bf16_t* dkdst = dqk_part + slot * slot_stride;
-                float dot = 0.f;
+                float dot4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) dot = __builtin_fmaf(kraw[dt][e], gacc[dt][e], dot);
+                    for (int e = 0; e < 16; ++e) dot4[e & 3] = __builtin_fmaf(kraw[dt][e], gacc[dt][e], dot4[e & 3]);
+                const float dot = (dot4[0] + dot4[1]) + (dot4[2] + dot4[3]);
                 // k . (G + dQ) - k . dQ = k . G; k^ = k / |k| = k * (8 ksc)
                 const float ncoef = -(rtts_xhalf_sum(dot) - sdq) * (ksc * 8.f) * (ksc * 8.f);
 #pragma unroll

@@ -68,6 +68,7 @@ def main():
             for i, lib in enumerate(libs):
                 dqk = torch.zeros(2, b * h, nh, t, dh, dtype=torch.bfloat16, device=dev)
                 dv = torch.zeros(2, b * h, nh, t, dh, dtype=torch.bfloat16, device=dev)
+                flags = torch.zeros(b * h, nh, t, dtype=torch.uint8, device=dev)     # row_flags of the walking form
                 if KERNEL == "fwd":
                     dqk = torch.zeros(b * h, nh, t, dh, dtype=torch.bfloat16, device=dev)   # o
                     dv = torch.zeros(b * h, nh, t, dtype=torch.float32, device=dev)        # lse
@@ -80,7 +81,7 @@ def main():
                         return
                     rc = lib.rtts_lsh_attn_bwd(qk.data_ptr(), v.data_ptr(), qkv.stride(1), st.data_ptr(), mask.data_ptr(),
                                                dout.data_ptr(), dout.stride(1), lse_tot.data_ptr(), delta.data_ptr(), b, h, t, dh, nh,
-                                               bs, int(causal), dqk.data_ptr(), dv.data_ptr(), None, 0.0, 0, None, s)
+                                               bs, int(causal), dqk.data_ptr(), dv.data_ptr(), flags.data_ptr(), 0.0, 0, None, s)
                     assert rc == 0
                 run()
                 torch.cuda.synchronize()
