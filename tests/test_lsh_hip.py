@@ -116,12 +116,16 @@ def _run_fwd(ops, b, h, t, bs, nh, causal, masked, seed=0):
     return dict(qkv=qkv, qk_d=qk_d, v_d=v_d, st=st, undo=undo, o=o, lse=lse, out=out, lse_tot=lse_tot, mask=mask, dh=dh)
 
 
+@pytest.mark.parametrize("walk", ["0", "4"])
 @pytest.mark.parametrize("b,h,t,bs,nh,causal,masked", CASES)
-def test_attention_forward_vs_oracle(ops, b, h, t, bs, nh, causal, masked):
+def test_attention_forward_vs_oracle(ops, monkeypatch, b, h, t, bs, nh, causal, masked, walk):
     """Tolerance: inputs are identical bf16 values; the kernel rounds P to bf16 (2^-9 rel) before
     PV and o/out to bf16 on store => |err| ~ 4e-3 * max|v| on rows that see other tokens (bounds: 3x achieved).
     Rows that can only see themselves (lse ~ -5e4) sit on fp32's 4e-3 logsumexp grid, so the
-    round weights legitimately differ there (see oracle/lsh_ref.py)."""
+    round weights legitimately differ there (see oracle/lsh_ref.py).  ``walk``: the one-chunk kernel / the walking kernel at
+    runs of 4 chunks (what the decoder shape gets; these test shapes would get the one-chunk kernel by themselves)."""
+    if (nh * (t // bs)) % int(walk or 1) == 0:
+        monkeypatch.setenv("RTTS_LSH_FWD_WALK", walk)
     r = _run_fwd(ops, b, h, t, bs, nh, causal, masked)
     dh = r["dh"]
     qk = _heads_first(r["qkv"][..., :h * dh], b, t, h, dh)
