@@ -124,7 +124,7 @@ def test_attention_forward_vs_oracle(ops, monkeypatch, b, h, t, bs, nh, causal, 
     Rows that can only see themselves (lse ~ -5e4) sit on fp32's 4e-3 logsumexp grid, so the
     round weights legitimately differ there (see oracle/lsh_ref.py).  ``walk``: the one-chunk kernel / the walking kernel at
     runs of 4 chunks (what the decoder shape gets; these test shapes would get the one-chunk kernel by themselves)."""
-    if (nh * (t // bs)) % int(walk or 1) == 0:
+    if int(walk) == 0 or (nh * (t // bs)) % int(walk) == 0:
         monkeypatch.setenv("RTTS_LSH_FWD_WALK", walk)
     r = _run_fwd(ops, b, h, t, bs, nh, causal, masked)
     dh = r["dh"]
