@@ -158,6 +158,12 @@ int rtts_ln_fwd(const float* x, const float* gamma, const float* beta, void* xn,
 int rtts_ln_bwd(const void* dxn, const float* x, const float* mean, const float* rstd, const float* gamma,
                 float* dx_io, float* dgamma, float* dbeta, float* partial_ws, int M, int d,
                 void* dyb_next, float* partial_next, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
+/* out-of-place form: dx_out = dx_in + dLN(dxn) (dx_in == dx_out is rtts_ln_bwd).  The stack executor uses it for the first update
+ * of each of the two gradient streams of a reversible stack's backward (reference: reversible.py:114-129,155-158 start from two
+ * chunks of one dy), which start as the caller's dout itself instead of a copy of it. */
+int rtts_ln_bwd_to(const void* dxn, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dx_in,
+                   float* dx_out, float* dgamma, float* dbeta, float* partial_ws, int M, int d,
+                   void* dyb_next, float* partial_next, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
 /* dyb_next (may be NULL): bf16 copy of the completed dx_io, times the keep-scale of (drop_p, seed) -- the next block's
  * rtts_cast_colsum folded in; partial_next then receives that copy's partial column sums (same layout as partial_ws). */
 int rtts_cast_colsum(const float* dy, void* dyb, float* dbias, float* partial_ws, int M, int d, float drop_p, uint32_t seed,

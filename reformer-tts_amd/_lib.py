@@ -62,6 +62,7 @@ SIGNATURES = {
     "rtts_grad_clip_scale": [_vp, _i64, _f32, _f32, _vp, _vp, _vp],
     "rtts_ln_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp],
     "rtts_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f32, _u32, _vp, _vp],
+    "rtts_ln_bwd_to": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f32, _u32, _vp, _vp],
     "rtts_cast_colsum": [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _u32, _vp, _vp, _vp],
     "rtts_colsum_bf16": [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp],
     "rtts_sum_streams": [_vp, _vp, _i64, _vp, _vp, _vp],

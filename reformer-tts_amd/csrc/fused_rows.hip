@@ -207,7 +207,7 @@ __global__ __launch_bounds__(FR_THREADS) void residual_ln_kernel(const float* x,
 template <int EPL, int VEC>
 __global__ __launch_bounds__(FR_THREADS) void ln_bwd_kernel(const bf16_t* __restrict__ dxn, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            const float* __restrict__ gamma, float* __restrict__ dx_io,
+                                                            const float* __restrict__ gamma, const float* dx_in, float* dx_io,
                                                             float* __restrict__ partial_g, float* __restrict__ partial_b, int M,
                                                             bf16_t* __restrict__ dyb_next, float* __restrict__ partial_next,
                                                             uint32_t seed, const uint32_t* __restrict__ seed_dev, uint32_t thresh,
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(FR_THREADS) void ln_bwd_kernel(const bf16_t* __rest
         float dy[EPL], xv[EPL], dx[EPL];
         load_row_bf16<EPL, VEC>(dxn + (size_t)row * D, lane, dy);
         load_row_f32<EPL, VEC>(x + (size_t)row * D, lane, xv);
-        load_row_f32<EPL, VEC>(dx_io + (size_t)row * D, lane, dx);
+        load_row_f32<EPL, VEC>(dx_in + (size_t)row * D, lane, dx);      // dx_in == dx_io: in place (a lane reads what it writes)
         const float mu = mean[row], rs = rstd[row];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -477,10 +477,24 @@ extern "C" int rtts_ln_fwd(const float* x, const float* gamma, const float* beta
     return 0;
 }
 
+extern "C" int rtts_ln_bwd_to(const void* dxn, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dx_in,
+                              float* dx_io, float* dgamma, float* dbeta, float* partial_ws, int M, int d, void* dyb_next, float* partial_next,
+                              float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
+
 extern "C" int rtts_ln_bwd(const void* dxn, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx_io,
                            float* dgamma, float* dbeta, float* partial_ws, int M, int d, void* dyb_next, float* partial_next,
                            float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream) {
+    return rtts_ln_bwd_to(dxn, x, mean, rstd, gamma, dx_io, dx_io, dgamma, dbeta, partial_ws, M, d, dyb_next, partial_next, drop_p, seed,
+                          seed_dev, stream);
+}
+
+// dx_out = dx_in + dLN(dxn): the out-of-place form (dx_in == dx_out: rtts_ln_bwd).  The stack executor uses it for the FIRST update
+// of each gradient stream, which starts as the caller's dout itself instead of a copy of it.
+extern "C" int rtts_ln_bwd_to(const void* dxn, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dx_in,
+                              float* dx_io, float* dgamma, float* dbeta, float* partial_ws, int M, int d, void* dyb_next, float* partial_next,
+                              float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream) {
     RTTS_ENTER(stream);
+    RTTS_REQUIRE(dx_in, "rtts_ln_bwd_to: null dx_in");
     RTTS_REQUIRE(!dyb_next || partial_next, "rtts_ln_bwd: dyb_next needs partial_next");
     RTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "rtts_ln_bwd: bad drop_p");
     RTTS_REQUIRE(dxn && x && mean && rstd && gamma && dx_io && partial_ws && M > 0 && (!dgamma == !dbeta), "rtts_ln_bwd: bad arguments");
@@ -489,7 +503,7 @@ extern "C" int rtts_ln_bwd(const void* dxn, const float* x, const float* mean, c
     float* pg = partial_ws;
     float* pb = partial_ws + (size_t)FR_PARTIAL_BLOCKS * d;
     const size_t lds = (size_t)FR_WAVES * d * sizeof(float);
-#define CALL(EPL, VEC) hipLaunchKernelGGL((ln_bwd_kernel<EPL, VEC>), dim3(blocks), dim3(FR_THREADS), lds, (hipStream_t)stream, (const bf16_t*)dxn, x, mean, rstd, gamma, dx_io, pg, pb, M, (bf16_t*)dyb_next, partial_next, seed, seed_dev, rtts_drop_thresh(drop_p), 1.f / (1.f - drop_p))
+#define CALL(EPL, VEC) hipLaunchKernelGGL((ln_bwd_kernel<EPL, VEC>), dim3(blocks), dim3(FR_THREADS), lds, (hipStream_t)stream, (const bf16_t*)dxn, x, mean, rstd, gamma, dx_in, dx_io, pg, pb, M, (bf16_t*)dyb_next, partial_next, seed, seed_dev, rtts_drop_thresh(drop_p), 1.f / (1.f - drop_p))
     FR_DISPATCH_D(d, CALL)
 #undef CALL
     if (dgamma) {       // NULL: the caller finalises the partial rows itself (rtts_colsum_final_grouped)

@@ -177,8 +177,8 @@ def flush_colsum(q: Optional[_Queue] = None):
                 _lib.call("rtts_colsum_final_grouped", arr, len(group), q.stream)
 
 
-def ln_bwd(dxn, x, mean, rstd, norm, dx_io, next_cast=None):
-    """dx_io += dLN(dxn); LayerNorm gradients queued (or added).  ``next_cast`` = (drop | None,): the completed dx_io is
+def ln_bwd(dxn, x, mean, rstd, norm, dx_io, next_cast=None, dx_in=None):
+    """dx_io += dLN(dxn) (``dx_in`` given: dx_io = dx_in + dLN(dxn), out of place); LayerNorm gradients queued (or added).  ``next_cast`` = (drop | None,): the completed dx_io is
     the next block's output gradient, so its bf16 copy (times that block's dropout keep-scale) and the partial column
     sums for that block's output bias are produced here -> (dyb, partial buffer, rows), else None."""
     m, d = x.shape
@@ -192,16 +192,17 @@ def ln_bwd(dxn, x, mean, rstd, norm, dx_io, next_cast=None):
         pn = torch.empty(256 * d, dtype=torch.float32, device=dev)
         args_next = (dyb.data_ptr(), pn.data_ptr(), float(p), seed, seed_base(dev).data_ptr())
         nxt = (dyb, pn, _partial_rows(m))
+    src = dx_io if dx_in is None else dx_in
     if DEFER_COLSUM:
         ws = torch.empty(2 * 256 * d, dtype=torch.float32, device=dev)
-        _lib.call("rtts_ln_bwd", dxn.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), norm.weight.data_ptr(),
-                  dx_io.data_ptr(), None, None, ws.data_ptr(), m, d, *args_next, _s())
+        _lib.call("rtts_ln_bwd_to", dxn.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), norm.weight.data_ptr(),
+                  src.data_ptr(), dx_io.data_ptr(), None, None, ws.data_ptr(), m, d, *args_next, _s())
         rows = _partial_rows(m)
         _queue_colsum(ws, 0, rows, d, _grad(norm.weight))
         _queue_colsum(ws, 256 * d, rows, d, _grad(norm.bias))
         return nxt
-    _lib.call("rtts_ln_bwd", dxn.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), norm.weight.data_ptr(),
-              dx_io.data_ptr(), _grad(norm.weight).data_ptr(), _grad(norm.bias).data_ptr(), _WS.partial(dev, d).data_ptr(),
+    _lib.call("rtts_ln_bwd_to", dxn.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), norm.weight.data_ptr(),
+              src.data_ptr(), dx_io.data_ptr(), _grad(norm.weight).data_ptr(), _grad(norm.bias).data_ptr(), _WS.partial(dev, d).data_ptr(),
               m, d, *args_next, _s())
     return nxt
 
@@ -341,6 +342,7 @@ DEFER_WGRAD = True
 # have left it by the end of the step.
 WGRAD_FLUSH_PER_LAYER = os.environ.get("RTTS_WGRAD_FLUSH", "layer") == "layer"
 WGRAD_MAX_PENDING = 64
+COPY_STREAMS = os.environ.get("RTTS_STREAM_COPIES", "0") == "1"     # A/B: copy x / dout into both streams instead of aliasing them
 # (A second HIP stream for the weight gradients, forked/joined by events = parallel branches of the captured hipGraph,
 #  was measured SLOWER on MI355X in round 1: 9.35 vs 8.94 ms/step; the cross-branch dependencies of the replayed graph
 #  cost more than the overlapped tails recover.  Removed.)
@@ -459,11 +461,14 @@ def wgrad(grad_view: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, accumulate
 
 
 # ------------------------------------------------------------------------------------------ blocks
-def _keep_streams(keep, slot, acc, inp, xn, mean, rstd):
+def _keep_streams(keep, slot, acc, inp, xn, mean, rstd, fresh=False):
     """``keep`` (the stack loop asks for it under STASH_STREAMS): -> the fresh buffer the updated stream goes to (also left in
     slot["acc_out"] for the loop to pick up), with the sublayer's LayerNorm input and output kept in the slot for its
     backward; else None: the stream is updated in place (an executor used on its own, or a recomputing mode)."""
     if not keep:
+        if fresh:       # the stream still IS the stack's input (both streams start as x, no copy): its first update goes elsewhere
+            out = slot["acc_out"] = torch.empty_like(acc)
+            return out
         return None
     out = torch.empty_like(acc)
     slot.update(inp=inp, pre=(xn, mean, rstd), acc_out=out)
@@ -527,7 +532,7 @@ class LSHExec:
             g = gemm(out.view(b * t, e), _bf16(lyr.to_out.weight))
         return xn, mean, rstd, wqkv, qkv, st, out, lse_tot, g
 
-    def forward(self, acc, inp, b, t, mask=None, pre=None, next_norm=None, slot=None, keep_streams=False, **_):
+    def forward(self, acc, inp, b, t, mask=None, pre=None, next_norm=None, slot=None, keep_streams=False, fresh_acc=False, **_):
         slot = self._own_slot if slot is None else slot
         # dropout on the attention probabilities (the layer's `dropout` knob): a (p, seed) pair the recompute and the backward reuse
         pa = getattr(self.layer, "dropout", 0.0) if self.layer.training else 0.0
@@ -537,9 +542,10 @@ class LSHExec:
         slot.clear()
         slot.update(st=st, stash=(out, lse_tot) if STASH_ATTENTION else None, g=g if STASH_BLOCK_OUTPUT else None,
                     qkv=qkv if STASH_PROJECTIONS else None, drop=(p, next_seed()) if p > 0.0 else None, adrop=adrop)
-        return residual(acc, g, self.layer.to_out.bias, 1.0, next_norm, slot["drop"], out=_keep_streams(keep_streams, slot, acc, inp, xn, mean, rstd))
+        return residual(acc, g, self.layer.to_out.bias, 1.0, next_norm, slot["drop"], out=_keep_streams(keep_streams, slot, acc, inp, xn, mean, rstd, fresh_acc))
 
-    def backward(self, acc, inp, d_acc, d_inp, b, t, mask=None, pre=None, next_norm=None, pre_cast=None, next_cast=None, slot=None, **_):
+    def backward(self, acc, inp, d_acc, d_inp, b, t, mask=None, pre=None, next_norm=None, pre_cast=None, next_cast=None, slot=None,
+                 d_src=None, **_):
         slot = self._own_slot if slot is None else slot
         if "st" not in slot:
             raise RuntimeError("LSHExec.backward: no forward state for this call (backward run twice, or without its forward)")
@@ -571,7 +577,7 @@ class LSHExec:
             pair[0].add_(full[:e])
             pair[1].add_(full[e:])
         dxn = gemm(dqkv2, wqkv, kn=True)
-        return post, ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp, next_cast)
+        return post, ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp, next_cast, dx_in=d_src)
 
 
 class FFNExec:
@@ -601,14 +607,14 @@ class FFNExec:
             g = gemm(h[0], _bf16(self.l2.weight))
         return xn, mean, rstd, h, g
 
-    def forward(self, acc, inp, b, t, pre=None, next_norm=None, slot=None, keep_streams=False, **_):
+    def forward(self, acc, inp, b, t, pre=None, next_norm=None, slot=None, keep_streams=False, fresh_acc=False, **_):
         slot = self._own_slot if slot is None else slot
         xn, mean, rstd, h, g = self._internals(inp, pre=pre)
         slot.clear()
         slot.update(g=g if STASH_BLOCK_OUTPUT else None, h=h if STASH_PROJECTIONS else None)
-        return residual(acc, g, self.l2.bias, 1.0, next_norm, out=_keep_streams(keep_streams, slot, acc, inp, xn, mean, rstd))
+        return residual(acc, g, self.l2.bias, 1.0, next_norm, out=_keep_streams(keep_streams, slot, acc, inp, xn, mean, rstd, fresh_acc))
 
-    def backward(self, acc, inp, d_acc, d_inp, b, t, pre=None, next_norm=None, pre_cast=None, next_cast=None, slot=None, **_):
+    def backward(self, acc, inp, d_acc, d_inp, b, t, pre=None, next_norm=None, pre_cast=None, next_cast=None, slot=None, d_src=None, **_):
         slot = self._own_slot if slot is None else slot
         if "g" not in slot:
             raise RuntimeError("FFNExec.backward: no forward state for this call (backward run twice, or without its forward)")
@@ -625,7 +631,7 @@ class FFNExec:
         dh = gemm(dyb, _bf16(self.l2.weight), kn=True, gate=h if words is None else True, gate_bias_grad=_grad(self.l1.bias), words=words)
         wgrad(_grad(self.l1.weight), dh, xn)
         dxn = gemm(dh, _bf16(self.l1.weight), kn=True)
-        return post, ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp, next_cast)
+        return post, ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp, next_cast, dx_in=d_src)
 
 
 class XAttnExec:
@@ -662,7 +668,8 @@ class XAttnExec:
             g = gemm(o, _bf16(m.out_proj.weight))
         return xn, mean, rstd, w, q, kv, o, lse, g, tk
 
-    def forward(self, acc, inp, b, t, keys_bf16=None, kvalid=None, pre=None, next_norm=None, slot=None, keep_streams=False, **_):
+    def forward(self, acc, inp, b, t, keys_bf16=None, kvalid=None, pre=None, next_norm=None, slot=None, keep_streams=False,
+                fresh_acc=False, **_):
         slot = self._own_slot if slot is None else slot
         p = self.mha.dropout if self.mha.training else 0.0
         pdrop = (p, next_seed()) if p > 0.0 else None
@@ -670,10 +677,10 @@ class XAttnExec:
         slot.clear()
         slot.update(stash=(o, lse) if STASH_ATTENTION else None, g=g if STASH_BLOCK_OUTPUT else None, pdrop=pdrop,
                     proj=(q, kv) if STASH_PROJECTIONS else None)
-        return residual(acc, g, self.mha.out_proj.bias, 1.0, next_norm, out=_keep_streams(keep_streams, slot, acc, inp, xn, mean, rstd))
+        return residual(acc, g, self.mha.out_proj.bias, 1.0, next_norm, out=_keep_streams(keep_streams, slot, acc, inp, xn, mean, rstd, fresh_acc))
 
     def backward(self, acc, inp, d_acc, d_inp, b, t, keys_bf16=None, kvalid=None, dkeys=None, pre=None, next_norm=None,
-                 pre_cast=None, next_cast=None, slot=None, **_):
+                 pre_cast=None, next_cast=None, slot=None, d_src=None, **_):
         slot = self._own_slot if slot is None else slot
         if "pdrop" not in slot:
             raise RuntimeError("XAttnExec.backward: no forward state for this call (backward run twice, or without its forward)")
@@ -710,7 +717,7 @@ class XAttnExec:
         wgrad(gw[:e], dq, xn)
         wgrad(gw[e:], dkv, keys_bf16)
         dxn = gemm(dq, w[:e], kn=True)
-        nxt = ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp, next_cast)
+        nxt = ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp, next_cast, dx_in=d_src)
         residual(dkeys, gemm(dkv, w[e:], kn=True), None, 1.0)                 # dkeys (fp32) += dkv W_kv
         return post, nxt
 
@@ -839,10 +846,13 @@ class FusedStackFn(torch.autograd.Function):
                 s1 = x.detach().reshape(b * t, d)
                 s1 = s2 = s1 if s1.dtype == torch.float32 and s1.is_contiguous() else s1.float().contiguous()
             else:
-                # both streams start as x: one broadcast copy into a (2, B*T, d) buffer (x is read once, one launch)
-                both = torch.empty(2, b * t, d, dtype=x.dtype, device=x.device)
-                both.copy_(x.detach().reshape(1, b * t, d).expand(2, -1, -1))
-                s1, s2 = both[0], both[1]
+                # both streams start as x ITSELF (no copy): an executor's first update of a stream that is still x goes to a
+                # fresh buffer (``fresh_acc``), later ones are in place -- the reference copies x twice (reformer.py:85,143)
+                s1 = x.detach().reshape(b * t, d)
+                s1 = s2 = s1 if s1.dtype == torch.float32 and s1.is_contiguous() else s1.float().contiguous()
+            own1 = own2 = kept            # does the stream have a buffer of its own?  (kept: every update is out of place anyway)
+            if not kept and COPY_STREAMS:          # A/B switch: round 2's form, two copies of x up front
+                s1, s2, own1, own2 = s1.clone(), s1.clone(), True, True
             extra = {}
             if context is not None:
                 kpm = next((k.get("key_padding_mask") for k in kwargs_list if "key" in k), None)
@@ -865,23 +875,28 @@ class FusedStackFn(torch.autograd.Function):
             keys_ready = getattr(context, "_rtts_ready", None) if context is not None else None
             for i, (kind, f, g, kw) in enumerate(steps):
                 if kind == "swap":
-                    s1, s2 = s2, s1
+                    s1, s2, own1, own2 = s2, s1, own2, own1
                 elif kind == "half":
                     if keys_ready is not None and "keys_bf16" in kw:
                         # the encoder ran on a stream of its own beside the decoder's first blocks (Trainer, overlapped step):
                         # the first cross-attention is where the two meet
                         torch.cuda.current_stream().wait_event(keys_ready)
                         keys_ready = None
-                    post = f.forward(s1, s2, b, t, slot=slots[(i, "f")], keep_streams=kept, **kw, **chain.args(i, "f", s2))
-                    s1 = slots[(i, "f")].pop("acc_out", s1)
+                    post = f.forward(s1, s2, b, t, slot=slots[(i, "f")], keep_streams=kept, fresh_acc=not own1, **kw,
+                                     **chain.args(i, "f", s2))
+                    s1, own1 = slots[(i, "f")].pop("acc_out", s1), True
                     chain.done(post, s1)
                 else:
-                    post = f.forward(s1, s2, b, t, slot=slots[(i, "f")], keep_streams=kept, **kw, **chain.args(i, "f", s2))
-                    s1 = slots[(i, "f")].pop("acc_out", s1)
+                    post = f.forward(s1, s2, b, t, slot=slots[(i, "f")], keep_streams=kept, fresh_acc=not own1, **kw,
+                                     **chain.args(i, "f", s2))
+                    s1, own1 = slots[(i, "f")].pop("acc_out", s1), True
                     chain.done(post, s1)
-                    post = g.forward(s2, s1, b, t, slot=slots[(i, "g")], keep_streams=kept, **chain.args(i, "g", s1))
-                    s2 = slots[(i, "g")].pop("acc_out", s2)
+                    post = g.forward(s2, s1, b, t, slot=slots[(i, "g")], keep_streams=kept, fresh_acc=not own2, **chain.args(i, "g", s1))
+                    s2, own2 = slots[(i, "g")].pop("acc_out", s2), True
                     chain.done(post, s2)
+            if not (own1 and own2) and not kept:
+                # a stack that never updated one of its streams: the backward reconstructs in place, so it must not be x
+                s1, s2 = (s1 if own1 else s1.clone()), (s2 if own2 else s2.clone())
             if x.dtype == torch.float32 and (b * t * d) % 4 == 0:
                 # the sum of the streams in fp32 (the autograd value) and in bf16 (what the heads / the cross attention's key
                 # projection read), one launch
@@ -932,9 +947,17 @@ def stack_backward_steps(ctx, dout, complete_layers: Optional[bool] = None, noti
     if guard is not None and guard[0]._version != guard[1]:
         raise RuntimeError("the input of a reversible stack was modified in place between its forward and its backward: with the streams "
                            "kept (engine.STASH_STREAMS) the first sublayer reads it again -- clone it before writing to it")
-    gboth = torch.empty(2, b * t, d, dtype=torch.float32, device=dout.device)
-    gboth.copy_(dout.detach().reshape(1, b * t, d).expand(2, -1, -1))
-    g1, g2 = gboth[0], gboth[1]
+    # both gradient streams start as dout ITSELF (read only): the first LayerNorm backward that completes a stream writes it to a
+    # fresh buffer (rtts_ln_bwd_to), later ones accumulate in place -- no (2, B*T, d) copy of dout
+    g1 = dout.detach().reshape(b * t, d)
+    g1 = g2 = g1 if g1.dtype == torch.float32 and g1.is_contiguous() else g1.float().contiguous()
+    gown1 = gown2 = False
+    if COPY_STREAMS:
+        g1, g2, gown1, gown2 = g1.clone(), g1.clone(), True, True
+
+    def target(g, owned):
+        """-> (buffer the executor accumulates into, its source when that differs)"""
+        return (g, None) if owned else (torch.empty_like(g), g)
     dkeys = None
     if has_ctx:
         dkeys = torch.zeros(extra["keys_bf16"].shape, dtype=torch.float32, device=dout.device)
@@ -945,23 +968,29 @@ def stack_backward_steps(ctx, dout, complete_layers: Optional[bool] = None, noti
     for i in range(len(steps) - 1, -1, -1):
         kind, f, g, kw = steps[i]
         if kind == "swap":
-            s1, s2, g1, g2 = s2, s1, g2, g1
+            s1, s2, g1, g2, gown1, gown2 = s2, s1, g2, g1, gown2, gown1
         elif kind == "half":
             if "keys_bf16" in kw:
                 kw = dict(kw, dkeys=dkeys)
-            post, nxt = f.backward(s1, s2, g1, g2, b, t, slot=slots[(i, "f")], **kw, **chain.args(i, "f", s2),
+            dst, src = target(g2, gown2)
+            post, nxt = f.backward(s1, s2, g1, dst, b, t, slot=slots[(i, "f")], d_src=src, **kw, **chain.args(i, "f", s2),
                                    **chain.grad_args(i, "f", g1))
+            g2, gown2 = dst, True
             chain.done(post, s1)
             chain.grad_done(nxt, g2)
             if notify_dkeys and key_blocks and i == key_blocks[0]:
                 yield seq, ("dkeys", dkeys.view(b, -1, d))
         else:
-            post, nxt = g.backward(s2, s1, g2, g1, b, t, slot=slots[(i, "g")], **chain.args(i, "g", s1),
+            dst, src = target(g1, gown1)
+            post, nxt = g.backward(s2, s1, g2, dst, b, t, slot=slots[(i, "g")], d_src=src, **chain.args(i, "g", s1),
                                    **chain.grad_args(i, "g", g2))
+            g1, gown1 = dst, True
             chain.done(post, s2)
             chain.grad_done(nxt, g1)
-            post, nxt = f.backward(s1, s2, g1, g2, b, t, slot=slots[(i, "f")], **kw, **chain.args(i, "f", s2),
+            dst, src = target(g2, gown2)
+            post, nxt = f.backward(s1, s2, g1, dst, b, t, slot=slots[(i, "f")], d_src=src, **kw, **chain.args(i, "f", s2),
                                    **chain.grad_args(i, "f", g1))
+            g2, gown2 = dst, True
             chain.done(post, s1)
             chain.grad_done(nxt, g2)
         done.append(i)
