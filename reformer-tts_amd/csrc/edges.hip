@@ -112,11 +112,21 @@ __global__ __launch_bounds__(ED_THREADS) void conv_w_perm_grouped_kernel(const C
     const int Co = J.Co, Ci = J.Ci, CP = J.CP;
     const float* __restrict__ w = J.w;
     bf16_t* __restrict__ wp = (bf16_t*)J.wp;
-    const size_t total = (size_t)Co * 5 * CP;
+    // one (co, ci) pair per thread and pass: its five taps are 20 contiguous bytes of w (a wave reads 1280 contiguous bytes; with a
+    // tap per thread every lane touched a different 20-byte group and used 4 of them), and each tap's row of wp takes a wave's 64
+    // values as one 128-byte store
+    const size_t total = (size_t)Co * CP;
     const size_t nthr = (size_t)(g.blk_start[ji + 1] - g.blk_start[ji]) * blockDim.x;
     for (size_t i = (size_t)((int)blockIdx.x - g.blk_start[ji]) * blockDim.x + threadIdx.x; i < total; i += nthr) {
-        const int ci = (int)(i % CP), k = (int)((i / CP) % 5), co = (int)(i / ((size_t)CP * 5));
-        wp[i] = ci < Ci ? f32_to_bf16(w[((size_t)co * Ci + ci) * 5 + k]) : (bf16_t)0;
+        const int ci = (int)(i % CP), co = (int)(i / CP);
+        float t[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (ci < Ci) {
+            const float* src = w + ((size_t)co * Ci + ci) * 5;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) t[k] = src[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) wp[((size_t)co * 5 + k) * CP + ci] = f32_to_bf16(t[k]);
     }
 }
 __global__ __launch_bounds__(ED_THREADS) void conv_dw_unperm_grouped_kernel(const CwGroup g) {
@@ -128,11 +138,14 @@ __global__ __launch_bounds__(ED_THREADS) void conv_dw_unperm_grouped_kernel(cons
     const int Co = J.Co, Ci = J.Ci, CP = J.CP;
     const float* __restrict__ dwp = J.w;
     float* __restrict__ dw = (float*)J.wp;
-    const size_t total = (size_t)Co * Ci * 5;
+    // one (co, ci) pair per thread and pass, as above: five coalesced row reads, 20 contiguous bytes of dw updated
+    const size_t total = (size_t)Co * Ci;
     const size_t nthr = (size_t)(g.blk_start[ji + 1] - g.blk_start[ji]) * blockDim.x;
     for (size_t i = (size_t)((int)blockIdx.x - g.blk_start[ji]) * blockDim.x + threadIdx.x; i < total; i += nthr) {
-        const int k = (int)(i % 5), ci = (int)((i / 5) % Ci), co = (int)(i / ((size_t)Ci * 5));
-        dw[i] += dwp[((size_t)co * 5 + k) * CP + ci];
+        const int ci = (int)(i % Ci), co = (int)(i / Ci);
+        float* dst = dw + i * 5;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) dst[k] += dwp[((size_t)co * 5 + k) * CP + ci];
     }
 }
 // dw[co][ci][k] += dwp[co][k][ci]
@@ -771,7 +784,7 @@ extern "C" int rtts_conv_w_perm_grouped(const rtts_conv_perm_job* jobs, int n, v
         RTTS_REQUIRE(jobs[i].w && jobs[i].wp && jobs[i].Co > 0 && jobs[i].Ci > 0 && jobs[i].CP >= jobs[i].Ci, "rtts_conv_w_perm_grouped: bad job %d", i);
         g.j[i] = jobs[i];
         g.blk_start[i] = blk;
-        blk += (int)ed_grid((size_t)jobs[i].Co * 5 * jobs[i].CP);
+        blk += (int)ed_grid((size_t)jobs[i].Co * jobs[i].CP);
     }
     for (int i = n; i <= RTTS_CONV_PERM_MAX_GROUP; ++i) g.blk_start[i] = blk;
     hipLaunchKernelGGL(conv_w_perm_grouped_kernel, dim3(blk), dim3(ED_THREADS), 0, (hipStream_t)stream, g);
@@ -789,7 +802,7 @@ extern "C" int rtts_conv_dw_unperm_grouped(const rtts_conv_perm_job* jobs, int n
         RTTS_REQUIRE(jobs[i].w && jobs[i].wp && jobs[i].Co > 0 && jobs[i].Ci > 0 && jobs[i].CP >= jobs[i].Ci, "rtts_conv_dw_unperm_grouped: bad job %d", i);
         g.j[i] = jobs[i];
         g.blk_start[i] = blk;
-        blk += (int)ed_grid((size_t)jobs[i].Co * jobs[i].Ci * 5);
+        blk += (int)ed_grid((size_t)jobs[i].Co * jobs[i].Ci);
     }
     for (int i = n; i <= RTTS_CONV_PERM_MAX_GROUP; ++i) g.blk_start[i] = blk;
     hipLaunchKernelGGL(conv_dw_unperm_grouped_kernel, dim3(blk), dim3(ED_THREADS), 0, (hipStream_t)stream, g);
