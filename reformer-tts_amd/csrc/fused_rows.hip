@@ -363,8 +363,11 @@ struct CsGroup {
     CsJob j[RTTS_COLSUM_MAX_GROUP];
     int n;
 };
-__global__ __launch_bounds__(FR_THREADS) void colsum_final_grouped_kernel(const CsGroup grp) {
-    __shared__ float red[FR_WAVES][64];
+// 16 waves per 64 columns: a job has up to 256 partial rows, i.e. <= 16 loads per wave, all in flight at once (with 4 waves
+// and 64 dependent-latency loads each the launch took 14 us for ~10 MB -- latency, not bandwidth)
+#define CS_WAVES 16
+__global__ __launch_bounds__(64 * CS_WAVES) void colsum_final_grouped_kernel(const CsGroup grp) {
+    __shared__ float red[CS_WAVES][64];
     int ji = 0;
 #pragma unroll 1
     for (int i = 1; i < grp.n; ++i)
@@ -374,12 +377,24 @@ __global__ __launch_bounds__(FR_THREADS) void colsum_final_grouped_kernel(const 
     const int c = ((int)blockIdx.x - J.blk_start) * 64 + lane;
     float s = 0.f;
     if (c < J.n) {
-#pragma unroll 8
-        for (int r = wave; r < J.nrows; r += FR_WAVES) s += J.partial[(size_t)r * J.ld + c];
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int r = wave + k * CS_WAVES;
+            v[k] = r < J.nrows ? J.partial[(size_t)r * J.ld + c] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) s += (v[k] + v[k + 1]) + (v[k + 2] + v[k + 3]);
+        for (int r = wave + 16 * CS_WAVES; r < J.nrows; r += CS_WAVES) s += J.partial[(size_t)r * J.ld + c];
     }
     red[wave][lane] = s;
     __syncthreads();
-    if (wave == 0 && c < J.n) J.out[c] += (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (wave == 0 && c < J.n) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < CS_WAVES; w += 4) t += (red[w][lane] + red[w + 1][lane]) + (red[w + 2][lane] + red[w + 3][lane]);
+        J.out[c] += t;
+    }
 }
 
 // ---------------------------------------------------------------- elementwise epilogues
@@ -599,7 +614,7 @@ extern "C" int rtts_colsum_final_grouped(const rtts_colsum_job* jobs, int n, voi
         grp.j[i].blk_start = blk;
         blk += (jobs[i].n + 63) / 64;
     }
-    hipLaunchKernelGGL(colsum_final_grouped_kernel, dim3(blk), dim3(FR_THREADS), 0, (hipStream_t)stream, grp);
+    hipLaunchKernelGGL(colsum_final_grouped_kernel, dim3(blk), dim3(64 * CS_WAVES), 0, (hipStream_t)stream, grp);
     RTTS_LAUNCH_CHECK("rtts_colsum_final_grouped");
     return 0;
 }
