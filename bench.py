@@ -59,12 +59,13 @@ def parse():
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     ap.add_argument("--strict", action="store_true", help="raise when the committed PMC traffic file does not match the kernel / shape of this run")
     ap.add_argument("--recompute", default="full", choices=["stash", "projection-stash", "output-stash", "attention-stash", "full"],
-                    help="what the reversible backward recomputes: 'full' = everything, as the reference does; "
-                         "'attention-stash' = attention outputs kept; 'output-stash' = block outputs f(x) kept too; 'projection-stash' = and the "
-                         "projections, streams still reconstructed by subtraction; 'stash' (default) = and the streams: every "
-                         "sublayer's LayerNorm input / output and projections stay in HBM (~1 GB of 288 GB), the backward "
-                         "recomputes nothing.  The mode named here is the headline (value / ms_per_step); the other end of the "
-                         "range is timed in the same run (top-level key 'stash' or 'full_recompute')")
+                    help="TTSTrainingConfig.recompute for the headline leg -- what the reversible backward recomputes: 'full' (the "
+                         "default HERE, the headline: BASELINE.json's north_star names the activation recompute) = everything, as the "
+                         "reference does; 'attention-stash' = attention outputs kept; 'output-stash' = block outputs f(x) kept too; "
+                         "'projection-stash' = and the projections, streams still reconstructed by subtraction; 'stash' (the "
+                         "package's own default for training, the secondary number reported here) = and the streams: every sublayer's "
+                         "LayerNorm input / output and projections stay in HBM (~1 GB of 288 GB), the backward recomputes nothing.  "
+                         "The other end of the range is timed in the same run (top-level key 'stash' or 'full_recompute')")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 12 if args.config == "baseline" else 4
@@ -158,13 +159,6 @@ def main():
 
     from reformer_tts_amd import engine, ops
 
-    def set_mode(mode):
-        engine.STASH_ATTENTION = mode != "full"
-        engine.STASH_BLOCK_OUTPUT = mode in ("stash", "projection-stash", "output-stash")
-        engine.STASH_PROJECTIONS = mode in ("stash", "projection-stash")
-        engine.STASH_STREAMS = mode == "stash"
-
-    set_mode(args.recompute)
     from reformer_tts_amd.model.config import (baseline_model_config, baseline_training_config,
                                                long_sequence_model_config)
     from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
@@ -172,6 +166,13 @@ def main():
     model_cfg = baseline_model_config() if args.config == "baseline" else long_sequence_model_config()
     tcfg = baseline_training_config()
     tcfg.batch_size = args.batch
+    tcfg.recompute = args.recompute                       # TTSTrainingConfig.recompute: a configuration, read by Trainer
+
+    def set_mode(mode):
+        """The second leg of the run re-uses the trainer in the other mode: its configuration field, nothing else."""
+        trainer.cfg.recompute = trainer.recompute = mode
+        trainer._recompute_for.clear()
+
     model = build_model(model_cfg, dev, seed=42)          # identical init on every rank ...
     trainer = Trainer(model, tcfg, dev)                   # ... rank-dependent rotations and dropout (Trainer._decorrelate_replicas)
     batch = synthetic_batch(args.batch, args.text_len, args.mel_len, seed=42 + rank, device=dev)

@@ -80,8 +80,13 @@ int rtts_lsh_attn_fwd(const void* qk, const void* v, int64_t ld, const int32_t* 
 /* how rtts_lsh_attn_fwd works a shape: 0 = one workgroup per chunk (lsh_attn_fwd_kernel; small grids), R > 0 = workgroups
  * that walk runs of R consecutive chunks of a (batch, head) ring (lsh_attn_fwd_walk_kernel: every K / V row gathered once,
  * the next chunk's rows fetched while the current one is merged and stored; same results bit for bit).  -1: bad arguments.
- * RTTS_LSH_FWD_WALK=<R> in the environment forces a run length (0: the one-chunk kernel) for tests and A/B runs. */
+ * rtts_debug_set_walk() below forces a run length for tests and A/B runs; the launch path reads no environment. */
 int rtts_lsh_attn_fwd_run_length(int B, int H, int T, int n_hashes, int bucket_size);
+/* TEST-ONLY, process-wide (two atomic words): run length of the walking forward / backward kernels.  -1 = the library's own
+ * pick (the default: what every product call gets), 0 = the one-chunk kernel, n >= 1 = runs of n where n divides the ring
+ * (else the one-chunk kernel).  Replaces the RTTS_LSH_{FWD,BWD}_WALK environment variables the launch path used to read on
+ * every call; the Python binding reads those variables ONCE, when it loads the library, and calls this. */
+int rtts_debug_set_walk(int fwd_run, int bwd_run);
 
 /* ---- combine the hash rounds (step 11) and merge heads (first half of step 12) -------
  *   out     bf16 (B,T,H*dh) row stride ld_out

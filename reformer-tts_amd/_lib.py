@@ -58,6 +58,7 @@ SIGNATURES = {
                           _vp],
     "rtts_lsh_bwd_qk_slots": [],
     "rtts_lsh_attn_bwd_run_length": [_i32, _i32, _i32, _i32, _i32],
+    "rtts_debug_set_walk": [_i32, _i32],
     "rtts_lsh_bwd_reduce": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp],
     "rtts_grad_clip_scale": [_vp, _i64, _f32, _f32, _vp, _vp, _vp],
     "rtts_ln_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp],
@@ -136,6 +137,15 @@ def note_general_path(where: str, reason: str) -> None:
     logging.getLogger("reformer_tts_amd").warning("%s: general (eager) path instead of the explicit HIP executor -- %s", where, reason)
 
 
+def log_once(key: str, message: str) -> None:
+    """One WARNING per ``key`` through the package logger (decisions the user did not ask for but should see)."""
+    if key in _NOTED:
+        return
+    _NOTED.add(key)
+    import logging
+    logging.getLogger("reformer_tts_amd").warning("%s", message)
+
+
 def load() -> C.CDLL:
     global _lib
     if _lib is None:
@@ -157,7 +167,35 @@ def load() -> C.CDLL:
             fn.restype = C.c_int
         lib.rtts_gemm_nt_gate_words.restype = C.c_int64
         _lib = lib
+        # A/B scripts may name a run length in the environment: read ONCE, here -- the library's launch path reads none
+        fw, bw = os.environ.get("RTTS_LSH_FWD_WALK"), os.environ.get("RTTS_LSH_BWD_WALK")
+        if fw is not None or bw is not None:
+            _WALK[:] = [-1 if fw is None else int(fw), -1 if bw is None else int(bw)]
+            lib.rtts_debug_set_walk(*_WALK)
     return _lib
+
+
+_WALK = [-1, -1]
+
+
+class forced_walk:
+    """TEST-ONLY context manager: force the run length of the walking LSH attention kernels (``rtts_debug_set_walk``:
+    None = leave as it is, -1 = the library's pick, 0 = the one-chunk kernel, n = runs of n chunks)."""
+
+    def __init__(self, fwd=None, bwd=None):
+        self.want = (fwd, bwd)
+
+    def __enter__(self):
+        self.old = list(_WALK)
+        new = [o if w is None else int(w) for o, w in zip(self.old, self.want)]
+        call("rtts_debug_set_walk", *new)
+        _WALK[:] = new
+        return self
+
+    def __exit__(self, *exc):
+        call("rtts_debug_set_walk", *self.old)
+        _WALK[:] = self.old
+        return False
 
 
 def call(name: str, *args) -> None:

@@ -440,15 +440,8 @@ constexpr int gn_nst() { return (4 * (BM + BN) * 128 <= 160 * 1024) ? 4 : ((3 * 
 template <int BM, int BN, int WM, int WN, bool W_KN, int EPI, int NST>
 static int gn_launch3(const GnArgs& P, hipStream_t s) {
     constexpr size_t lds = (size_t)NST * (BM + BN) * 128;
-    static bool attr[64] = {};                   // per device: the dynamic-LDS limit is an attribute of the loaded function
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!attr[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<BM, BN, WM, WN, W_KN, EPI, NST>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        RTTS_REQUIRE(e == hipSuccess, "rtts_gemm_nt: cannot raise the dynamic LDS limit to %zu bytes", lds);
-        attr[dev] = true;
-    }
+    static RttsLdsState attr;                    // per device: the dynamic-LDS limit is an attribute of the loaded function
+    RTTS_ENSURE_LDS("rtts_gemm_nt", (gemm_nt_kernel<BM, BN, WM, WN, W_KN, EPI, NST>), lds, attr);
     const int grid = (P.M / BM) * (P.N / BN);
     hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, W_KN, EPI, NST>), dim3(grid), dim3(64 * WM * WN), lds, s, P);
     return 0;

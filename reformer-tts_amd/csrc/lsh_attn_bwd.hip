@@ -1049,7 +1049,7 @@ extern "C" int rtts_lsh_bwd_qk_slots(void) { return RTTS_LSH_BWD_QK_SLOTS; }
 // one-chunk kernel (small problems).  Measured (kbench, backward + reduce, us): decoder shape (128-row buckets) 272 + 83 ->
 // 231 + 40 at runs of 8; encoder shape (64-row buckets, T = 256) 50.8 + 16.0 -> 46.9 + 13.9 at runs of 4 (51.2 + 12.3 at 8:
 // too few workgroups); T = 4096 with 64-row buckets 246 + 109 -> 206 + 72 at runs of 8.
-// RTTS_LSH_BWD_WALK=<run> forces a run length for tests and A/B runs (0: the one-chunk kernel).
+// rtts_debug_set_walk() forces a run length for tests and A/B runs (0: the one-chunk kernel).
 extern "C" int rtts_lsh_attn_bwd_run_length(int B, int H, int T, int n_hashes, int bucket_size) {
     if (B <= 0 || H <= 0 || n_hashes <= 0 || bucket_size <= 0 || T <= 0 || T % bucket_size) return -1;
     const int C = n_hashes * (T / bucket_size);
@@ -1058,11 +1058,8 @@ extern "C" int rtts_lsh_attn_bwd_run_length(int B, int H, int T, int n_hashes, i
     if (AB_KT2 == 1)
         for (int cand = 8; cand >= 4; cand >>= 1)
             if (C % cand == 0 && chunks / cand >= 768) { R = cand; break; }
-    const char* walk_s = getenv("RTTS_LSH_BWD_WALK");
-    if (walk_s && AB_KT2 == 1) {
-        const int w = atoi(walk_s);
-        R = (w >= 1 && C % w == 0) ? w : 0;
-    }
+    const int w = rtts_walk_override(1);          // tests / A-B runs only (rtts_debug_set_walk); -1 in every product call
+    if (w >= 0 && AB_KT2 == 1) R = (w >= 1 && C % w == 0) ? w : 0;
     return R;
 }
 
@@ -1076,8 +1073,6 @@ static int launch_attn_bwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const 
     const bool drop = drop_p > 0.f;
     const int vi = (drop ? 4 : 0) + (causal ? 2 : 0) + (mask ? 1 : 0);
     const AbDrop dr{drop_seed, seed_dev, rtts_drop_thresh(drop_p), 1.f / (1.f - drop_p)};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     const int C = n_hashes * (T / BS);
     const long long chunks = (long long)B * H * C;
     const int R = rtts_lsh_attn_bwd_run_length(B, H, T, n_hashes, BS);
@@ -1086,16 +1081,12 @@ static int launch_attn_bwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const 
                                 "row_flags (B*H*n_hashes*T bytes) is required", R);
         const size_t ds_bytes = (size_t)NK * (BS * 2), stg_bytes = (size_t)(NK / 32) * 32 * AB_ROWB;
         const size_t wlds = (size_t)BS * 40 + 5 * (size_t)BS * 128 + (ds_bytes > stg_bytes ? ds_bytes : stg_bytes);
-        static bool wattr[64][8] = {};
+        static RttsLdsState wattr[8];
         const dim3 wgrid((unsigned)(chunks / R)), wblock(BS * 4);
 #define AB_WGO(C_, M_, D_)                                                                                                 \
     do {                                                                                                                   \
         auto kern = lsh_attn_bwd_walk_kernel<BS, C_, M_, D_>;                                                              \
-        if (!wattr[dev][vi]) {                                                                                             \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds); \
-            RTTS_REQUIRE(e == hipSuccess, "rtts_lsh_attn_bwd: cannot raise the dynamic LDS limit to %zu bytes", wlds);     \
-            wattr[dev][vi] = true;                                                                                         \
-        }                                                                                                                  \
+        RTTS_ENSURE_LDS("rtts_lsh_attn_bwd", kern, wlds, wattr[vi]);                                                       \
         hipLaunchKernelGGL(kern, wgrid, wblock, wlds, stream, qk, v, ld, st, mask, dout, ld_do, lse_tot, delta, H, T, n_hashes, \
                            dqk_part, dv_part, slot_stride, R, row_flags, dr);                                              \
     } while (0)
@@ -1112,15 +1103,11 @@ static int launch_attn_bwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const 
     }
     const size_t lds = NK * 128 + BS * 128 + NK * (BS * 2) + (NK / 32) * 32 * AB_ROWB + NK * 12 + BS * 12;
     const dim3 grid(B * H * n_hashes * (T / BS)), block(BS * 4 / AB_KT2);
-    static bool attr[64][8] = {};                // per device: the dynamic-LDS limit is an attribute of the loaded function
+    static RttsLdsState attr[8];                 // per device: the dynamic-LDS limit is an attribute of the loaded function
 #define AB_GO(C_, M_, D_)                                                                                                  \
     do {                                                                                                                   \
         auto kern = lsh_attn_bwd_kernel<BS, C_, M_, D_>;                                                                   \
-        if (!attr[dev][vi]) {                                                                                              \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            RTTS_REQUIRE(e == hipSuccess, "rtts_lsh_attn_bwd: cannot raise the dynamic LDS limit to %zu bytes", lds);      \
-            attr[dev][vi] = true;                                                                                          \
-        }                                                                                                                  \
+        RTTS_ENSURE_LDS("rtts_lsh_attn_bwd", kern, lds, attr[vi]);                                                         \
         hipLaunchKernelGGL(kern, grid, block, lds, stream, qk, v, ld, st, mask, dout, ld_do, lse_tot, delta, H, T, n_hashes, \
                            dqk_part, dv_part, slot_stride, dr);                                                            \
     } while (0)
@@ -1152,6 +1139,8 @@ extern "C" int rtts_lsh_attn_bwd(const void* qk, const void* v, int64_t ld, cons
     RTTS_REQUIRE((((uintptr_t)qk | (uintptr_t)v | (uintptr_t)dout | (uintptr_t)dqk_part | (uintptr_t)dv_part) & 15) == 0,
                  "rtts_lsh_attn_bwd: buffers must be 16-byte aligned");
     RTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "rtts_lsh_attn_bwd: drop_p must be in [0, 1)");
+    RTTS_REQUIRE(drop_p == 0.f || (uint64_t)B * H * n_hashes * T * 2 * bucket_size < (1ull << 32),
+                 "rtts_lsh_attn_bwd: dropout on more than 2^32 query-key pairs (the forward refuses the same shape)");
     hipStream_t s = (hipStream_t)stream;
     if (bucket_size == 64)
         return launch_attn_bwd<64>((const bf16_t*)qk, (const bf16_t*)v, ld, st, mask, (const bf16_t*)dout, ld_dout, lse_tot, delta,

@@ -17,13 +17,12 @@
 //   4. O^T += V^T P^T: the P^T accumulators are the B operand as they stand (rows of X are the
 //      contraction index), V^T fragments come from the row-major V image by ds_read_b64_tr_b16;
 //   5. rows of o and lse are written directly at their UNSORTED position (round, t).
-// The kernel is built for occupancy: ~120 VGPRs, tile loop not unrolled, 2 workgroups (16 waves) per CU.  It is LATENCY-bound,
-// not VALU-bound as round 2 assumed: a variant with the running maximum replaced by the bound |q| dh^-1/2 of the normalised
-// keys' logits (no max, no rescale, one exp per logit: 6.5 vector issue slots per logit instead of 8.5, same registers, no
-// spills) measured 124-125 us against 121 us at the decoder shape and 116 against 107 us at T = 4096
-// (gpurun_out/r03_kbench_fwd_{fixed,nofixed}.log; round 3) -- removed again.  A wave's chain through a key tile
-// (4 dependent MFMAs, ~150 dependent vector instructions at one issue per 4 cycles, 4 MFMAs) sets the pace, four waves per
-// SIMD out of phase do not fill the issue slots, and gather -> tiles -> merge -> stores is one serial chain per workgroup.
+// The kernel is built for occupancy: ~120 VGPRs, tile loop not unrolled, 2 workgroups (16 waves) per CU.  What bounds it is the
+// VECTOR ALU and the transcendental unit, not latency (an earlier reading of the counters said "latency"
+// and was wrong: SQ_ACTIVE_INST_VALU is in quad-cycles per wave, four waves share a SIMD, the vector ALU is ~90 % busy): per
+// wave and chunk ~1030 vector instructions against 32 MFMAs, of which the tile loop is 4 x (111 vector + 16 v_exp_f32).  Hence
+// the lazy running maximum (the rescale of O and l almost never runs), v_dot2c row norms, tree-shaped sums, and the walking form
+// below (every K / V row gathered once).  Ablations: profiles/r03_lsh_attn_fwd_ablation.log, r03_lsh_attn_fwd_walk_ablation.log.
 #include "rtts_common.h"
 #include <float.h>
 
@@ -686,7 +685,7 @@ static RttsLdsState g_fwd_walk_lds[2][8];
 
 // Chunks a workgroup of the walking form works in a row: the longest run (8, 4, 2) that divides the ring and still leaves three
 // rounds of workgroups for the chip (256 CUs x 2 resident workgroups of 128-row buckets, x 4 of 64-row buckets); 0 = the
-// one-chunk kernel (small grids: the encoder's T = 256).  RTTS_LSH_FWD_WALK=<run> forces a run length (tests, A/B runs).
+// one-chunk kernel (small grids: the encoder's T = 256).  rtts_debug_set_walk() forces a run length (tests, A/B runs).
 extern "C" int rtts_lsh_attn_fwd_run_length(int B, int H, int T, int n_hashes, int bucket_size) {
     if (B <= 0 || H <= 0 || n_hashes <= 0 || (bucket_size != 64 && bucket_size != 128) || T <= 0 || T % bucket_size) return -1;
     const int C = n_hashes * (T / bucket_size);
@@ -695,11 +694,8 @@ extern "C" int rtts_lsh_attn_fwd_run_length(int B, int H, int T, int n_hashes, i
     int R = 0;
     for (int cand = 8; cand >= 2; cand >>= 1)
         if (C % cand == 0 && chunks / cand >= 3 * resident) { R = cand; break; }
-    const char* walk_s = getenv("RTTS_LSH_FWD_WALK");
-    if (walk_s) {
-        const int w = atoi(walk_s);
-        R = (w >= 1 && w <= 16 && C % w == 0) ? w : 0;
-    }
+    const int w = rtts_walk_override(0);          // tests / A-B runs only (rtts_debug_set_walk); -1 in every product call
+    if (w >= 0) R = (w >= 1 && w <= 16 && C % w == 0) ? w : 0;
     return R;
 }
 
@@ -753,7 +749,10 @@ extern "C" int rtts_lsh_attn_fwd(const void* qk, const void* v, int64_t ld, cons
     RTTS_REQUIRE(ld >= (int64_t)H * dh && ld % 8 == 0, "rtts_lsh_attn_fwd: ld must be >= H*dh and a multiple of 8");
     RTTS_REQUIRE((((uintptr_t)qk | (uintptr_t)v | (uintptr_t)o) & 15) == 0, "rtts_lsh_attn_fwd: qk, v, o must be 16-byte aligned");
     RTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "rtts_lsh_attn_fwd: drop_p must be in [0, 1)");
-    RTTS_REQUIRE((uint64_t)B * H * n_hashes * T * 2 * bucket_size < (1ull << 32), "rtts_lsh_attn_fwd: more than 2^32 query-key pairs");
+    // the dropout mask is a hash of the 32-bit pair index: beyond 2^32 pairs masks would repeat (forward and backward wrap alike,
+    // so gradients would still match; refused all the same).  Without dropout nothing indexes pairs: no limit.
+    RTTS_REQUIRE(drop_p == 0.f || (uint64_t)B * H * n_hashes * T * 2 * bucket_size < (1ull << 32),
+                 "rtts_lsh_attn_fwd: dropout on more than 2^32 query-key pairs");
     hipStream_t s = (hipStream_t)stream;
     if (bucket_size == 64)
         return launch_attn_fwd<64>((const bf16_t*)qk, (const bf16_t*)v, ld, st, mask, B, H, T, n_hashes, causal, (bf16_t*)o, lse, drop_p,

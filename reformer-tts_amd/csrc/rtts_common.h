@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 
 #include "../../include/rtts.h"
 
@@ -17,6 +18,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define RTTS_LDS __attribute__((address_space(3)))
 
 extern "C" void rtts_set_error(const char* fmt, ...);
+// test-only overrides of the LSH kernels' run lengths (rtts_debug_set_walk, rtts_api.cpp): -1 = the library's own pick
+int rtts_walk_override(int backward);
 
 #define RTTS_REQUIRE(cond, ...)            \
     do {                                   \
@@ -68,14 +71,19 @@ static inline int rtts_bind_device(void* stream) {
 
 // The dynamic-LDS limit is an attribute of a LOADED function, i.e. per device: raise it once per (function, device), again when
 // a later call needs more, and report a failure at the call that caused it instead of at some later launch.
-struct RttsLdsState { size_t set[64]; };
+// Forwards (Python main thread) and backwards (autograd's worker thread) launch concurrently: the per-device record is atomic,
+// and two threads that both find it too small both raise the limit (idempotent) -- no launch can run ahead of its attribute.
+struct RttsLdsState { std::atomic<size_t> set[64]; };
 static inline hipError_t rtts_ensure_lds(const void* func, size_t lds, RttsLdsState& st) {
     if (lds <= 64 * 1024) return hipSuccess;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (st.set[dev] >= lds) return hipSuccess;
+    if (st.set[dev].load(std::memory_order_acquire) >= lds) return hipSuccess;
     const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) st.set[dev] = lds;
+    if (e == hipSuccess) {
+        size_t cur = st.set[dev].load(std::memory_order_relaxed);
+        while (cur < lds && !st.set[dev].compare_exchange_weak(cur, lds, std::memory_order_release, std::memory_order_relaxed)) {}
+    }
     return e;
 }
 #define RTTS_ENSURE_LDS(name, func, lds, state)                                                                   \

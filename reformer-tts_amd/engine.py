@@ -52,6 +52,67 @@ _NO_G = object()          # "the block output is not needed" (no reconstruction)
 
 def _streams_kept() -> bool:
     return STASH_STREAMS and STASH_ATTENTION and STASH_BLOCK_OUTPUT and STASH_PROJECTIONS
+
+
+# The four switches above as ONE named mode, from the reference's behaviour (everything recomputed from the reconstructed
+# streams: /root/reference/reformer_tts/model/reversible.py:114-129, 69-98) to "the backward recomputes nothing", ordered by
+# what they hold in HBM.  This is what ``TTSTrainingConfig.recompute`` names and what ``Trainer`` applies before every forward.
+RECOMPUTE_MODES = ("full", "attention-stash", "output-stash", "projection-stash", "stash")
+
+
+def set_recompute(mode: str) -> str:
+    """Select what a stack's forward keeps for its backward; -> the mode that was active.  A forward and ITS backward agree by
+    construction (the backward reads what the forward's slot holds), so the mode may change between steps."""
+    global STASH_ATTENTION, STASH_BLOCK_OUTPUT, STASH_PROJECTIONS, STASH_STREAMS
+    if mode not in RECOMPUTE_MODES:
+        raise ValueError(f"recompute mode {mode!r}: expected one of {RECOMPUTE_MODES}")
+    old = recompute_mode()
+    rank = RECOMPUTE_MODES.index(mode)
+    STASH_ATTENTION, STASH_BLOCK_OUTPUT, STASH_PROJECTIONS, STASH_STREAMS = rank >= 1, rank >= 2, rank >= 3, rank >= 4
+    return old
+
+
+def recompute_mode() -> str:
+    """Name of the active mode (the four switches set by hand to a combination without a name: the nearest lower one)."""
+    rank = 0
+    for on in (STASH_ATTENTION, STASH_BLOCK_OUTPUT, STASH_PROJECTIONS, STASH_STREAMS):
+        if not on:
+            break
+        rank += 1
+    return RECOMPUTE_MODES[rank]
+
+
+def stash_bytes(program, rows: int, d: int, mode: str, key_rows: int = 0) -> int:
+    """Estimate of what the forward of one stack (``build_program`` list) holds in HBM for its backward in ``mode``, beyond
+    the two final streams every mode keeps: ``rows`` = B x T_pad tokens of width ``d``, ``key_rows`` = B x T_text for the cross
+    attention.  Counted per sublayer: attention-stash the attention output (bf16) + one fp32 logsumexp per token.head;
+    output-stash + f(x) (bf16); projection-stash + qk|v, q, k|v, the feed-forward hidden activation and its 1-bit gate;
+    stash + the sublayer's input stream (fp32), its LayerNorm output (bf16) and statistics."""
+    if mode not in RECOMPUTE_MODES:
+        raise ValueError(f"recompute mode {mode!r}: expected one of {RECOMPUTE_MODES}")
+    rank = RECOMPUTE_MODES.index(mode)
+    total = 0
+    for step in program:
+        for ex in step[1:3]:
+            if ex is None:
+                continue
+            per = 0
+            if isinstance(ex, (LSHExec, XAttnExec)):
+                heads = ex.layer.heads if isinstance(ex, LSHExec) else ex.mha.num_heads
+                if rank >= 1:
+                    per += rows * d * 2 + rows * heads * 4
+                if rank >= 3:
+                    per += rows * 2 * d * 2 if isinstance(ex, LSHExec) else rows * d * 2 + key_rows * 2 * d * 2
+            elif isinstance(ex, FFNExec):
+                ff = ex.l1.weight.shape[0]
+                if rank >= 3:
+                    per += rows * ff * 2 + rows * ff // 8
+            if rank in (2, 3):                      # with the streams kept nothing is reconstructed: f(x) is dropped again
+                per += rows * d * 2
+            if rank >= 4:
+                per += rows * d * 4 + rows * d * 2 + rows * 8
+            total += per
+    return total
 WEIGHT_EPOCH = [0]   # bumped by the trainer after every optimizer step (its kernels write parameters through raw pointers)
 
 
@@ -149,9 +210,25 @@ def _queue() -> _Queue:
     return q
 
 
-def _all_queues():
+def _all_queues(keys=None):
+    """Every queue, or -- ``keys`` = an iterable of (device index, stream handle) -- only those an owner names: a trainer
+    flushes / discards / counts what ITS streams queued, not what another trainer or thread of the process has pending."""
     with _QLOCK:
-        return list(_QUEUES.values())
+        if keys is None:
+            return list(_QUEUES.values())
+        return [_QUEUES[k] for k in keys if k in _QUEUES]
+
+
+def drop_stream_state(device_index: int, stream: int) -> None:
+    """Forget the scratch and the (empty) queue of a stream that will not be used again (a warm-up stream): the 64 MB slab,
+    the column-sum scratch and the queue object are keyed by stream handle and would otherwise live as long as the process."""
+    with _QLOCK:
+        q = _QUEUES.get((device_index, stream))
+        if q is not None and not len(q):
+            del _QUEUES[(device_index, stream)]
+    for key in [k for k in _WS._cache if isinstance(k, tuple) and k[-1] == stream and
+                (getattr(k[0], "index", None) == device_index or getattr(k[1], "index", None) == device_index)]:
+        del _WS._cache[key]
 
 
 def _partial_rows(m: int) -> int:
@@ -372,13 +449,14 @@ def _queue_final_flush():
             pass
 
 
-def flush_wgrad(colsums: bool = True):
-    """Launch every queued weight gradient and (``colsums``) column-sum finalisation, grouped; release the held operands.
+def flush_wgrad(colsums: bool = True, keys=None):
+    """(``keys``: only the queues of these (device index, stream handle) pairs -- see ``_all_queues``.)
+    Launch every queued weight gradient and (``colsums``) column-sum finalisation, grouped; release the held operands.
     ``colsums=False`` (the per-layer flush of the stack loop when nobody waits for a block's gradients): the small partial
     buffers stay queued for fewer, fuller launches -- the end-of-backward flush takes them.
     EVERY queue is drained (all devices, all streams, whichever thread filled them), each on its own stream: the trainer's
     flush after ``loss.backward()`` on the main thread sees what autograd's worker thread queued."""
-    for q in _all_queues():
+    for q in _all_queues(keys):
         q.flush_queued = False         # the next deferral queues a fresh end-of-backward callback (extra ones are no-ops);
         #                                a backward that died half-way cannot leave the flag stuck
         if not len(q):
@@ -402,11 +480,11 @@ def flush_wgrad(colsums: bool = True):
                 hook(q)
 
 
-def discard_pending() -> int:
-    """Drop everything queued (a backward that raised half-way must not leak its entries into the next step's gradients).
-    -> number of entries dropped."""
+def discard_pending(keys=None) -> int:
+    """Drop everything queued (a backward that raised half-way must not leak its entries into the next step's gradients);
+    ``keys``: only the caller's own queues.  -> number of entries dropped."""
     n = 0
-    for q in _all_queues():
+    for q in _all_queues(keys):
         n += len(q)
         q.clear()
     return n
@@ -420,9 +498,9 @@ def pending_wgrads() -> int:
     return len(_queue().wgrads)
 
 
-def pending_all() -> int:
-    """Every deferred entry of every queue (0 after a flush: Trainer.backward asserts it)."""
-    return sum(len(q) for q in _all_queues())
+def pending_all(keys=None) -> int:
+    """Every deferred entry of every queue -- of the caller's own queues with ``keys`` (0 after a flush: Trainer.backward asserts it)."""
+    return sum(len(q) for q in _all_queues(keys))
 
 
 def wgrad(grad_view: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, accumulate: bool = True):

@@ -120,6 +120,12 @@ class TTSTrainingConfig:
     # this package's addition (not a key of the reference's TTSTrainingConfig): under data parallelism, BatchNorm statistics
     # over the GLOBAL batch (what the reference's single-process BatchNorm sees) instead of each rank's own rows
     sync_batchnorm: bool = False
+    # this package's addition: what the reversible backward recomputes (``engine.RECOMPUTE_MODES``).  "full" is the reference
+    # (``model/reversible.py:114-129``: only each stack's output survives the forward, every block is re-run in the backward);
+    # "attention-stash" / "output-stash" / "projection-stash" keep the attention outputs / + the block outputs f(x) / + the
+    # projections; "stash" keeps the streams too and recomputes nothing (~1 GB more at the baseline shapes, of 288 GB).  A mode
+    # whose estimated footprint does not fit the free HBM is lowered, with one log line (``Trainer.resolve_recompute``).
+    recompute: str = "stash"
 
 
 def _merge(dc, overrides: dict):

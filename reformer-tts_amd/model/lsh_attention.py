@@ -63,6 +63,60 @@ class _LSHAttnFn(torch.autograd.Function):
         return dqkv, None, None, None, None, None, None
 
 
+def _gemm_tiles(m: int, n: int, k: int) -> bool:
+    """Does rtts_gemm_nt take y (m, n) = x (m, k) W^T, its input gradient (m, k) = dy (m, n) W and rtts_gemm_tn the weight
+    gradient?  (row tiles of 96 / 128 / 192 / 256, column tiles of 64 / 128, 64-deep K stages; dW: 128 | n, 128 | k, 64 | m)"""
+    rows = any(m % r == 0 for r in (96, 128))
+    return rows and n % 128 == 0 and k % 128 == 0 and m % 64 == 0
+
+
+class _ProjectFn(torch.autograd.Function):
+    """y (M, N) bf16 = x (M, K) bf16 @ cat(weights)^T [+ bias], every product on the in-tree MFMA kernels: forward and input
+    gradient on ``rtts_gemm_nt`` (the weight read in place as [N][K] resp. [K][N]), weight gradient on ``rtts_gemm_tn``, bias
+    gradient by ``rtts_colsum_bf16`` -- the projections of the layer a maintainer gets from INTEGRATION.md section 1
+    (``/root/reference/reformer_tts/model/reformer.py:198-217``) run no library GEMM.  ``weights``: one fp32 parameter (N, K), or
+    two that are stacked along N (toqk | tov: ONE (M, d) x (d, 2d) product)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, *weights):
+        from .. import engine
+        wb = (weights[0] if len(weights) == 1 else torch.cat(weights, dim=0)).detach().to(torch.bfloat16)
+        y = engine.gemm(x, wb, bias=None if bias is None else bias.detach().float().contiguous())
+        ctx.save_for_backward(x, wb)
+        ctx.split = [w.shape[0] for w in weights]
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import _lib, engine
+        x, wb = ctx.saved_tensors
+        dy = dy if (dy.dtype == torch.bfloat16 and dy.is_contiguous()) else dy.to(torch.bfloat16).contiguous()
+        dx = engine.gemm(dy, wb, kn=True) if ctx.needs_input_grad[0] else None
+        dw = torch.empty(wb.shape, dtype=torch.float32, device=x.device)
+        engine.wgrad(dw, dy, x, accumulate=False)
+        db = None
+        if ctx.has_bias:
+            m, n = dy.shape
+            db = torch.zeros(n, dtype=torch.float32, device=x.device)
+            ws = torch.empty(256 * n, dtype=torch.float32, device=x.device)
+            _lib.call("rtts_colsum_bf16", dy.data_ptr(), None, dy.stride(0), db.data_ptr(), ws.data_ptr(), m, n, 0, 1.0, None,
+                      torch.cuda.current_stream().cuda_stream)
+        return (dx, db, *torch.split(dw, ctx.split, dim=0))
+
+
+def _project(x2, bias, *weights):
+    """(M, K) bf16 -> (M, N) bf16 on the in-tree GEMMs where the shape tiles, else the library (said once)."""
+    m, k = x2.shape
+    n = sum(w.shape[0] for w in weights)
+    if x2.is_cuda and _gemm_tiles(m, n, k):
+        return _ProjectFn.apply(x2, bias, *weights)
+    from .._lib import note_general_path
+    note_general_path("LSH attention projections", f"({m} x {k}) -> {n} does not tile (rows % 96 or 128, widths % 128): library GEMM")
+    w = (weights[0] if len(weights) == 1 else torch.cat(weights, dim=0)).to(torch.bfloat16)
+    return F.linear(x2, w, None if bias is None else bias.to(torch.bfloat16))
+
+
 class LSHSelfAttention(nn.Module):
     def __init__(self, dim, heads=8, bucket_size=64, n_hashes=8, causal=False, add_local_attn_hash=False,
                  attn_chunks=1, random_rotations_per_head=False, attend_across_buckets=True,
@@ -149,8 +203,8 @@ class LSHSelfAttention(nn.Module):
             raise NotImplementedError("full-attention shortcut (T <= full_attn_thres) is outside the HIP path")
         if t % (self.bucket_size * 2) != 0:
             raise AssertionError(f"Sequence length ({t}) needs to be divisible by target bucket size  x 2 - {self.bucket_size * 2}")
-        w = torch.cat([self.toqk.weight, self.tov.weight], dim=0).to(torch.bfloat16)
-        qkv = F.linear(x.to(torch.bfloat16), w)                              # (B,T,2d) = [qk | v]
+        # (B,T,2d) = [qk | v]: ONE product over the stacked weights, on rtts_gemm_nt (forward, input gradient) / rtts_gemm_tn
+        qkv = _project(x.to(torch.bfloat16).reshape(b * t, e), None, self.toqk.weight, self.tov.weight).view(b, t, 2 * e)
         state = self._generator_state(x.device)
         saved, st = self._saved, None
         grad_on = torch.is_grad_enabled()        # read here: the block below runs under no_grad
@@ -179,5 +233,5 @@ class LSHSelfAttention(nn.Module):
         self.last_st = st
         mask = None if input_mask is None else input_mask.to(torch.uint8)
         out = _LSHAttnFn.apply(qkv, st, mask, self.heads, self.bucket_size, self.causal, drop)
-        y = F.linear(out, self.to_out.weight.to(torch.bfloat16), self.to_out.bias.to(torch.bfloat16))
+        y = _project(out.reshape(b * t, e), self.to_out.bias, self.to_out.weight).view(b, t, e)     # bias in the GEMM's fp32 epilogue
         return self.post_attn_dropout(y.float())

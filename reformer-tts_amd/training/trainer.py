@@ -81,9 +81,16 @@ class Trainer:
                 raise ValueError("lr_scheduler: end_schedule_epoch or max_epochs must be set")
             if end <= sch.start_schedule_epoch:
                 raise ValueError(f"lr_scheduler: the schedule must end after it starts (start {sch.start_schedule_epoch}, end {end})")
-        if getattr(cfg, "sync_batchnorm", False) and self.world > 1:
-            from .. import edges
-            edges.SYNC_BN = process_group if process_group is not None else dist.group.WORLD
+        from .. import edges
+        # the group lives on this trainer and is (re)installed before every forward (``_apply_modes``): a later trainer of the
+        # same process with the option off must not inherit it
+        self._sync_bn = (process_group if process_group is not None else dist.group.WORLD) \
+            if (getattr(cfg, "sync_batchnorm", False) and self.world > 1) else None
+        edges.SYNC_BN = self._sync_bn
+        self.recompute = str(getattr(cfg, "recompute", "stash"))
+        if self.recompute not in engine.RECOMPUTE_MODES:
+            raise ValueError(f"tts_training.recompute = {self.recompute!r}: expected one of {engine.RECOMPUTE_MODES}")
+        self._recompute_for = {}                         # padded batch shape -> the mode that fits the free HBM
         self._decorrelate_replicas()
         self._flatten()
         self._make_buckets()
@@ -233,8 +240,61 @@ class Trainer:
         self._pre_in = x.detach().requires_grad_(True)
         return self._pre_in
 
+    # ------------------------------------------------------------------ what the backward recomputes
+    HBM_HEADROOM = 0.85         # share of the free HBM a stash may claim (the rest: workspaces, the allocator's slack)
+
+    def stash_estimate(self, batch, mode: str) -> int:
+        """Bytes the forward of both stacks holds for the backward in ``mode`` at this batch's padded shape
+        (``engine.stash_bytes``; 0 when a stack runs the general path)."""
+        pb = self.model.pad_base
+        b, lp = batch["phonemes"].shape
+        lm = self._frames(batch)[0].shape[1]
+        te, td = -(-lp // pb) * pb, -(-lm // pb) * pb
+        total = 0
+        for seq, rows, keys in ((self.model.enc.reformer.layers, b * te, 0), (self.model.dec.reformer.layers, b * td, b * te)):
+            if not getattr(seq, "_program_built", True):          # built lazily by the stack's first forward: do it now
+                seq._program, seq._program_built = engine.build_program(seq), True
+            prog = getattr(seq, "_program", None)
+            if prog:
+                total += engine.stash_bytes(prog, rows, self.model.dec.mel_linear.in_features, mode, keys)
+        return total
+
+    def resolve_recompute(self, batch, free_bytes: Optional[int] = None) -> str:
+        """The configured mode, or -- when its estimated footprint does not fit ``HBM_HEADROOM`` of the free HBM -- the
+        highest lower mode that does ("full" always does: it holds nothing).  Decided once per padded batch shape, logged
+        once when it differs from the configuration; a captured graph keeps the mode it was captured in."""
+        key = self._shape_key(batch) if "spectrogram" in batch else tuple(batch["phonemes"].shape) + tuple(self._frames(batch)[0].shape[:2])
+        hit = self._recompute_for.get(key)
+        if hit is not None and free_bytes is None:
+            return hit
+        mode = self.recompute
+        if self.device.type == "cuda" or free_bytes is not None:
+            if free_bytes is None:
+                free, _ = torch.cuda.mem_get_info(self.device)
+                # what the caching allocator holds but does not use is available to the stash too
+                free += torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
+            else:
+                free = int(free_bytes)
+            rank = engine.RECOMPUTE_MODES.index(mode)
+            while rank > 0 and self.stash_estimate(batch, engine.RECOMPUTE_MODES[rank]) > self.HBM_HEADROOM * free:
+                rank -= 1
+            if engine.RECOMPUTE_MODES[rank] != mode:
+                need = self.stash_estimate(batch, mode)
+                mode = engine.RECOMPUTE_MODES[rank]
+                _lib.log_once(f"recompute:{key}", f"tts_training.recompute = {self.recompute!r} would hold ~{need / 2**30:.2f} GiB for the "
+                              f"backward at batch shape {key}; {free / 2**30:.2f} GiB of HBM are free: running this shape in mode {mode!r}")
+        self._recompute_for[key] = mode
+        return mode
+
+    def _apply_modes(self, batch):
+        """Process-wide switches this trainer owns, installed before each of its forwards (two trainers may alternate)."""
+        from .. import edges
+        edges.SYNC_BN = self._sync_bn
+        engine.set_recompute(self.resolve_recompute(batch))     # cached per shape: a capture (after its warm-up passes) asks nothing of the device
+
     def forward_loss(self, batch, split: bool = False):
         """``wrappers.py:53-72``: input frames [0, L-1), targets [1, L), mask = loss_mask.mean(-1)."""
+        self._apply_modes(batch)
         spec = self._frames(batch)[0]
         from ..model.lsh_attention import LSHSelfAttention
         if getattr(self, "_graph_rotations", False):
@@ -285,22 +345,39 @@ class Trainer:
                 w.wait()
             self._pending.clear()
 
-    @staticmethod
-    def _run_backward(loss):
+    def _queue_keys(self):
+        """(device index, stream handle) of the streams this trainer launches on -- the deferred-gradient queues it owns."""
+        if self.device.type != "cuda":
+            return None
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        keys = [(idx, torch.cuda.current_stream(self.device).cuda_stream)]
+        if getattr(self, "_enc_stream_obj", None) is not None:
+            keys.append((idx, self._enc_stream_obj.cuda_stream))
+        return keys
+
+    def _warm_stream(self):
+        """ONE side stream per trainer for every warm-up pass in front of a capture (scratch buffers and queues are keyed by
+        stream handle: a fresh stream per capture would pin a 64 MB slab each for the life of the process)."""
+        if getattr(self, "_warm_stream_obj", None) is None:
+            self._warm_stream_obj = torch.cuda.Stream(self.device)
+        return self._warm_stream_obj
+
+    def _run_backward(self, loss):
         """``loss.backward()`` + the flush of the deferred gradient work (weight gradients, column sums, convolution
         re-layouts are queued by the executors and launched grouped).  The executors queue from autograd's worker thread; the
         queues are keyed by (device, stream), so this flush on the calling thread drains them.  Nothing may stay queued: a
         leftover entry would be added to the NEXT step's gradients after ``zero_grad``.  A backward that raises drops its
         entries."""
+        keys = self._queue_keys()             # this trainer's queues only: another trainer / thread keeps what it has pending
         try:
             loss.backward()
-            engine.flush_wgrad()
+            engine.flush_wgrad(keys=keys)
         except BaseException:
-            engine.discard_pending()
+            engine.discard_pending(keys)
             raise
-        left = engine.pending_all()
+        left = engine.pending_all(keys)
         if left:
-            engine.discard_pending()
+            engine.discard_pending(keys)
             raise RuntimeError(f"{left} deferred gradient launches were still queued after the flush")
 
     def backward(self, loss):
@@ -618,7 +695,7 @@ class Trainer:
         # the warm-up passes below must not leak into the running step: gradients and BatchNorm statistics are put back
         saved_g = self.flat_g.clone()
         saved_buffers = [(t, t.clone()) for t in self.model.buffers()]
-        side = torch.cuda.Stream()
+        side = self._warm_stream()
         side.wait_stream(torch.cuda.current_stream())
         try:
             for seq, _ in hooks:
@@ -667,7 +744,7 @@ class Trainer:
             self._acc_scale.fill_(1.0 / n)
         if getattr(self, "_graph_opt_only", None) is None and any(e is not None for e in entries):
             self.set_step_hyper(self.global_step)
-            side = torch.cuda.Stream()
+            side = self._warm_stream()
             side.wait_stream(torch.cuda.current_stream())
             saved = [t.clone() for t in (self.flat_p, self.flat_m, self.flat_v, self.flat_pb)]
             with torch.cuda.stream(side):
@@ -744,7 +821,7 @@ class Trainer:
                 m.use_default_generator = True
         self._graph_rotations = True
         self._bulk_allreduce = bool(segmented)
-        side = torch.cuda.Stream()
+        side = self._warm_stream()
         side.wait_stream(torch.cuda.current_stream())
         step = self.train_step_overlapped if (self.overlap_encoder and self.world == 1 and not segmented) else self.train_step
         with torch.cuda.stream(side):

@@ -10,6 +10,20 @@ from oracle import lsh_int, lsh_ref
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture
+def force_walk():
+    """Force the run length of the walking kernels for the rest of the test (``rtts_debug_set_walk`` of include/rtts.h through
+    ``_lib.forced_walk``: the library's launch path reads no environment variable); undone when the test ends."""
+    import contextlib
+    from reformer_tts_amd import _lib
+    stack = contextlib.ExitStack()
+
+    def force(fwd=None, bwd=None):
+        stack.enter_context(_lib.forced_walk(fwd, bwd))
+    yield force
+    stack.close()
+
+
 @pytest.fixture(scope="module")
 def ops():
     if not torch.cuda.is_available():
@@ -118,14 +132,14 @@ def _run_fwd(ops, b, h, t, bs, nh, causal, masked, seed=0):
 
 @pytest.mark.parametrize("walk", ["0", "4"])
 @pytest.mark.parametrize("b,h,t,bs,nh,causal,masked", CASES)
-def test_attention_forward_vs_oracle(ops, monkeypatch, b, h, t, bs, nh, causal, masked, walk):
+def test_attention_forward_vs_oracle(ops, force_walk, b, h, t, bs, nh, causal, masked, walk):
     """Tolerance: inputs are identical bf16 values; the kernel rounds P to bf16 (2^-9 rel) before
     PV and o/out to bf16 on store => |err| ~ 4e-3 * max|v| on rows that see other tokens (bounds: 3x achieved).
     Rows that can only see themselves (lse ~ -5e4) sit on fp32's 4e-3 logsumexp grid, so the
     round weights legitimately differ there (see oracle/lsh_ref.py).  ``walk``: the one-chunk kernel / the walking kernel at
     runs of 4 chunks (what the decoder shape gets; these test shapes would get the one-chunk kernel by themselves)."""
     if int(walk) == 0 or (nh * (t // bs)) % int(walk) == 0:
-        monkeypatch.setenv("RTTS_LSH_FWD_WALK", walk)
+        force_walk(fwd=int(walk))
     r = _run_fwd(ops, b, h, t, bs, nh, causal, masked)
     dh = r["dh"]
     qk = _heads_first(r["qkv"][..., :h * dh], b, t, h, dh)
@@ -153,16 +167,17 @@ def test_attention_forward_vs_oracle(ops, monkeypatch, b, h, t, bs, nh, causal, 
 
 
 # ------------------------------------------------------------------ attention backward
-@pytest.mark.parametrize("walk", ["0", "4"])
+@pytest.mark.parametrize("walk", ["0", "4", "8"])
 @pytest.mark.parametrize("b,h,t,bs,nh,causal,masked", CASES)
-def test_attention_backward_vs_oracle_autograd(ops, monkeypatch, b, h, t, bs, nh, causal, masked, walk):
+def test_attention_backward_vs_oracle_autograd(ops, force_walk, b, h, t, bs, nh, causal, masked, walk):
     """Gradients of sum(out * dout) w.r.t. qk and v against autograd through the oracle on the same
-    permutation, for both forms of the kernel (``walk``: one workgroup per chunk / workgroups walking 4 chunks --
-    the library picks by shape, the small test shapes would all get the first).  bf16 partials and bf16 P/dS operands
+    permutation, for both forms of the kernel (``walk``: one workgroup per chunk / workgroups walking 4 or 8 chunks -- 8 is what
+    the library picks at the bench shape, the small test shapes would all get the first; the library's own pick at the bench
+    shape is ``test_attention_backward_at_the_bench_shape_with_the_library_pick``).  bf16 partials and bf16 P/dS operands
     put the error at ~0.5% of the gradient scale; the bounds are 3x what is achieved."""
     if (nh * (t // bs)) % max(int(walk), 1):
         pytest.skip("the run length does not divide this ring")
-    monkeypatch.setenv("RTTS_LSH_BWD_WALK", walk)
+    force_walk(bwd=int(walk))
     r = _run_fwd(ops, b, h, t, bs, nh, causal, masked, seed=3)
     dh = r["dh"]
     g = torch.Generator().manual_seed(11)
@@ -190,9 +205,44 @@ def test_attention_backward_vs_oracle_autograd(ops, monkeypatch, b, h, t, bs, nh
           " (tol max 1.5e-2, mean 1e-3, rel-L2 1e-2)")
 
 
+def test_attention_at_the_bench_shape_with_the_library_pick(ops):
+    """BASELINE config #2's decoder shape (B = 12, H = 8, T = 1024, 128-row buckets, 8 rounds, causal): NOTHING forced -- the
+    library's own pick is the walking forward at runs of 4 and the walking backward at runs of 8 (what ``bench.py`` times as
+    ``roofline``), compared directly with the oracle and its autograd on the same permutation (about 10 s of CPU oracle)."""
+    from reformer_tts_amd import _lib
+    b, h, t, bs, nh, causal = 12, 8, 1024, 128, 8, True
+    lib = _lib.load()
+    assert _lib._WALK == [-1, -1], "a run length is forced (RTTS_LSH_*_WALK in the environment?): this test is about the library's pick"
+    assert lib.rtts_lsh_attn_fwd_run_length(b, h, t, nh, bs) == 4 and lib.rtts_lsh_attn_bwd_run_length(b, h, t, nh, bs) == 8
+    r = _run_fwd(ops, b, h, t, bs, nh, causal, False, seed=21)
+    dh = r["dh"]
+    dout = torch.randn(b, t, h * dh, generator=torch.Generator().manual_seed(17)).bfloat16()
+    dqk, dv = ops.lsh_attn_bwd(r["qk_d"], r["v_d"], r["st"], r["out"], dout.cuda(), r["lse_tot"], h, bs, causal, None)
+    torch.cuda.synchronize()
+    qk = _heads_first(r["qkv"][..., :h * dh], b, t, h, dh).requires_grad_()
+    v = _heads_first(r["qkv"][..., h * dh:], b, t, h, dh).requires_grad_()
+    sticker, undo = _flat_perm(r["st"].cpu())
+    out_ref, o_ref, lse_ref = lsh_ref.lsh_attention_sorted(qk, v, sticker, undo, bs, nh, causal, None, return_parts=True)
+    vmax = v.abs().max().item()
+    e_o = (r["o"].float().cpu() - o_ref.detach()).abs().max().item() / vmax
+    e_out = (_heads_first(r["out"], b, t, h, dh) - out_ref.detach()).abs().max().item() / vmax
+    torch.testing.assert_close(r["lse"].cpu(), lse_ref.detach(), rtol=1e-3, atol=1e-3)
+    assert e_o < 1.2e-2 and e_out < 1.2e-2, (e_o, e_out)
+    out_ref.backward(_heads_first(dout, b, t, h, dh))
+    msgs = []
+    for got, ref, name in ((_heads_first(dv, b, t, h, dh), v.grad, "dv"), (_heads_first(dqk, b, t, h, dh), qk.grad, "dqk")):
+        scale = ref.abs().max().item()
+        err = (got - ref).abs()
+        rel = float((got - ref).norm() / ref.norm())
+        msgs.append(f"{name} max {err.max().item() / scale:.2e} mean {err.mean().item() / scale:.2e} rel-L2 {rel:.2e}")
+        assert err.max().item() < 1.5e-2 * scale and err.mean().item() < 1e-3 * scale and rel < 1e-2, (name, msgs[-1])
+    print(f"\n[lsh attention at the bench shape, library's pick: forward runs of 4, backward runs of 8] o max {e_o:.2e}, out max {e_out:.2e} "
+          f"of max|v|; " + "; ".join(msgs) + " (tol max 1.5e-2, mean 1e-3, rel-L2 1e-2)")
+
+
 @pytest.mark.parametrize("walk", ["0", "4"])
 @pytest.mark.parametrize("b,h,t,bs,nh,causal,masked", [CASES[0], CASES[2], CASES[5]])
-def test_attention_probability_dropout_vs_oracle(ops, monkeypatch, b, h, t, bs, nh, causal, masked, walk):
+def test_attention_probability_dropout_vs_oracle(ops, force_walk, b, h, t, bs, nh, causal, masked, walk):
     """The layer's `dropout` knob (reference reformer_tts/model/config.py:27): the chunk's softmax output
     is dropped before it meets the values, lse is that of the undropped probabilities.  The kernels draw the mask from a
     counter hash of (seed, pair index); the oracle gets the SAME mask as explicit keep-scales (oracle/synth.py rebuilds the
@@ -202,7 +252,7 @@ def test_attention_probability_dropout_vs_oracle(ops, monkeypatch, b, h, t, bs, 
     from reformer_tts_amd._seeds import seed_base
     if (nh * (t // bs)) % max(int(walk), 1):
         pytest.skip("the run length does not divide this ring")
-    monkeypatch.setenv("RTTS_LSH_BWD_WALK", walk)
+    force_walk(bwd=int(walk))
     p_drop, seed = 0.25, 0x1234567
     r = _run_fwd(ops, b, h, t, bs, nh, causal, masked, seed=9)
     dh = r["dh"]
@@ -244,7 +294,7 @@ def test_attention_probability_dropout_vs_oracle(ops, monkeypatch, b, h, t, bs, 
 
 @pytest.mark.parametrize("drop", [None, (0.25, 77)])
 @pytest.mark.parametrize("b,h,t,bs,nh,causal,masked", CASES)
-def test_walking_forward_matches_the_one_chunk_kernel(ops, monkeypatch, b, h, t, bs, nh, causal, masked, drop):
+def test_walking_forward_matches_the_one_chunk_kernel(ops, force_walk, b, h, t, bs, nh, causal, masked, drop):
     """lsh_attn_fwd as workgroups that walk a run of consecutive chunks (every K / V row gathered once, the next chunk's
     rows fetched while the current one is merged and stored) against the one-chunk kernel: the arithmetic of a chunk is the
     same instruction sequence in both, so o and lse must agree BIT FOR BIT for every run length that divides the ring --
@@ -258,7 +308,7 @@ def test_walking_forward_matches_the_one_chunk_kernel(ops, monkeypatch, b, h, t,
     for run in (0, 1, 2, 4, 8):
         if run and ring % run:
             continue
-        monkeypatch.setenv("RTTS_LSH_FWD_WALK", str(run))
+        force_walk(fwd=run)
         assert _lib.load().rtts_lsh_attn_fwd_run_length(b, h, t, nh, bs) == run
         o, lse = ops.lsh_attn_fwd(r["qk_d"], r["v_d"], r["st"], h, bs, causal, m, drop)
         torch.cuda.synchronize()
@@ -270,7 +320,7 @@ def test_walking_forward_matches_the_one_chunk_kernel(ops, monkeypatch, b, h, t,
 
 
 @pytest.mark.parametrize("b,h,t,bs,nh,causal,masked", CASES)
-def test_walking_backward_matches_the_one_chunk_kernel(ops, monkeypatch, b, h, t, bs, nh, causal, masked):
+def test_walking_backward_matches_the_one_chunk_kernel(ops, force_walk, b, h, t, bs, nh, causal, masked):
     """lsh_attn_bwd as workgroups that walk R consecutive chunks of a ring (operands of the next chunk prefetched by
     LDS-DMA, a chunk's keys worked by the same waves in their own and their looked-back step, every key row written
     once) against the one-chunk kernel: the same sums, with ONE bf16 rounding per key row where the one-chunk kernel
@@ -284,7 +334,7 @@ def test_walking_backward_matches_the_one_chunk_kernel(ops, monkeypatch, b, h, t
     for run in (0, 1, 2, 4, 8):
         if run and ring % run:
             continue
-        monkeypatch.setenv("RTTS_LSH_BWD_WALK", str(run))
+        force_walk(bwd=run)
         dqk, dv = ops.lsh_attn_bwd(r["qk_d"], r["v_d"], r["st"], r["out"], dout, r["lse_tot"], h, bs, causal, m)
         torch.cuda.synchronize()
         outs[run] = (dqk.float(), dv.float())

@@ -616,10 +616,11 @@ def test_conv1d_k5_implicit_gemm_vs_float64(gpu, b, l, ci, co):
 def test_attention_stash_matches_pure_recompute(gpu, attn_dropout):
     """(attn_dropout > 0: the LSH layers' `dropout` knob -- probability dropout inside the attention kernels; the recomputing
     modes must redraw the forward's mask from the kept (p, seed), else the reconstruction and the gradients drift apart.)
-    STASH_ATTENTION / STASH_BLOCK_OUTPUT / STASH_PROJECTIONS keep the attention outputs / the block outputs f(x) / the
-    projections (qk|v, q, k|v, the feed-forward hidden activation) of the forward for the
-    backward instead of recomputing them from the RECONSTRUCTED stream (which differs from the forward's stream in the
-    last fp32 bits, so the modes are not bitwise equal): gradients agree to rounding with the reference's pure recompute."""
+    ``TTSTrainingConfig.recompute`` -- the CONFIGURATION field the Trainer reads, YAML-loadable -- selects what the forward
+    keeps: "attention-stash" / "output-stash" / "projection-stash" keep the attention outputs / + the block outputs f(x) / + the
+    projections (qk|v, q, k|v, the feed-forward hidden activation); "stash" the streams too; "full" is the reference's pure
+    recompute from the RECONSTRUCTED stream (which differs from the forward's stream in the last fp32 bits, so the modes are
+    not bitwise equal): gradients of every mode agree with "full" to rounding."""
     from reformer_tts_amd import engine
     from reformer_tts_amd.model.config import TTSTrainingConfig, model_config_from_dict
     from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
@@ -629,27 +630,79 @@ def test_attention_stash_matches_pure_recompute(gpu, attn_dropout):
     cfg["enc_reformer_kwargs"]["attn_kwargs"]["dropout"] = attn_dropout
     cfg["dec_reformer_kwargs"]["self_attn_kwargs"]["dropout"] = attn_dropout
     batch = synthetic_batch(2, 100, 256, device=gpu)
-    grads = []
-    old = engine.STASH_ATTENTION, engine.STASH_BLOCK_OUTPUT, engine.STASH_PROJECTIONS, engine.STASH_STREAMS
+    grads, held = {}, {}
+    before = engine.recompute_mode()
     try:
-        for stash, stash_out, stash_proj, streams in ((True, True, True, True), (True, True, True, False), (True, True, False, False),
-                                                      (True, False, False, False), (False, False, False, False)):
-            engine.STASH_ATTENTION, engine.STASH_BLOCK_OUTPUT, engine.STASH_PROJECTIONS, engine.STASH_STREAMS = stash, stash_out, stash_proj, streams
+        for mode in reversed(engine.RECOMPUTE_MODES):           # stash ... full
             from reformer_tts_amd import _seeds
             _seeds.reset()                              # every mode draws the same dropout seeds
             model = build_model(model_config_from_dict(cfg), gpu)
-            tr = Trainer(model, TTSTrainingConfig(batch_size=2), gpu)
+            tr = Trainer(model, TTSTrainingConfig(batch_size=2, recompute=mode), gpu)
             model.train()
             tr.zero_grad()
-            tr.forward_loss(batch)[0].backward()
             torch.cuda.synchronize()
-            grads.append(tr.flat_g.clone())
+            base = torch.cuda.memory_allocated(gpu)
+            loss = tr.forward_loss(batch)[0]
+            assert engine.recompute_mode() == mode              # the trainer installed its configuration, nobody poked a global
+            torch.cuda.synchronize()
+            held[mode] = torch.cuda.memory_allocated(gpu) - base
+            loss.backward()
+            torch.cuda.synchronize()
+            grads[mode] = tr.flat_g.clone()
+            est = tr.stash_estimate(batch, mode)
+            print(f"[recompute {mode}] estimate {est / 2**20:.1f} MiB, held after the forward {held[mode] / 2**20:.1f} MiB")
     finally:
-        engine.STASH_ATTENTION, engine.STASH_BLOCK_OUTPUT, engine.STASH_PROJECTIONS, engine.STASH_STREAMS = old
-    errs = [((g - grads[4]).norm() / grads[4].norm()).item() for g in grads[:4]]
-    print(f"\n[parity] stash modes vs pure recompute, relative gradient distance: streams kept {errs[0]:.2e}, streams reconstructed "
-          f"{errs[1]:.2e}, without projections {errs[2]:.2e}, attention only {errs[3]:.2e} (tol 1e-2)")
-    assert max(errs) < 1e-2
+        engine.set_recompute(before)
+    errs = {m: ((g - grads["full"]).norm() / grads["full"].norm()).item() for m, g in grads.items() if m != "full"}
+    print(f"\n[parity] recompute modes vs the reference's pure recompute, relative gradient distance: {errs} (tol 1e-2)")
+    assert max(errs.values()) < 1e-2
+    # the estimate orders the modes the way the measured footprint does, and is within a factor 2 of the measured difference to "full"
+    order = [held[m] for m in engine.RECOMPUTE_MODES]
+    assert order == sorted(order), held
+    for m in engine.RECOMPUTE_MODES[1:]:
+        measured = held[m] - held["full"]
+        est = tr.stash_estimate(batch, m)
+        assert 0.5 * measured <= est <= 2.0 * measured + (1 << 20), (m, est, measured)
+
+
+def test_recompute_falls_back_when_the_stash_does_not_fit(gpu, caplog):
+    """``Trainer.resolve_recompute``: a mode whose estimated footprint exceeds the free HBM is lowered to the highest mode that
+    fits -- logged once through the package logger -- instead of failing with an out-of-memory error in the middle of a step."""
+    import logging
+    from reformer_tts_amd import engine
+    from reformer_tts_amd.model.config import TTSTrainingConfig, model_config_from_dict
+    from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
+    cfg = model_ref.small_cfg()
+    cfg["enc_reformer_kwargs"]["attn_kwargs"]["implementation"] = "hip"
+    cfg["dec_reformer_kwargs"]["self_attn_kwargs"]["implementation"] = "hip"
+    batch = synthetic_batch(2, 100, 256, device=gpu)
+    model = build_model(model_config_from_dict(cfg), gpu)
+    tr = Trainer(model, TTSTrainingConfig(batch_size=2, recompute="stash"), gpu)
+    est = {m: tr.stash_estimate(batch, m) for m in engine.RECOMPUTE_MODES}
+    assert est["full"] == 0 and all(est[a] < est[b] for a, b in zip(engine.RECOMPUTE_MODES, engine.RECOMPUTE_MODES[1:])), est
+    before = engine.recompute_mode()
+    try:
+        assert tr.resolve_recompute(batch) == "stash"                      # plenty of HBM: the configuration stands
+        tr._recompute_for.clear()
+        with caplog.at_level(logging.WARNING, logger="reformer_tts_amd"):
+            budget = int((est["output-stash"] + est["projection-stash"]) / 2 / tr.HBM_HEADROOM)
+            assert tr.resolve_recompute(batch, free_bytes=budget) == "output-stash"
+            assert tr.resolve_recompute(batch, free_bytes=0) == "full"
+        assert any("recompute" in r.getMessage() and "output-stash" in r.getMessage() for r in caplog.records)
+        # the lowered mode is what the step then runs in, and it trains
+        tr._recompute_for.clear()
+        tr.resolve_recompute(batch, free_bytes=budget)
+        model.train()
+        tr.zero_grad()
+        loss = tr.forward_loss(batch)[0]
+        assert engine.recompute_mode() == "output-stash"
+        loss.backward()
+        torch.cuda.synchronize()
+        assert torch.isfinite(tr.flat_g).all()
+    finally:
+        engine.set_recompute(before)
+    with pytest.raises(ValueError, match="recompute"):
+        Trainer(build_model(model_config_from_dict(cfg), gpu), TTSTrainingConfig(batch_size=2, recompute="everything"), gpu)
 
 
 @pytest.mark.parametrize("segmented", [False, True])
@@ -724,15 +777,14 @@ def test_long_sequence_config_runs_on_the_executor(gpu):
     cfg.dec_reformer_kwargs.depth = 1
     grads = []
     batch = synthetic_batch(1, 200, 4096, device=gpu)
-    old = engine.STASH_ATTENTION, engine.STASH_BLOCK_OUTPUT, engine.STASH_PROJECTIONS
-    try:       # (STASH_STREAMS stays on: it only acts when the other three are)
+    old = engine.recompute_mode()
+    try:
         for seed0, stash in ((0, True), (0, True), (0, False), (1000, True)):
-            engine.STASH_ATTENTION = engine.STASH_BLOCK_OUTPUT = engine.STASH_PROJECTIONS = stash
             _seeds.reset(seed0)
             torch.manual_seed(123)
             torch.cuda.manual_seed(123)
             model = build_model(cfg, gpu)
-            tr = Trainer(model, TTSTrainingConfig(batch_size=1), gpu)
+            tr = Trainer(model, TTSTrainingConfig(batch_size=1, recompute="stash" if stash else "full"), gpu)
             model.train()
             tr.zero_grad()
             loss = tr.forward_loss(batch)[0]
@@ -742,7 +794,7 @@ def test_long_sequence_config_runs_on_the_executor(gpu):
             assert torch.isfinite(loss) and torch.isfinite(tr.flat_g).all()
             grads.append(tr.flat_g.clone())
     finally:
-        engine.STASH_ATTENTION, engine.STASH_BLOCK_OUTPUT, engine.STASH_PROJECTIONS = old
+        engine.set_recompute(old)
     zero = [n for n, (s, e) in tr.offsets.items() if float(grads[0][s:e].abs().max()) == 0.0]
     assert all(".conv" in n and n.endswith(".bias") for n in zero), zero
     assert torch.equal(grads[0], grads[1])
@@ -1268,8 +1320,7 @@ def test_overlapped_step_matches_the_serial_step(gpu, mode):
     from reformer_tts_amd import engine
     from reformer_tts_amd.model.config import TTSTrainingConfig
     from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
-    keep = (engine.STASH_ATTENTION, engine.STASH_BLOCK_OUTPUT, engine.STASH_PROJECTIONS, engine.STASH_STREAMS)
-    engine.STASH_ATTENTION = engine.STASH_BLOCK_OUTPUT = engine.STASH_PROJECTIONS = engine.STASH_STREAMS = (mode == "stash")
+    keep = engine.recompute_mode()
     try:
         cfg = model_ref.small_cfg()
         cfg["enc_reformer_kwargs"]["depth"] = 2
@@ -1287,7 +1338,8 @@ def test_overlapped_step_matches_the_serial_step(gpu, mode):
             model.load_state_dict(synth.synth_state_dict(shapes, seed=13), strict=False)
             for layer in _lsh_layers(model):
                 layer.forced_rotations = {nb: torch.randn(1, 64, 4, nb // 2, generator=torch.Generator().manual_seed(nb)) for nb in (2, 4)}
-            tr = Trainer(model, TTSTrainingConfig(batch_size=2, learning_rate=1e-3, warmup_steps=None, gradient_clip_val=1.0), gpu)
+            tr = Trainer(model, TTSTrainingConfig(batch_size=2, learning_rate=1e-3, warmup_steps=None, gradient_clip_val=1.0,
+                                                  recompute=mode), gpu)
             if how == "captured":
                 tr.capture(batch)                              # two warm-up steps, then the capture of the overlapped step
                 assert tr.overlap_encoder and tr._graph_opt is None
@@ -1307,11 +1359,13 @@ def test_overlapped_step_matches_the_serial_step(gpu, mode):
               f"parameters after 5 steps: captured vs serial rel {rel_c:.2e}")
         assert rel_c < 1e-4, rel_c
     finally:
-        engine.STASH_ATTENTION, engine.STASH_BLOCK_OUTPUT, engine.STASH_PROJECTIONS, engine.STASH_STREAMS = keep
+        engine.set_recompute(keep)
 
 
-def test_fit_graph_cache_follows_the_eager_trajectory(gpu):
-    """Trainer.fit with one captured forward + loss + backward per PADDED shape (wrappers.py:213-222 yields few of them at
+@pytest.mark.parametrize("recompute", ["stash", "full"])
+def test_fit_graph_cache_follows_the_eager_trajectory(gpu, recompute):
+    """(``recompute``: the configuration field -- "full" is the reference's activation recompute, the bench's headline mode.)
+    Trainer.fit with one captured forward + loss + backward per PADDED shape (wrappers.py:213-222 yields few of them at
     pad_base granularity) against eager fit from the same start: ragged batches of three (text, mel) lengths that fall into
     two padded shapes -- so one graph serves two different real lengths (the loss length is a device word) -- with
     accumulate_grad_batches = 2 (a group mixes shapes) and a trailing partial group.  Same hash rotations on both sides;
@@ -1337,10 +1391,13 @@ def test_fit_graph_cache_follows_the_eager_trajectory(gpu):
         model.load_state_dict(synth.synth_state_dict(shapes, seed=11), strict=False)
         for layer in _lsh_layers(model):
             layer.forced_rotations = {nb: torch.randn(1, 64, 4, nb // 2, generator=torch.Generator().manual_seed(nb)) for nb in (2, 4, 6)}
-        tr = Trainer(model, TTSTrainingConfig(batch_size=2, learning_rate=1e-3, warmup_steps=None, accumulate_grad_batches=2), gpu)
+        tr = Trainer(model, TTSTrainingConfig(batch_size=2, learning_rate=1e-3, warmup_steps=None, accumulate_grad_batches=2,
+                                              recompute=recompute), gpu)
         model.train()
         losses = [float(x) for x in tr.fit(batches, graphs=graphs)]
         torch.cuda.synchronize()
+        from reformer_tts_amd import engine
+        assert engine.recompute_mode() == recompute
         assert tr.global_step == 4 and len(losses) == 4
         if graphs:
             cache = tr._shape_graphs

@@ -127,3 +127,53 @@ model:
     with pytest.raises(KeyError, match="unknown config key"):
         from reformer_tts_amd.model.config import LRSchedulerConfig, _merge
         _merge(LRSchedulerConfig(), dict(initial=1.0))
+
+
+def test_recompute_mode_is_a_yaml_loadable_configuration_field():
+    """``tts_training.recompute`` (this package's addition to the reference's TTSTrainingConfig): what the reversible backward
+    recomputes -- "full" = ``/root/reference/reformer_tts/model/reversible.py:114-129`` -- is a configuration the Trainer reads,
+    not a module global somebody pokes; unknown names are refused; the engine's named modes round-trip."""
+    from reformer_tts_amd import engine
+    from reformer_tts_amd.model.config import TTSTrainingConfig, load_yaml
+    assert TTSTrainingConfig().recompute == "stash"
+    text = "experiment:\n  tts_training:\n    batch_size: 12\n    recompute: full\nmodel:\n  pad_base: 256\n"
+    with tempfile.NamedTemporaryFile("w", suffix=".yml", delete=False) as fh:
+        fh.write(text)
+    try:
+        _, tr = load_yaml(fh.name)
+    finally:
+        os.unlink(fh.name)
+    assert tr.recompute == "full"
+    before = engine.recompute_mode()
+    try:
+        for mode in engine.RECOMPUTE_MODES:
+            engine.set_recompute(mode)
+            assert engine.recompute_mode() == mode
+            assert engine._streams_kept() == (mode == "stash")
+        assert (engine.STASH_ATTENTION, engine.STASH_BLOCK_OUTPUT, engine.STASH_PROJECTIONS, engine.STASH_STREAMS) == (True,) * 4
+        engine.set_recompute("full")
+        assert not (engine.STASH_ATTENTION or engine.STASH_BLOCK_OUTPUT or engine.STASH_PROJECTIONS or engine.STASH_STREAMS)
+        with pytest.raises(ValueError, match="recompute mode"):
+            engine.set_recompute("some")
+    finally:
+        engine.set_recompute(before)
+
+
+def test_stash_footprint_estimate_of_the_baseline_model():
+    """``engine.stash_bytes`` on the executors' program of config/baseline.yml at B = 12 (rows 3072 / 12288): "full" holds
+    nothing, every higher mode holds more, and "stash" is the ~1 GB DESIGN.md section 4 quotes (peak_hbm_gb of the two bench legs)."""
+    from reformer_tts_amd import engine
+    from reformer_tts_amd.model.config import baseline_model_config
+    from reformer_tts_amd.training import build_model
+    model = build_model(baseline_model_config())
+    enc, dec = engine.build_program(model.enc.reformer.layers), engine.build_program(model.dec.reformer.layers)
+    assert enc is not None and dec is not None
+    tot = {m: engine.stash_bytes(enc, 12 * 256, 512, m) + engine.stash_bytes(dec, 12 * 1024, 512, m, 12 * 256) for m in engine.RECOMPUTE_MODES}
+    print("\n[stash footprint, baseline.yml B=12] " + ", ".join(f"{m}: {v / 2**20:.0f} MiB" for m, v in tot.items()))
+    assert tot["full"] == 0
+    vals = [tot[m] for m in engine.RECOMPUTE_MODES]
+    assert vals == sorted(vals) and len(set(vals)) == len(vals)
+    assert 0.6 * 2**30 < tot["stash"] < 1.6 * 2**30
+    # one decoder LSH sublayer in attention-stash: the attention output (bf16) + one fp32 logsumexp per token.head
+    lsh_only = [("half", dec[0][1], None)]
+    assert engine.stash_bytes(lsh_only, 12288, 512, "attention-stash") == 12288 * 512 * 2 + 12288 * 8 * 4
