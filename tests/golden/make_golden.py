@@ -17,6 +17,8 @@ Fixtures
                    ``oracle.lsh_ref.LSHSelfAttention`` -- "reference wiring x
                    restated LSH" (SURVEY.md 8c (2)); parameters come from
                    ``oracle.synth`` and are therefore not stored.
+  model_cfg1.npz   the same wiring fixture at BASELINE config #1's values: config/baseline.yml with 1 + 1 layers, d = 512,
+                   8 heads, buckets 64 / 128, pad_base 256, feed-forward 2048 (B = 1, 150 phonemes, 800 frames)
   infer_small.npz  the reference's ReformerTTS.infer (autoregressive loop of full eval-mode forwards) on the same
                    wiring, three strategies; rotations recorded in call order
   squeezewave_{small,full}.npz  the reference's SqueezeWave.infer (vocoder)
@@ -158,7 +160,19 @@ small_cfg = model_ref.small_cfg
 
 
 def model_small():
-    cfg = small_cfg()
+    _whole_model("model_small.npz", small_cfg(), model_ref.synthetic_batch(2, 40, 150, ragged=True, seed=1), store_outputs=True)
+
+
+def model_cfg1():
+    """The reference's ReformerTTS + TTSLoss at BASELINE config #1's values (``oracle.model_ref.cfg1``: config/baseline.yml with
+    1 + 1 layers at d = 512 / 8 heads, buckets 64 / 128, pad_base 256, feed-forward 2048 in 100 ``Chunk`` pieces), B = 1, one
+    LJSpeech-shaped utterance of 150 phonemes / 800 frames (padded to 256 / 1024 by the model): pins the encoder-64 /
+    decoder-128 bucket asymmetry, pad_base = 2 x bucket and the 94-piece feed-forward split of the ORACLE'S wiring against the
+    reference's.  The 800 x 80 outputs are stored as float16 (the comparison is at 1e-3), gradients as norms."""
+    _whole_model("model_cfg1.npz", model_ref.cfg1(), model_ref.synthetic_batch(1, 150, 800, seed=5), store_outputs="f16")
+
+
+def _whole_model(fname, cfg, batch, store_outputs):
     torch.manual_seed(7)
     m = ReformerTTS(**cfg).train()
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
@@ -169,7 +183,6 @@ def model_small():
     for mod in m.modules():
         if isinstance(mod, lsh_ref.LSHSelfAttention):
             mod.rotation_log = rot_log
-    batch = model_ref.synthetic_batch(2, 40, 150, ragged=True, seed=1)
     spec = batch["spectrogram"]
     torch.manual_seed(11)
     raw, post, stop, _ = m(batch["phonemes"], spec[:, :-1], batch["loss_mask"].mean(-1))
@@ -185,7 +198,8 @@ def model_small():
         out[f"batch/{k}"] = npy(v)
     for i, r in enumerate(rot_log[:n_fwd]):
         out[f"rot/{i}"] = npy(r)
-    out["out/raw"], out["out/post"], out["out/stop"] = npy(raw), npy(post), npy(stop)
+    cast = (lambda a: a.astype(np.float16)) if store_outputs == "f16" else (lambda a: a)
+    out["out/raw"], out["out/post"], out["out/stop"] = cast(npy(raw)), cast(npy(post)), cast(npy(stop))
     out["out/loss"] = np.array([float(r) for r in res], dtype=np.float32)
     for k, p in m.named_parameters():
         out[f"gradnorm/{k}"] = np.array(float(p.grad.norm()), dtype=np.float32)
@@ -193,8 +207,8 @@ def model_small():
               "enc.reformer.layers.blocks.0.f.net.fn.layer.to_out.bias",
               "dec.reformer.layers.blocks.0.f.net.norm.weight", "dec.reformer.layers.blocks.2.f.net.fn.layer.in_proj_bias"):
         out[f"grad/{k}"] = npy(dict(m.named_parameters())[k].grad)
-    np.savez_compressed(os.path.join(HERE, "model_small.npz"), **out)
-    print("model_small.npz: loss", out["out/loss"], "layers", n_fwd)
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, ": loss", out["out/loss"], "layers", n_fwd, "padded lengths", [tuple(r.shape) for r in rot_log[:n_fwd]])
 
 
 STOP_T = float(os.environ.get("GOLDEN_STOP_T", "0.995"))   # synthetic weights give large stop logits
@@ -322,6 +336,7 @@ if __name__ == "__main__":
     torch.set_num_threads(4)
     pieces()
     model_small()
+    model_cfg1()
     infer_small()
     squeezewave()
     hf_lsh_int()

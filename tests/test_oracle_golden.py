@@ -117,11 +117,15 @@ def test_pad_and_collate(pieces):
         assert torch.equal(v.to(_t(pieces, f"collate/out/{k}").dtype), _t(pieces, f"collate/out/{k}")), k
 
 
-def test_whole_model_wiring(golden_dir):
+@pytest.mark.parametrize("fixture", ["model_small.npz", "model_cfg1.npz"])
+def test_whole_model_wiring(golden_dir, fixture):
     """Reference ReformerTTS + TTSLoss (LSH class = restated one) vs the functional oracle:
-    forward outputs, the four losses and every parameter-gradient norm."""
-    z = _load(golden_dir, "model_small.npz")
-    cfg = model_ref.small_cfg()
+    forward outputs, the four losses and every parameter-gradient norm.  ``model_cfg1.npz`` = BASELINE config #1's values
+    (config/baseline.yml with 1 + 1 layers at d = 512 / 8 heads, encoder buckets 64, decoder buckets 128, pad_base 256,
+    feed-forward 2048 in 100 Chunk pieces; ``/root/reference/config/baseline.yml:35-52``, ``model/config.py:11-27,73-84``):
+    the widths and the bucket asymmetry the full-size GPU tests run at, pinned to the reference's own wiring."""
+    z = _load(golden_dir, fixture)
+    cfg = model_ref.small_cfg() if fixture == "model_small.npz" else model_ref.cfg1()
     shapes = {k[len("shape/"):]: tuple(z[k]) for k in z.files if k.startswith("shape/")}
     sd = {k: v.requires_grad_(v.dtype.is_floating_point and not k.endswith("inv_freq"))
           for k, v in synth.synth_state_dict(shapes, seed=3).items()}
@@ -132,9 +136,11 @@ def test_whole_model_wiring(golden_dir):
     spec = batch["spectrogram"]
     raw, post, stop = model_ref.reformer_tts_forward(sd, cfg, batch["phonemes"], spec[:, :-1],
                                                      batch["loss_mask"].mean(-1), rots)
-    torch.testing.assert_close(raw, _t(z, "out/raw"), rtol=1e-4, atol=1e-4)
-    torch.testing.assert_close(post, _t(z, "out/post"), rtol=1e-4, atol=1e-4)
-    torch.testing.assert_close(stop, _t(z, "out/stop"), rtol=1e-4, atol=1e-4)
+    # (model_cfg1 stores its 800 x 80 outputs as float16: 2^-11 relative; the loss values below are fp32 and pin the same outputs)
+    tol = dict(rtol=1e-4, atol=1e-4) if z["out/raw"].dtype == np.float32 else dict(rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(raw, _t(z, "out/raw").float(), **tol)
+    torch.testing.assert_close(post, _t(z, "out/post").float(), **tol)
+    torch.testing.assert_close(stop, _t(z, "out/stop").float(), **tol)
     res = model_ref.tts_loss(raw, post, stop.view(stop.shape[0], -1), spec[:, 1:], batch["stop_tokens"], batch["loss_mask"])
     np.testing.assert_allclose([float(r.detach()) for r in res], z["out/loss"], rtol=1e-5)
     res[0].backward()
