@@ -392,6 +392,34 @@ int rtts_gemm_nt(const void* a, int64_t lda, const void* w, int64_t ldw, int w_i
                  int64_t ldc, const float* bias, int epilogue, const void* gate, int64_t ldg, float* colsum_partial,
                  void* stream);
 int rtts_gemm_nt_partial_rows(int M, int N);
+/* Grouped / extended form of rtts_gemm_nt (round 4).  n = 2..4 INDEPENDENT problems of one weight layout and one epilogue run as
+ * ONE launch: one grid over all their tiles, a workgroup finds its problem by tile range -- the cross-attention's q and k|v
+ * projections of one layer (reformer.py:161-186: two separate in_proj products inside nn.MultiheadAttention) and their
+ * input-gradient pair (dxn = dq Wq beside dkeys += dkv Wkv) pay one launch ramp, tail and kernel boundary instead of two.
+ * n = 1: one problem, with the epilogues rtts_gemm_nt has no arguments for:
+ *   epilogue 4 + accumulate: c is fp32 (rows of ldc floats), c += result (+ bias) -- the gradient of the encoder keys summed over
+ *                the decoder layers in the GEMM that produces each layer's share (no separate add launch);
+ *   epilogue 5: [K][N] weights only -- the input gradient of to_out / out_proj (c = dout, bf16) AND delta[b*H + h][t] =
+ *                sum over the 64 columns of head h of aux[m][.] * dout[m][.] (aux = the attention output, bf16 (M, N) stride
+ *                ld_aux; rows m = b*T + t; delta f32 (B*H, T)), i.e. rtts_lsh_bwd_delta folded into the product that makes dout.
+ * Epilogues 0, 1, 4 in a group (each problem its own); 0, 1, 4, 5 alone.  Shapes: as rtts_gemm_nt (a group needs one tile shape that tiles every
+ * problem: 192x128, 96x64 or 128x64).  Tested in tests/test_gemm_hip.py against float64 on the same bf16 operands. */
+typedef struct {
+    const void* a; int64_t lda;
+    const void* w; int64_t ldw;
+    void* c; int64_t ldc;
+    const float* bias;
+    const void* aux; int64_t ld_aux;
+    float* aux_out;
+    int32_t M, N, K, epilogue;
+    int32_t T, H, accumulate, reserved;
+} rtts_gemm_nt_problem;
+#define RTTS_GEMM_NT_MAX_GROUP 4
+int rtts_gemm_nt_grouped(const rtts_gemm_nt_problem* problems, int n, int w_is_kn, void* stream);
+/* TEST / A-B ONLY, process-wide: launch form of rtts_gemm_nt problems with several tiles per CU.  0 = the library's pick,
+ * 1 = one tile per workgroup (round 3), 2 = persistent workgroups on a 2-deep ring (two per CU), 3 = persistent on the deepest
+ * ring (one per CU).  Results are identical bit for bit in every form. */
+int rtts_debug_set_gemm_mode(int mode);
 /* FeedForward pair with a 1-bit ReLU gate: the forward GEMM (epilogue 2: bias + ReLU) also writes one 64-bit word per
  * lane and tile -- bit b set <=> the b-th output of that lane is a positive bf16 -- and the input-gradient GEMM of the same
  * (M, N) (epilogue 3, [K][N] weight) reads the words instead of re-reading the (M, N) activation (50 MB at the baseline

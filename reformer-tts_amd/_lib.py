@@ -22,6 +22,16 @@ class GemmTnProblem(C.Structure):
 GEMM_TN_MAX_GROUP = 16
 
 
+class GemmNtProblem(C.Structure):
+    """rtts_gemm_nt_problem of include/rtts.h."""
+    _fields_ = [("a", _vp), ("lda", _i64), ("w", _vp), ("ldw", _i64), ("c", _vp), ("ldc", _i64), ("bias", _vp), ("aux", _vp),
+                ("ld_aux", _i64), ("aux_out", _vp), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("epilogue", C.c_int32),
+                ("T", C.c_int32), ("H", C.c_int32), ("accumulate", C.c_int32), ("reserved", C.c_int32)]
+
+
+GEMM_NT_MAX_GROUP = 4
+
+
 class ColsumJob(C.Structure):
     """rtts_colsum_job of include/rtts.h."""
     _fields_ = [("partial", _vp), ("out", _vp), ("nrows", C.c_int32), ("n", C.c_int32), ("ld", C.c_int32), ("reserved", C.c_int32)]
@@ -103,6 +113,8 @@ SIGNATURES = {
     "rtts_gemm_tn_grouped": [C.POINTER(GemmTnProblem), _i32, _vp, _i64, _vp],
     "rtts_gemm_nt": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _vp],
     "rtts_gemm_nt_partial_rows": [_i32, _i32],
+    "rtts_gemm_nt_grouped": [C.POINTER(GemmNtProblem), _i32, _i32, _vp],
+    "rtts_debug_set_gemm_mode": [_i32],
     "rtts_gemm_nt_gate_words": [_i32, _i32],
     "rtts_gemm_nt_gated": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _vp, _vp, _vp],
     "rtts_peak_copy": [_vp, _vp, _i64, _vp],

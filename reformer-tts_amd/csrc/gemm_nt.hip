@@ -22,8 +22,20 @@
 //     columns of one row: the epilogue stores 8 bytes per lane straight from the accumulators, bias / gate are 16 / 8-byte loads;
 //   * XCD-aware tile order: the N/BN tiles that share an A row panel run on one XCD back to back (one fetch of the panel
 //     from HBM / Infinity Cache per XCD, the weight stays resident in every L2).
+// Three launch forms of the same body (template MODE):
+//   0  one problem, one tile per workgroup (the form every small problem keeps);
+//   1  GROUPED: one grid over the tiles of up to GN_MAX_GROUP independent problems of one layout and epilogue (the cross-attention's
+//      q and k|v projections; its input-gradient pair dxn / dkeys): a workgroup looks its problem up by tile range -- one launch
+//      ramp, one tail and one kernel boundary instead of one per problem;
+//   2  PERSISTENT: problems of several tiles per CU (N >= 1024 at M = 12288) run on a grid of resident workgroups that walk the
+//      tiles; the LDS ring keeps turning across a tile boundary -- the first NST stages of the next tile are in flight while the
+//      current tile's accumulators are stored -- so the 1.8 us launch-to-first-stage latency is paid once per workgroup, not per tile.
+// More epilogues: 4 with `accum` (fp32 C += result: the keys' gradient accumulates over the decoder layers without a separate add
+// launch) and 5 (input gradient of to_out / out_proj + delta = rowsum(out * dout) per (token, head) for the attention backward: the
+// separate rtts_lsh_bwd_delta launch and its re-read of dout are gone).
 #include "rtts_common.h"
 #include <stdlib.h>
+#include <atomic>
 
 typedef __attribute__((ext_vector_type(4))) int gn_v4i;
 typedef __attribute__((ext_vector_type(2))) int gn_v2i;
@@ -74,6 +86,19 @@ struct GnArgs {
     // [K][N] weight (input gradient) is addressed as row = channel, column offset tap * conv_wtap.
     int conv_cpt, conv_sign;
     int64_t conv_wtap;
+    // epilogue 5: aux = the attention output `out` (M, N) bf16 (row stride ldaux), aux_out = delta f32 (B*H, T) with rows
+    // m = b * T + t and heads of 64 columns; epilogue 4: accum != 0 -> C (fp32) += result
+    const bf16_t* aux;
+    int64_t ldaux;
+    float* aux_out;
+    int T, H, accum;
+};
+
+#define GN_MAX_GROUP 4
+struct GnGroup {
+    GnArgs p[GN_MAX_GROUP];
+    int tile_end[GN_MAX_GROUP];        // MODE 1: cumulative tile counts of the problems
+    int n;
 };
 
 // swizzle of the [K][N] weight image: XOR applied to the index of a 32-byte chunk (16 columns) of k row `k`
@@ -83,8 +108,9 @@ __device__ __forceinline__ int gn_kn_swz(int k) {
     else return (k & 3) | (((k >> 3) & 1) << 2);
 }
 
-template <int BM, int BN, int WM, int WN, bool W_KN, int EPI, int NST>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
+// the 2-deep ring of the 192 x 128 tile exists to put TWO 8-wave workgroups on a CU: 4 waves per SIMD, i.e. at most 128 registers
+template <int BM, int BN, int WM, int WN, bool W_KN, int EPI, int NST, int MODE>
+__global__ __launch_bounds__(64 * WM * WN, (BM == 192 && NST == 2) ? 4 : 1) void gemm_nt_kernel(const GnGroup G) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;          // 16 x 16 MFMA tiles per wave
     constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
@@ -112,11 +138,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int ntn = P.N / BN;
     const uint32_t logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (int)(logical / ntn) * BM, n0 = (int)(logical % ntn) * BN;
+    // which problem, which tile: MODE 1 looks the problem up by tile range (wave-uniform: scalar compares on kernel arguments)
+    int pi = 0;
+    uint32_t tile = logical;
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int i = 0; i + 1 < GN_MAX_GROUP; ++i)
+            if (i + 1 < G.n && logical >= (uint32_t)G.tile_end[i]) pi = i + 1;
+        pi = __builtin_amdgcn_readfirstlane(pi);
+        tile = logical - (pi ? (uint32_t)G.tile_end[pi - 1] : 0u);
+    }
+    const GnArgs& P = G.p[pi];
+    const int ntn = P.N / BN;
+    int m0 = (int)(tile / ntn) * BM, n0 = (int)(tile % ntn) * BN;
     const int nk = P.K / GN_BK;
     const int64_t lda = P.lda, ldw = P.ldw;
+    // MODE 2: this workgroup works tiles tile, tile + gridDim.x, ... of the one problem
+    const uint32_t ntiles = MODE == 2 ? (uint32_t)(P.M / BM) * (uint32_t)ntn : 0u;
+    (void)ntiles;
 
     // ---- DMA sources: ONE per-lane pointer per operand (the wave's piece 0 of stage 0).  Piece t of a wave is 8 NW t rows
     // further on ([row][k] images; (1024 / RP) NW t k rows for the [K][N] weight image) -- a wave-uniform offset -- and needs
@@ -141,6 +181,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
     const size_t pstepA = (size_t)8 * NW * lda, pstepW = W_KN ? (size_t)(1024 / RP) * NW * ldw : (size_t)8 * NW * ldw;
     const size_t wstep = W_KN ? (size_t)GN_BK * ldw : (size_t)GN_BK;
     const int conv_cpt = P.conv_cpt;
+    // MODE 2: element offsets from this tile's operand rows to the next tile's (wave-uniform); stages >= nk name the next tile
+    int64_t nxtA = 0, nxtW = 0;
+    bool has_next = false, first_tile = true;
+    (void)nxtA; (void)nxtW; (void)has_next; (void)first_tile;
     // element offsets of K stage `st` into the A rows / the weight (wave-uniform scalar arithmetic)
     auto a_off = [&](int st) -> int64_t {
         if (conv_cpt == 0) return (int64_t)st * GN_BK;
@@ -228,11 +272,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
     auto issue_piece = [&](auto qc, int stage_, int bufi_) {
         constexpr int q = decltype(qc)::value;
         unsigned char* sb_ = smem + bufi_ * STAGE;
+        int64_t ka_, kw_;
+        if constexpr (MODE == 2) {             // a stage index beyond this tile's last stage: the next tile's stage (stage_ - nk)
+            const bool nx_ = stage_ >= nk;
+            const int st_ = nx_ ? stage_ - nk : stage_;
+            ka_ = a_off(st_) + (nx_ ? nxtA : 0);
+            kw_ = w_off(st_) + (nx_ ? nxtW : 0);
+        } else {
+            ka_ = a_off(stage_);
+            kw_ = w_off(stage_);
+        }
         if constexpr (q < PA)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA0 + q * pstepA + a_off(stage_)),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA0 + q * pstepA + ka_),
                                              (RTTS_LDS void*)(sb_ + (wave + NW * q) * 1024), 16, 0, 0);
         else
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW0 + (q - PA) * pstepW + w_off(stage_)),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW0 + (q - PA) * pstepW + kw_),
                                              (RTTS_LDS void*)(sb_ + A_BYTES + (wave + NW * (q - PA)) * 1024), 16, 0, 0);
     };
 #define GN_MFMA(AF, WF, WL, WH, COND_, ST_, BUF_, Q0, Q1)                                                                  \
@@ -298,6 +352,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
     } while (0)
 #endif
     int pbuf = 0;                                    // buffer of stage s-1: the second half of stage s-1+NST's pieces goes there
+    static_assert(MODE != 2 || (EPI != 4 && true), "persistent form: bf16 epilogues");
+  for (;;) {                                         // MODE 2: one pass per tile of this workgroup; else a single pass
+    if constexpr (MODE == 2) {
+        const uint32_t nt_ = tile + gridDim.x;
+        has_next = nt_ < ntiles;
+        if (has_next) {
+            const int m0n = (int)(nt_ / ntn) * BM, n0n = (int)(nt_ % ntn) * BN;
+            nxtA = (int64_t)(m0n - m0) * lda;
+            nxtW = W_KN ? (int64_t)(n0n - n0) : (int64_t)(n0n - n0) * ldw;
+        }
+    }
     for (int s = 0; s < nk; ++s) {
         const uint32_t sb = smem_base + buf * STAGE;
         int nb = buf + 1 == NST ? 0 : buf + 1;
@@ -306,21 +371,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
         // reads per half stage (the 256-wide tile's transposed weight fragments) "at most 15 outstanding" already implies it
         gn_wait_lgkm<(RD_PER_KS < 15 ? RD_PER_KS : 15)>();
         __builtin_amdgcn_sched_barrier(0);
+        // MODE 2: the ring does not stop at a tile boundary -- stage indices >= nk are the next tile's first stages (issue_piece),
+        // the second half of the stage whose first half the previous tile's last step issued goes out at s = 0
 #ifndef GN_ABL_NODMA
-        GN_MFMA(a0, w0, wl0, wh0, s >= 1 && s - 1 + NST < nk, s - 1 + NST, pbuf, SPB, PER);
+        GN_MFMA(a0, w0, wl0, wh0, MODE == 2 ? ((s >= 1 || !first_tile) && (s - 1 + NST < nk || has_next)) : (s >= 1 && s - 1 + NST < nk),
+                s - 1 + NST, pbuf, SPB, PER);
 #else
         GN_MFMA(a0, w0, wl0, wh0, false, 0, 0, 0, 0);
 #endif
         __builtin_amdgcn_sched_barrier(0);
         gn_wait_lgkm<0>();                           // F1 is back: this wave has no read of stage s left
-        if (s + 1 < nk) {
-            GN_WAIT_STAGE(min(NST - 2, nk - 2 - s));
+        if (s + 1 < nk || (MODE == 2 && has_next)) {
+            GN_WAIT_STAGE((MODE == 2 && has_next) ? NST - 2 : min(NST - 2, nk - 2 - s));
             asm volatile("s_barrier" ::: "memory");  // stage s+1 complete in LDS; everybody is done reading stage s
             GN_READ(a0, w0, wl0, wh0, smem_base + nb * STAGE, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
 #ifndef GN_ABL_NODMA
-        GN_MFMA(a1, w1, wl1, wh1, s + NST < nk, s + NST, buf, 0, SPB);    // (s + NST < nk implies s + 1 < nk: behind the barrier)
+        GN_MFMA(a1, w1, wl1, wh1, s + NST < nk || (MODE == 2 && has_next), s + NST, buf, 0, SPB);    // (implies: behind the barrier)
 #else
         GN_MFMA(a1, w1, wl1, wh1, false, 0, 0, 0, 0);
 #endif
@@ -328,11 +396,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
         pbuf = buf;
         buf = nb;
     }
-#undef GN_READ
-#undef GN_MFMA
-#undef GN_WAIT_STAGE
     GN_STAMP(2);
-#undef GN_ISSUE
 
     // ---- epilogue: lane holds C[m][n .. n+3], m = m0 + wave rows + 16 i + (lane & 15), n = n0 + wave cols + 16 j + 4 (lane >> 4)
     constexpr int epi = EPI;
@@ -341,6 +405,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
     f32x4 cs[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) cs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float dl[TM];                                  // epilogue 5: this lane's share of delta of row tile i (its 4 x TN columns)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) dl[i] = 0.f;
+    (void)dl;
+    static_assert(EPI != 5 || (W_KN && BN / WN == 64), "epilogue 5: an input gradient whose waves each cover one 64-wide head");
     // 1-bit gate: bit ((i * TN + j) * 4 + e) of this lane's word <=> output (i, j, e) of this lane is a positive bf16.  The
     // forward (epilogue 2) and the input gradient (epilogue 3) of one (M, N) get the same tile shape, hence the same lane ->
     // element map; 16 x TM x TN bits fit one word for every tile but 256 x 256 (rtts_gemm_nt_gate_words() = 0 there).
@@ -355,7 +424,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
         const int n = ncol + 16 * j;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if constexpr (epi == 1 || epi == 2) bv = *reinterpret_cast<const f32x4*>(P.bias + n);
-        if constexpr (epi == 4) if (P.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(P.bias + n);
+        if constexpr (epi == 4 || epi == 6) if (P.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(P.bias + n);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const size_t m = (size_t)(mrow + 16 * i);
@@ -379,13 +448,23 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
                 }
                 cs[j] += v;
             }
-            if constexpr (epi == 4) {          // unrounded fp32 result (rows of ldc floats): in front of a BatchNorm / the loss
-                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(P.c) + m * P.ldc + n) = v;
+            // epilogue 4: unrounded fp32 result (rows of ldc floats): in front of a BatchNorm / the loss.  Epilogue 6 is the GROUP's
+            // epilogue: each problem says at run time (a wave-uniform branch) whether it stores fp32 (its own epilogue 4) or bf16
+            // (0, or 1 when it has a bias)
+            if (epi == 4 || (epi == 6 && P.epi == 4)) {
+                f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(P.c) + m * P.ldc + n);
+                if (P.accum) v += *dst;        // C += result (the keys' gradient over the decoder layers)
+                *dst = v;
                 continue;
             }
             uint2 o;
             o.x = pack_bf16x2(v[0], v[1]);
             o.y = pack_bf16x2(v[2], v[3]);
+            if constexpr (epi == 5) {          // delta += out * dout on the ROUNDED dout: what the attention backward will read
+                const uint2 ov = *reinterpret_cast<const uint2*>(P.aux + m * P.ldaux + n);
+                dl[i] += __uint_as_float(ov.x << 16) * __uint_as_float(o.x << 16) + __uint_as_float(ov.x & 0xFFFF0000u) * __uint_as_float(o.x & 0xFFFF0000u) +
+                         __uint_as_float(ov.y << 16) * __uint_as_float(o.y << 16) + __uint_as_float(ov.y & 0xFFFF0000u) * __uint_as_float(o.y & 0xFFFF0000u);
+            }
             if constexpr (kBitsFit && epi == 2) {      // the values are >= 0: positive <=> the rounded bf16 is not zero
                 const unsigned nib = ((o.x & 0xFFFFu) ? 1u : 0u) | ((o.x >> 16) ? 2u : 0u) | ((o.y & 0xFFFFu) ? 4u : 0u) | ((o.y >> 16) ? 8u : 0u);
                 gbits |= (unsigned long long)nib << ((i * TN + j) * 4);
@@ -399,6 +478,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
         }
     }
     if constexpr (kBitsFit && epi == 2) if (use_bits) P.bits[widx] = gbits;
+    if constexpr (epi == 5) {
+        // the four lane groups g hold different columns of the same 16 rows: sum over g (lane ^ 16 by ds_swizzle, lane ^ 32 by
+        // v_permlane32_swap), then the lanes of group 0 write delta[(b * H + head) * T + t] of their row m = b * T + t
+        const int head = (n0 + wn * (BN / WN)) >> 6;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float x = dl[i];
+            x += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F));      // bit mode: and 0x1F, xor 0x10
+            x = rtts_xhalf_sum(x);
+            if (g == 0) {
+                const int m = mrow + 16 * i;
+                const int b_ = m / P.T;
+                P.aux_out[((size_t)b_ * P.H + head) * P.T + (m - b_ * P.T)] = x;
+            }
+        }
+    }
     if constexpr (epi == 3) if (P.colsum != nullptr) {
         // sum over the wave's rows: the 16 lanes of a group hold 16 different rows of the same 4 columns
         float* dst = P.colsum + ((size_t)(m0 / BM) * WM + wm) * P.N;
@@ -417,6 +512,26 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
             if (r == 0) *reinterpret_cast<f32x4*>(dst + ncol + 16 * j) = v;
         }
     }
+    if constexpr (MODE != 2) break;
+    else {
+        if (!has_next) break;
+        // next tile: the ring already holds (or has in flight) its first stages, F0 of its stage 0 is in a0 / w0
+        tile += gridDim.x;
+        m0 = (int)(tile / ntn) * BM;
+        n0 = (int)(tile % ntn) * BN;
+        srcA0 += nxtA;
+        srcW0 += nxtW;
+        first_tile = false;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+#undef GN_READ
+#undef GN_MFMA
+#undef GN_WAIT_STAGE
+#undef GN_ISSUE
 #ifdef GN_STAMPS
     if constexpr (EPI == 0) {
         GN_STAMP(3);
@@ -437,50 +552,82 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GnArgs P) {
 template <int BM, int BN>
 constexpr int gn_nst() { return (4 * (BM + BN) * 128 <= 160 * 1024) ? 4 : ((3 * (BM + BN) * 128 <= 160 * 1024) ? 3 : 2); }
 
-template <int BM, int BN, int WM, int WN, bool W_KN, int EPI, int NST>
-static int gn_launch3(const GnArgs& P, hipStream_t s) {
+// TEST / A-B ONLY (rtts_debug_set_gemm_mode): how problems of several tiles per CU are launched.  0 = the library's pick,
+// 1 = never persistent (round 3's forms), 2 = persistent on a 2-deep ring, two workgroups per CU, 3 = persistent on the
+// deepest ring, one workgroup per CU.  Process-wide, atomic; no environment is read on the launch path.
+static std::atomic<int> g_gn_mode{0};
+extern "C" int rtts_debug_set_gemm_mode(int mode) {
+    if (mode < 0 || mode > 3) { rtts_set_error("rtts_debug_set_gemm_mode: 0..3 (got %d)", mode); return -1; }
+    g_gn_mode.store(mode, std::memory_order_relaxed);
+    return 0;
+}
+
+template <int BM, int BN, int WM, int WN, bool W_KN, int EPI, int NST, int MODE>
+static int gn_launch3(const GnGroup& G, int grid, hipStream_t s) {
     constexpr size_t lds = (size_t)NST * (BM + BN) * 128;
     static RttsLdsState attr;                    // per device: the dynamic-LDS limit is an attribute of the loaded function
-    RTTS_ENSURE_LDS("rtts_gemm_nt", (gemm_nt_kernel<BM, BN, WM, WN, W_KN, EPI, NST>), lds, attr);
-    const int grid = (P.M / BM) * (P.N / BN);
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, W_KN, EPI, NST>), dim3(grid), dim3(64 * WM * WN), lds, s, P);
+    RTTS_ENSURE_LDS("rtts_gemm_nt", (gemm_nt_kernel<BM, BN, WM, WN, W_KN, EPI, NST, MODE>), lds, attr);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, W_KN, EPI, NST, MODE>), dim3(grid), dim3(64 * WM * WN), lds, s, G);
     return 0;
 }
 
 template <int BM, int BN, int WM, int WN, bool W_KN, int EPI>
-static int gn_launch2(const GnArgs& P, hipStream_t s) {
+static int gn_launch2(const GnGroup& G, hipStream_t s) {
     constexpr int NST = gn_nst<BM, BN>();
-#ifdef RTTS_GEMM_NT_AB
-    static const int want = [] { const char* e = getenv("RTTS_GEMM_NT_NST"); return e ? atoi(e) : 0; }();   // kernel A/B runs
-    if (want == 4) return gn_launch3<BM, BN, WM, WN, W_KN, EPI, NST>(P, s);
-    if (want == 3) return gn_launch3<BM, BN, WM, WN, W_KN, EPI, 3>(P, s);
-    if (want == 2) return gn_launch3<BM, BN, WM, WN, W_KN, EPI, 2>(P, s);
-#endif
-    // A grid of one workgroup per CU wants the deepest ring; a grid of several waves of workgroups runs faster with TWO
-    // workgroups per CU on a 2-deep ring (80 KB each): they are not barrier-coupled, so one's prologue, epilogue and
-    // barrier stalls fill with the other's MFMAs (N = 2048, K = 512: 37.4 vs 45.5 us; profiles/r02_gemm_nt_probe.log)
-    if constexpr (BM == 192 && BN == 128) {
-        if ((P.M / BM) * (P.N / BN) >= 512) return gn_launch3<BM, BN, WM, WN, W_KN, EPI, 2>(P, s);
+    const GnArgs& P = G.p[0];
+    const int tiles = (P.M / BM) * (P.N / BN);
+    if constexpr (BM == 192 && BN == 128 && EPI != 4 && EPI != 5) {
+        // Several tiles per CU (N >= 1024 at M = 12288: 512 / 1024 tiles).  Round 3 launched them all, two workgroups per CU on a
+        // 2-deep ring, so that one workgroup's prologue / epilogue fills with the other's MFMAs (N = 2048, K = 512: 37.4 vs 45.5 us
+        // on the deep ring; profiles/r02_gemm_nt_probe.log).  Round 4: a grid of RESIDENT workgroups walks the tiles (MODE 2)
+        // and the ring keeps turning across the tile boundary -- measured forms in profiles/r04_gemm_nt_persistent_ab.log.
+        const int mode = g_gn_mode.load(std::memory_order_relaxed);
+        const bool multi = tiles >= 512 && tiles % 256 == 0 && P.K / GN_BK >= NST && P.conv_cpt == 0;
+        if (multi && mode != 1) {
+            if (mode == 3) return gn_launch3<BM, BN, WM, WN, W_KN, EPI, NST, 2>(G, 256, s);
+            return gn_launch3<BM, BN, WM, WN, W_KN, EPI, 2, 2>(G, 512, s);
+        }
+        if (tiles >= 512) return gn_launch3<BM, BN, WM, WN, W_KN, EPI, 2, 0>(G, tiles, s);
     }
-    return gn_launch3<BM, BN, WM, WN, W_KN, EPI, NST>(P, s);
+    return gn_launch3<BM, BN, WM, WN, W_KN, EPI, NST, 0>(G, tiles, s);
 }
 
 template <int BM, int BN, int WM, int WN>
-static int gn_launch(const GnArgs& P, int w_kn, hipStream_t s) {
+static int gn_launch(const GnGroup& G, int w_kn, hipStream_t s) {
+    const GnArgs& P = G.p[0];
     if (w_kn) {                       // input gradients: plain / fp32 store or the ReLU gate of the FeedForward hidden layer
-        if (P.epi == 3) return gn_launch2<BM, BN, WM, WN, true, 3>(P, s);
-        if (P.epi == 0) return gn_launch2<BM, BN, WM, WN, true, 0>(P, s);
-        if (P.epi == 4) return gn_launch2<BM, BN, WM, WN, true, 4>(P, s);
-        rtts_set_error("rtts_gemm_nt: a [K][N] weight (input gradient) takes epilogue 0, 3 or 4, got %d", P.epi);
+        if (P.epi == 3) return gn_launch2<BM, BN, WM, WN, true, 3>(G, s);
+        if (P.epi == 0) return gn_launch2<BM, BN, WM, WN, true, 0>(G, s);
+        if (P.epi == 4) return gn_launch2<BM, BN, WM, WN, true, 4>(G, s);
+        if constexpr (BN / WN == 64) if (P.epi == 5) return gn_launch2<BM, BN, WM, WN, true, 5>(G, s);
+        rtts_set_error("rtts_gemm_nt: a [K][N] weight (input gradient) takes epilogue 0, 3, 4 or 5 (5: tiles whose waves span one head), got %d", P.epi);
         return -1;
     }
     switch (P.epi) {
-        case 0: return gn_launch2<BM, BN, WM, WN, false, 0>(P, s);
-        case 1: return gn_launch2<BM, BN, WM, WN, false, 1>(P, s);
-        case 2: return gn_launch2<BM, BN, WM, WN, false, 2>(P, s);
-        case 3: return gn_launch2<BM, BN, WM, WN, false, 3>(P, s);
-        default: return gn_launch2<BM, BN, WM, WN, false, 4>(P, s);
+        case 0: return gn_launch2<BM, BN, WM, WN, false, 0>(G, s);
+        case 1: return gn_launch2<BM, BN, WM, WN, false, 1>(G, s);
+        case 2: return gn_launch2<BM, BN, WM, WN, false, 2>(G, s);
+        case 3: return gn_launch2<BM, BN, WM, WN, false, 3>(G, s);
+        case 4: return gn_launch2<BM, BN, WM, WN, false, 4>(G, s);
+        default: rtts_set_error("rtts_gemm_nt: an [N][K] weight takes epilogue 0..4, got %d", P.epi); return -1;
     }
+}
+
+// grouped launch (MODE 1): every problem on one tile shape and one weight layout; epilogue 6 = each problem's own choice of
+// {0, 1 (bias), 4 (fp32 store, + accumulate)} at run time
+template <int BM, int BN, int WM, int WN>
+static int gn_launch_group(const GnGroup& G, int total_tiles, int w_kn, hipStream_t s) {
+    constexpr int NST = gn_nst<BM, BN>();
+    // up to two workgroups per CU on the 2-deep ring take a grid that is not a whole number of one-per-CU waves (384 tiles of the
+    // cross-attention's q + k|v projections) in one go; small grids keep the deep ring
+    constexpr int NST2 = BM == 192 ? 2 : NST;
+    const bool two = BM == 192 && total_tiles > 256;
+    if (w_kn) {
+        if (two) return gn_launch3<BM, BN, WM, WN, true, 6, NST2, 1>(G, total_tiles, s);
+        return gn_launch3<BM, BN, WM, WN, true, 6, NST, 1>(G, total_tiles, s);
+    }
+    if (two) return gn_launch3<BM, BN, WM, WN, false, 6, NST2, 1>(G, total_tiles, s);
+    return gn_launch3<BM, BN, WM, WN, false, 6, NST, 1>(G, total_tiles, s);
 }
 
 // Tile choice.  The kernel is bound by operand ingest (bytes per workgroup and K stage ~ BM + BN), so the largest tile wins
@@ -516,7 +663,7 @@ static int gn_run(const void* a, int64_t lda, const void* w, int64_t ldw, int w_
                   int64_t conv_wtap, void* stream, unsigned long long* gate_bits = nullptr) {
     RTTS_REQUIRE(a && w && c, "rtts_gemm_nt: null pointer");
     RTTS_REQUIRE(M > 0 && N > 0 && K > 0 && K % GN_BK == 0, "rtts_gemm_nt: K must be a positive multiple of 64 (got M=%d N=%d K=%d)", M, N, K);
-    RTTS_REQUIRE(epilogue >= 0 && epilogue <= 4, "rtts_gemm_nt: epilogue 0..4");
+    RTTS_REQUIRE(epilogue >= 0 && epilogue <= 4, "rtts_gemm_nt: epilogue 0..4 (5 and fp32 accumulation: rtts_gemm_nt_grouped)");
     RTTS_REQUIRE(!(epilogue == 1 || epilogue == 2) || bias, "rtts_gemm_nt: epilogue %d needs a bias", epilogue);
     RTTS_REQUIRE(epilogue != 3 || gate_bits || (gate && ldg >= N && ldg % 4 == 0),
                  "rtts_gemm_nt: epilogue 3 needs a gate (M, N) with ldg %% 4 == 0, or the forward's gate words");
@@ -527,7 +674,9 @@ static int gn_run(const void* a, int64_t lda, const void* w, int64_t ldw, int w_
                  (((uintptr_t)bias | (uintptr_t)colsum_partial) & 15) == 0, "rtts_gemm_nt: misaligned buffer");
     const int pick = gn_pick(M, N);
     RTTS_REQUIRE(pick >= 0, "rtts_gemm_nt: M x N = %d x %d tiles by none of 256x256, 192x128, 256x128, 96x64, 128x64", M, N);
-    GnArgs P;
+    GnGroup G = {};
+    G.n = 1;
+    GnArgs& P = G.p[0];
     P.a = (const bf16_t*)a; P.w = (const bf16_t*)w; P.c = (bf16_t*)c; P.bias = bias; P.gate = (const bf16_t*)gate;
     P.colsum = colsum_partial; P.lda = lda; P.ldw = ldw; P.ldc = ldc; P.ldg = ldg; P.M = M; P.N = N; P.K = K; P.epi = epilogue;
     P.conv_cpt = conv_cpt; P.conv_sign = conv_sign; P.conv_wtap = conv_wtap;
@@ -538,14 +687,100 @@ static int gn_run(const void* a, int64_t lda, const void* w, int64_t ldw, int w_
     hipStream_t s = (hipStream_t)stream;
     int rc = 0;
     switch (pick) {
-        case 0: rc = gn_launch<256, 256, 4, 2>(P, w_is_kn, s); break;
-        case 1: rc = gn_launch<192, 128, 4, 2>(P, w_is_kn, s); break;
-        case 2: rc = gn_launch<256, 128, 4, 2>(P, w_is_kn, s); break;
-        case 3: rc = gn_launch<96, 64, 2, 2>(P, w_is_kn, s); break;
-        default: rc = gn_launch<128, 64, 2, 2>(P, w_is_kn, s); break;
+        case 0: rc = gn_launch<256, 256, 4, 2>(G, w_is_kn, s); break;
+        case 1: rc = gn_launch<192, 128, 4, 2>(G, w_is_kn, s); break;
+        case 2: rc = gn_launch<256, 128, 4, 2>(G, w_is_kn, s); break;
+        case 3: rc = gn_launch<96, 64, 2, 2>(G, w_is_kn, s); break;
+        default: rc = gn_launch<128, 64, 2, 2>(G, w_is_kn, s); break;
     }
     if (rc) return rc;
     RTTS_LAUNCH_CHECK("rtts_gemm_nt");
+    return 0;
+}
+
+// ---- rtts_gemm_nt_grouped: n independent problems in one launch (n = 1: one problem with the extended epilogues)
+static int gn_fill(GnArgs& P, const rtts_gemm_nt_problem& q, int w_is_kn, int i) {
+    RTTS_REQUIRE(q.a && q.w && q.c, "rtts_gemm_nt_grouped: problem %d: null pointer", i);
+    RTTS_REQUIRE(q.M > 0 && q.N > 0 && q.K > 0 && q.K % GN_BK == 0, "rtts_gemm_nt_grouped: problem %d: K must be a positive multiple of 64 (M=%d N=%d K=%d)",
+                 i, q.M, q.N, q.K);
+    RTTS_REQUIRE(q.lda % 8 == 0 && q.lda >= q.K && q.ldc >= q.N && q.ldc % 4 == 0 && q.ldw % 8 == 0 && q.ldw >= (w_is_kn ? q.N : q.K),
+                 "rtts_gemm_nt_grouped: problem %d: bad leading dimensions", i);
+    RTTS_REQUIRE(q.epilogue == 0 || q.epilogue == 1 || q.epilogue == 4 || q.epilogue == 5, "rtts_gemm_nt_grouped: problem %d: epilogue 0, 1, 4 or 5", i);
+    RTTS_REQUIRE(q.epilogue != 1 || q.bias, "rtts_gemm_nt_grouped: problem %d: epilogue 1 needs a bias", i);
+    RTTS_REQUIRE(!q.accumulate || q.epilogue == 4, "rtts_gemm_nt_grouped: problem %d: accumulate goes with the fp32 epilogue (4)", i);
+    RTTS_REQUIRE((((uintptr_t)q.a | (uintptr_t)q.w | (uintptr_t)q.bias) & 15) == 0 && ((uintptr_t)q.c & (q.epilogue == 4 ? 15 : 7)) == 0,
+                 "rtts_gemm_nt_grouped: problem %d: misaligned buffer", i);
+    if (q.epilogue == 5) {
+        RTTS_REQUIRE(w_is_kn && q.aux && q.aux_out && q.ld_aux >= q.N && q.ld_aux % 4 == 0 && ((uintptr_t)q.aux & 7) == 0 && q.T > 0 && q.M % q.T == 0 &&
+                     q.H * 64 == q.N, "rtts_gemm_nt_grouped: problem %d: epilogue 5 (input gradient + delta) takes a [K][N] weight, aux = out (M, N) bf16, "
+                     "aux_out = delta (B*H, T) f32, M = B*T, N = 64 H", i);
+    }
+    P = GnArgs{};
+    P.a = (const bf16_t*)q.a; P.w = (const bf16_t*)q.w; P.c = (bf16_t*)q.c; P.bias = q.bias; P.lda = q.lda; P.ldw = q.ldw; P.ldc = q.ldc;
+    P.M = q.M; P.N = q.N; P.K = q.K; P.epi = q.epilogue; P.aux = (const bf16_t*)q.aux; P.ldaux = q.ld_aux; P.aux_out = q.aux_out;
+    P.T = q.T; P.H = q.H; P.accum = q.accumulate;
+    return 0;
+}
+
+extern "C" int rtts_gemm_nt_grouped(const rtts_gemm_nt_problem* problems, int n, int w_is_kn, void* stream) {
+    RTTS_ENTER(stream);
+    RTTS_REQUIRE(problems && n >= 1 && n <= GN_MAX_GROUP, "rtts_gemm_nt_grouped: 1..%d problems", GN_MAX_GROUP);
+    GnGroup G = {};
+    G.n = n;
+    for (int i = 0; i < n; ++i) {
+        const int rc = gn_fill(G.p[i], problems[i], w_is_kn, i);
+        if (rc) return rc;
+        RTTS_REQUIRE(n == 1 || problems[i].epilogue != 5, "rtts_gemm_nt_grouped: epilogue 5 is a single-problem form (problem %d)", i);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    int rc = 0;
+    if (n == 1) {
+        const GnArgs& P = G.p[0];
+        if (P.epi == 5) {
+            // waves that span exactly one 64-wide head: 192 x 128 when its grid fills the chip, else 128 x 64 as four row waves
+            if (P.M % 192 == 0 && P.N % 128 == 0 && (P.M / 192) * (P.N / 128) >= 192) rc = gn_launch<192, 128, 4, 2>(G, w_is_kn, s);
+            else if (P.M % 128 == 0 && P.N % 64 == 0) rc = gn_launch<128, 64, 4, 1>(G, w_is_kn, s);
+            else if (P.M % 192 == 0 && P.N % 128 == 0) rc = gn_launch<192, 128, 4, 2>(G, w_is_kn, s);
+            else { rtts_set_error("rtts_gemm_nt_grouped: epilogue 5 needs M x N = %d x %d to tile by 192 x 128 or 128 x 64", P.M, P.N); return -1; }
+        } else {
+            const int pick = gn_pick(P.M, P.N);
+            RTTS_REQUIRE(pick >= 0, "rtts_gemm_nt_grouped: M x N = %d x %d tiles by none of 256x256, 192x128, 256x128, 96x64, 128x64", P.M, P.N);
+            switch (pick) {
+                case 0: rc = gn_launch<256, 256, 4, 2>(G, w_is_kn, s); break;
+                case 1: rc = gn_launch<192, 128, 4, 2>(G, w_is_kn, s); break;
+                case 2: rc = gn_launch<256, 128, 4, 2>(G, w_is_kn, s); break;
+                case 3: rc = gn_launch<96, 64, 2, 2>(G, w_is_kn, s); break;
+                default: rc = gn_launch<128, 64, 2, 2>(G, w_is_kn, s); break;
+            }
+        }
+    } else {
+        // one tile shape for the whole group: 192 x 128 when every problem tiles by it and the grid is worth it, else 96 x 64 / 128 x 64
+        auto tiles_by = [&](int bm, int bn) {
+            int t = 0;
+            for (int i = 0; i < n; ++i) {
+                if (G.p[i].M % bm || G.p[i].N % bn) return -1;
+                t += (G.p[i].M / bm) * (G.p[i].N / bn);
+            }
+            return t;
+        };
+        int bm = 192, bn = 128, total = tiles_by(192, 128);
+        if (total < 192) {
+            const int t96 = tiles_by(96, 64), t128 = tiles_by(128, 64);
+            if (t96 > 0) { bm = 96; bn = 64; total = t96; }
+            else if (t128 > 0) { bm = 128; bn = 64; total = t128; }
+        }
+        RTTS_REQUIRE(total > 0, "rtts_gemm_nt_grouped: the problems share none of the tile shapes 192x128, 96x64, 128x64");
+        int acc = 0;
+        for (int i = 0; i < n; ++i) {
+            acc += (G.p[i].M / bm) * (G.p[i].N / bn);
+            G.tile_end[i] = acc;
+        }
+        if (bm == 192) rc = gn_launch_group<192, 128, 4, 2>(G, total, w_is_kn, s);
+        else if (bm == 96) rc = gn_launch_group<96, 64, 2, 2>(G, total, w_is_kn, s);
+        else rc = gn_launch_group<128, 64, 2, 2>(G, total, w_is_kn, s);
+    }
+    if (rc) return rc;
+    RTTS_LAUNCH_CHECK("rtts_gemm_nt_grouped");
     return 0;
 }
 

@@ -406,6 +406,72 @@ def gemm(a: torch.Tensor, w: torch.Tensor, kn: bool = False, bias: Optional[torc
     return c
 
 
+def _nt_problem(e, a, w, kn, c, bias=None, epi=0, accumulate=False, aux=None, aux_out=None, t=0, h=0):
+    m, k = a.shape
+    n = w.shape[1] if kn else w.shape[0]
+    if (w.shape[0] if kn else w.shape[1]) != k or a.stride(1) != 1 or w.stride(1) != 1 or c.shape != (m, n) or c.stride(1) != 1:
+        raise ValueError(f"gemm: operand shapes {tuple(a.shape)} x {tuple(w.shape)} (kn={kn}) -> {tuple(c.shape)} do not match")
+    e.a, e.lda, e.w, e.ldw, e.c, e.ldc = a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), c.data_ptr(), c.stride(0)
+    e.bias = None if bias is None else bias.data_ptr()
+    e.aux, e.ld_aux = (None, 0) if aux is None else (aux.data_ptr(), aux.stride(0))
+    e.aux_out = None if aux_out is None else aux_out.data_ptr()
+    e.M, e.N, e.K, e.epilogue, e.T, e.H, e.accumulate, e.reserved = m, n, k, epi, t, h, int(accumulate), 0
+    return 2.0 * m * n * k
+
+
+def gemm_group(problems, kn: bool = False):
+    """Up to ``_lib.GEMM_NT_MAX_GROUP`` INDEPENDENT products in ONE launch of csrc/gemm_nt.hip (``rtts_gemm_nt_grouped``: one
+    grid over all their tiles).  ``problems``: dicts with ``a`` (M, K) bf16, ``w`` ((N, K), or (K, N) with ``kn``), optional
+    ``bias`` (fp32, N), ``out_f32`` (unrounded fp32 result), ``into`` (an fp32 (M, N) tensor the result is ADDED to: the keys'
+    gradient over the decoder layers).  -> list of outputs (bf16, fp32, or ``into`` itself)."""
+    if not 1 <= len(problems) <= _lib.GEMM_NT_MAX_GROUP:
+        raise ValueError(f"gemm_group: 1..{_lib.GEMM_NT_MAX_GROUP} problems")
+    arr = (_lib.GemmNtProblem * len(problems))()
+    outs, flop = [], 0.0
+    for e, p in zip(arr, problems):
+        a, w = p["a"], p["w"]
+        m = a.shape[0]
+        n = w.shape[1] if kn else w.shape[0]
+        into = p.get("into")
+        f32 = bool(p.get("out_f32")) or into is not None
+        c = into if into is not None else torch.empty(m, n, dtype=torch.float32 if f32 else torch.bfloat16, device=a.device)
+        if into is not None and (into.dtype != torch.float32 or into.shape != (m, n)):
+            raise ValueError("gemm_group: `into` must be an fp32 (M, N) tensor")
+        bias = p.get("bias")
+        flop += _nt_problem(e, a, w, kn, c, bias, 4 if f32 else (1 if bias is not None else 0), accumulate=into is not None)
+        outs.append(c)
+    ev = ops.TIMING.start("rtts_gemm_nt/group" + "+".join(f"{e.M}x{e.N}x{e.K}" for e in arr))
+    _lib.call("rtts_gemm_nt_grouped", arr, len(problems), int(kn), _s())
+    ops.TIMING.stop(ev, flop)
+    return outs
+
+
+def gemm_dgrad_delta(dy: torch.Tensor, w: torch.Tensor, out: torch.Tensor, t: int, heads: int):
+    """dout (M, N) bf16 = dy (M, K) @ w (K, N) -- the input gradient of to_out / out_proj -- AND delta (B*H, T) fp32 =
+    rowsum over each 64-wide head of out * dout, in the same launch (epilogue 5): what ``rtts_lsh_bwd_delta`` computed in a
+    launch of its own from a second read of dout.  ``out``: the attention output (M, N) bf16, rows m = b * T + t."""
+    m = dy.shape[0]
+    n = w.shape[1]
+    if n != heads * 64 or m % t:
+        raise ValueError("gemm_dgrad_delta: N must be 64 x heads and M a multiple of T")
+    dout = torch.empty(m, n, dtype=torch.bfloat16, device=dy.device)
+    delta = torch.empty((m // t) * heads, t, dtype=torch.float32, device=dy.device)
+    arr = (_lib.GemmNtProblem * 1)()
+    flop = _nt_problem(arr[0], dy, w, True, dout, None, 5, aux=out, aux_out=delta, t=t, h=heads)
+    ev = ops.TIMING.start(f"rtts_gemm_nt/{m}x{n}x{dy.shape[1]}")
+    _lib.call("rtts_gemm_nt_grouped", arr, 1, 1, _s())
+    ops.TIMING.stop(ev, flop)
+    return dout, delta
+
+
+def dgrad_delta_ok(m: int, n: int) -> bool:
+    """Does epilogue 5 tile (M, N)?  (192 x 128 or 128 x 64 tiles: waves that span one 64-wide head)"""
+    return (m % 192 == 0 and n % 128 == 0) or (m % 128 == 0 and n % 64 == 0)
+
+
+FUSE_DELTA = os.environ.get("RTTS_FUSE_DELTA", "1") != "0"          # A/B: the separate rtts_lsh_bwd_delta launch
+GROUP_XATTN = os.environ.get("RTTS_GROUP_XATTN", "1") != "0"        # A/B: q and k|v projections / dxn and dkeys as two launches each
+
 _SLAB_FLOATS = 16 * 1024 * 1024   # 64 MB: 16 splits of a 2048 x 512 gradient
 
 # Weight gradients are leaves of the backward's dependency graph: nothing reads them before the block's all-reduce /
@@ -641,10 +707,15 @@ class LSHExec:
         dyb = _out_grad(d_acc, _grad(lyr.to_out.bias), drop, pre_cast)
         out2 = out.view(b * t, e)
         wgrad(_grad(lyr.to_out.weight), dyb, out2)
-        dout = gemm(dyb, _bf16(lyr.to_out.weight), kn=True).view(b, t, e)
+        delta = None
+        if FUSE_DELTA and e == 64 * lyr.heads and dgrad_delta_ok(b * t, e):
+            dout, delta = gemm_dgrad_delta(dyb, _bf16(lyr.to_out.weight), out2, t, lyr.heads)     # delta rides in the dgrad's epilogue
+            dout = dout.view(b, t, e)
+        else:
+            dout = gemm(dyb, _bf16(lyr.to_out.weight), kn=True).view(b, t, e)
         dqkv = torch.empty_like(qkv)
         ops.lsh_attn_bwd(qkv[..., :e], qkv[..., e:], st, out, dout, lse_tot, lyr.heads, lyr.bucket_size, lyr.causal, mask,
-                         dqkv=(dqkv[..., :e], dqkv[..., e:]), drop=adrop)
+                         dqkv=(dqkv[..., :e], dqkv[..., e:]), drop=adrop, delta=delta)
         dqkv2 = dqkv.view(b * t, 2 * e)
         gview, pair = self._wqkv_grad()
         if gview is not None:
@@ -733,7 +804,12 @@ class XAttnExec:
         tk = keys_bf16.shape[0] // b
         w, bias = _bf16(m.in_proj_weight), m.in_proj_bias
         xn, mean, rstd = pre if pre is not None else ln_fwd(inp, self.norm)
-        q, kv = proj if proj is not None else (gemm(xn, w[:e], bias=bias[:e]), gemm(keys_bf16, w[e:], bias=bias[e:]))
+        if proj is not None:
+            q, kv = proj
+        elif GROUP_XATTN:      # the two in_proj products of nn.MultiheadAttention (reformer.py:161-186) in one launch
+            q, kv = gemm_group([dict(a=xn, w=w[:e], bias=bias[:e]), dict(a=keys_bf16, w=w[e:], bias=bias[e:])])
+        else:
+            q, kv = gemm(xn, w[:e], bias=bias[:e]), gemm(keys_bf16, w[e:], bias=bias[e:])
         if stash is not None:
             o, lse = stash
         else:
@@ -774,10 +850,13 @@ class XAttnExec:
         post = None if kept else residual(acc, g, m.out_proj.bias, -1.0, next_norm)
         dyb = _out_grad(d_acc, _grad(m.out_proj.bias), None, pre_cast)
         wgrad(_grad(m.out_proj.weight), dyb, o)
-        do = gemm(dyb, _bf16(m.out_proj.weight), kn=True)
         dev = inp.device
-        delta = torch.empty(b * h, t, dtype=torch.float32, device=dev)
-        _lib.call("rtts_lsh_bwd_delta", o.data_ptr(), e, do.data_ptr(), e, b, h, t, e // h, delta.data_ptr(), _s())
+        if FUSE_DELTA and e == 64 * h and dgrad_delta_ok(b * t, e):
+            do, delta = gemm_dgrad_delta(dyb, _bf16(m.out_proj.weight), o, t, h)
+        else:
+            do = gemm(dyb, _bf16(m.out_proj.weight), kn=True)
+            delta = torch.empty(b * h, t, dtype=torch.float32, device=dev)
+            _lib.call("rtts_lsh_bwd_delta", o.data_ptr(), e, do.data_ptr(), e, b, h, t, e // h, delta.data_ptr(), _s())
         dq = torch.empty(b * t, e, dtype=torch.bfloat16, device=dev)
         nqb = t // 128
         part = torch.empty(nqb, b * tk, 2 * e, dtype=torch.bfloat16, device=dev)
@@ -794,9 +873,12 @@ class XAttnExec:
         colsum_bf16(dkv, gb[e:])
         wgrad(gw[:e], dq, xn)
         wgrad(gw[e:], dkv, keys_bf16)
-        dxn = gemm(dq, w[:e], kn=True)
+        if GROUP_XATTN:      # dxn = dq W_q beside dkeys (fp32) += dkv W_kv: one launch, the sum in the second problem's epilogue
+            dxn, _ = gemm_group([dict(a=dq, w=w[:e]), dict(a=dkv, w=w[e:], into=dkeys)], kn=True)
+        else:
+            dxn = gemm(dq, w[:e], kn=True)
+            residual(dkeys, gemm(dkv, w[e:], kn=True), None, 1.0)             # dkeys (fp32) += dkv W_kv
         nxt = ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp, next_cast, dx_in=d_src)
-        residual(dkeys, gemm(dkv, w[e:], kn=True), None, 1.0)                 # dkeys (fp32) += dkv W_kv
         return post, nxt
 
 

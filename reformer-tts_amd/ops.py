@@ -147,8 +147,9 @@ def lsh_combine_fwd(o, lse, batch: int, heads: int, out: Optional[torch.Tensor] 
 
 
 def lsh_attn_bwd(qk, v, st, out, dout, lse_tot, heads: int, bucket_size: int, causal: bool, mask=None,
-                 dqkv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, drop=None):
-    """Backward of hash-sorted attention + round combine.  -> dqk, dv (B,T,H*dh) bf16."""
+                 dqkv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, drop=None, delta: Optional[torch.Tensor] = None):
+    """Backward of hash-sorted attention + round combine.  -> dqk, dv (B,T,H*dh) bf16.  ``delta`` (B*H, T) fp32 = rowsum(out *
+    dout) per head when the caller already has it (the to_out input-gradient GEMM's epilogue 5), else computed here."""
     ld = _check_rows(qk, "qk")
     if _check_rows(v, "v") != ld:
         raise ValueError("qk and v must share a row stride")
@@ -158,8 +159,11 @@ def lsh_attn_bwd(qk, v, st, out, dout, lse_tot, heads: int, bucket_size: int, ca
     n_hashes = st.shape[1]
     mask = _check_mask(mask, b, t, qk.device)
     dev = qk.device
-    delta = torch.empty(b * heads, t, dtype=torch.float32, device=dev)
-    _lib.call("rtts_lsh_bwd_delta", out.data_ptr(), ld_out, dout.data_ptr(), ld_do, b, heads, t, dh, delta.data_ptr(), _stream())
+    if delta is None:
+        delta = torch.empty(b * heads, t, dtype=torch.float32, device=dev)
+        _lib.call("rtts_lsh_bwd_delta", out.data_ptr(), ld_out, dout.data_ptr(), ld_do, b, heads, t, dh, delta.data_ptr(), _stream())
+    elif delta.shape != (b * heads, t) or delta.dtype != torch.float32 or not delta.is_contiguous():
+        raise ValueError("delta: expected contiguous fp32 (B*H, T)")
     dqk_part = torch.empty(_lib.load().rtts_lsh_bwd_qk_slots(), b * heads, n_hashes, t, dh, dtype=torch.bfloat16, device=dev)
     dv_part = torch.empty(2, b * heads, n_hashes, t, dh, dtype=torch.bfloat16, device=dev)
     # the walking kernel writes most key rows once (slot 0 only) and flags the few that have a slot-1 partner

@@ -212,3 +212,132 @@ def test_ffn_executor_vs_oracle_feed_forward(gpu, b, t):
     for k, v in res.items():
         if k.startswith("d_"):
             assert v[1] <= (6e-2 if ("net.0" in k or "norm" in k or k == "d_input") else 1e-2), (k, v)
+
+
+# ------------------------------------------------------------------ round 4: grouped launches, persistent tiles, delta / accumulate epilogues
+def test_grouped_launch_vs_float64(gpu):
+    """``rtts_gemm_nt_grouped``: independent problems in ONE launch, each against float64 on its own bf16 operands -- the
+    cross-attention's q and k|v projections (reformer.py:161-186; M = 12288 / 3072, bias epilogue), their input-gradient pair (dxn
+    bf16 beside dkeys fp32 += ..., different K), three encoder-sized problems on the small tile, and a group whose members need
+    different epilogues (bf16 / bias / fp32)."""
+    from reformer_tts_amd import engine
+    g = torch.Generator(device=gpu).manual_seed(5)
+
+    def rnd(*s, scale=1.0):
+        return (torch.randn(*s, device=gpu, generator=g) * scale)
+
+    msgs = []
+    # (1) q | kv projections
+    xn, keys = rnd(12288, 512).bfloat16(), rnd(3072, 512).bfloat16()
+    w = rnd(1536, 512, scale=512 ** -0.5).bfloat16()
+    bias = rnd(1536)
+    q, kv = engine.gemm_group([dict(a=xn, w=w[:512], bias=bias[:512]), dict(a=keys, w=w[512:], bias=bias[512:])])
+    for name, got, ref in (("q", q, xn.double() @ w[:512].double().t() + bias[:512].double()),
+                           ("kv", kv, keys.double() @ w[512:].double().t() + bias[512:].double())):
+        emax, el2 = _rel(got, ref)
+        msgs.append(f"{name} max {emax:.2e} l2 {el2:.2e}")
+        assert got.dtype == torch.bfloat16 and emax <= 1.02 * BF16_HALF_ULP and el2 <= 2e-3, (name, emax, el2)
+    # the same two products as separate launches: bit-identical (same tile arithmetic, only the grid differs)
+    assert torch.equal(q, _gemm(xn, w[:512], bias=bias[:512])) and torch.equal(kv, _gemm(keys, w[512:], bias=bias[512:]))
+    # (2) dxn beside dkeys += dkv W_kv (fp32, accumulated into what is there)
+    dq, dkv = rnd(12288, 512).bfloat16(), rnd(3072, 1024).bfloat16()
+    dkeys0 = rnd(3072, 512)
+    dkeys = dkeys0.clone()
+    dxn, same = engine.gemm_group([dict(a=dq, w=w[:512]), dict(a=dkv, w=w[512:], into=dkeys)], kn=True)
+    assert same is dkeys
+    emax, el2 = _rel(dxn, dq.double() @ w[:512].double())
+    assert emax <= 1.02 * BF16_HALF_ULP and el2 <= 2e-3, (emax, el2)
+    ref = dkeys0.double() + dkv.double() @ w[512:].double()
+    e32 = ((dkeys.double() - ref).abs().max() / ref.abs().max()).item()
+    msgs.append(f"dxn max {emax:.2e}; dkeys (fp32, accumulated) max {e32:.2e}")
+    assert e32 <= 2e-6, e32
+    # (3) three small problems (the 96 x 64 tile), mixed epilogues: bf16, bias, fp32
+    a1, a2, a3 = rnd(768, 256).bfloat16(), rnd(384, 128).bfloat16(), rnd(192, 64).bfloat16()
+    w1, w2, w3 = rnd(128, 256, scale=0.1).bfloat16(), rnd(320, 128, scale=0.1).bfloat16(), rnd(64, 64, scale=0.1).bfloat16()
+    b2 = rnd(320)
+    o1, o2, o3 = engine.gemm_group([dict(a=a1, w=w1), dict(a=a2, w=w2, bias=b2), dict(a=a3, w=w3, out_f32=True)])
+    for name, got, ref, tol in (("small/plain", o1, a1.double() @ w1.double().t(), 1.02 * BF16_HALF_ULP),
+                                ("small/bias", o2, a2.double() @ w2.double().t() + b2.double(), 1.02 * BF16_HALF_ULP),
+                                ("small/f32", o3, a3.double() @ w3.double().t(), 2e-6)):
+        emax, _ = _rel(got, ref)
+        msgs.append(f"{name} max {emax:.2e}")
+        assert emax <= tol, (name, emax)
+    assert o3.dtype == torch.float32
+    torch.cuda.synchronize()
+    print("\n[grouped gemm_nt vs float64] " + "; ".join(msgs))
+    with pytest.raises(Exception, match="1\\.\\."):
+        engine.gemm_group([dict(a=a1, w=w1)] * 5)
+
+
+@pytest.mark.parametrize("m,n,k,epi", [(12288, 2048, 512, "bias+relu"), (12288, 1024, 512, "plain"), (12288, 2048, 512, "kn+gate"),
+                                       (12288, 1024, 512, "kn"), (6144, 2048, 256, "plain"), (12288, 4096, 512, "bias")])
+def test_persistent_tiles_are_bit_identical_to_one_tile_per_workgroup(gpu, m, n, k, epi):
+    """MODE 2 of csrc/gemm_nt.hip: resident workgroups walk the tiles of a problem with several tiles per CU (N >= 1024 at
+    M = 12288), the LDS ring turning across tile boundaries.  The arithmetic of a tile is the same instruction sequence in
+    every form, so the results -- including the 1-bit gate words and the partial column sums of the gated input gradient --
+    must agree BIT FOR BIT with one tile per workgroup, on the 2-deep ring (two workgroups per CU) and on the deep ring."""
+    from reformer_tts_amd import _lib, engine
+    g = torch.Generator(device=gpu).manual_seed(m + n + k)
+    a = torch.randn(m, k, device=gpu, generator=g).bfloat16()
+    w = (torch.randn(n, k, device=gpu, generator=g) / k ** 0.5).bfloat16()
+    bias = torch.randn(n, device=gpu, generator=g)
+    wkn = w.t().contiguous()
+    outs = {}
+    for mode in (1, 2, 3, 0):
+        _lib.call("rtts_debug_set_gemm_mode", mode)
+        try:
+            if epi == "plain":
+                res = (_gemm(a, w),)
+            elif epi == "bias":
+                res = (_gemm(a, w, bias=bias),)
+            elif epi == "kn":
+                res = (_gemm(a, wkn, kn=True),)
+            elif epi == "bias+relu":
+                words = engine.gate_words(m, n, gpu)
+                res = (_gemm(a, w, bias=bias, relu=True, words=words), words.clone())
+            else:
+                words = engine.gate_words(m, n, gpu)
+                _gemm(a, w, bias=bias, relu=True, words=words)
+                db = torch.zeros(n, device=gpu)
+                res = (_gemm(a, wkn, kn=True, gate=True, words=words, gate_bias_grad=db),)
+                engine.flush_wgrad()
+                res = res + (db.clone(),)
+            torch.cuda.synchronize()
+        finally:
+            _lib.call("rtts_debug_set_gemm_mode", 0)
+        outs[mode] = res
+    for mode in (2, 3, 0):
+        for x, y in zip(outs[mode], outs[1]):
+            assert torch.equal(x, y), f"launch form {mode} differs from one tile per workgroup"
+    ref = a.double() @ w.double().t()
+    if epi in ("plain", "kn"):
+        emax, el2 = _rel(outs[0][0], ref)
+        assert emax <= 1.02 * BF16_HALF_ULP and el2 <= 2e-3, (emax, el2)
+
+
+@pytest.mark.parametrize("b,t,heads,k", [(12, 1024, 8, 512), (12, 256, 8, 512), (2, 256, 2, 128), (1, 384, 4, 256)])
+def test_dgrad_with_delta_epilogue_vs_float64(gpu, b, t, heads, k):
+    """Epilogue 5: dout = dy W (the input gradient of to_out / out_proj) and delta[b*H + h][t] = sum over head h's 64 columns of
+    out * dout in ONE launch, against float64 (dout: one bf16 rounding; delta: fp32 sums of the ROUNDED dout, as the attention
+    backward needs them) and against the separate ``rtts_lsh_bwd_delta`` launch it replaces."""
+    from reformer_tts_amd import _lib, engine
+    m, n = b * t, 64 * heads
+    g = torch.Generator(device=gpu).manual_seed(b * t + heads)
+    dy = torch.randn(m, k, device=gpu, generator=g).bfloat16()
+    w = (torch.randn(k, n, device=gpu, generator=g) / k ** 0.5).bfloat16()
+    out = torch.randn(m, n, device=gpu, generator=g).bfloat16()
+    assert engine.dgrad_delta_ok(m, n)
+    dout, delta = engine.gemm_dgrad_delta(dy, w, out, t, heads)
+    plain = _gemm(dy, w, kn=True)
+    torch.cuda.synchronize()
+    assert torch.equal(dout, plain), "the delta epilogue must not change dout"
+    emax, el2 = _rel(dout, dy.double() @ w.double())
+    assert emax <= 1.02 * BF16_HALF_ULP and el2 <= 2e-3, (emax, el2)
+    ref = (out.double() * dout.double()).view(b, t, heads, 64).sum(-1).permute(0, 2, 1).reshape(b * heads, t)
+    ed = ((delta.double() - ref).abs().max() / ref.abs().max()).item()
+    sep = torch.empty(b * heads, t, dtype=torch.float32, device=gpu)
+    _lib.call("rtts_lsh_bwd_delta", out.data_ptr(), n, dout.data_ptr(), n, b, heads, t, 64, sep.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    es = ((delta - sep).abs().max() / sep.abs().max()).item()
+    print(f"\n[dgrad + delta B={b} T={t} H={heads} K={k}] dout max {emax:.2e} l2 {el2:.2e}; delta vs float64 {ed:.2e}, vs rtts_lsh_bwd_delta {es:.2e} (tol 1e-5)")
+    assert ed <= 1e-5 and es <= 1e-5, (ed, es)
