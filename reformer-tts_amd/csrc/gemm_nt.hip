@@ -99,6 +99,7 @@ struct GnGroup {
     GnArgs p[GN_MAX_GROUP];
     int tile_end[GN_MAX_GROUP];        // MODE 1: cumulative tile counts of the problems
     int n;
+    int spread;                        // MODE 1: every tile count is a multiple of 8 -> each XCD gets an eighth of EVERY problem
 };
 
 // swizzle of the [K][N] weight image: XOR applied to the index of a 32-byte chunk (16 columns) of k row `k`
@@ -143,11 +144,24 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 192 && NST == 2) ? 4 : 1) void
     int pi = 0;
     uint32_t tile = logical;
     if constexpr (MODE == 1) {
+        if (G.spread) {
+            // logical ids [x q, (x + 1) q) share an XCD (xcd_remap), q = total / 8: give every XCD an eighth of EVERY problem --
+            // problems of different depth (K = 512 beside K = 1024) then load the eight XCDs alike.  Inside its slice a problem's
+            // tiles stay consecutive (the N tiles of an A row panel back to back on one L2).
+            const uint32_t q = gridDim.x >> 3, x = logical / q, rr = logical - x * q;
 #pragma unroll
-        for (int i = 0; i + 1 < GN_MAX_GROUP; ++i)
-            if (i + 1 < G.n && logical >= (uint32_t)G.tile_end[i]) pi = i + 1;
-        pi = __builtin_amdgcn_readfirstlane(pi);
-        tile = logical - (pi ? (uint32_t)G.tile_end[pi - 1] : 0u);
+            for (int i = 0; i + 1 < GN_MAX_GROUP; ++i)
+                if (i + 1 < G.n && rr >= ((uint32_t)G.tile_end[i] >> 3)) pi = i + 1;
+            pi = __builtin_amdgcn_readfirstlane(pi);
+            const uint32_t lo = pi ? ((uint32_t)G.tile_end[pi - 1] >> 3) : 0u, cnt = ((uint32_t)G.tile_end[pi] >> 3) - lo;
+            tile = x * cnt + (rr - lo);
+        } else {
+#pragma unroll
+            for (int i = 0; i + 1 < GN_MAX_GROUP; ++i)
+                if (i + 1 < G.n && logical >= (uint32_t)G.tile_end[i]) pi = i + 1;
+            pi = __builtin_amdgcn_readfirstlane(pi);
+            tile = logical - (pi ? (uint32_t)G.tile_end[pi - 1] : 0u);
+        }
     }
     const GnArgs& P = G.p[pi];
     const int ntn = P.N / BN;
@@ -583,7 +597,13 @@ static int gn_launch2(const GnGroup& G, hipStream_t s) {
         // and the ring keeps turning across the tile boundary -- measured forms in profiles/r04_gemm_nt_persistent_ab.log.
         const int mode = g_gn_mode.load(std::memory_order_relaxed);
         const bool multi = tiles >= 512 && tiles % 256 == 0 && P.K / GN_BK >= NST && P.conv_cpt == 0;
-        if (multi && mode != 1) {
+        // MEASURED (profiles/r04_gemm_nt_persistent_ab.log, one box, interleaved): the persistent forms LOSE -- N = 2048, K = 512:
+        // 41.0 us one tile per workgroup, 44.9 persistent on the 2-deep ring, 49.8 on the deep ring; N = 1024: 20.3 / 21.3 / 24.2.
+        // Two co-resident workgroups already hide each other's prologue and epilogue, the dispatcher re-fills a CU slot the moment a
+        // workgroup retires (its stores drain while the successor's first stage loads), and a resident workgroup has to wait for its
+        // own epilogue stores before the counted vmcnt of its next tile's second stage.  The library's pick stays round 3's form;
+        // the persistent forms remain selectable (bit-identical results: tests/test_gemm_hip.py) for A/B runs on other shapes.
+        if (multi && mode >= 2) {
             if (mode == 3) return gn_launch3<BM, BN, WM, WN, W_KN, EPI, NST, 2>(G, 256, s);
             return gn_launch3<BM, BN, WM, WN, W_KN, EPI, 2, 2>(G, 512, s);
         }
@@ -771,8 +791,11 @@ extern "C" int rtts_gemm_nt_grouped(const rtts_gemm_nt_problem* problems, int n,
         }
         RTTS_REQUIRE(total > 0, "rtts_gemm_nt_grouped: the problems share none of the tile shapes 192x128, 96x64, 128x64");
         int acc = 0;
+        G.spread = 1;
         for (int i = 0; i < n; ++i) {
-            acc += (G.p[i].M / bm) * (G.p[i].N / bn);
+            const int t = (G.p[i].M / bm) * (G.p[i].N / bn);
+            if (t % 8) G.spread = 0;
+            acc += t;
             G.tile_end[i] = acc;
         }
         if (bm == 192) rc = gn_launch_group<192, 128, 4, 2>(G, total, w_is_kn, s);

@@ -470,7 +470,8 @@ def dgrad_delta_ok(m: int, n: int) -> bool:
 
 
 FUSE_DELTA = os.environ.get("RTTS_FUSE_DELTA", "1") != "0"          # A/B: the separate rtts_lsh_bwd_delta launch
-GROUP_XATTN = os.environ.get("RTTS_GROUP_XATTN", "1") != "0"        # A/B: q and k|v projections / dxn and dkeys as two launches each
+GROUP_XATTN = os.environ.get("RTTS_GROUP_XATTN", "1") != "0"        # A/B: the q and k|v projections as two launches
+GROUP_XATTN_BWD = os.environ.get("RTTS_GROUP_XATTN_BWD", "0") == "1"   # A/B: dxn and dkeys as one grouped launch (measured: no gain)
 
 _SLAB_FLOATS = 16 * 1024 * 1024   # 64 MB: 16 splits of a 2048 x 512 gradient
 
@@ -873,11 +874,14 @@ class XAttnExec:
         colsum_bf16(dkv, gb[e:])
         wgrad(gw[:e], dq, xn)
         wgrad(gw[e:], dkv, keys_bf16)
-        if GROUP_XATTN:      # dxn = dq W_q beside dkeys (fp32) += dkv W_kv: one launch, the sum in the second problem's epilogue
+        # dkeys (fp32) += dkv W_kv in the product's own epilogue (no separate add launch).  Grouping it with dxn = dq W_q into one
+        # launch measured no gain (28.7 against 27.7 us for the two launches + the add: a K = 1024 tile beside K = 512 tiles on two
+        # workgroups per CU; profiles/r04_gemm_nt_persistent_ab.log), so the two products stay two launches
+        if GROUP_XATTN_BWD:
             dxn, _ = gemm_group([dict(a=dq, w=w[:e]), dict(a=dkv, w=w[e:], into=dkeys)], kn=True)
         else:
             dxn = gemm(dq, w[:e], kn=True)
-            residual(dkeys, gemm(dkv, w[e:], kn=True), None, 1.0)             # dkeys (fp32) += dkv W_kv
+            gemm_group([dict(a=dkv, w=w[e:], into=dkeys)], kn=True)
         nxt = ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp, next_cast, dx_in=d_src)
         return post, nxt
 
