@@ -418,7 +418,8 @@ typedef struct {
 int rtts_gemm_nt_grouped(const rtts_gemm_nt_problem* problems, int n, int w_is_kn, void* stream);
 /* TEST / A-B ONLY, process-wide: launch form of rtts_gemm_nt problems with several tiles per CU.  0 = the library's pick,
  * 1 = one tile per workgroup (round 3), 2 = persistent workgroups on a 2-deep ring (two per CU), 3 = persistent on the deepest
- * ring (one per CU).  Results are identical bit for bit in every form. */
+ * ring (one per CU).  10 / 11 / 12: store form of the bf16 epilogues (8-byte stores / 16-byte stores after a lane-pair exchange /
+ * 16-byte write-through stores), 9: the library's pick again.  Results are identical bit for bit in every form. */
 int rtts_debug_set_gemm_mode(int mode);
 /* FeedForward pair with a 1-bit ReLU gate: the forward GEMM (epilogue 2: bias + ReLU) also writes one 64-bit word per
  * lane and tile -- bit b set <=> the b-th output of that lane is a positive bf16 -- and the input-gradient GEMM of the same

@@ -92,6 +92,7 @@ struct GnArgs {
     int64_t ldaux;
     float* aux_out;
     int T, H, accum;
+    int store_mode;      // bf16 outputs: 0 = 8-byte stores, 1 = 16-byte stores (lane-pair exchange), 2 = 16-byte write-through stores
 };
 
 #define GN_MAX_GROUP 4
@@ -433,64 +434,101 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 192 && NST == 2) ? 4 : 1) void
     bool use_bits = false;
     if constexpr (kBitsFit && (epi == 2 || epi == 3)) use_bits = P.bits != nullptr;
     if constexpr (kBitsFit && epi == 3) if (use_bits) gbits = P.bits[widx];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
+    // store form (wave-uniform): 0 = 8 bytes per lane straight from the accumulators, 1 = 16 bytes after a lane-pair exchange,
+    // 2 = the same as write-through (sc1) stores -- the output leaves the XCD's L2 while the kernel still runs instead of being
+    // flushed as dirty lines at its end (no consumer sits on this L2 alone: the next kernel's workgroups are on all eight)
+    const int wide = (TN % 2 == 0) ? P.store_mode : 0;
+    static_assert(TN % 2 == 0, "column tiles are worked in pairs");
+    // one (row tile i, column tile j) of this lane: 4 consecutive columns of one row through the epilogue's arithmetic.
+    // -> true: `o` holds the four bf16 to store; false: the fp32 forms have stored already
+    auto one = [&](auto ic_, auto jc_, const f32x4 bv, uint2& o) -> bool {
+        constexpr int i = decltype(ic_)::value, j = decltype(jc_)::value;
         const int n = ncol + 16 * j;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (epi == 1 || epi == 2) bv = *reinterpret_cast<const f32x4*>(P.bias + n);
-        if constexpr (epi == 4 || epi == 6) if (P.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(P.bias + n);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const size_t m = (size_t)(mrow + 16 * i);
-            f32x4 v = acc[i][j] + bv;
-            if constexpr (epi == 2) {
-                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-            } else if constexpr (epi == 3) {
-                if (kBitsFit && use_bits) {
-                    const unsigned nib = (unsigned)(gbits >> ((i * TN + j) * 4)) & 15u;
-                    v[0] = (nib & 1u) ? v[0] : 0.f;
-                    v[1] = (nib & 2u) ? v[1] : 0.f;
-                    v[2] = (nib & 4u) ? v[2] : 0.f;
-                    v[3] = (nib & 8u) ? v[3] : 0.f;
-                } else {
-                    const uint2 hv = *reinterpret_cast<const uint2*>(P.gate + m * P.ldg + n);
-                    // bf16 h > 0  <=>  sign bit clear and magnitude non-zero
-                    v[0] = ((hv.x & 0x8000u) == 0 && (hv.x & 0x7FFFu) != 0) ? v[0] : 0.f;
-                    v[1] = ((hv.x & 0x80000000u) == 0 && (hv.x & 0x7FFF0000u) != 0) ? v[1] : 0.f;
-                    v[2] = ((hv.y & 0x8000u) == 0 && (hv.y & 0x7FFFu) != 0) ? v[2] : 0.f;
-                    v[3] = ((hv.y & 0x80000000u) == 0 && (hv.y & 0x7FFF0000u) != 0) ? v[3] : 0.f;
-                }
-                cs[j] += v;
+        const size_t m = (size_t)(mrow + 16 * i);
+        f32x4 v = acc[i][j] + bv;
+        if constexpr (epi == 2) {
+            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+        } else if constexpr (epi == 3) {
+            if (kBitsFit && use_bits) {
+                const unsigned nib = (unsigned)(gbits >> ((i * TN + j) * 4)) & 15u;
+                v[0] = (nib & 1u) ? v[0] : 0.f;
+                v[1] = (nib & 2u) ? v[1] : 0.f;
+                v[2] = (nib & 4u) ? v[2] : 0.f;
+                v[3] = (nib & 8u) ? v[3] : 0.f;
+            } else {
+                const uint2 hv = *reinterpret_cast<const uint2*>(P.gate + m * P.ldg + n);
+                // bf16 h > 0  <=>  sign bit clear and magnitude non-zero
+                v[0] = ((hv.x & 0x8000u) == 0 && (hv.x & 0x7FFFu) != 0) ? v[0] : 0.f;
+                v[1] = ((hv.x & 0x80000000u) == 0 && (hv.x & 0x7FFF0000u) != 0) ? v[1] : 0.f;
+                v[2] = ((hv.y & 0x8000u) == 0 && (hv.y & 0x7FFFu) != 0) ? v[2] : 0.f;
+                v[3] = ((hv.y & 0x80000000u) == 0 && (hv.y & 0x7FFF0000u) != 0) ? v[3] : 0.f;
             }
-            // epilogue 4: unrounded fp32 result (rows of ldc floats): in front of a BatchNorm / the loss.  Epilogue 6 is the GROUP's
-            // epilogue: each problem says at run time (a wave-uniform branch) whether it stores fp32 (its own epilogue 4) or bf16
-            // (0, or 1 when it has a bias)
-            if (epi == 4 || (epi == 6 && P.epi == 4)) {
-                f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(P.c) + m * P.ldc + n);
-                if (P.accum) v += *dst;        // C += result (the keys' gradient over the decoder layers)
-                *dst = v;
-                continue;
-            }
-            uint2 o;
-            o.x = pack_bf16x2(v[0], v[1]);
-            o.y = pack_bf16x2(v[2], v[3]);
-            if constexpr (epi == 5) {          // delta += out * dout on the ROUNDED dout: what the attention backward will read
-                const uint2 ov = *reinterpret_cast<const uint2*>(P.aux + m * P.ldaux + n);
-                dl[i] += __uint_as_float(ov.x << 16) * __uint_as_float(o.x << 16) + __uint_as_float(ov.x & 0xFFFF0000u) * __uint_as_float(o.x & 0xFFFF0000u) +
-                         __uint_as_float(ov.y << 16) * __uint_as_float(o.y << 16) + __uint_as_float(ov.y & 0xFFFF0000u) * __uint_as_float(o.y & 0xFFFF0000u);
-            }
-            if constexpr (kBitsFit && epi == 2) {      // the values are >= 0: positive <=> the rounded bf16 is not zero
-                const unsigned nib = ((o.x & 0xFFFFu) ? 1u : 0u) | ((o.x >> 16) ? 2u : 0u) | ((o.y & 0xFFFFu) ? 4u : 0u) | ((o.y >> 16) ? 8u : 0u);
-                gbits |= (unsigned long long)nib << ((i * TN + j) * 4);
-            }
-#ifdef GN_NT_STORE
-            __builtin_nontemporal_store(o.x, reinterpret_cast<uint32_t*>(P.c + m * P.ldc + n));
-            __builtin_nontemporal_store(o.y, reinterpret_cast<uint32_t*>(P.c + m * P.ldc + n) + 1);
-#else
-            *reinterpret_cast<uint2*>(P.c + m * P.ldc + n) = o;
-#endif
+            cs[j] += v;
         }
-    }
+        // epilogue 4: unrounded fp32 result (rows of ldc floats): in front of a BatchNorm / the loss.  Epilogue 6 is the GROUP's
+        // epilogue: each problem says at run time (a wave-uniform branch) whether it stores fp32 (its own epilogue 4) or bf16
+        // (0, or 1 when it has a bias)
+        if (epi == 4 || (epi == 6 && P.epi == 4)) {
+            f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(P.c) + m * P.ldc + n);
+            if (P.accum) v += *dst;        // C += result (the keys' gradient over the decoder layers)
+            *dst = v;
+            return false;
+        }
+        o.x = pack_bf16x2(v[0], v[1]);
+        o.y = pack_bf16x2(v[2], v[3]);
+        if constexpr (epi == 5) {          // delta += out * dout on the ROUNDED dout: what the attention backward will read
+            const uint2 ov = *reinterpret_cast<const uint2*>(P.aux + m * P.ldaux + n);
+            dl[i] += __uint_as_float(ov.x << 16) * __uint_as_float(o.x << 16) + __uint_as_float(ov.x & 0xFFFF0000u) * __uint_as_float(o.x & 0xFFFF0000u) +
+                     __uint_as_float(ov.y << 16) * __uint_as_float(o.y << 16) + __uint_as_float(ov.y & 0xFFFF0000u) * __uint_as_float(o.y & 0xFFFF0000u);
+        }
+        if constexpr (kBitsFit && epi == 2) {      // the values are >= 0: positive <=> the rounded bf16 is not zero
+            const unsigned nib = ((o.x & 0xFFFFu) ? 1u : 0u) | ((o.x >> 16) ? 2u : 0u) | ((o.y & 0xFFFFu) ? 4u : 0u) | ((o.y >> 16) ? 8u : 0u);
+            gbits |= (unsigned long long)nib << ((i * TN + j) * 4);
+        }
+        return true;
+    };
+    gn_static_for<0, TN / 2>([&](auto jpc_) {
+        constexpr int jl = 2 * decltype(jpc_)::value, jh = jl + 1;
+        const int nl = ncol + 16 * jl, nh = nl + 16;
+        f32x4 bvl = {0.f, 0.f, 0.f, 0.f}, bvh = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (epi == 1 || epi == 2) {
+            bvl = *reinterpret_cast<const f32x4*>(P.bias + nl);
+            bvh = *reinterpret_cast<const f32x4*>(P.bias + nh);
+        }
+        if constexpr (epi == 4 || epi == 6) if (P.bias != nullptr) {
+            bvl = *reinterpret_cast<const f32x4*>(P.bias + nl);
+            bvh = *reinterpret_cast<const f32x4*>(P.bias + nh);
+        }
+        gn_static_for<0, TM>([&](auto ic_) {
+            constexpr int i = decltype(ic_)::value;
+            const size_t m = (size_t)(mrow + 16 * i);
+            uint2 ol = {0u, 0u}, oh = {0u, 0u};
+            const bool sl = one(ic_, std::integral_constant<int, jl>{}, bvl, ol);
+            const bool sh = one(ic_, std::integral_constant<int, jh>{}, bvh, oh);
+            if (!(sl && sh)) return;               // fp32 forms: stored inside
+            if (wide) {
+                // 16-byte stores: the lane pair (l, l ^ 16) -- column groups g and g ^ 1 of the same row -- trades halves of the tile
+                // pair (jl, jh): the even group ends up with 8 consecutive columns of tile jl, the odd group with 8 of tile jh.
+                // One store instruction then writes 16 rows x 64 contiguous bytes instead of 16 x 32, and half as many are issued.
+                const bool odd = (g & 1) != 0;
+                const uint2 send = odd ? ol : oh;
+                uint2 recv;
+                recv.x = (uint32_t)__builtin_amdgcn_ds_swizzle((int)send.x, 0x401F);      // lane ^ 16 (bit mode: and 0x1F, xor 0x10)
+                recv.y = (uint32_t)__builtin_amdgcn_ds_swizzle((int)send.y, 0x401F);
+                gn_v4i wv;
+                wv[0] = (int)(odd ? recv.x : ol.x);
+                wv[1] = (int)(odd ? recv.y : ol.y);
+                wv[2] = (int)(odd ? oh.x : recv.x);
+                wv[3] = (int)(odd ? oh.y : recv.y);
+                bf16_t* dst = P.c + m * P.ldc + (odd ? nh - 4 : nl);
+                if (wide == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(wv) : "memory");   // write-through
+                else *reinterpret_cast<gn_v4i*>(dst) = wv;
+            } else {
+                *reinterpret_cast<uint2*>(P.c + m * P.ldc + nl) = ol;
+                *reinterpret_cast<uint2*>(P.c + m * P.ldc + nh) = oh;
+            }
+        });
+    });
     if constexpr (kBitsFit && epi == 2) if (use_bits) P.bits[widx] = gbits;
     if constexpr (epi == 5) {
         // the four lane groups g hold different columns of the same 16 rows: sum over g (lane ^ 16 by ds_swizzle, lane ^ 32 by
@@ -570,10 +608,30 @@ constexpr int gn_nst() { return (4 * (BM + BN) * 128 <= 160 * 1024) ? 4 : ((3 * 
 // 1 = never persistent (round 3's forms), 2 = persistent on a 2-deep ring, two workgroups per CU, 3 = persistent on the
 // deepest ring, one workgroup per CU.  Process-wide, atomic; no environment is read on the launch path.
 static std::atomic<int> g_gn_mode{0};
+static std::atomic<int> g_gn_store{-1};
 extern "C" int rtts_debug_set_gemm_mode(int mode) {
-    if (mode < 0 || mode > 3) { rtts_set_error("rtts_debug_set_gemm_mode: 0..3 (got %d)", mode); return -1; }
+    // 0..3: launch form (see above); 10 + s: store form s of the bf16 epilogues (0 = 8-byte, 1 = 16-byte, 2 = 16-byte write-through),
+    // 9 = the library's pick of the store form again
+    if (mode >= 9 && mode <= 12) { g_gn_store.store(mode - 10, std::memory_order_relaxed); return 0; }
+    if (mode < 0 || mode > 3) { rtts_set_error("rtts_debug_set_gemm_mode: 0..3 or 9..12 (got %d)", mode); return -1; }
     g_gn_mode.store(mode, std::memory_order_relaxed);
     return 0;
+}
+// MEASURED (profiles/r04_gemm_nt_store_forms_ab.log, one box, interleaved, us per launch inside a replayed graph):
+//   M = 12288, N x K = 512 x 512: 12.9 (8-byte) / 11.7 (16-byte) / 10.3 (16-byte write-through);  1024 x 512: 20.7 / 18.3 / 15.6;
+//   2048 x 512: 41.7 / 36.4 / 33.4;  512 x 2048: 34.2 / 33.9 / 31.9;  M = 3072, 512 x 512: 6.3 / 6.1 / 5.8.
+// With plain stores the whole output (12.6 .. 50 MB) sits in the XCDs' L2 as dirty lines when the kernel ends and is written back
+// at the kernel boundary (B / 6 TB/s on top of the boundary itself: MI355X_MICROARCH.md, price list, "boundary"); written through,
+// it leaves while the MFMAs still run -- the fabric is idle under an ingest-bound GEMM -- and nothing is left to flush.  No consumer
+// loses an L2 hit: the next kernel's workgroups sit on all eight XCDs and read through their own L2 either way.
+#ifndef GN_DEFAULT_STORE
+#define GN_DEFAULT_STORE 2
+#endif
+// store form of a bf16 output: the 16-byte forms need 16-byte aligned rows
+static int gn_store_mode(const void* c, int64_t ldc) {
+    const int want = g_gn_store.load(std::memory_order_relaxed);
+    const int m = want >= 0 ? want : GN_DEFAULT_STORE;
+    return ((((uintptr_t)c & 15) == 0 && ldc % 8 == 0) ? m : 0);
 }
 
 template <int BM, int BN, int WM, int WN, bool W_KN, int EPI, int NST, int MODE>
@@ -701,6 +759,7 @@ static int gn_run(const void* a, int64_t lda, const void* w, int64_t ldw, int w_
     P.colsum = colsum_partial; P.lda = lda; P.ldw = ldw; P.ldc = ldc; P.ldg = ldg; P.M = M; P.N = N; P.K = K; P.epi = epilogue;
     P.conv_cpt = conv_cpt; P.conv_sign = conv_sign; P.conv_wtap = conv_wtap;
     P.bits = gate_bits;
+    P.store_mode = epilogue == 4 ? 0 : gn_store_mode(c, ldc);
     RTTS_REQUIRE(!gate_bits || (pick != 0 && (epilogue == 2 || epilogue == 3) && ((uintptr_t)gate_bits & 7) == 0),
                  "rtts_gemm_nt_gated: gate words go with epilogue 2 (written) or 3 (read) and a tile shape that has them "
                  "(rtts_gemm_nt_gate_words(M, N) > 0)");
@@ -739,6 +798,7 @@ static int gn_fill(GnArgs& P, const rtts_gemm_nt_problem& q, int w_is_kn, int i)
     P.a = (const bf16_t*)q.a; P.w = (const bf16_t*)q.w; P.c = (bf16_t*)q.c; P.bias = q.bias; P.lda = q.lda; P.ldw = q.ldw; P.ldc = q.ldc;
     P.M = q.M; P.N = q.N; P.K = q.K; P.epi = q.epilogue; P.aux = (const bf16_t*)q.aux; P.ldaux = q.ld_aux; P.aux_out = q.aux_out;
     P.T = q.T; P.H = q.H; P.accum = q.accumulate;
+    P.store_mode = q.epilogue == 4 ? 0 : gn_store_mode(q.c, q.ldc);
     return 0;
 }
 

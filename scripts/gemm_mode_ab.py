@@ -82,6 +82,22 @@ for m, n, k, kind in ((12288, 2048, 512, "bias+relu"), (12288, 1024, 512, "plain
         return run
     ab(f"M={m} N={n} K={k} {kind:9s}", {"one tile/WG": variant(1), "persistent 2-deep x2": variant(2), "persistent deep x1": variant(3)}, flop=2.0 * m * n * k)
 
+# ---- store forms of the bf16 epilogues: inside a chain (the consumer of a GEMM's output is the next launch: what a dirty L2 costs
+#      shows at the kernel boundary, so the GEMM is timed together with a streaming reader of its output)
+for m, n, k in ((12288, 512, 512), (12288, 1024, 512), (12288, 2048, 512), (12288, 512, 2048), (3072, 512, 512)):
+    a = rnd(m, k).bfloat16()
+    w = rnd(n, k, scale=k ** -0.5).bfloat16()
+
+    def form(f):
+        def run():
+            _lib.call("rtts_debug_set_gemm_mode", 10 + f)
+            try:
+                return timed(lambda: engine.gemm(a, w))
+            finally:
+                _lib.call("rtts_debug_set_gemm_mode", 9)
+        return run
+    ab(f"store form M={m} N={n} K={k}", {"8-byte": form(0), "16-byte": form(1), "16-byte write-through": form(2)}, flop=2.0 * m * n * k)
+
 # ---- grouped pairs
 xn, keys = rnd(12288, 512).bfloat16(), rnd(3072, 512).bfloat16()
 w = rnd(1536, 512, scale=512 ** -0.5).bfloat16()

@@ -341,3 +341,43 @@ def test_dgrad_with_delta_epilogue_vs_float64(gpu, b, t, heads, k):
     es = ((delta - sep).abs().max() / sep.abs().max()).item()
     print(f"\n[dgrad + delta B={b} T={t} H={heads} K={k}] dout max {emax:.2e} l2 {el2:.2e}; delta vs float64 {ed:.2e}, vs rtts_lsh_bwd_delta {es:.2e} (tol 1e-5)")
     assert ed <= 1e-5 and es <= 1e-5, (ed, es)
+
+
+@pytest.mark.parametrize("m,n,k", [(12288, 512, 512), (3072, 1024, 512), (768, 384, 384), (12288, 2048, 512), (256, 128, 128)])
+def test_store_forms_of_the_bf16_epilogues_are_bit_identical(gpu, m, n, k):
+    """The bf16 epilogues store 8 bytes per lane straight from the accumulators (form 0), or 16 bytes after the lane pair
+    (l, l ^ 16) has traded halves of a column-tile pair (form 1), or the same as write-through stores (form 2: the output
+    leaves L2 while the kernel runs instead of being flushed at its end).  Same values at the same addresses: every layout /
+    epilogue must agree bit for bit across the forms, gate words, column sums and the delta epilogue included."""
+    from reformer_tts_amd import _lib, engine
+    g = torch.Generator(device=gpu).manual_seed(m + 3 * n + k)
+    a = torch.randn(m, k, device=gpu, generator=g).bfloat16()
+    w = (torch.randn(n, k, device=gpu, generator=g) / k ** 0.5).bfloat16()
+    bias = torch.randn(n, device=gpu, generator=g)
+    wkn = w.t().contiguous()
+    aux = torch.randn(m, n, device=gpu, generator=g).bfloat16()
+    outs = {}
+    for form in (0, 1, 2):
+        _lib.call("rtts_debug_set_gemm_mode", 10 + form)
+        try:
+            words = engine.gate_words(m, n, gpu)
+            res = [_gemm(a, w), _gemm(a, w, bias=bias), _gemm(a, wkn, kn=True)]
+            if words is not None:
+                res.append(_gemm(a, w, bias=bias, relu=True, words=words))
+                db = torch.zeros(n, device=gpu)
+                res.append(_gemm(a, wkn, kn=True, gate=True, words=words, gate_bias_grad=db))
+                engine.flush_wgrad()
+                res += [words.clone(), db]
+            if n % 64 == 0 and engine.dgrad_delta_ok(m, n) and m % 256 == 0:
+                res += list(engine.gemm_dgrad_delta(a, wkn, aux, 256, n // 64))
+            res += engine.gemm_group([dict(a=a, w=w, bias=bias), dict(a=a, w=w)])
+            torch.cuda.synchronize()
+        finally:
+            _lib.call("rtts_debug_set_gemm_mode", 9)
+        outs[form] = res
+    for form in (1, 2):
+        assert len(outs[form]) == len(outs[0])
+        for idx, (x, y) in enumerate(zip(outs[form], outs[0])):
+            assert torch.equal(x, y), f"store form {form}: result {idx} differs from the 8-byte form"
+    emax, el2 = _rel(outs[2][0], a.double() @ w.double().t())
+    assert emax <= 1.02 * BF16_HALF_ULP and el2 <= 2e-3, (emax, el2)
