@@ -184,6 +184,9 @@ def load() -> C.CDLL:
         if fw is not None or bw is not None:
             _WALK[:] = [-1 if fw is None else int(fw), -1 if bw is None else int(bw)]
             lib.rtts_debug_set_walk(*_WALK)
+        gs = os.environ.get("RTTS_GEMM_STORE")            # A/B runs: store form of the GEMM's bf16 epilogues (0 / 1 / 2)
+        if gs is not None:
+            lib.rtts_debug_set_gemm_mode(10 + int(gs))
     return _lib
 
 

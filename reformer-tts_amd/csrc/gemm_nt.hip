@@ -521,7 +521,8 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 192 && NST == 2) ? 4 : 1) void
                 wv[2] = (int)(odd ? oh.x : recv.x);
                 wv[3] = (int)(odd ? oh.y : recv.y);
                 bf16_t* dst = P.c + m * P.ldc + (odd ? nh - 4 : nl);
-                if (wide == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(wv) : "memory");   // write-through
+                // write-through; the s_nop pads the store-data hazard hipcc does not pad for an asm statement (cdna_hip_programming.md 5.7)
+                if (wide == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(wv) : "memory");
                 else *reinterpret_cast<gn_v4i*>(dst) = wv;
             } else {
                 *reinterpret_cast<uint2*>(P.c + m * P.ldc + nl) = ol;

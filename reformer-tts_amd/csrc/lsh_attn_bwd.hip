@@ -440,7 +440,7 @@ __global__ __launch_bounds__(BS * 4 / AB_KT2, AB_KT2 == 2 ? 1 : 2) void lsh_attn
 #pragma unroll
         for (int i = 0; i < 4; ++i) rowv[i] = *reinterpret_cast<const uint4*>(stg + (i * 8 + srow) * AB_ROWB + spiece * 16);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dvdst + (obase + rpos[k2][i]) * AB_DH + spiece * 8) = rowv[i];
+        for (int i = 0; i < 4; ++i) rtts_store16_out(dvdst + (obase + rpos[k2][i]) * AB_DH + spiece * 8, rowv[i]);
     }
 
     AB_STAMP(4);
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(BS * 4 / AB_KT2, AB_KT2 == 2 ? 1 : 2) void lsh_attn
 #pragma unroll
         for (int i = 0; i < 4; ++i) rowv[i] = *reinterpret_cast<const uint4*>(stg + (i * 8 + srow) * AB_ROWB + spiece * 16);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dkdst + (obase + rpos[k2][i]) * AB_DH + spiece * 8) = rowv[i];
+        for (int i = 0; i < 4; ++i) rtts_store16_out(dkdst + (obase + rpos[k2][i]) * AB_DH + spiece * 8, rowv[i]);
     }
     AB_STAMP(8);
 #ifdef AB_PHASE_TIMING
@@ -996,7 +996,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
 #pragma unroll
                 for (int i = 0; i < 4; ++i) rowv[i] = *reinterpret_cast<const uint4*>(stg + (i * 8 + srow) * AB_ROWB + spiece * 16);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dvdst + (obase + rpos[i]) * AB_DH + spiece * 8) = rowv[i];
+                for (int i = 0; i < 4; ++i) rtts_store16_out(dvdst + (obase + rpos[i]) * AB_DH + spiece * 8, rowv[i]);
                 __builtin_amdgcn_wave_barrier();
             }
             {
@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
 #pragma unroll
                 for (int i = 0; i < 4; ++i) rowv[i] = *reinterpret_cast<const uint4*>(stg + (i * 8 + srow) * AB_ROWB + spiece * 16);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dkdst + (obase + rpos[i]) * AB_DH + spiece * 8) = rowv[i];
+                for (int i = 0; i < 4; ++i) rtts_store16_out(dkdst + (obase + rpos[i]) * AB_DH + spiece * 8, rowv[i]);
             }
             // slot-0 rows say whether a slot-1 partner exists: only the own keys of a run's last step have one
             if (slot == 0 && spiece == 0) {

@@ -345,7 +345,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
         rpos[i] = kpos[qt * 32 + i * 8 + srow];
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(o + (obase + rpos[i]) * AF_DH + spiece * 8) = rowv[i];
+    for (int i = 0; i < 4; ++i) rtts_store16_out(o + (obase + rpos[i]) * AF_DH + spiece * 8, rowv[i]);
     AF_STAMP(5);
 }
 
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_walk_kernel(const bf16
                 rpos[i] = allpos[(j + 1) * BS + qt * 32 + i * 8 + srow];
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(o + (obase + rpos[i]) * AF_DH + spiece * 8) = rowv[i];
+            for (int i = 0; i < 4; ++i) rtts_store16_out(o + (obase + rpos[i]) * AF_DH + spiece * 8, rowv[i]);
             AF_WSTAMP(5);
             if (j + 1 == L) return;
             __syncthreads();                         // (3) staging read: the dead slot may take the next chunk

@@ -93,6 +93,26 @@ static inline hipError_t rtts_ensure_lds(const void* func, size_t lds, RttsLdsSt
                      hipGetErrorString(e_lds_));                                                                  \
     } while (0)
 
+// Output rows of the compute-bound kernels leave as 16-byte WRITE-THROUGH stores (global_store_dwordx4 ... sc1): the bytes go out to
+// the fabric while the kernel still computes, instead of sitting in the XCD's L2 as dirty lines that are written back at the kernel
+// boundary (B / 6 TB/s on top of every boundary: MI355X_MICROARCH.md price list).  Nobody re-reads them from this L2: the consumer is
+// the next launch, whose workgroups sit on all eight XCDs.  -DRTTS_WT_STORES=0 builds plain stores (A/B runs: scripts/ab_attn.py).
+#ifndef RTTS_WT_STORES
+#define RTTS_WT_STORES 1
+#endif
+typedef int rtts_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void rtts_store16_out(void* p, const uint4 v) {
+#if RTTS_WT_STORES
+    const rtts_v4i w = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+    // s_nop 1 INSIDE the statement: the hardware needs wait states between a store of more than 64 bits and a VALU write of its data
+    // registers; hipcc pads its own stores, not an asm statement's (cdna_hip_programming.md 5.7: without it the next instruction
+    // may overwrite the data before the store has read it -- seen as NaN rows in the forward's output)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
+#else
+    *reinterpret_cast<uint4*>(p) = v;
+#endif
+}
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
 
 // round-to-nearest-even; the plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN
