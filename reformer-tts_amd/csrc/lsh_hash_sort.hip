@@ -76,6 +76,22 @@ __device__ __forceinline__ unsigned long long match_lanes(int v) {
     return m;
 }
 
+// histogram step of one wave: lane adds 1 to cnt[v] for every active lane (v >= 0).  Sixty-four lanes on a handful of buckets
+// made the plain per-lane LDS add an N-way same-address serialisation (43 % of the sort kernel's LDS cycles were bank
+// conflicts: profiles/r03g_pmc_*); the first lane of each group of equal values adds the group's size instead -- distinct
+// addresses, one add each.
+// With many buckets (32, 64: the T = 4096 configuration) equal values in one wave are rare, the per-lane add has nothing to
+// serialise, and the BITS + 1 ballots would cost more than they save (measured: 71 against 62-67 us at 64 buckets): plain adds there.
+template <int BITS>
+__device__ __forceinline__ void count_lanes(int* cnt, int v, int lane) {
+    if constexpr (BITS <= 4) {
+        const unsigned long long m = match_lanes<BITS>(v);
+        if (v >= 0 && (m & ((1ull << lane) - 1ull)) == 0) cnt[v] += __popcll(m);
+    } else {
+        if (v >= 0) atomicAdd(&cnt[v], 1);                     // integer LDS add: order-free, deterministic
+    }
+}
+
 template <int HALF, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void lsh_hash_sort_kernel(
     const bf16_t* __restrict__ qk, int64_t ld, const float* __restrict__ rotations, int rot_rows,
@@ -192,9 +208,9 @@ __global__ __launch_bounds__(64 * WAVES) void lsh_hash_sort_kernel(
                 const int idx = hh ? idx2[1] : idx2[0];     // lane <-> row of the 64-row tile again
                 if (lane < rows) {
                     bkt[s0 + t0 + lane] = (uint16_t)idx;
-                    atomicAdd(&cntw[wave * 64 + idx], 1);      // integer LDS add: order-free, deterministic
                     if (buckets) buckets[((size_t)bh * n_hashes + r) * T + s0 + t0 + lane] = idx + r * NB;
                 }
+                count_lanes<BITS>(cntw + wave * 64, lane < rows ? idx : -1, lane);      // this wave's own row: no other wave adds to it
                 __builtin_amdgcn_wave_barrier();
                 continue;
             }
@@ -212,9 +228,9 @@ __global__ __launch_bounds__(64 * WAVES) void lsh_hash_sort_kernel(
             const int idx = hash_row<HALF>(q, rot_lds, half);   // lanes >= rows hash stale LDS rows: results dropped below
             if (lane < rows) {
                 bkt[s0 + t0 + lane] = (uint16_t)idx;
-                atomicAdd(&cntw[wave * 64 + idx], 1);      // integer LDS add: order-free, deterministic
                 if (buckets) buckets[((size_t)bh * n_hashes + r) * T + s0 + t0 + lane] = idx + r * NB;
             }
+            count_lanes<BITS>(cntw + wave * 64, lane < rows ? idx : -1, lane);
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -408,10 +424,12 @@ __global__ __launch_bounds__(64 * WAVES) void lsh_sort_ids_kernel(int T, int NB,
     const int seg = T / WAVES, s0 = wave * seg;
     for (int i = tid; i < WAVES * 64; i += 64 * WAVES) cntw[i] = 0;
     __syncthreads();
-    for (int t = lane; t < seg; t += 64) {                     // wave w counts the segment it will place
-        const int id = st_out[s0 + t];
-        bkt[s0 + t] = (uint16_t)id;
-        atomicAdd(&cntw[wave * 64 + id], 1);                   // integer LDS add: order-free, deterministic
+    for (int t0 = 0; t0 < seg; t0 += 64) {                     // wave w counts the segment it will place
+        const bool act = t0 + lane < seg;
+        const int id = act ? st_out[s0 + t0 + lane] : -1;
+        if (act) bkt[s0 + t0 + lane] = (uint16_t)id;
+        count_lanes<BITS>(cntw + wave * 64, id, lane);         // this wave's own row of counters
+        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();                                           // all ids are in LDS: st may be overwritten from here on
     if (tid < NB) {

@@ -1,13 +1,26 @@
 // On-box peak probes for bench.py's roofline lines ("peaks must be measured on the box"):
-//   rtts_peak_copy   float4 stream copy dst = src: the HBM rate a plain coalesced kernel reaches (read + write bytes / time)
+//   rtts_peak_copy   float4 stream copy dst = src, four loads in flight per thread: the HBM rate a plain coalesced kernel reaches
+//                    (read + write bytes / time)
 //   rtts_peak_mfma   back-to-back v_mfma_f32_16x16x32_bf16 on register operands (random, non-zero: zero operands let the chip
 //                    hold a higher clock, cdna_hip_programming.md rule 25), two waves per SIMD on every CU: the dense bf16
 //                    matrix rate the chip sustains at the clock it holds under that load
 // Neither is on the training path.
 #include "rtts_common.h"
 
+// FOUR 16-byte loads in flight per thread before the first store (one in flight -- round 3's probe -- reached 4.8 TB/s where
+// MI355X_MICROARCH.md measures 6.29 TB/s for a float4 copy: a probe that understates the peak flatters every "fraction of the
+// measured peak" derived from it); the tail (n4 not a multiple of 4 x the grid's threads) is copied one float4 at a time
 __global__ __launch_bounds__(256) void peak_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    const size_t nthr = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t i = t;
+    for (; i + 3 * nthr < n4; i += 4 * nthr) {
+        const float4 a = src[i], b = src[i + nthr], c = src[i + 2 * nthr], d = src[i + 3 * nthr];
+        dst[i] = a;
+        dst[i + nthr] = b;
+        dst[i + 2 * nthr] = c;
+        dst[i + 3 * nthr] = d;
+    }
+    for (; i < n4; i += nthr) dst[i] = src[i];
 }
 
 __global__ __launch_bounds__(512) void peak_mfma_kernel(float* __restrict__ sink, int iters) {
