@@ -436,6 +436,10 @@ int rtts_gemm_nt_gated(const void* a, int64_t lda, const void* w, int64_t ldw, i
  * rtts_peak_mfma: `workgroups` x 8 waves each issue iters x 8 back-to-back v_mfma_f32_16x16x32_bf16 on random register
  *                 operands -> dense bf16 matrix rate = workgroups*8*iters*8*16384 FLOP / time. */
 int rtts_peak_copy(const void* src, void* dst, int64_t bytes, void* stream);
+/* Probe, not on the training path: a ring all-reduce as the CUs see it -- `workgroups` resident workgroups (8-32) copy `bytes`
+ * (+1 on every word) in 16 KB pieces with write-through stores and sleep `sleep` x ~0.5 us between pieces (pace of a link, not of
+ * HBM).  scripts/comm_overlap_probe.py runs it beside the data-parallel chain of hipGraphs. */
+int rtts_comm_probe(const void* src, void* dst, int64_t bytes, int workgroups, int sleep, void* stream);
 int rtts_peak_mfma(float* sink, int workgroups, int iters, void* stream);
 
 /* ---- SqueezeWave vocoder, inference -----------------------------------

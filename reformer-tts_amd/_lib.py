@@ -118,6 +118,7 @@ SIGNATURES = {
     "rtts_gemm_nt_gate_words": [_i32, _i32],
     "rtts_gemm_nt_gated": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _vp, _vp, _vp],
     "rtts_peak_copy": [_vp, _vp, _i64, _vp],
+    "rtts_comm_probe": [_vp, _vp, _i64, _i32, _i32, _vp],
     "rtts_peak_mfma": [_vp, _i32, _i32, _vp],
     "rtts_sw_depthwise_k3": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "rtts_sw_gate": [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],

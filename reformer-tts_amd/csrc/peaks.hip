@@ -47,6 +47,38 @@ __global__ __launch_bounds__(512) void peak_mfma_kernel(float* __restrict__ sink
     if (s == 123.456f) sink[lane] = s;          // keeps the chain alive; (practically) never true
 }
 
+// rtts_comm_probe: what a ring all-reduce looks like to the CUs -- a SMALL grid of resident workgroups that moves a message
+// through the fabric at the pace of a link, not of HBM: each workgroup copies 16 KB pieces (four 16-byte loads in flight per thread,
+// +1 on every word, write-through stores) and sleeps `sleep` x ~0.5 us between pieces.  scripts/comm_overlap_probe.py runs it on a second
+// stream beside the data-parallel chain of hipGraphs to see how much of such a kernel hides behind the backward and what it costs
+// the chain.  Not on the training path.
+__global__ __launch_bounds__(256) void comm_probe_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16, int sleep) {
+    for (size_t base = (size_t)blockIdx.x * 1024; base < n16; base += (size_t)gridDim.x * 1024) {
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t i = base + k * 256 + threadIdx.x;
+            v[k] = i < n16 ? src[i] : uint4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t i = base + k * 256 + threadIdx.x;
+            v[k].x += 1u; v[k].y += 1u; v[k].z += 1u; v[k].w += 1u;
+            if (i < n16) rtts_store16_out(dst + i, v[k]);
+        }
+#pragma unroll 1
+        for (int t = 0; t < sleep; ++t) __builtin_amdgcn_s_sleep(16);      // ~1 k cycles = 0.5 us per unit
+    }
+}
+
+extern "C" int rtts_comm_probe(const void* src, void* dst, int64_t bytes, int workgroups, int sleep, void* stream) {
+    RTTS_ENTER(stream);
+    RTTS_REQUIRE(src && dst && bytes > 0 && bytes % 16 == 0 && workgroups > 0 && workgroups <= 256 && sleep >= 0, "rtts_comm_probe: bad arguments");
+    hipLaunchKernelGGL(comm_probe_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst, (size_t)bytes / 16, sleep);
+    RTTS_LAUNCH_CHECK("rtts_comm_probe");
+    return 0;
+}
+
 extern "C" int rtts_peak_copy(const void* src, void* dst, int64_t bytes, void* stream) {
     RTTS_ENTER(stream);
     RTTS_REQUIRE(src && dst && bytes > 0 && bytes % 16 == 0, "rtts_peak_copy: bytes must be a positive multiple of 16");

@@ -1091,7 +1091,7 @@ class FusedStackFn(torch.autograd.Function):
         return dx, dkeys, None, None
 
 
-def stack_backward_steps(ctx, dout, complete_layers: Optional[bool] = None, notify_dkeys: bool = False):
+def stack_backward_steps(ctx, dout, complete_layers: Optional[bool] = None, notify_dkeys: bool = False, flush_at: int = 7):
     """The backward of one FusedStackFn.forward as a GENERATOR: runs the blocks in reverse and yields ``(seq, [block indices])``
     every time a layer's worth of weight gradients has been flushed -- from that point the listed blocks' slices of the flat
     gradient buffer are final -- and returns ``(dx, dkeys)`` through StopIteration.  FusedStackFn.backward drives it to the end
@@ -1101,7 +1101,8 @@ def stack_backward_steps(ctx, dout, complete_layers: Optional[bool] = None, noti
     ``complete_layers``: also finalise the deferred column sums (bias / LayerNorm gradients) at every stop (default: only
     when a block-done hook is waiting for the gradients).  ``notify_dkeys``: additionally yield ``(seq, ("dkeys", dkeys))`` as soon
     as the gradient of the cross-attention keys is complete (after the LOWEST cross-attention block's backward): the encoder's
-    backward can start there, beside the remaining decoder blocks."""
+    backward can start there, beside the remaining decoder blocks.  ``flush_at``: weight gradients queued before a stop (7 = one
+    decoder layer's worth -- LSH 2, cross-attention 3, feed-forward 2; 4 = one encoder block's)."""
     if ctx.state is None:
         raise RuntimeError("FusedStackFn.backward: this forward's state was already consumed (the streams are rebuilt in "
                            "place; a second backward through the same stack call is not possible)")
@@ -1161,7 +1162,7 @@ def stack_backward_steps(ctx, dout, complete_layers: Optional[bool] = None, noti
         hook = seq.block_done_hook
         waited_for = (hook is not None and getattr(hook, "active", lambda: True)()) if complete_layers is None else bool(complete_layers)
         if WGRAD_FLUSH_PER_LAYER or waited_for:
-            if pending_wgrads() >= 7 or i == 0:
+            if pending_wgrads() >= flush_at or i == 0:
                 # one grouped launch per layer's worth of weight gradients; only then are the finished blocks'
                 # gradient slices final, so their all-reduce hooks run here
                 flush_wgrad(colsums=waited_for)

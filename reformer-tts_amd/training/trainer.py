@@ -853,8 +853,11 @@ class Trainer:
         if any(n.startswith(("dec.prenet", "dec.positional_encoding", "dec.reformer")) for n in tail) or not tail:
             raise RuntimeError("flat buffer: heads and postnet are expected behind the decoder stack")
         dec_seq = self.model.dec.reformer.layers
+        enc_seq = self.model.enc.reformer.layers
         segs = []
         dec_seq.manual = {}
+        enc_seq.manual = {}          # the encoder stack too: its backward is cut per block, so that its 35 MB of gradients leave in
+        #                              three messages behind the following blocks instead of in one behind the 0.15 ms prenet backward
         try:
             with self._capturing(self._graph):
                 self.model.train()
@@ -891,22 +894,63 @@ class Trainer:
                 segs.append((g, (lo, hi)))
         finally:
             dec_seq.manual = None
-        g = torch.cuda.CUDAGraph()
-        with self._capturing(g, pool=self._graph.pool()):
-            self._enc_out.backward(self._enc_in.grad)
-            engine.flush_wgrad()
-            assert engine.pending_all() == 0
-            if self.overlap_encoder:             # the encoder's nodes (and its deferred launches) ran on the encoder's stream: join
-                torch.cuda.current_stream().wait_stream(self._enc_stream())
-        segs.append((g, (stack_begin, enc_end)))
-        g = torch.cuda.CUDAGraph()
-        with self._capturing(g, pool=self._graph.pool()):
-            self._pre_out.backward(self._pre_in.grad)
-            engine.flush_wgrad()
-            assert engine.pending_all() == 0
-            if self.overlap_encoder:
-                torch.cuda.current_stream().wait_stream(self._enc_stream())
-        segs.append((g, (0, stack_begin)))
+            enc_call = enc_seq.manual.get("call") if enc_seq.manual is not None else None
+            enc_seq.manual = None
+        if enc_call is not None:
+            # the encoder stack driven by hand like the decoder's: one graph per encoder block (LSH + feed-forward: 4 weight
+            # gradients, 11.6 MB of gradients at the baseline widths), each block's range exchanged while the next one replays
+            ctx_e, enc_x, _, _ = enc_call
+            gen = engine.stack_backward_steps(ctx_e, self._enc_in.grad, complete_layers=True, flush_at=4)
+            finished, dx_enc = False, None
+            while not finished:
+                g = torch.cuda.CUDAGraph()
+                with self._capturing(g, pool=self._graph.pool()):
+                    with torch.no_grad():
+                        try:
+                            _, done = next(gen)
+                        except StopIteration as fin:      # (only when the stack yields nothing: cannot happen with >= 1 block)
+                            raise RuntimeError("encoder stack backward ended without a stop") from fin
+                    rng = [self.block_bucket[("enc", j)] for j in done if ("enc", j) in self.block_bucket]
+                    lo, hi = min(r[0] for r in rng), max(r[1] for r in rng)
+                    if 0 in done:
+                        try:
+                            with torch.no_grad():
+                                next(gen)
+                            raise RuntimeError("stack_backward_steps yielded after block 0")
+                        except StopIteration as fin:
+                            dx_enc = fin.value[0]
+                        engine.flush_wgrad()
+                        assert engine.pending_all() == 0
+                        lo = stack_begin
+                        finished = True
+                segs.append((g, (lo, hi)))
+            if enc_x is not self._pre_in:
+                raise RuntimeError("segmented capture: the encoder stack's input is expected to be the cut behind the prenet")
+            g = torch.cuda.CUDAGraph()
+            with self._capturing(g, pool=self._graph.pool()):
+                self._pre_out.backward(dx_enc)
+                engine.flush_wgrad()
+                assert engine.pending_all() == 0
+                if self.overlap_encoder:
+                    torch.cuda.current_stream().wait_stream(self._enc_stream())
+            segs.append((g, (0, stack_begin)))
+        else:
+            g = torch.cuda.CUDAGraph()
+            with self._capturing(g, pool=self._graph.pool()):
+                self._enc_out.backward(self._enc_in.grad)
+                engine.flush_wgrad()
+                assert engine.pending_all() == 0
+                if self.overlap_encoder:             # the encoder's nodes (and its deferred launches) ran on the encoder's stream: join
+                    torch.cuda.current_stream().wait_stream(self._enc_stream())
+            segs.append((g, (stack_begin, enc_end)))
+            g = torch.cuda.CUDAGraph()
+            with self._capturing(g, pool=self._graph.pool()):
+                self._pre_out.backward(self._pre_in.grad)
+                engine.flush_wgrad()
+                assert engine.pending_all() == 0
+                if self.overlap_encoder:
+                    torch.cuda.current_stream().wait_stream(self._enc_stream())
+            segs.append((g, (0, stack_begin)))
         self._enc_out = self._enc_in = self._pre_out = self._pre_in = None
         cover = sorted(r for _, r in segs)
         if cover[0][0] != 0 or cover[-1][1] != self.n_params or any(a[1] != b[0] for a, b in zip(cover, cover[1:])):
@@ -921,9 +965,11 @@ class Trainer:
     def segment_plan(self):
         """[(bytes of the gradient range all-reduced after segment k, launches-free description)] of the captured data-parallel
         schedule (bench.py prints it): which collective overlaps which graph."""
-        n_dec = len(self._segments) - 3
+        n_dec = len(self.model.dec.reformer.layers.blocks) // 6          # f, swap, f, swap, f, swap per decoder layer
+        n_enc = len(self._segments) - 2 - n_dec                          # encoder-stack graphs: one per block, or one for the stack
+        enc_names = [f"encoder block {k} backward" for k in range(n_enc - 1, -1, -1)] if n_enc > 1 else ["encoder stack backward"]
         names = ["forward + loss + heads/postnet backward"] + [f"decoder layer {k} backward" for k in range(n_dec - 1, -1, -1)] + \
-                ["encoder stack backward", "encoder prenet backward"]
+                enc_names + ["encoder prenet backward"]
         names[n_dec] += " + decoder prenet backward"
         out = []
         for k, ((_, (s, e)), nm) in enumerate(zip(self._segments, names)):

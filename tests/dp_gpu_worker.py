@@ -1,7 +1,7 @@
 """Worker of tests/test_dp_gpu.py: one rank of a 2-process gloo job sharing cuda:0.  Runs three training steps of the small
 model in the two data-parallel modes of the trainer and checks (a) replicas stay identical, (b) the modes agree:
     eager      per-block all-reduce issued from the block-done hooks, overlapped with the backward
-    graphs     a chain of hipGraphs (fwd + heads/postnet bwd | one per decoder layer | encoder stack bwd | encoder prenet bwd | clip + AdamW)
+    graphs     a chain of hipGraphs (fwd + heads/postnet bwd | one per decoder layer | one per encoder block | encoder prenet bwd | clip + AdamW)
                with the all-reduce of each graph's gradient range issued while the next one replays
 (parameters after three steps, loss of the third step)."""
 import os
@@ -21,6 +21,7 @@ def run(mode, rank, dev):
     cfg = model_ref.small_cfg()
     cfg["enc_reformer_kwargs"]["attn_kwargs"]["implementation"] = "hip"
     cfg["dec_reformer_kwargs"]["self_attn_kwargs"]["implementation"] = "hip"
+    cfg["enc_reformer_kwargs"]["depth"] = 2            # two encoder blocks: the chain cuts the encoder stack's backward per block
     torch.manual_seed(1)
     model = build_model(model_config_from_dict(cfg), dev)
     for m in model.modules():
@@ -36,10 +37,11 @@ def run(mode, rank, dev):
             losses.append(float(tr.train_step(batch)[0]))
     else:
         tr.capture(batch)                      # two eager steps (bulk all-reduce), then the graphs are captured
-        # forward+loss+heads | one graph per decoder layer (depth 1 here) | encoder stack | encoder prenet, then the optimizer
-        assert len(tr._segments) == 4 and tr._graph_opt is not None, len(tr._segments)
+        # forward+loss+heads | one graph per decoder layer (depth 1 here) | one per encoder block (2) | encoder prenet, then the optimizer
+        assert len(tr._segments) == 5 and tr._graph_opt is not None, len(tr._segments)
         plan = tr.segment_plan()
         assert sum(p["allreduce_bytes"] for p in plan) == 4 * tr.n_params and plan[-1]["overlaps"].startswith("nothing")
+        assert [p["after"] for p in plan][2:4] == ["encoder block 1 backward", "encoder block 0 backward"], plan
         losses = [None, None, float(tr.replay()[0])]
     torch.cuda.synchronize()
     return tr, losses
