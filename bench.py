@@ -327,7 +327,13 @@ def main():
                                 "allreduce_bytes_per_step": (4 * n_par if world > 1 else 0),
                                 "collectives_per_step": (len(trainer._segments) if (world > 1 and use_graph) else (0 if world == 1 else "per block")),
                                 "schedule": (trainer.segment_plan() if (world > 1 and use_graph) else None),
-                                "rank_seeds": "rotations and dropout seeded with seed + rank"}},
+                                "rank_seeds": "rotations and dropout seeded with seed + rank",
+                                # the communication policy (one-GPU probe: profiles/r04_comm_overlap_probe.log)
+                                "policy": ("all-reduces on the collective library's own stream beside the chain of graphs: one graph per "
+                                           "decoder layer and per encoder block, a graph's gradient range exchanged while the next graph "
+                                           "replays, only the encoder prenet's 17 MB has nothing to hide behind; NO CU mask on the compute "
+                                           "stream (grids are sized for 256 CUs: 248 cost +26 % in the probe); fp32 messages of 7-17 MB")
+                                if world > 1 else None}},
         }
         if other is not None:
             out["stash" if other_mode == "stash" else "full_recompute"] = other

@@ -44,6 +44,27 @@ __device__ __forceinline__ void store_row_f32(float* __restrict__ row, int lane,
     }
 }
 
+// Rows that leave for HBM (not the LDS staging of block_partial).  RTTS_ROW_WT (A/B builds, scripts/build_ab.sh): 1 = the fp32
+// rows as 16-byte write-through stores, 2 = the 8-byte bf16 rows too; 0 = plain stores.
+#ifndef RTTS_ROW_WT
+#define RTTS_ROW_WT 0
+#endif
+template <int EPL, int VEC>
+__device__ __forceinline__ void store_row_f32_out(float* __restrict__ row, int lane, const float* v) {
+#if RTTS_ROW_WT >= 1
+    if constexpr (VEC == 4) {
+#pragma unroll
+        for (int k = 0; k < EPL / VEC; ++k) {
+            uint4 t;
+            t.x = __float_as_uint(v[k * 4]); t.y = __float_as_uint(v[k * 4 + 1]); t.z = __float_as_uint(v[k * 4 + 2]); t.w = __float_as_uint(v[k * 4 + 3]);
+            rtts_store16_out(row + (k * 64 + lane) * 4, t);
+        }
+        return;
+    }
+#endif
+    store_row_f32<EPL, VEC>(row, lane, v);
+}
+
 template <int EPL, int VEC>
 __device__ __forceinline__ void load_row_bf16(const bf16_t* __restrict__ row, int lane, float* v) {
 #pragma unroll
@@ -71,7 +92,7 @@ __device__ __forceinline__ void load_row_bf16(const bf16_t* __restrict__ row, in
     }
 }
 
-template <int EPL, int VEC>
+template <int EPL, int VEC, bool WT = true>
 __device__ __forceinline__ void store_row_bf16(bf16_t* __restrict__ row, int lane, const float* v) {
 #pragma unroll
     for (int k = 0; k < EPL / VEC; ++k) {
@@ -87,6 +108,14 @@ __device__ __forceinline__ void store_row_bf16(bf16_t* __restrict__ row, int lan
             uint2 t;
             t.x = pack_bf16x2(v[k * 4], v[k * 4 + 1]);
             t.y = pack_bf16x2(v[k * 4 + 2], v[k * 4 + 3]);
+#if RTTS_ROW_WT >= 2
+            if (WT) {
+                typedef int rv2i __attribute__((ext_vector_type(2)));
+                const rv2i w2 = {(int)t.x, (int)t.y};
+                asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(w2) : "memory");
+                continue;
+            }
+#endif
             *reinterpret_cast<uint2*>(p) = t;
         } else {
             *reinterpret_cast<uint32_t*>(p) = pack_bf16x2(v[k * 2], v[k * 2 + 1]);
@@ -178,7 +207,7 @@ __global__ __launch_bounds__(FR_THREADS) void residual_ln_kernel(const float* x,
     }
 #pragma unroll
     for (int e = 0; e < EPL; ++e) v[e] += sign * gv[e];
-    store_row_f32<EPL, VEC>(y + (size_t)row * D, lane, v);      // y == x: the stream is updated in place
+    store_row_f32_out<EPL, VEC>(y + (size_t)row * D, lane, v);      // y == x: the stream is updated in place
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) s += v[e];
@@ -243,7 +272,7 @@ __global__ __launch_bounds__(FR_THREADS) void ln_bwd_kernel(const bf16_t* __rest
         s2 = wave_sum(s2) * (1.f / D);
 #pragma unroll
         for (int e = 0; e < EPL; ++e) dx[e] += rs * (dy[e] - s1 - xv[e] * s2);
-        store_row_f32<EPL, VEC>(dx_io + (size_t)row * D, lane, dx);
+        store_row_f32_out<EPL, VEC>(dx_io + (size_t)row * D, lane, dx);
         if (dyb_next) {
             if (thresh) {
 #pragma unroll

@@ -78,6 +78,85 @@ __device__ __forceinline__ float af_sum16(const f32x16& a) {
 // per-chunk softmax output is dropped before it multiplies the values; lse -- hence the round weights -- sees the undropped
 // probabilities).  Counter-hash mask keyed by (seed, pair index): pair = ((head * chunks + chunk) * BS + query row) * 2BS +
 // key row, the same index in the backward kernels, so no mask is stored and the reversible recompute redraws the same one.
+// ---- the softmax arithmetic of one 32 x 32 tile, shared by both kernel forms (so that they agree bit for bit) -------------
+// acc: this lane's query against the tile's 32 keys, raw q.k (rows = keys 8g + 4hh + j).  -> acc = 2^(x - m) with x = q.k * scale[key],
+// masked; (m, l, O) updated.  AF_FOLD (default): scale and the reference ride in ONE fma, x' = fma(q.k, scale, -mref), so the tile
+// costs 16 fma + the masks + the maxima + 16 exp + the sums -- the separate 16 multiplies and 16 subtractions of round 3 are gone
+// (the ISA census had them at 32 of 113 vector instructions per tile).  mref = m, or 0 for a lane that has seen no live key but itself yet
+// (m = AF_NEG, or the self constant, would swallow the logit in the fma); when the lazy reference moves (rarely), the 16 values are shifted once.
+#ifndef AF_FOLD
+#define AF_FOLD 1
+#endif
+__device__ __forceinline__ void af_tile_probs(f32x16& acc, const float* __restrict__ ksc_t, const int* __restrict__ kpos_t,
+                                              const int* __restrict__ kpe_t, int keyt, int hh, bool chk_self, int qpos, int qpe, float& m,
+                                              float& l, f32x16 (&oacc)[2]) {
+    // "fresh": nothing live seen yet (m = AF_NEG), or only the query itself (m = -5e4 log2 e = -72134.75: a reference of that size
+    // would cost the next real logit its low bits in the fma -- fp32 has 2^-7 of resolution there; seen as lse errors of 2.7e-3
+    // on early causal positions before this line read `m < -1e4`).  Real logits are bounded by |q| dh^-1/2 log2 e.
+    const bool fresh = m < -1.0e4f;
+    const float mref = fresh ? 0.f : m;
+    const float nref = -mref, selfv = (-5e4f * AF_LOG2E) - mref;
+    float gmax[2] = {AF_NEG, AF_NEG};                    // two independent chains, joined below
+    // can a key of this tile BE the query itself?  (wave-uniform: the common path skips the test)
+    if (chk_self) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int key0 = keyt + 8 * g + 4 * hh;
+            const float4 sc = *reinterpret_cast<const float4*>(ksc_t + key0);
+            const int4 kp = *reinterpret_cast<const int4*>(kpos_t + key0);
+            const int4 ke = *reinterpret_cast<const int4*>(kpe_t + key0);
+            const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
+            const int kpv[4] = {kp.x, kp.y, kp.z, kp.w};
+            const int kev[4] = {ke.x, ke.y, ke.z, ke.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = __builtin_fmaf(acc[4 * g + j], scv[j], nref);
+                x = (kev[j] > qpe) ? AF_NEG : x;
+                x = (kpv[j] == qpos) ? selfv : x;
+                acc[4 * g + j] = x;
+                gmax[g & 1] = fmaxf(gmax[g & 1], x);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int key0 = keyt + 8 * g + 4 * hh;
+            const float4 sc = *reinterpret_cast<const float4*>(ksc_t + key0);
+            const int4 ke = *reinterpret_cast<const int4*>(kpe_t + key0);
+            const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
+            const int kev[4] = {ke.x, ke.y, ke.z, ke.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = __builtin_fmaf(acc[4 * g + j], scv[j], nref);
+                x = (kev[j] > qpe) ? AF_NEG : x;
+                acc[4 * g + j] = x;
+                gmax[g & 1] = fmaxf(gmax[g & 1], x);
+            }
+        }
+    }
+    const float tmax = rtts_xhalf_max(fmaxf(gmax[0], gmax[1]));       // relative to mref
+    // LAZY reference: m follows the running maximum only when a tile exceeds it by more than AF_SLACK (log2 units), so
+    // probabilities stay below 2^AF_SLACK (exact in fp32, and bf16 keeps its relative precision) and the rescale of O
+    // and l runs for the first live tile of a wave and then almost never (wave-uniform branch).  (m, l, O) stay a
+    // consistent triple, so the merge and lse = m + log2 l need no change.  A fresh lane moves at its first live key.
+    if (__any(tmax > (fresh ? 0.5f * AF_NEG : AF_SLACK))) {
+        const float mnew = fmaxf(m, tmax + mref);
+        const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+        const float d = mnew - mref;
+        m = mnew;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            oacc[0][i] *= alpha;
+            oacc[1][i] *= alpha;
+            acc[i] -= d;
+        }
+        l *= alpha;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_exp2f(acc[i]);
+    l += af_sum16(acc);
+}
+
 template <int BS, bool CAUSAL, bool MASKED, bool DROP>
 __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v,
                                                                  int64_t ld, const int32_t* __restrict__ st,
@@ -187,6 +266,9 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + r) * AF_ROWB + (ks * 16 + 8 * hh) * 2);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc, 0, 0, 0);
         }
+#if AF_FOLD && !defined(AF_ABLATE)
+        af_tile_probs(acc, ksc, kpos, kpe, kt * 32, hh, (kt < NQT) ? (kt == qt) : wrap, qpos, qpe, m, l, oacc);
+#else
         float tmax = AF_NEG;
         float gmax[2] = {AF_NEG, AF_NEG};                    // two independent chains, joined below
 #if defined(AF_ABLATE) && AF_ABLATE == 3
@@ -258,6 +340,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_exp2f(acc[i] - m);
         l += af_sum16(acc);
+#endif
 #endif
         if constexpr (DROP) {
             const uint32_t seed = drop_seed + (seed_dev ? seed_dev[0] : 0u);
@@ -382,6 +465,9 @@ __device__ __forceinline__ void af_walk_tiles(const unsigned char* __restrict__ 
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kt + (t * 32 + r) * AF_ROWB + (ks * 16 + 8 * hh) * 2);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc, 0, 0, 0);
         }
+#if AF_FOLD && !defined(AF_ABLATE)
+        af_tile_probs(acc, ksc_t, kpos_t, kpe_t, t * 32, hh, t >= self_lo && t < self_hi, qpos, qpe, m, l, oacc);
+#else
         float tmax = AF_NEG;
         float gmax[2] = {AF_NEG, AF_NEG};                    // two independent chains, joined below
         if (t >= self_lo && t < self_hi) {          // wave-uniform: a key of this tile can be the query itself
@@ -444,6 +530,7 @@ __device__ __forceinline__ void af_walk_tiles(const unsigned char* __restrict__ 
         }
 #if !defined(AF_ABLATE) || AF_ABLATE != 6
         l += af_sum16(acc);
+#endif
 #endif
         if constexpr (DROP) {
             const uint32_t pair0 = pair_base + (uint32_t)(t * 32 + 4 * hh);
