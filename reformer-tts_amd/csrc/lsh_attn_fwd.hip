@@ -87,9 +87,12 @@ __device__ __forceinline__ float af_sum16(const f32x16& a) {
 #ifndef AF_FOLD
 #define AF_FOLD 1
 #endif
+#ifndef AF_TILE_SKIP
+#define AF_TILE_SKIP 1
+#endif
 __device__ __forceinline__ void af_tile_probs(f32x16& acc, const float* __restrict__ ksc_t, const int* __restrict__ kpos_t,
                                               const int* __restrict__ kpe_t, int keyt, int hh, bool chk_self, int qpos, int qpe, float& m,
-                                              float& l, f32x16 (&oacc)[2]) {
+                                              float& l, f32x16 (&oacc)[2], bool live_all = false) {
     // "fresh": nothing live seen yet (m = AF_NEG), or only the query itself (m = -5e4 log2 e = -72134.75: a reference of that size
     // would cost the next real logit its low bits in the fma -- fp32 has 2^-7 of resolution there; seen as lse errors of 2.7e-3
     // on early causal positions before this line read `m < -1e4`).  Real logits are bounded by |q| dh^-1/2 log2 e.
@@ -113,6 +116,20 @@ __device__ __forceinline__ void af_tile_probs(f32x16& acc, const float* __restri
                 float x = __builtin_fmaf(acc[4 * g + j], scv[j], nref);
                 x = (kev[j] > qpe) ? AF_NEG : x;
                 x = (kpv[j] == qpos) ? selfv : x;
+                acc[4 * g + j] = x;
+                gmax[g & 1] = fmaxf(gmax[g & 1], x);
+            }
+        }
+    } else if (live_all) {
+        // every key of the tile is visible to every query of this wave (wave-uniform, from the tile's largest effective key
+        // position): no compares, no selects -- 32 of the tile's ~100 vector instructions
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 sc = *reinterpret_cast<const float4*>(ksc_t + keyt + 8 * g + 4 * hh);
+            const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x = __builtin_fmaf(acc[4 * g + j], scv[j], nref);
                 acc[4 * g + j] = x;
                 gmax[g & 1] = fmaxf(gmax[g & 1], x);
             }
@@ -453,12 +470,26 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_kernel(const bf16_t* _
 template <int BS, bool DROP>
 __device__ __forceinline__ void af_walk_tiles(const unsigned char* __restrict__ Kt, const unsigned char* __restrict__ Vt,
                                               const float* __restrict__ ksc_t, const int* __restrict__ kpos_t,
-                                              const int* __restrict__ kpe_t, const bf16x8 (&qf)[4], int qpos, int qpe, int self_lo,
+                                              const int* __restrict__ kpe_t, const int* __restrict__ kmin_t, const int* __restrict__ kmax_t,
+                                              const bf16x8 (&qf)[4], int qpos, int qpe, int self_lo,
                                               int self_hi, int r, int hh, const int (&tro)[2], float& m, float& l, f32x16 (&oacc)[2],
                                               uint32_t pair_base, uint32_t seed, uint32_t drop_thresh, float drop_scale) {
     constexpr int NT = BS / 32;
 #pragma unroll AF_UNROLL
     for (int t = 0; t < NT; ++t) {
+        // AF_TILE_SKIP: positions inside a bucket are sorted, so whole 32 x 32 tiles are often uniformly dead (every key behind every
+        // query of this wave: nothing to add -- the tile is skipped, MFMAs included) or uniformly live (no masks needed): 18 % and
+        // 19 % of the tiles at random inputs, more on real text.  Both decisions are wave-uniform, from the tile's smallest / largest
+        // effective key position (kmin_t / kmax_t, one word per tile, written once per run); a tile that may hold the query itself is
+        // never skipped.  A skipped tile contributes exact zeros either way: results are bit-identical with and without.
+        const bool self_tile = t >= self_lo && t < self_hi;
+        bool live_all = false;
+#if AF_TILE_SKIP
+        if (!self_tile) {
+            if (__all(kmin_t[t] > qpe)) continue;
+            live_all = __all(kmax_t[t] <= qpe);
+        }
+#endif
         f32x16 acc = {0};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -466,7 +497,7 @@ __device__ __forceinline__ void af_walk_tiles(const unsigned char* __restrict__ 
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc, 0, 0, 0);
         }
 #if AF_FOLD && !defined(AF_ABLATE)
-        af_tile_probs(acc, ksc_t, kpos_t, kpe_t, t * 32, hh, t >= self_lo && t < self_hi, qpos, qpe, m, l, oacc);
+        af_tile_probs(acc, ksc_t, kpos_t, kpe_t, t * 32, hh, self_tile, qpos, qpe, m, l, oacc, live_all);
 #else
         float tmax = AF_NEG;
         float gmax[2] = {AF_NEG, AF_NEG};                    // two independent chains, joined below
@@ -577,7 +608,9 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_walk_kernel(const bf16
     int* allpos = reinterpret_cast<int*>(smem);                  // positions of the L+1 chunks of the run: [0] looked back at first
     int* allkpe = allpos + NPOS;                                 // effective positions (`dead` compare)
     float* ksc = reinterpret_cast<float*>(allkpe + NPOS);        // [2][BS]  dh^-1/2 / |k| * log2(e) of the rows in the two slots
-    unsigned char* Ks = reinterpret_cast<unsigned char*>(ksc + NK);   // [2][BS][144]
+    int* tkmin = reinterpret_cast<int*>(ksc + NK);               // smallest / largest effective position of every 32-key tile of the run
+    int* tkmax = tkmin + 128;                                    // ((L + 1) * BS / 32 <= 68 entries each; 128 keeps the images 16-byte aligned)
+    unsigned char* Ks = reinterpret_cast<unsigned char*>(tkmax + 128);   // [2][BS][144]
     unsigned char* Vs = Ks + NK * AF_ROWB;                       // [2][BS][128] swizzled
 
     const int nb = T / BS;
@@ -601,6 +634,16 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_walk_kernel(const bf16
         allkpe[i] = valid ? (CAUSAL ? pos : 0) : AF_BIGPOS;      // dead <=> kpe > qpe; an invalid key is beyond every query
     }
     __syncthreads();
+    // per-tile extremes of the effective key positions (read after the next barrier): wave w takes tiles w, w + waves, ...
+    for (int tile = wave; tile < NPOS / 32; tile += NTHR / 64) {
+        int lo = allkpe[tile * 32 + (lane & 31)], hi = lo;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            lo = min(lo, __shfl_xor(lo, o));
+            hi = max(hi, __shfl_xor(hi, o));
+        }
+        if (lane == 0) { tkmin[tile] = lo; tkmax[tile] = hi; }
+    }
     // ---- first step: both chunks (image rows [0, BS) = slot 0 = chunk c0, [BS, 2BS) = slot 1 = chunk c0 - 1) --------------
     {
         constexpr int ITERS = NK * 8 / NTHR;   // = 4
@@ -661,7 +704,8 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_fwd_walk_kernel(const bf16
         float m = AF_NEG, l = 0.f;
         f32x16 oacc[2] = {{0}, {0}};
         af_walk_tiles<BS, DROP>(Ks + ms * (BS * AF_ROWB), Vs + ms * (BS * 128), ksc + ms * BS, allpos + (j + 1 - kh) * BS,
-                                allkpe + (j + 1 - kh) * BS, qf, qpos, qpe, self_lo, self_hi, r, hh, tro, m, l, oacc,
+                                allkpe + (j + 1 - kh) * BS, tkmin + (j + 1 - kh) * NQT, tkmax + (j + 1 - kh) * NQT, qf, qpos, qpe, self_lo,
+                                self_hi, r, hh, tro, m, l, oacc,
                                 ((uint32_t)(bh * C + c) * BS + (uint32_t)qrow) * (uint32_t)NK + (uint32_t)(kh * BS), seed,
                                 drop_thresh, drop_scale);
         l = rtts_xhalf_sum(l);
@@ -793,7 +837,7 @@ static int launch_attn_fwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const 
     constexpr int NK = 2 * BS;
     const int L = rtts_lsh_attn_fwd_run_length(B, H, T, n_hashes, BS);
     const int C = n_hashes * (T / BS);
-    const size_t lds = L > 0 ? (size_t)(2 * (L + 1) * BS + NK) * 4 + (size_t)NK * (AF_ROWB + 128) : 2 * NK * AF_ROWB + NK * 12;
+    const size_t lds = L > 0 ? (size_t)(2 * (L + 1) * BS + NK + 256) * 4 + (size_t)NK * (AF_ROWB + 128) : 2 * NK * AF_ROWB + NK * 12;
     const dim3 grid(L > 0 ? B * H * (C / L) : B * H * C), block(BS * 4);
     const bool drop = drop_p > 0.f;
     const int vi = (drop ? 4 : 0) + (causal ? 2 : 0) + (mask ? 1 : 0);
