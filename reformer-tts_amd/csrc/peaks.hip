@@ -6,21 +6,23 @@
 //                    matrix rate the chip sustains at the clock it holds under that load
 // Neither is on the training path.
 #include "rtts_common.h"
+#include <stdlib.h>
 
 // FOUR 16-byte loads in flight per thread before the first store (one in flight -- round 3's probe -- reached 4.8 TB/s where
 // MI355X_MICROARCH.md measures 6.29 TB/s for a float4 copy: a probe that understates the peak flatters every "fraction of the
 // measured peak" derived from it); the tail (n4 not a multiple of 4 x the grid's threads) is copied one float4 at a time
 __global__ __launch_bounds__(256) void peak_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
-    const size_t nthr = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t i = t;
-    for (; i + 3 * nthr < n4; i += 4 * nthr) {
-        const float4 a = src[i], b = src[i + nthr], c = src[i + 2 * nthr], d = src[i + 3 * nthr];
+    // a workgroup walks 16 KB tiles (4 x 256 float4, contiguous): the four loads of a thread are 4 KB apart inside one tile
+    const size_t ntile = n4 / 1024;
+    for (size_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const size_t i = tile * 1024 + threadIdx.x;
+        const float4 a = src[i], b = src[i + 256], c = src[i + 512], d = src[i + 768];
         dst[i] = a;
-        dst[i + nthr] = b;
-        dst[i + 2 * nthr] = c;
-        dst[i + 3 * nthr] = d;
+        dst[i + 256] = b;
+        dst[i + 512] = c;
+        dst[i + 768] = d;
     }
-    for (; i < n4; i += nthr) dst[i] = src[i];
+    for (size_t i = ntile * 1024 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
 __global__ __launch_bounds__(512) void peak_mfma_kernel(float* __restrict__ sink, int iters) {
@@ -82,7 +84,8 @@ extern "C" int rtts_comm_probe(const void* src, void* dst, int64_t bytes, int wo
 extern "C" int rtts_peak_copy(const void* src, void* dst, int64_t bytes, void* stream) {
     RTTS_ENTER(stream);
     RTTS_REQUIRE(src && dst && bytes > 0 && bytes % 16 == 0, "rtts_peak_copy: bytes must be a positive multiple of 16");
-    hipLaunchKernelGGL(peak_copy_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, (size_t)bytes / 16);
+    static const int grid = [] { const char* e = getenv("RTTS_PEAK_COPY_GRID"); return e ? atoi(e) : 16384; }();     // probe tuning only (1024: 5.27, 8192: 5.59, 32768: 5.67 TB/s on one box)
+    hipLaunchKernelGGL(peak_copy_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, (size_t)bytes / 16);
     RTTS_LAUNCH_CHECK("rtts_peak_copy");
     return 0;
 }
