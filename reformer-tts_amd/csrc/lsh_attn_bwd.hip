@@ -592,7 +592,11 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
     unsigned char* KsR = reinterpret_cast<unsigned char*>(qpeS + 2 * BS);   // [3][BS][128] qk rows, swizzled
     unsigned char* OsR = KsR + 3 * KSLOT;                            // [2][BS][128] dout rows, later the parked dQ
     unsigned char* Ds = OsR + 2 * KSLOT;                             // [NK][DSROW] dS'^T; after the dQ product: row staging
+#if AB_SPLIT_EPI
+    unsigned char* Stg = (BS == 128) ? Ds : Ds + NK * DSROW;         // 64-row buckets: [NW][32][AB_ROWB] behind the image
+#else
     unsigned char* Stg = Ds;
+#endif
 
     const int nb = T / BS;
     const int C = n_hashes * nb;
@@ -688,8 +692,20 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
 
 #define AB_JSTAMP(i) do { if (j == 2) AB_STAMP(i); } while (0)
         AB_JSTAMP(0);
+#if AB_SPLIT_EPI
+        // Only the first step waits here (for the prologue's gather).  Later steps: every wave has waited for its share of the
+        // prefetch in front of the barrier that ends the previous step's dQ phase, and the previous step's row stores are NOT
+        // waited for -- the group that stores rows (four of the eight waves) arrives late at this step's main loop, the other
+        // group is already in it: one wave of each group shares a SIMD, so the stores' staging / store issue of one wave runs
+        // under the MFMAs of the other instead of in front of an idle matrix pipe.
+        if (j == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+#else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the prefetch (issued from assembly) has landed
         __syncthreads();   // this step's rows and words are on chip (each wave waited for its own DMA); the previous step is over
+#endif
         AB_JSTAMP(1);
 
         // ---- prefetch of chunk j + 1 (rows by LDS-DMA, query words, positions of chunk j + 2): issued piecewise INSIDE the main
@@ -930,6 +946,34 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
             }
         }
         AB_JSTAMP(6);
+#if AB_SPLIT_EPI
+        // What the NEXT step's main loop overwrites is read out in front of the two barriers below, so that a wave may enter that
+        // main loop while others still store rows: the next chunk's words are published, the raw key rows (slot j % 3 = the
+        // slot the next step's prefetch lands in) are taken into registers, and each wave waits for ITS share of this step's
+        // prefetch (and the V rows it has just requested).
+        if (more && tid < BS) {
+            qlseS[(par ^ 1) * BS + tid] = nlse * 1.4426950408889634f;
+            qdelS[(par ^ 1) * BS + tid] = -ndel;
+            qpeS[(par ^ 1) * BS + tid] = nval ? (CAUSAL ? npos : 0) : -1;
+            if (j + 2 < R) kposS[((j + 3) & 3) * BS + tid] = p2;
+        }
+        uint2 kk2[2][4];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) kk2[dt][g] = *reinterpret_cast<const uint2*>(Kt + ab_off(r, dt * 4 + g) + 8 * hh);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // dQ parked; the dS'^T image is free; the next step's rows and words are on chip
+        AB_JSTAMP(7);
+        uint2 dqp[2][4];
+        if (own_tile) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) dqp[dt][g] = *reinterpret_cast<const uint2*>(Os + ab_off(myrow, dt * 4 + g) + 8 * hh);
+        }
+        __syncthreads();   // the parked dQ rows have been read: the next step's prefetch may land in this dout image
+#else
         __syncthreads();   // dQ parked; the dS'^T image is free: it becomes the row staging
         AB_JSTAMP(7);
 
@@ -940,6 +984,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
             qpeS[(par ^ 1) * BS + tid] = nval ? (CAUSAL ? npos : 0) : -1;
             if (j + 2 < R) kposS[((j + 3) & 3) * BS + tid] = p2;
         }
+#endif
 
         // ---- end of the step.  Own keys: the parked query-role gradient of the row joins the key-role accumulator (they are the
         //      same rows).  Looked-back keys (and the own keys of a run's last step): the row is complete -- dK = G - k^ (k^ . G) on
@@ -949,7 +994,11 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+#if AB_SPLIT_EPI
+                const uint2 kk = kk2[dt][g];
+#else
                 const uint2 kk = *reinterpret_cast<const uint2*>(Kt + ab_off(r, dt * 4 + g) + 8 * hh);
+#endif
                 kraw[dt][4 * g] = __uint_as_float(kk.x << 16);
                 kraw[dt][4 * g + 1] = __uint_as_float(kk.x & 0xffff0000u);
                 kraw[dt][4 * g + 2] = __uint_as_float(kk.y << 16);
@@ -961,7 +1010,11 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
+#if AB_SPLIT_EPI
+                    const uint2 dqv = dqp[dt][g];
+#else
                     const uint2 dqv = *reinterpret_cast<const uint2*>(Os + ab_off(myrow, dt * 4 + g) + 8 * hh);
+#endif
                     const float dqf[4] = {__uint_as_float(dqv.x << 16), __uint_as_float(dqv.x & 0xffff0000u), __uint_as_float(dqv.y << 16),
                                           __uint_as_float(dqv.y & 0xffff0000u)};
 #pragma unroll
@@ -976,7 +1029,14 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
             const int slot = (!own_tile && j == 0) ? 1 : 0;
             const size_t obase = ((size_t)bh * n_hashes + (own_tile ? c / nb : cprev / nb)) * T;
             const int srow = lane >> 3, spiece = lane & 7;
+#if AB_SPLIT_EPI
+            // the staging must not lie where another wave's next main loop writes dS'^T.  128-row buckets: the rows of the dS'^T
+            // image this wave itself writes NEXT (8 KB: own keys after a looked-back step; the own keys of a run's last step
+            // take their looked-back twin's rows); 64-row buckets (4 KB of rows per wave < 4.5 KB of staging): a region of its own
+            unsigned char* stg = (BS == 128) ? Ds + ((own_tile ? BS : 0) + wt * 32) * DSROW : Stg + wave * (32 * AB_ROWB);
+#else
             unsigned char* stg = Stg + wave * (32 * AB_ROWB);
+#endif
             int rpos[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) rpos[i] = own_tile ? kq[wt * 32 + i * 8 + srow] : kl[wt * 32 + i * 8 + srow];

@@ -809,13 +809,16 @@ class Trainer:
 
         Rotations and dropout draw from the graph-safe default generator."""
         from ..model.lsh_attention import LSHSelfAttention
-        from .. import edges
-        if edges.SYNC_BN is not None:
-            raise _lib.RttsError("sync_batchnorm all-reduces BatchNorm sums inside the forward and the backward: such steps run eagerly "
-                                 "(train_step / fit(graphs=False)); no collective is captured into a hipGraph")
         if segmented is None:
             segmented = self.world > 1
         segmented = bool(segmented) and self._fused_edges_ok(batch) if segmented else False
+        if self._sync_bn is not None:
+            # SyncBatchNorm all-reduces per-channel sums inside the forward and the backward of the two convolution stacks: no
+            # collective is captured into a hipGraph, so those pieces stay eager BETWEEN the graphs (_capture_around_sync_bn)
+            if not self._fused_edges_ok(batch):
+                raise _lib.RttsError("sync_batchnorm: this batch shape is outside the fused edges' envelope: such steps run eagerly "
+                                     "(train_step / fit(graphs=False))")
+            segmented = True
         for m in self.model.modules():
             if isinstance(m, LSHSelfAttention):
                 m.use_default_generator = True
@@ -832,26 +835,17 @@ class Trainer:
         self._graph = torch.cuda.CUDAGraph()
         self._graph_opt = None
         self._segments = []
+        self._segment_names = None
         self.set_step_hyper(self.global_step)
+        if self._sync_bn is not None:
+            return self._capture_around_sync_bn(batch)
         if not segmented:
             with self._capturing(self._graph):
                 self._graph_out = step(batch, update_hyper=False)
             self.global_step -= 1                        # capturing does not execute: the captured step has not run yet
             return self._graph_out
         # ---- segmented capture: [(graph, gradient range that is final when it ends)] in replay order
-        enc_names = [n for n in self.offsets if n.startswith("enc.")]
-        enc_end = max(self.offsets[n][1] for n in enc_names)
-        if min(self.offsets[n][0] for n in self.offsets if not n.startswith("enc.")) < enc_end:
-            raise RuntimeError("flat buffer: encoder parameters are expected to come first")
-        stack_names = [n for n in enc_names if n.startswith("enc.reformer.")]
-        stack_begin = min(self.offsets[n][0] for n in stack_names)
-        if any(self.offsets[n][0] >= stack_begin for n in enc_names if n not in stack_names):
-            raise RuntimeError("flat buffer: the encoder prenet is expected in front of the encoder stack")
-        dec_stack = [n for n in self.offsets if n.startswith("dec.reformer.")]
-        dec_stack_end = max(self.offsets[n][1] for n in dec_stack)
-        tail = [n for n in self.offsets if not n.startswith("enc.") and self.offsets[n][0] >= dec_stack_end]
-        if any(n.startswith(("dec.prenet", "dec.positional_encoding", "dec.reformer")) for n in tail) or not tail:
-            raise RuntimeError("flat buffer: heads and postnet are expected behind the decoder stack")
+        enc_end, stack_begin, dec_stack_end = self._flat_layout()
         dec_seq = self.model.dec.reformer.layers
         enc_seq = self.model.enc.reformer.layers
         segs = []
@@ -868,64 +862,14 @@ class Trainer:
             segs.append((self._graph, (dec_stack_end, self.n_params)))
             if "call" not in dec_seq.manual:
                 raise RuntimeError("the decoder stack did not take the explicit executor: the segmented capture needs it")
-            ctx, dec_x, _, dec_out = dec_seq.manual["call"]
-            gen = engine.stack_backward_steps(ctx, dec_out.grad, complete_layers=True)
-            finished = False
-            while not finished:
-                g = torch.cuda.CUDAGraph()
-                with self._capturing(g, pool=self._graph.pool()):
-                    with torch.no_grad():
-                        _, done = next(gen)      # one decoder layer's backward + its weight gradients and column sums
-                    rng = [self.block_bucket[("dec", j)] for j in done if ("dec", j) in self.block_bucket]
-                    lo, hi = min(r[0] for r in rng), max(r[1] for r in rng)
-                    if 0 in done:                # the bottom layer: the generator ends; the decoder prenet's backward joins this graph
-                        try:
-                            with torch.no_grad():
-                                next(gen)
-                            raise RuntimeError("stack_backward_steps yielded after block 0")
-                        except StopIteration as fin:
-                            dx, dkeys = fin.value
-                        dec_x.backward(dx)
-                        self._enc_in.grad = dkeys
-                        engine.flush_wgrad()
-                        assert engine.pending_all() == 0
-                        lo = enc_end             # decoder prenet + positional encoding sit between the encoder and the stack
-                        finished = True
-                segs.append((g, (lo, hi)))
+            segs += self._capture_decoder_layers(dec_seq.manual["call"], enc_end)
         finally:
             dec_seq.manual = None
             enc_call = enc_seq.manual.get("call") if enc_seq.manual is not None else None
             enc_seq.manual = None
         if enc_call is not None:
-            # the encoder stack driven by hand like the decoder's: one graph per encoder block (LSH + feed-forward: 4 weight
-            # gradients, 11.6 MB of gradients at the baseline widths), each block's range exchanged while the next one replays
-            ctx_e, enc_x, _, _ = enc_call
-            gen = engine.stack_backward_steps(ctx_e, self._enc_in.grad, complete_layers=True, flush_at=4)
-            finished, dx_enc = False, None
-            while not finished:
-                g = torch.cuda.CUDAGraph()
-                with self._capturing(g, pool=self._graph.pool()):
-                    with torch.no_grad():
-                        try:
-                            _, done = next(gen)
-                        except StopIteration as fin:      # (only when the stack yields nothing: cannot happen with >= 1 block)
-                            raise RuntimeError("encoder stack backward ended without a stop") from fin
-                    rng = [self.block_bucket[("enc", j)] for j in done if ("enc", j) in self.block_bucket]
-                    lo, hi = min(r[0] for r in rng), max(r[1] for r in rng)
-                    if 0 in done:
-                        try:
-                            with torch.no_grad():
-                                next(gen)
-                            raise RuntimeError("stack_backward_steps yielded after block 0")
-                        except StopIteration as fin:
-                            dx_enc = fin.value[0]
-                        engine.flush_wgrad()
-                        assert engine.pending_all() == 0
-                        lo = stack_begin
-                        finished = True
-                segs.append((g, (lo, hi)))
-            if enc_x is not self._pre_in:
-                raise RuntimeError("segmented capture: the encoder stack's input is expected to be the cut behind the prenet")
+            block_segs, dx_enc = self._capture_encoder_blocks(enc_call, stack_begin)
+            segs += block_segs
             g = torch.cuda.CUDAGraph()
             with self._capturing(g, pool=self._graph.pool()):
                 self._pre_out.backward(dx_enc)
@@ -952,7 +896,93 @@ class Trainer:
                     torch.cuda.current_stream().wait_stream(self._enc_stream())
             segs.append((g, (0, stack_begin)))
         self._enc_out = self._enc_in = self._pre_out = self._pre_in = None
-        cover = sorted(r for _, r in segs)
+        self._finish_chain(segs)
+        return self._graph_out
+
+    def _flat_layout(self):
+        """(end of the encoder's parameters, begin of the encoder stack's, end of the decoder stack's) in the flat buffer; checks
+        the order the chain's gradient ranges rely on: encoder prenet | encoder stack | decoder prenet | decoder stack | heads, postnet."""
+        enc_names = [n for n in self.offsets if n.startswith("enc.")]
+        enc_end = max(self.offsets[n][1] for n in enc_names)
+        if min(self.offsets[n][0] for n in self.offsets if not n.startswith("enc.")) < enc_end:
+            raise RuntimeError("flat buffer: encoder parameters are expected to come first")
+        stack_names = [n for n in enc_names if n.startswith("enc.reformer.")]
+        stack_begin = min(self.offsets[n][0] for n in stack_names)
+        if any(self.offsets[n][0] >= stack_begin for n in enc_names if n not in stack_names):
+            raise RuntimeError("flat buffer: the encoder prenet is expected in front of the encoder stack")
+        dec_stack = [n for n in self.offsets if n.startswith("dec.reformer.")]
+        dec_stack_end = max(self.offsets[n][1] for n in dec_stack)
+        tail = [n for n in self.offsets if not n.startswith("enc.") and self.offsets[n][0] >= dec_stack_end]
+        if any(n.startswith(("dec.prenet", "dec.positional_encoding", "dec.reformer")) for n in tail) or not tail:
+            raise RuntimeError("flat buffer: heads and postnet are expected behind the decoder stack")
+        return enc_end, stack_begin, dec_stack_end
+
+    def _capture_decoder_layers(self, dec_call, enc_end):
+        """One graph per decoder layer, top to bottom, from d(loss)/d(stack output) = ``dec_out.grad`` (a buffer the first graph
+        -- or the eager postnet island -- fills); the bottom layer's graph also holds the decoder prenet's backward and leaves
+        d(loss)/d(keys) on ``self._enc_in.grad``.  -> [(graph, gradient range)]"""
+        ctx, dec_x, _, dec_out = dec_call
+        gen = engine.stack_backward_steps(ctx, dec_out.grad, complete_layers=True)
+        segs, finished = [], False
+        while not finished:
+            g = torch.cuda.CUDAGraph()
+            with self._capturing(g, pool=self._graph.pool()):
+                with torch.no_grad():
+                    _, done = next(gen)      # one decoder layer's backward + its weight gradients and column sums
+                rng = [self.block_bucket[("dec", j)] for j in done if ("dec", j) in self.block_bucket]
+                lo, hi = min(r[0] for r in rng), max(r[1] for r in rng)
+                if 0 in done:                # the bottom layer: the generator ends; the decoder prenet's backward joins this graph
+                    try:
+                        with torch.no_grad():
+                            next(gen)
+                        raise RuntimeError("stack_backward_steps yielded after block 0")
+                    except StopIteration as fin:
+                        dx, dkeys = fin.value
+                    dec_x.backward(dx)
+                    self._enc_in.grad = dkeys
+                    engine.flush_wgrad()
+                    assert engine.pending_all() == 0
+                    lo = enc_end             # decoder prenet + positional encoding sit between the encoder and the stack
+                    finished = True
+            segs.append((g, (lo, hi)))
+        return segs
+
+    def _capture_encoder_blocks(self, enc_call, stack_begin):
+        """The encoder stack driven by hand like the decoder's: one graph per encoder block (LSH + feed-forward: 4 weight
+        gradients, 11.6 MB of gradients at the baseline widths), each block's range exchanged while the next one replays.
+        -> ([(graph, gradient range)], d(loss)/d(stack input))"""
+        ctx_e, enc_x, _, _ = enc_call
+        if enc_x is not self._pre_in:
+            raise RuntimeError("segmented capture: the encoder stack's input is expected to be the cut behind the prenet")
+        gen = engine.stack_backward_steps(ctx_e, self._enc_in.grad, complete_layers=True, flush_at=4)
+        segs, finished, dx_enc = [], False, None
+        while not finished:
+            g = torch.cuda.CUDAGraph()
+            with self._capturing(g, pool=self._graph.pool()):
+                with torch.no_grad():
+                    try:
+                        _, done = next(gen)
+                    except StopIteration as fin:      # (only when the stack yields nothing: cannot happen with >= 1 block)
+                        raise RuntimeError("encoder stack backward ended without a stop") from fin
+                rng = [self.block_bucket[("enc", j)] for j in done if ("enc", j) in self.block_bucket]
+                lo, hi = min(r[0] for r in rng), max(r[1] for r in rng)
+                if 0 in done:
+                    try:
+                        with torch.no_grad():
+                            next(gen)
+                        raise RuntimeError("stack_backward_steps yielded after block 0")
+                    except StopIteration as fin:
+                        dx_enc = fin.value[0]
+                    engine.flush_wgrad()
+                    assert engine.pending_all() == 0
+                    lo = stack_begin
+                    finished = True
+            segs.append((g, (lo, hi)))
+        return segs, dx_enc
+
+    def _finish_chain(self, segs):
+        """Checks that the exchanged ranges tile the flat gradient buffer, stores the chain, captures clip + AdamW behind it."""
+        cover = sorted(r for _, r in segs if r is not None)
         if cover[0][0] != 0 or cover[-1][1] != self.n_params or any(a[1] != b[0] for a, b in zip(cover, cover[1:])):
             raise RuntimeError(f"segmented capture: the gradient ranges do not tile the flat buffer: {cover}")
         self._segments = segs
@@ -960,21 +990,142 @@ class Trainer:
         with self._capturing(self._graph_opt, pool=self._graph.pool()):
             self.optimizer_step(update_hyper=False)
         self.global_step -= 1
+
+    class _Eager:
+        """A piece of the chain that is not a hipGraph (it holds a collective): launched from the host on every ``replay``."""
+
+        def __init__(self, fn):
+            self.replay = fn
+
+    def _capture_around_sync_bn(self, batch):
+        """The data-parallel chain with ``sync_batchnorm``: the BatchNorm layers of the encoder prenet (3) and of the postnet (5)
+        all-reduce their per-channel sums in the forward AND in the backward (edges.ConvBNAct; reference modules.py:29,127 under
+        ``torch.nn.SyncBatchNorm``).  No collective is captured: those three pieces run eagerly between the graphs, everything
+        else -- both reversible stacks, the decoder prenet, clip + AdamW: 85 % of the step's launches -- replays:
+
+              E1  eager  conv weight re-layouts, encoder prenet forward (3 exchanges of 2 x 512 floats)
+              F   graph  hash rotations, encoder stack forward, decoder prenet + decoder stack forward
+              E2  eager  heads + postnet + loss, forward and backward (5 + 5 exchanges)      -> all-reduce of their gradients
+              D_l graph  decoder layer l backward (bottom one: + decoder prenet)             -> all-reduce of the layer
+              B_k graph  encoder block k backward                                            -> all-reduce of the block
+              E3  eager  encoder prenet backward (3 exchanges)                               -> all-reduce of its gradients
+              C   graph  clip + AdamW + mirror refresh
+
+        What crosses a graph / eager boundary lives in buffers with fixed addresses: the encoder stack's input (E1 copies into it),
+        the padded masks and frames, the decoder stack's output and ITS gradient (E2 accumulates into it; zeroed first), the
+        gradient of the encoder stack's input (E3 reads it)."""
+        from ..model.lsh_attention import LSHSelfAttention
+        from ..edges import ConvK5, PostnetLoss
+        model, dev = self.model, self.device
+        enc_end, stack_begin, dec_stack_end = self._flat_layout()
+        if getattr(self, "_postnet_loss", None) is None:
+            self._postnet_loss = PostnetLoss(model, self.loss)
+        spec_in, spec_tgt = self._frames(batch)
+        st = {}
+
+        def pre_forward():
+            """E1 (also zeroes the flat gradient: the first launch of a step)."""
+            model.train()
+            self.zero_grad()
+            self._apply_modes(batch)
+            ConvK5.refresh_all(dev)
+            pad_ph, ph_mask, sp_mask, pad_spec = model._encode_inputs(batch["phonemes"], spec_in, batch["loss_mask"].mean(dim=-1))
+            x = model.enc.prenet(pad_ph, pe=model.enc.positional_encoding)
+            if "x" not in st:                      # first call (before the capture): the hand-over buffers
+                st.update(x=x.detach().clone().requires_grad_(True), ph_mask=ph_mask.clone(), sp_mask=sp_mask.clone(), pad_spec=pad_spec.clone())
+            else:
+                with torch.no_grad():
+                    st["x"].copy_(x)
+                    st["ph_mask"].copy_(ph_mask)
+                    st["sp_mask"].copy_(sp_mask)
+                    st["pad_spec"].copy_(pad_spec)
+            st["pre_out"] = x
+
+        def postnet():
+            """E2"""
+            y = st["dec_out"]
+            y.grad.zero_()
+            total, raw_l, post_l, stop_l = self._postnet_loss.apply(y, spec_tgt, batch["stop_tokens"], batch["loss_mask"], batch.get("valid_len"))
+            self._run_backward(total)
+            for dst, src in zip(self._graph_out, (total, raw_l, post_l, stop_l)):
+                dst.copy_(src.detach())
+
+        def pre_backward():
+            """E3"""
+            st.pop("pre_out").backward(st["dx_enc"])
+            keys = self._queue_keys()
+            engine.flush_wgrad(keys=keys)
+            assert engine.pending_all(keys) == 0
+
+        dec_seq, enc_seq = model.dec.reformer.layers, model.enc.reformer.layers
+        self._graph_out = tuple(torch.zeros((), dtype=torch.float32, device=dev) for _ in range(4))
+        engine.WEIGHT_EPOCH[0] += 1        # caches refreshed by launches the host decides on (the decoder prenet's padded weight) must be IN the capture
+        # the eager pieces EXECUTE while the chain is being built (a capture does not): BatchNorm's running statistics are put back
+        saved_buffers = [(t, t.clone()) for t in model.buffers()]
+        pre_forward()
+        segs = [(self._Eager(pre_forward), None)]
+        dec_seq.manual, enc_seq.manual = {}, {}
+        try:
+            with self._capturing(self._graph):
+                LSHSelfAttention.rotation_pool = (torch.randn(1 << 18, device=dev, dtype=torch.float32), [0])
+                try:
+                    keys = model.enc.reformer(st["x"], input_mask=st["ph_mask"])
+                    self._pre_in = st["x"]
+                    keys = self._cut_at_encoder(keys)
+                    kpm = ~st["ph_mask"]
+                    kpm._rtts_not = st["ph_mask"]
+                    y = model.dec.hidden(st["pad_spec"], keys=keys, key_padding_mask=kpm, input_mask=st["sp_mask"])[0]
+                finally:
+                    LSHSelfAttention.rotation_pool = None
+            segs.append((self._graph, None))
+            if "call" not in dec_seq.manual or "call" not in enc_seq.manual or dec_seq.manual["call"][3] is not y:
+                raise RuntimeError("sync_batchnorm chain: both stacks have to take the explicit executor")
+            y.grad = torch.zeros_like(y)
+            st["dec_out"] = y
+            self._graph.replay()                   # real values in the hand-over buffers for the eager piece below (and its exchanges)
+            postnet()
+            segs.append((self._Eager(postnet), (dec_stack_end, self.n_params)))
+            segs += self._capture_decoder_layers(dec_seq.manual["call"], enc_end)
+            n_dec = len(segs) - 3
+            block_segs, st["dx_enc"] = self._capture_encoder_blocks(enc_seq.manual["call"], stack_begin)
+            segs += block_segs
+            n_enc = len(block_segs)
+            for g, _ in segs[3:]:
+                g.replay()                         # d(loss)/d(encoder stack input) of THIS batch for the eager piece below
+            pre_backward()
+            segs.append((self._Eager(pre_backward), (0, stack_begin)))
+        finally:
+            dec_seq.manual = enc_seq.manual = None
+            engine.discard_pending(self._queue_keys())
+            with torch.no_grad():
+                for t, c in saved_buffers:
+                    t.copy_(c)
+        self._enc_out = self._enc_in = self._pre_out = self._pre_in = None
+        self._segment_names = (["encoder prenet forward (eager: SyncBatchNorm)", "both stacks forward",
+                                "heads + postnet + loss, forward and backward (eager: SyncBatchNorm)"] +
+                               [f"decoder layer {k} backward" + (" + decoder prenet backward" if k == 0 else "") for k in range(n_dec - 1, -1, -1)] +
+                               [f"encoder block {k} backward" for k in range(n_enc - 1, -1, -1)] + ["encoder prenet backward (eager: SyncBatchNorm)"])
+        self._finish_chain(segs)
         return self._graph_out
 
     def segment_plan(self):
         """[(bytes of the gradient range all-reduced after segment k, launches-free description)] of the captured data-parallel
         schedule (bench.py prints it): which collective overlaps which graph."""
-        n_dec = len(self.model.dec.reformer.layers.blocks) // 6          # f, swap, f, swap, f, swap per decoder layer
-        n_enc = len(self._segments) - 2 - n_dec                          # encoder-stack graphs: one per block, or one for the stack
-        enc_names = [f"encoder block {k} backward" for k in range(n_enc - 1, -1, -1)] if n_enc > 1 else ["encoder stack backward"]
-        names = ["forward + loss + heads/postnet backward"] + [f"decoder layer {k} backward" for k in range(n_dec - 1, -1, -1)] + \
-                enc_names + ["encoder prenet backward"]
-        names[n_dec] += " + decoder prenet backward"
+        if getattr(self, "_segment_names", None):
+            names = self._segment_names
+        else:
+            n_dec = len(self.model.dec.reformer.layers.blocks) // 6          # f, swap, f, swap, f, swap per decoder layer
+            n_enc = len(self._segments) - 2 - n_dec                          # encoder-stack graphs: one per block, or one for the stack
+            enc_names = [f"encoder block {k} backward" for k in range(n_enc - 1, -1, -1)] if n_enc > 1 else ["encoder stack backward"]
+            names = ["forward + loss + heads/postnet backward"] + [f"decoder layer {k} backward" for k in range(n_dec - 1, -1, -1)] + \
+                    enc_names + ["encoder prenet backward"]
+            names[n_dec] += " + decoder prenet backward"
         out = []
-        for k, ((_, (s, e)), nm) in enumerate(zip(self._segments, names)):
+        for k, ((_, rng), nm) in enumerate(zip(self._segments, names)):
+            if rng is None:
+                continue
             nxt = names[k + 1] if k + 1 < len(names) else "nothing (exposed)"
-            out.append(dict(after=nm, allreduce_bytes=4 * (e - s), overlaps=nxt))
+            out.append(dict(after=nm, allreduce_bytes=4 * (rng[1] - rng[0]), overlaps=nxt))
         return out
 
     def bulk_allreduce(self):
@@ -990,11 +1141,13 @@ class Trainer:
         # data parallel: every segment's gradient range is final when its graph ends -- its all-reduce is issued at once and
         # runs while the next segment replays; only the last (the encoder prenet's 17 MB) has nothing to hide behind
         works = []
-        for g, (s, e) in self._segments:
-            g.replay()
-            if self.world > 1:
-                works.append(dist.all_reduce(self.flat_g[s:e], group=self.pg, async_op=True))
+        for g, rng in self._segments:
+            g.replay()                   # a hipGraph, or an eager piece that holds SyncBatchNorm's exchanges (_capture_around_sync_bn)
+            if self.world > 1 and rng is not None:
+                works.append(dist.all_reduce(self.flat_g[rng[0]:rng[1]], group=self.pg, async_op=True))
         for w in works:
             w.wait()
         self._graph_opt.replay()
+        if self._sync_bn is not None:
+            engine.WEIGHT_EPOCH[0] += 1  # the eager pieces' cached weight re-layouts follow the optimizer step
         return self._graph_out

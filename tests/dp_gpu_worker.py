@@ -3,7 +3,9 @@ model in the two data-parallel modes of the trainer and checks (a) replicas stay
     eager      per-block all-reduce issued from the block-done hooks, overlapped with the backward
     graphs     a chain of hipGraphs (fwd + heads/postnet bwd | one per decoder layer | one per encoder block | encoder prenet bwd | clip + AdamW)
                with the all-reduce of each graph's gradient range issued while the next one replays
-(parameters after three steps, loss of the third step)."""
+(parameters after three steps, loss of the third step).  Then the same pair with ``sync_batchnorm``: the chain keeps the three pieces
+that hold BatchNorm's exchanges eager between its graphs (Trainer._capture_around_sync_bn); BatchNorm's running statistics
+after three steps must agree too (the eager pieces execute once more while the chain is built: that must leave no trace)."""
 import os
 import sys
 
@@ -17,7 +19,7 @@ from reformer_tts_amd.model.lsh_attention import LSHSelfAttention  # noqa: E402
 from reformer_tts_amd.training import Trainer, build_model, synthetic_batch  # noqa: E402
 
 
-def run(mode, rank, dev):
+def run(mode, rank, dev, sync_bn=False):
     cfg = model_ref.small_cfg()
     cfg["enc_reformer_kwargs"]["attn_kwargs"]["implementation"] = "hip"
     cfg["dec_reformer_kwargs"]["self_attn_kwargs"]["implementation"] = "hip"
@@ -28,7 +30,8 @@ def run(mode, rank, dev):
         if isinstance(m, LSHSelfAttention):
             m.forced_rotations = torch.randn(1, 64, 4, (128 if not m.causal else 256) // 64 // 2,
                                              generator=torch.Generator().manual_seed(5))
-    tr = Trainer(model, TTSTrainingConfig(batch_size=2, learning_rate=1e-3, warmup_steps=4, gradient_clip_val=1.0), dev)
+    tr = Trainer(model, TTSTrainingConfig(batch_size=2, learning_rate=1e-3, warmup_steps=4, gradient_clip_val=1.0, sync_batchnorm=sync_bn), dev)
+    assert (tr._sync_bn is not None) == sync_bn
     assert tr.world == 2
     batch = synthetic_batch(2, 100, 256, seed=42 + rank, device=dev)
     losses = []
@@ -37,6 +40,15 @@ def run(mode, rank, dev):
             losses.append(float(tr.train_step(batch)[0]))
     else:
         tr.capture(batch)                      # two eager steps (bulk all-reduce), then the graphs are captured
+        if sync_bn:
+            # encoder prenet fwd (eager) | both stacks fwd | heads + postnet + loss fwd/bwd (eager) | decoder layer | 2 encoder blocks |
+            # encoder prenet bwd (eager), then the optimizer: four graphs + clip/AdamW around three eager pieces
+            assert len(tr._segments) == 7 and sum(isinstance(g, torch.cuda.CUDAGraph) for g, _ in tr._segments) == 4, tr._segments
+            plan = tr.segment_plan()
+            assert len(plan) == 5 and sum(p["allreduce_bytes"] for p in plan) == 4 * tr.n_params and plan[-1]["overlaps"].startswith("nothing"), plan
+            losses = [None, None, float(tr.replay()[0])]
+            torch.cuda.synchronize()
+            return tr, losses
         # forward+loss+heads | one graph per decoder layer (depth 1 here) | one per encoder block (2) | encoder prenet, then the optimizer
         assert len(tr._segments) == 5 and tr._graph_opt is not None, len(tr._segments)
         plan = tr.segment_plan()
@@ -52,23 +64,29 @@ def main():
     dist.init_process_group("gloo")
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    res = {}
-    for mode in ("eager", "graphs"):
-        tr, losses = run(mode, rank, dev)
-        chk = tr.flat_p.double().sum().reshape(1).cpu()
-        both = [torch.zeros_like(chk) for _ in range(2)]
-        dist.all_gather(both, chk)
-        assert torch.equal(both[0], both[1]), f"{mode}: replicas diverged {both}"
-        res[mode] = (tr.flat_p.clone(), losses)
-    pe, le = res["eager"]
-    pg, lg = res["graphs"]
-    rel = float((pe - pg).norm() / pe.norm())
-    assert rel < 2e-3, f"parameters after 3 steps differ between the modes: rel {rel}"
-    assert abs(le[2] - lg[2]) <= 2e-2 * abs(le[2]), (le, lg)
+    report = []
+    for sync_bn in (False, True):
+        res = {}
+        for mode in ("eager", "graphs"):
+            tr, losses = run(mode, rank, dev, sync_bn)
+            chk = tr.flat_p.double().sum().reshape(1).cpu()
+            both = [torch.zeros_like(chk) for _ in range(2)]
+            dist.all_gather(both, chk)
+            assert torch.equal(both[0], both[1]), f"{mode} sync_bn={sync_bn}: replicas diverged {both}"
+            stats = torch.cat([b.detach().float().flatten() for n, b in tr.model.named_buffers() if "running_" in n])
+            res[mode] = (tr.flat_p.clone(), losses, stats)
+        pe, le, se = res["eager"]
+        pg, lg, sg = res["graphs"]
+        rel = float((pe - pg).norm() / pe.norm())
+        assert rel < 2e-3, f"sync_bn={sync_bn}: parameters after 3 steps differ between the modes: rel {rel}"
+        assert abs(le[2] - lg[2]) <= 2e-2 * abs(le[2]), (sync_bn, le, lg)
+        rel_stats = float((se - sg).norm() / se.norm())
+        assert rel_stats < 2e-3, f"sync_bn={sync_bn}: BatchNorm running statistics after 3 steps differ between the modes: rel {rel_stats}"
+        report += [rel, rel_stats, le[2], lg[2]]
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
-        print("DP_GPU_OK", rel, le[2], lg[2])
+        print("DP_GPU_OK", *report)
 
 
 if __name__ == "__main__":
