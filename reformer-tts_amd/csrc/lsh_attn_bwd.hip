@@ -22,6 +22,9 @@
 
 #define AB_DH 64
 #define AB_ROWB 144
+#ifndef AB_SPLIT_EPI
+#define AB_SPLIT_EPI 1   // walking kernel: a step's row stores run beside the next step's main loop (0: round 3's form, for A/B runs)
+#endif
 #ifndef AB_DQ_UNROLL
 #define AB_DQ_UNROLL 16
 #endif
@@ -654,6 +657,12 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
         }
         if (R > 1 && tid < BS) kposS[2 * BS + tid] = pnext;
     }
+#if AB_SPLIT_EPI
+    // the builtin, so that the compiler's wait-count pass knows the gather's LDS-DMA has landed: it treats a pending LDS-DMA as a
+    // store that may alias any LDS read, and would wait with vmcnt(0) in front of the first LDS read of EVERY step
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    __syncthreads();
+#endif
 
     // Per-lane state that crosses a step: the K and V fragments, scale and position of this wave's 32 keys.  The wave groups
     // swap roles every step -- the group that works the OWN keys of chunk j works the same keys as LOOKED-BACK keys of chunk
@@ -698,10 +707,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
         // waited for -- the group that stores rows (four of the eight waves) arrives late at this step's main loop, the other
         // group is already in it: one wave of each group shares a SIMD, so the stores' staging / store issue of one wave runs
         // under the MFMAs of the other instead of in front of an idle matrix pipe.
-        if (j == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
+        // (that first wait sits in front of the loop)
 #else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the prefetch (issued from assembly) has landed
         __syncthreads();   // this step's rows and words are on chip (each wave waited for its own DMA); the previous step is over
@@ -738,6 +744,12 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
                 myvalid = MASKED ? (int)mask[(size_t)b * T + pos_now] : 1;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) vf[ks] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)pos_now * ld + ks * 16 + 8 * hh);
+#if AB_SPLIT_EPI
+                // used HERE (an empty asm that reads them), on the first step's path only: the compiler waits for the loads in front of
+                // it; where the two paths into the code below meet it would otherwise wait with vmcnt(0) in every step -- behind the
+                // previous step's row stores, which leave from asm statements it cannot count
+                asm volatile("" : "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]), "+v"(myvalid));
+#endif
             }
             mypos = pos_now;
 #pragma unroll
@@ -962,16 +974,17 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) kk2[dt][g] = *reinterpret_cast<const uint2*>(Kt + ab_off(r, dt * 4 + g) + 8 * hh);
+        // (the empty asm reads the V rows requested above: the compiler's wait-count pass then KNOWS they have arrived -- otherwise it
+        //  waits for them in the next main loop with vmcnt(0), i.e. behind this step's row stores, which it cannot count)
+        asm volatile("" : "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]), "+v"(myvalid));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // dQ parked; the dS'^T image is free; the next step's rows and words are on chip
         AB_JSTAMP(7);
-        uint2 dqp[2][4];
-        if (own_tile) {
+        uint2 dqp[2][4];          // (every wave reads: a conditional fill of the array sends it through scratch)
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+        for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) dqp[dt][g] = *reinterpret_cast<const uint2*>(Os + ab_off(myrow, dt * 4 + g) + 8 * hh);
-        }
+            for (int g = 0; g < 4; ++g) dqp[dt][g] = *reinterpret_cast<const uint2*>(Os + ab_off(wt * 32 + r, dt * 4 + g) + 8 * hh);
         __syncthreads();   // the parked dQ rows have been read: the next step's prefetch may land in this dout image
 #else
         __syncthreads();   // dQ parked; the dS'^T image is free: it becomes the row staging
@@ -1140,7 +1153,11 @@ static int launch_attn_bwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const 
         RTTS_REQUIRE(row_flags, "rtts_lsh_attn_bwd: this shape is worked by the walking kernel (rtts_lsh_attn_bwd_run_length() = %d): "
                                 "row_flags (B*H*n_hashes*T bytes) is required", R);
         const size_t ds_bytes = (size_t)NK * (BS * 2), stg_bytes = (size_t)(NK / 32) * 32 * AB_ROWB;
+#if AB_SPLIT_EPI
+        const size_t wlds = (size_t)BS * 40 + 5 * (size_t)BS * 128 + (BS == 128 ? ds_bytes : ds_bytes + stg_bytes);
+#else
         const size_t wlds = (size_t)BS * 40 + 5 * (size_t)BS * 128 + (ds_bytes > stg_bytes ? ds_bytes : stg_bytes);
+#endif
         static RttsLdsState wattr[8];
         const dim3 wgrid((unsigned)(chunks / R)), wblock(BS * 4);
 #define AB_WGO(C_, M_, D_)                                                                                                 \
