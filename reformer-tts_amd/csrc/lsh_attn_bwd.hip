@@ -21,7 +21,7 @@
 #include <float.h>
 
 #define AB_DH 64
-#define AB_ROWB 144
+#define AB_ROWB 128   // row staging: unpadded 128-byte rows, swizzled (ab_stg_w / ab_stg_r)
 #ifndef AB_SPLIT_EPI
 #define AB_SPLIT_EPI 1   // walking kernel: a step's row stores run beside the next step's main loop (0: round 3's form, for A/B runs)
 #endif
@@ -70,6 +70,17 @@ __device__ __forceinline__ int ab_ds_off(int key, int gran) {
     if (BS == 128) return key * 256 + ((gran ^ ((k1 << 4) | (k0 << 3) | (k1 << 2) | (k2 << 1) | k3)) << 3);
     return key * 128 + ((gran ^ ((k1 << 3) | (k0 << 2) | (k2 << 1) | k3)) << 3);
 }
+
+// Row staging of the epilogues: [32 keys][128 B].  The accumulators hold a key per lane, so lane (r, hh) writes the 8 bytes
+// (16-byte piece p, half hh) of row r with ds_write_b64 (16 consecutive lanes = 16 rows per LDS cycle, banks mod 32: the
+// 16 rows must land on the 16 distinct 8-byte slots of a 128-byte window) and the rows leave as 16-byte pieces read with
+// ds_read_b128 (lane = (row & 7, piece), groups of 16 lanes = 4 rows x 4 pieces, banks mod 64: rows of equal parity must
+// hold different pieces).  piece ^ (row & 7) serves both; the half is swapped in rows with bit 3 set, which the reader
+// undoes for free: bit 3 of its row is the compile-time index of the read.  (The padded [32][144 B] staging of rounds 1-3 was
+// 2-way conflicted on both sides: 10.9 % of this kernel's LDS cycles; tests/test_lds_swizzle_model.py holds the model.)
+__device__ __forceinline__ int ab_stg_w(int r, int piece, int hh) { return r * 128 + ((piece ^ (r & 7)) << 4) + ((hh ^ ((r >> 3) & 1)) << 3); }
+__device__ __forceinline__ int ab_stg_r(int i, int srow, int spiece) { return (i * 8 + srow) * 128 + ((spiece ^ srow) << 4); }
+__device__ __forceinline__ uint4 ab_stg_fix(int i, const uint4 v) { return (i & 1) ? uint4{v.z, v.w, v.x, v.y} : v; }
 
 // AB_KT2 = 32-key tiles owned by one wave.  1: 8 waves per 128-key chunk pair, two waves per SIMD (<= 256 registers each).
 // 2: 4 waves, ONE wave per SIMD with the whole 512-entry register file: a query tile's fragments, per-query words and
@@ -436,12 +447,12 @@ __global__ __launch_bounds__(BS * 4 / AB_KT2, AB_KT2 == 2 ? 1 : 2) void lsh_attn
                 uint2 pk;
                 pk.x = pack_bf16x2(dvacc[k2][dt][4 * g], dvacc[k2][dt][4 * g + 1]);
                 pk.y = pack_bf16x2(dvacc[k2][dt][4 * g + 2], dvacc[k2][dt][4 * g + 3]);
-                *reinterpret_cast<uint2*>(stg + r * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2) = pk;
+                *reinterpret_cast<uint2*>(stg + ab_stg_w(r, dt * 4 + g, hh)) = pk;
             }
         __builtin_amdgcn_wave_barrier();
         uint4 rowv[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rowv[i] = *reinterpret_cast<const uint4*>(stg + (i * 8 + srow) * AB_ROWB + spiece * 16);
+        for (int i = 0; i < 4; ++i) rowv[i] = ab_stg_fix(i, *reinterpret_cast<const uint4*>(stg + ab_stg_r(i, srow, spiece)));
 #pragma unroll
         for (int i = 0; i < 4; ++i) rtts_store16_out(dvdst + (obase + rpos[k2][i]) * AB_DH + spiece * 8, rowv[i]);
     }
@@ -535,12 +546,12 @@ __global__ __launch_bounds__(BS * 4 / AB_KT2, AB_KT2 == 2 ? 1 : 2) void lsh_attn
                 uint2 pk;
                 pk.x = pack_bf16x2(dk[0], dk[1]);
                 pk.y = pack_bf16x2(dk[2], dk[3]);
-                *reinterpret_cast<uint2*>(stg + r * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2) = pk;
+                *reinterpret_cast<uint2*>(stg + ab_stg_w(r, dt * 4 + g, hh)) = pk;
             }
         __builtin_amdgcn_wave_barrier();
         uint4 rowv[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rowv[i] = *reinterpret_cast<const uint4*>(stg + (i * 8 + srow) * AB_ROWB + spiece * 16);
+        for (int i = 0; i < 4; ++i) rowv[i] = ab_stg_fix(i, *reinterpret_cast<const uint4*>(stg + ab_stg_r(i, srow, spiece)));
 #pragma unroll
         for (int i = 0; i < 4; ++i) rtts_store16_out(dkdst + (obase + rpos[k2][i]) * AB_DH + spiece * 8, rowv[i]);
     }
@@ -595,11 +606,7 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
     unsigned char* KsR = reinterpret_cast<unsigned char*>(qpeS + 2 * BS);   // [3][BS][128] qk rows, swizzled
     unsigned char* OsR = KsR + 3 * KSLOT;                            // [2][BS][128] dout rows, later the parked dQ
     unsigned char* Ds = OsR + 2 * KSLOT;                             // [NK][DSROW] dS'^T; after the dQ product: row staging
-#if AB_SPLIT_EPI
-    unsigned char* Stg = (BS == 128) ? Ds : Ds + NK * DSROW;         // 64-row buckets: [NW][32][AB_ROWB] behind the image
-#else
     unsigned char* Stg = Ds;
-#endif
 
     const int nb = T / BS;
     const int C = n_hashes * nb;
@@ -1043,10 +1050,11 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
             const size_t obase = ((size_t)bh * n_hashes + (own_tile ? c / nb : cprev / nb)) * T;
             const int srow = lane >> 3, spiece = lane & 7;
 #if AB_SPLIT_EPI
-            // the staging must not lie where another wave's next main loop writes dS'^T.  128-row buckets: the rows of the dS'^T
-            // image this wave itself writes NEXT (8 KB: own keys after a looked-back step; the own keys of a run's last step
-            // take their looked-back twin's rows); 64-row buckets (4 KB of rows per wave < 4.5 KB of staging): a region of its own
-            unsigned char* stg = (BS == 128) ? Ds + ((own_tile ? BS : 0) + wt * 32) * DSROW : Stg + wave * (32 * AB_ROWB);
+            // the staging (4 KB) must not lie where another wave's next main loop writes dS'^T: it takes the rows of the dS'^T
+            // image this wave itself writes NEXT (32 keys x DSROW >= 4 KB: own keys after a looked-back step; the own keys of a
+            // run's last step take their looked-back twin's rows)
+            unsigned char* stg = Ds + ((own_tile ? BS : 0) + wt * 32) * DSROW;
+            static_assert(32 * DSROW >= 32 * AB_ROWB, "the staging must fit a wave's rows of the dS'^T image");
 #else
             unsigned char* stg = Stg + wave * (32 * AB_ROWB);
 #endif
@@ -1062,12 +1070,12 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
                         uint2 pk;
                         pk.x = pack_bf16x2(dvacc[dt][4 * g], dvacc[dt][4 * g + 1]);
                         pk.y = pack_bf16x2(dvacc[dt][4 * g + 2], dvacc[dt][4 * g + 3]);
-                        *reinterpret_cast<uint2*>(stg + r * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2) = pk;
+                        *reinterpret_cast<uint2*>(stg + ab_stg_w(r, dt * 4 + g, hh)) = pk;
                     }
                 __builtin_amdgcn_wave_barrier();
                 uint4 rowv[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) rowv[i] = *reinterpret_cast<const uint4*>(stg + (i * 8 + srow) * AB_ROWB + spiece * 16);
+                for (int i = 0; i < 4; ++i) rowv[i] = ab_stg_fix(i, *reinterpret_cast<const uint4*>(stg + ab_stg_r(i, srow, spiece)));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) rtts_store16_out(dvdst + (obase + rpos[i]) * AB_DH + spiece * 8, rowv[i]);
                 __builtin_amdgcn_wave_barrier();
@@ -1092,12 +1100,12 @@ __global__ __launch_bounds__(BS * 4, 2) void lsh_attn_bwd_walk_kernel(
                         uint2 pk;
                         pk.x = pack_bf16x2(dk[0], dk[1]);
                         pk.y = pack_bf16x2(dk[2], dk[3]);
-                        *reinterpret_cast<uint2*>(stg + r * AB_ROWB + (dt * 32 + 8 * g + 4 * hh) * 2) = pk;
+                        *reinterpret_cast<uint2*>(stg + ab_stg_w(r, dt * 4 + g, hh)) = pk;
                     }
                 __builtin_amdgcn_wave_barrier();
                 uint4 rowv[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) rowv[i] = *reinterpret_cast<const uint4*>(stg + (i * 8 + srow) * AB_ROWB + spiece * 16);
+                for (int i = 0; i < 4; ++i) rowv[i] = ab_stg_fix(i, *reinterpret_cast<const uint4*>(stg + ab_stg_r(i, srow, spiece)));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) rtts_store16_out(dkdst + (obase + rpos[i]) * AB_DH + spiece * 8, rowv[i]);
             }
@@ -1153,11 +1161,7 @@ static int launch_attn_bwd(const bf16_t* qk, const bf16_t* v, int64_t ld, const 
         RTTS_REQUIRE(row_flags, "rtts_lsh_attn_bwd: this shape is worked by the walking kernel (rtts_lsh_attn_bwd_run_length() = %d): "
                                 "row_flags (B*H*n_hashes*T bytes) is required", R);
         const size_t ds_bytes = (size_t)NK * (BS * 2), stg_bytes = (size_t)(NK / 32) * 32 * AB_ROWB;
-#if AB_SPLIT_EPI
-        const size_t wlds = (size_t)BS * 40 + 5 * (size_t)BS * 128 + (BS == 128 ? ds_bytes : ds_bytes + stg_bytes);
-#else
         const size_t wlds = (size_t)BS * 40 + 5 * (size_t)BS * 128 + (ds_bytes > stg_bytes ? ds_bytes : stg_bytes);
-#endif
         static RttsLdsState wattr[8];
         const dim3 wgrid((unsigned)(chunks / R)), wblock(BS * 4);
 #define AB_WGO(C_, M_, D_)                                                                                                 \

@@ -114,3 +114,54 @@ def test_gemm_tn_ring_dma_fill_is_a_permutation_of_the_row():
             row = rowbase + sub
             logical = sorted((((pp >> 2) ^ (row & 3)) << 2) | (pp & 3) for pp in range(32))
             assert logical == list(range(32))
+
+
+# ---- the row staging of the backward kernel's epilogues (ab_stg_w / ab_stg_r of csrc/lsh_attn_bwd.hip)
+def ab_stg_w(r, piece, hh):
+    return r * 128 + ((piece ^ (r & 7)) << 4) + ((hh ^ ((r >> 3) & 1)) << 3)
+
+
+def ab_stg_r(i, srow, spiece):
+    return (i * 8 + srow) * 128 + ((spiece ^ srow) << 4)
+
+
+B128_GROUPS_ALL = B128_GROUPS + [[l + 32 for l in g] for g in B128_GROUPS]
+
+
+@pytest.mark.parametrize("piece", range(8))
+def test_row_staging_stores_b64(piece):
+    """lane (r, hh) stores 8 bytes of row r: ds_write_b64, four groups of 16 CONSECUTIVE lanes, 32 banks."""
+    for first in range(0, 64, 16):
+        acc = [ab_stg_w(lane & 31, piece, lane >> 5) for lane in range(first, first + 16)]
+        assert conflict_free(acc, 8, 32)
+
+
+@pytest.mark.parametrize("i", range(4))
+def test_row_staging_reads_b128(i):
+    """lane (srow = lane >> 3, spiece = lane & 7) reads a 16-byte piece of row 8 i + srow: ds_read_b128, four 16-lane groups, 64 banks."""
+    for grp in B128_GROUPS_ALL:
+        acc = [ab_stg_r(i, lane >> 3, lane & 7) for lane in grp]
+        assert conflict_free(acc, 16, 64)
+
+
+def test_row_staging_round_trip():
+    """What the reader hands to the global store is the row in its natural order: piece q of row (8 i + srow), halves swapped back
+    where bit 3 of the row (= i & 1) is set."""
+    mem = {}
+    for lane in range(64):
+        r, hh = lane & 31, lane >> 5
+        for piece in range(8):
+            mem[ab_stg_w(r, piece, hh)] = (r, piece, hh)          # the 8-byte unit (row, piece, half)
+    for i in range(4):
+        for lane in range(64):
+            srow, spiece = lane >> 3, lane & 7
+            a = ab_stg_r(i, srow, spiece)
+            lo, hi = mem[a], mem[a + 8]
+            if i & 1:
+                lo, hi = hi, lo
+            assert lo == (8 * i + srow, spiece, 0) and hi == (8 * i + srow, spiece, 1)
+
+
+def test_the_padded_staging_of_rounds_1_to_3_was_conflicted():
+    acc = [(lane & 31) * 144 + (lane >> 5) * 8 for lane in range(16)]
+    assert not conflict_free(acc, 8, 32)
