@@ -400,11 +400,27 @@ def test_full_depth_gradients_vs_oracle(gpu, case):
     rels = _gradients_vs_oracle(gpu, cfg, batch, 7, f"grad_rel_err_full_depth_{case}.txt", through_trainer=True)
     _report(f"full depth, {case}", rels)
     assert len(rels) > (100 if case == "baseline_3+3" else 200)
-    # every ReLU gate between a parameter and the loss adds its bf16 sign flips (sqrt(2 f) each, ~4e-2 per feed-forward layer,
-    # test_gemm_hip.py): deeper stacks collect more of them than the one-layer tests' 8e-2.  Bounds = ~1.5x the largest
-    # achieved error of each group; a wiring mistake (a block reading another layer's mask, keys or permutation) is O(1).
+    # Bounds per GROUP of parameters, each ~1.5x the largest error the group shows (round 4; rounds 2-3 had 0.15 / 0.12 for
+    # everything).  Measured, baseline 3 + 3 | long 6 + 6:
+    #   encoder prenet (behind every layer, three conv / BatchNorm / ReLU stages whose gates flip under bf16 rounding: explained to
+    #                   1e-2 by the float64 rounding model of tests/test_prenet_rounding_hip.py)            9.8e-2 | 9.9e-2
+    #   toqk.weight    (the shared query / key projection of the LSH layers: its gradient sums the query role and the
+    #                   key role through the key normalisation; 64-row buckets at T = 4096 grow with the layer)  2.9e-2 | 9.6e-2
+    #   everything else (incl. the ReLU-gated feed-forward gradients, 2e-2 each: tests/test_decoder_layer_rounding_hip.py
+    #                   shows the same 2e-2 against the executor's own rounding model)                     2.1e-2 | 3.8e-2
+    #   median over all parameters                                                                         7.0e-3 | 8.4e-3
+    # A wiring mistake (a block reading another layer's mask, keys or permutation) is O(1) in at least one parameter.
+    long_case = case == "long_6+6"
     for name, rel in rels.items():
-        assert rel < (0.15 if name.startswith("enc.") else 0.12), (name, rel)
+        if name.startswith("enc.prenet"):
+            bound = 0.15
+        elif name.endswith("toqk.weight"):
+            bound = 0.145 if long_case else 0.045
+        else:
+            bound = 0.057 if long_case else 0.032
+        assert rel < bound, (name, rel, bound)
+    vals = sorted(rels.values())
+    assert vals[len(vals) // 2] < (0.014 if long_case else 0.012), vals[len(vals) // 2]
 
 
 def test_fused_engine_matches_general_path(gpu):
