@@ -169,6 +169,12 @@ int rtts_ln_bwd(const void* dxn, const float* x, const float* mean, const float*
 int rtts_ln_bwd_to(const void* dxn, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dx_in,
                    float* dx_out, float* dgamma, float* dbeta, float* partial_ws, int M, int d,
                    void* dyb_next, float* partial_next, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
+/* the joining form: dx_out = dx_in + addend + dLN(dxn) (addend NULL: rtts_ln_bwd_to; must not alias dx_out).  The stack executor's LAST
+ * LayerNorm backward: both streams of a reversible stack start as its input (reference reformer.py:85-93, x = cat([x, x])), so
+ * d(input) = g1 + g2 -- the other stream joins in the pass that completes this one. */
+int rtts_ln_bwd_join(const void* dxn, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dx_in,
+                     const float* addend, float* dx_out, float* dgamma, float* dbeta, float* partial_ws, int M, int d,
+                     void* dyb_next, float* partial_next, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
 /* dyb_next (may be NULL): bf16 copy of the completed dx_io, times the keep-scale of (drop_p, seed) -- the next block's
  * rtts_cast_colsum folded in; partial_next then receives that copy's partial column sums (same layout as partial_ws). */
 int rtts_cast_colsum(const float* dy, void* dyb, float* dbias, float* partial_ws, int M, int d, float drop_p, uint32_t seed,
@@ -345,6 +351,14 @@ int rtts_pe_add(const void* y, const float* table, const float* alpha, float dro
 int rtts_pe_dalpha(const float* dy, const float* table, float drop_p, uint32_t seed, const uint32_t* seed_dev, int T, int64_t M,
                    int d, float* dalpha, float* partial_ws, void* stream);
 int rtts_relu_drop(void* h, float drop_p, uint32_t seed, const uint32_t* seed_dev, int64_t n, void* stream);
+
+/* What ReformerTTS.forward derives from a batch before its first layer (reference reformer_tts.py:119-125, wrappers.py:60), one
+ * launch: pad_phonemes (B, Lp_pad) = phonemes right-padded with 0; phoneme_mask = pad_phonemes != 0 and its inverse (the
+ * cross-attention's key_padding_mask); frame_mask (B, Lm_pad) = (mean over the n_mels columns of loss_mask != 0), 0 behind Lm.
+ * Masks are one byte per element (torch.bool storage).  Strides in elements. */
+int rtts_batch_masks(const int64_t* phonemes, int64_t ph_stride, int B, int Lp, int Lp_pad, const float* loss_mask, int64_t lm_bstride,
+                     int64_t lm_rstride, int Lm, int Lm_pad, int n_mels, int64_t* pad_phonemes, uint8_t* phoneme_mask,
+                     uint8_t* phoneme_pad_mask, uint8_t* frame_mask, void* stream);
 
 /* nn.Embedding + the Dropout behind it (reference modules.py:17,22,56): out (rows, C) fp32 = dropout_p(E[ids]); backward:
  * dE[id] += sum of (dx * the same keep-scales) over the rows whose id matches; padding_idx skipped.  dE accumulates: it may be

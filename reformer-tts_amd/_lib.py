@@ -74,6 +74,7 @@ SIGNATURES = {
     "rtts_ln_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp],
     "rtts_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f32, _u32, _vp, _vp],
     "rtts_ln_bwd_to": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f32, _u32, _vp, _vp],
+    "rtts_ln_bwd_join": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f32, _u32, _vp, _vp],
     "rtts_cast_colsum": [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _u32, _vp, _vp, _vp],
     "rtts_colsum_bf16": [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp],
     "rtts_sum_streams": [_vp, _vp, _i64, _vp, _vp, _vp],
@@ -105,6 +106,7 @@ SIGNATURES = {
     "rtts_tts_loss": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32,
                       _vp, _i64, _i32, _i32, _i64, _i64, _vp, _i64, _i64, _vp],
     "rtts_pe_add": [_vp, _vp, _vp, _f32, _u32, _vp, _i32, _i64, _i32, _vp, _vp],
+    "rtts_batch_masks": [_vp, _i64, _i32, _i32, _i32, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "rtts_pe_dalpha": [_vp, _vp, _f32, _u32, _vp, _i32, _i64, _i32, _vp, _vp, _vp],
     "rtts_relu_drop": [_vp, _f32, _u32, _vp, _i64, _vp],
     "rtts_embedding_bwd": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _f32, _u32, _vp, _vp],

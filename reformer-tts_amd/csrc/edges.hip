@@ -1092,6 +1092,49 @@ extern "C" int rtts_pe_dalpha(const float* dy, const float* table, float drop_p,
     return 0;
 }
 
+// ---------------------------------------------------------------- what the model derives from a batch before its first layer
+// reference reformer_tts.py:119-125: phonemes right-padded with 0 to a multiple of pad_base, phoneme_mask = padded != 0, the frame
+// mask (here: loss_mask.mean(-1), wrappers.py:60) padded with 0 and cast to bool.  One launch instead of seven (pad = fill + copy,
+// compare, mean, pad, cast, the inverted key mask the cross-attention wants).
+__global__ __launch_bounds__(256) void batch_masks_kernel(const int64_t* __restrict__ phonemes, int64_t ph_stride, int B, int Lp, int Lp_pad,
+                                                          const float* __restrict__ loss_mask, int64_t lm_bstride, int64_t lm_rstride, int Lm,
+                                                          int Lm_pad, int n_mels, int64_t* __restrict__ pad_ph, uint8_t* __restrict__ ph_mask,
+                                                          uint8_t* __restrict__ ph_not, uint8_t* __restrict__ sp_mask) {
+    const int per_b = Lp_pad + Lm_pad;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * per_b; i += gridDim.x * blockDim.x) {
+        const int b = i / per_b, j = i % per_b;
+        if (j < Lp_pad) {
+            const int64_t v = j < Lp ? phonemes[(int64_t)b * ph_stride + j] : 0;
+            pad_ph[(size_t)b * Lp_pad + j] = v;
+            ph_mask[(size_t)b * Lp_pad + j] = v != 0;
+            ph_not[(size_t)b * Lp_pad + j] = v == 0;
+        } else {
+            const int t = j - Lp_pad;
+            bool on = false;
+            if (t < Lm) {
+                const float* row = loss_mask + (int64_t)b * lm_bstride + (int64_t)t * lm_rstride;
+                float sum = 0.f;
+                for (int c = 0; c < n_mels; ++c) sum += row[c];
+                on = (sum / (float)n_mels) != 0.f;       // torch: mean(-1) then .to(bool)  (NaN -> true, like torch)
+            }
+            sp_mask[(size_t)b * Lm_pad + t] = on;
+        }
+    }
+}
+
+extern "C" int rtts_batch_masks(const int64_t* phonemes, int64_t ph_stride, int B, int Lp, int Lp_pad, const float* loss_mask, int64_t lm_bstride,
+                                int64_t lm_rstride, int Lm, int Lm_pad, int n_mels, int64_t* pad_phonemes, uint8_t* phoneme_mask,
+                                uint8_t* phoneme_pad_mask, uint8_t* frame_mask, void* stream) {
+    RTTS_ENTER(stream);
+    RTTS_REQUIRE(phonemes && loss_mask && pad_phonemes && phoneme_mask && phoneme_pad_mask && frame_mask, "rtts_batch_masks: null pointer");
+    RTTS_REQUIRE(B > 0 && Lp > 0 && Lp_pad >= Lp && Lm > 0 && Lm_pad >= Lm && n_mels > 0 && ph_stride >= Lp, "rtts_batch_masks: bad shape");
+    const int n = B * (Lp_pad + Lm_pad);
+    hipLaunchKernelGGL(batch_masks_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, phonemes, ph_stride, B, Lp, Lp_pad, loss_mask,
+                       lm_bstride, lm_rstride, Lm, Lm_pad, n_mels, pad_phonemes, phoneme_mask, phoneme_pad_mask, frame_mask);
+    RTTS_LAUNCH_CHECK("rtts_batch_masks");
+    return 0;
+}
+
 extern "C" int rtts_relu_drop(void* h, float drop_p, uint32_t seed, const uint32_t* seed_dev, int64_t n, void* stream) {
     RTTS_ENTER(stream);
     RTTS_REQUIRE(h && n > 0 && n % 8 == 0 && drop_p >= 0.f && drop_p < 1.f, "rtts_relu_drop: bad arguments");

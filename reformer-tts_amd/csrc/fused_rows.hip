@@ -236,8 +236,8 @@ __global__ __launch_bounds__(FR_THREADS) void residual_ln_kernel(const float* x,
 template <int EPL, int VEC>
 __global__ __launch_bounds__(FR_THREADS) void ln_bwd_kernel(const bf16_t* __restrict__ dxn, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            const float* __restrict__ gamma, const float* dx_in, float* dx_io,
-                                                            float* __restrict__ partial_g, float* __restrict__ partial_b, int M,
+                                                            const float* __restrict__ gamma, const float* dx_in, const float* __restrict__ addend,
+                                                            float* dx_io, float* __restrict__ partial_g, float* __restrict__ partial_b, int M,
                                                             bf16_t* __restrict__ dyb_next, float* __restrict__ partial_next,
                                                             uint32_t seed, const uint32_t* __restrict__ seed_dev, uint32_t thresh,
                                                             float dscale) {
@@ -257,6 +257,12 @@ __global__ __launch_bounds__(FR_THREADS) void ln_bwd_kernel(const bf16_t* __rest
         load_row_bf16<EPL, VEC>(dxn + (size_t)row * D, lane, dy);
         load_row_f32<EPL, VEC>(x + (size_t)row * D, lane, xv);
         load_row_f32<EPL, VEC>(dx_in + (size_t)row * D, lane, dx);      // dx_in == dx_io: in place (a lane reads what it writes)
+        if (addend) {       // the last update of a reversible stack's backward: the OTHER gradient stream joins here (dx = g1 + g2)
+            float ad[EPL];
+            load_row_f32<EPL, VEC>(addend + (size_t)row * D, lane, ad);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) dx[e] += ad[e];
+        }
         const float mu = mean[row], rs = rstd[row];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -521,15 +527,15 @@ extern "C" int rtts_ln_fwd(const float* x, const float* gamma, const float* beta
     return 0;
 }
 
-extern "C" int rtts_ln_bwd_to(const void* dxn, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dx_in,
-                              float* dx_io, float* dgamma, float* dbeta, float* partial_ws, int M, int d, void* dyb_next, float* partial_next,
-                              float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
+extern "C" int rtts_ln_bwd_join(const void* dxn, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dx_in,
+                                const float* addend, float* dx_io, float* dgamma, float* dbeta, float* partial_ws, int M, int d, void* dyb_next,
+                                float* partial_next, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
 
 extern "C" int rtts_ln_bwd(const void* dxn, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx_io,
                            float* dgamma, float* dbeta, float* partial_ws, int M, int d, void* dyb_next, float* partial_next,
                            float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream) {
-    return rtts_ln_bwd_to(dxn, x, mean, rstd, gamma, dx_io, dx_io, dgamma, dbeta, partial_ws, M, d, dyb_next, partial_next, drop_p, seed,
-                          seed_dev, stream);
+    return rtts_ln_bwd_join(dxn, x, mean, rstd, gamma, dx_io, nullptr, dx_io, dgamma, dbeta, partial_ws, M, d, dyb_next, partial_next, drop_p,
+                            seed, seed_dev, stream);
 }
 
 // dx_out = dx_in + dLN(dxn): the out-of-place form (dx_in == dx_out: rtts_ln_bwd).  The stack executor uses it for the FIRST update
@@ -537,8 +543,19 @@ extern "C" int rtts_ln_bwd(const void* dxn, const float* x, const float* mean, c
 extern "C" int rtts_ln_bwd_to(const void* dxn, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dx_in,
                               float* dx_io, float* dgamma, float* dbeta, float* partial_ws, int M, int d, void* dyb_next, float* partial_next,
                               float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream) {
+    return rtts_ln_bwd_join(dxn, x, mean, rstd, gamma, dx_in, nullptr, dx_io, dgamma, dbeta, partial_ws, M, d, dyb_next, partial_next, drop_p,
+                            seed, seed_dev, stream);
+}
+
+// dx_out = dx_in + addend + dLN(dxn) (addend may be NULL: rtts_ln_bwd_to).  The last LayerNorm backward of a reversible stack's
+// backward: both streams started as the stack's input, so d(input) = g1 + g2 -- the sum rides in the pass that completes g2
+// instead of a separate pass over both streams.
+extern "C" int rtts_ln_bwd_join(const void* dxn, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dx_in,
+                                const float* addend, float* dx_io, float* dgamma, float* dbeta, float* partial_ws, int M, int d, void* dyb_next,
+                                float* partial_next, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream) {
     RTTS_ENTER(stream);
     RTTS_REQUIRE(dx_in, "rtts_ln_bwd_to: null dx_in");
+    RTTS_REQUIRE(addend != dx_io, "rtts_ln_bwd_join: the addend must not be the output");
     RTTS_REQUIRE(!dyb_next || partial_next, "rtts_ln_bwd: dyb_next needs partial_next");
     RTTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "rtts_ln_bwd: bad drop_p");
     RTTS_REQUIRE(dxn && x && mean && rstd && gamma && dx_io && partial_ws && M > 0 && (!dgamma == !dbeta), "rtts_ln_bwd: bad arguments");
@@ -547,7 +564,7 @@ extern "C" int rtts_ln_bwd_to(const void* dxn, const float* x, const float* mean
     float* pg = partial_ws;
     float* pb = partial_ws + (size_t)FR_PARTIAL_BLOCKS * d;
     const size_t lds = (size_t)FR_WAVES * d * sizeof(float);
-#define CALL(EPL, VEC) hipLaunchKernelGGL((ln_bwd_kernel<EPL, VEC>), dim3(blocks), dim3(FR_THREADS), lds, (hipStream_t)stream, (const bf16_t*)dxn, x, mean, rstd, gamma, dx_in, dx_io, pg, pb, M, (bf16_t*)dyb_next, partial_next, seed, seed_dev, rtts_drop_thresh(drop_p), 1.f / (1.f - drop_p))
+#define CALL(EPL, VEC) hipLaunchKernelGGL((ln_bwd_kernel<EPL, VEC>), dim3(blocks), dim3(FR_THREADS), lds, (hipStream_t)stream, (const bf16_t*)dxn, x, mean, rstd, gamma, dx_in, addend, dx_io, pg, pb, M, (bf16_t*)dyb_next, partial_next, seed, seed_dev, rtts_drop_thresh(drop_p), 1.f / (1.f - drop_p))
     FR_DISPATCH_D(d, CALL)
 #undef CALL
     if (dgamma) {       // NULL: the caller finalises the partial rows itself (rtts_colsum_final_grouped)

@@ -254,8 +254,9 @@ def flush_colsum(q: Optional[_Queue] = None):
                 _lib.call("rtts_colsum_final_grouped", arr, len(group), q.stream)
 
 
-def ln_bwd(dxn, x, mean, rstd, norm, dx_io, next_cast=None, dx_in=None):
-    """dx_io += dLN(dxn) (``dx_in`` given: dx_io = dx_in + dLN(dxn), out of place); LayerNorm gradients queued (or added).  ``next_cast`` = (drop | None,): the completed dx_io is
+def ln_bwd(dxn, x, mean, rstd, norm, dx_io, next_cast=None, dx_in=None, join=None):
+    """dx_io += dLN(dxn) (``dx_in`` given: dx_io = dx_in + dLN(dxn), out of place; ``join``: + that stream too -- the last update of a
+    stack's backward, d(input) = g1 + g2); LayerNorm gradients queued (or added).  ``next_cast`` = (drop | None,): the completed dx_io is
     the next block's output gradient, so its bf16 copy (times that block's dropout keep-scale) and the partial column
     sums for that block's output bias are produced here -> (dyb, partial buffer, rows), else None."""
     m, d = x.shape
@@ -270,16 +271,17 @@ def ln_bwd(dxn, x, mean, rstd, norm, dx_io, next_cast=None, dx_in=None):
         args_next = (dyb.data_ptr(), pn.data_ptr(), float(p), seed, seed_base(dev).data_ptr())
         nxt = (dyb, pn, _partial_rows(m))
     src = dx_io if dx_in is None else dx_in
+    other = None if join is None else join.data_ptr()
     if DEFER_COLSUM:
         ws = torch.empty(2 * 256 * d, dtype=torch.float32, device=dev)
-        _lib.call("rtts_ln_bwd_to", dxn.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), norm.weight.data_ptr(),
-                  src.data_ptr(), dx_io.data_ptr(), None, None, ws.data_ptr(), m, d, *args_next, _s())
+        _lib.call("rtts_ln_bwd_join", dxn.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), norm.weight.data_ptr(),
+                  src.data_ptr(), other, dx_io.data_ptr(), None, None, ws.data_ptr(), m, d, *args_next, _s())
         rows = _partial_rows(m)
         _queue_colsum(ws, 0, rows, d, _grad(norm.weight))
         _queue_colsum(ws, 256 * d, rows, d, _grad(norm.bias))
         return nxt
-    _lib.call("rtts_ln_bwd_to", dxn.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), norm.weight.data_ptr(),
-              src.data_ptr(), dx_io.data_ptr(), _grad(norm.weight).data_ptr(), _grad(norm.bias).data_ptr(), _WS.partial(dev, d).data_ptr(),
+    _lib.call("rtts_ln_bwd_join", dxn.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), norm.weight.data_ptr(),
+              src.data_ptr(), other, dx_io.data_ptr(), _grad(norm.weight).data_ptr(), _grad(norm.bias).data_ptr(), _WS.partial(dev, d).data_ptr(),
               m, d, *args_next, _s())
     return nxt
 
@@ -486,6 +488,7 @@ DEFER_WGRAD = True
 # have left it by the end of the step.
 WGRAD_FLUSH_PER_LAYER = os.environ.get("RTTS_WGRAD_FLUSH", "layer") == "layer"
 WGRAD_MAX_PENDING = 64
+JOIN_STREAMS = os.environ.get("RTTS_JOIN_STREAMS", "1") != "0"      # A/B: d(input) = g1 + g2 as a separate (ATen) pass after the stack's backward
 COPY_STREAMS = os.environ.get("RTTS_STREAM_COPIES", "0") == "1"     # A/B: copy x / dout into both streams instead of aliasing them
 # (A second HIP stream for the weight gradients, forked/joined by events = parallel branches of the captured hipGraph,
 #  was measured SLOWER on MI355X in round 1: 9.35 vs 8.94 ms/step; the cross-branch dependencies of the replayed graph
@@ -690,7 +693,7 @@ class LSHExec:
         return residual(acc, g, self.layer.to_out.bias, 1.0, next_norm, slot["drop"], out=_keep_streams(keep_streams, slot, acc, inp, xn, mean, rstd, fresh_acc))
 
     def backward(self, acc, inp, d_acc, d_inp, b, t, mask=None, pre=None, next_norm=None, pre_cast=None, next_cast=None, slot=None,
-                 d_src=None, **_):
+                 d_src=None, join=None, **_):
         slot = self._own_slot if slot is None else slot
         if "st" not in slot:
             raise RuntimeError("LSHExec.backward: no forward state for this call (backward run twice, or without its forward)")
@@ -727,7 +730,7 @@ class LSHExec:
             pair[0].add_(full[:e])
             pair[1].add_(full[e:])
         dxn = gemm(dqkv2, wqkv, kn=True)
-        return post, ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp, next_cast, dx_in=d_src)
+        return post, ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp, next_cast, dx_in=d_src, join=join)
 
 
 class FFNExec:
@@ -764,7 +767,8 @@ class FFNExec:
         slot.update(g=g if STASH_BLOCK_OUTPUT else None, h=h if STASH_PROJECTIONS else None)
         return residual(acc, g, self.l2.bias, 1.0, next_norm, out=_keep_streams(keep_streams, slot, acc, inp, xn, mean, rstd, fresh_acc))
 
-    def backward(self, acc, inp, d_acc, d_inp, b, t, pre=None, next_norm=None, pre_cast=None, next_cast=None, slot=None, d_src=None, **_):
+    def backward(self, acc, inp, d_acc, d_inp, b, t, pre=None, next_norm=None, pre_cast=None, next_cast=None, slot=None, d_src=None,
+                 join=None, **_):
         slot = self._own_slot if slot is None else slot
         if "g" not in slot:
             raise RuntimeError("FFNExec.backward: no forward state for this call (backward run twice, or without its forward)")
@@ -781,7 +785,7 @@ class FFNExec:
         dh = gemm(dyb, _bf16(self.l2.weight), kn=True, gate=h if words is None else True, gate_bias_grad=_grad(self.l1.bias), words=words)
         wgrad(_grad(self.l1.weight), dh, xn)
         dxn = gemm(dh, _bf16(self.l1.weight), kn=True)
-        return post, ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp, next_cast, dx_in=d_src)
+        return post, ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp, next_cast, dx_in=d_src, join=join)
 
 
 class XAttnExec:
@@ -835,7 +839,7 @@ class XAttnExec:
         return residual(acc, g, self.mha.out_proj.bias, 1.0, next_norm, out=_keep_streams(keep_streams, slot, acc, inp, xn, mean, rstd, fresh_acc))
 
     def backward(self, acc, inp, d_acc, d_inp, b, t, keys_bf16=None, kvalid=None, dkeys=None, pre=None, next_norm=None,
-                 pre_cast=None, next_cast=None, slot=None, d_src=None, **_):
+                 pre_cast=None, next_cast=None, slot=None, d_src=None, join=None, **_):
         slot = self._own_slot if slot is None else slot
         if "pdrop" not in slot:
             raise RuntimeError("XAttnExec.backward: no forward state for this call (backward run twice, or without its forward)")
@@ -882,7 +886,7 @@ class XAttnExec:
         else:
             dxn = gemm(dq, w[:e], kn=True)
             gemm_group([dict(a=dkv, w=w[e:], into=dkeys)], kn=True)
-        nxt = ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp, next_cast, dx_in=d_src)
+        nxt = ln_bwd(dxn, inp, mean, rstd, self.norm, d_inp, next_cast, dx_in=d_src, join=join)
         return post, nxt
 
 
@@ -1123,6 +1127,11 @@ def stack_backward_steps(ctx, dout, complete_layers: Optional[bool] = None, noti
     def target(g, owned):
         """-> (buffer the executor accumulates into, its source when that differs)"""
         return (g, None) if owned else (torch.empty_like(g), g)
+    join_last = JOIN_STREAMS and steps[0][0] != "swap"
+
+    def joined(i):
+        """The stack's LAST LayerNorm backward (block 0's f) writes d(input) = g1 + g2 itself: the other stream joins in its pass."""
+        return g1 if (i == 0 and join_last and g1 is not dst) else None
     dkeys = None
     if has_ctx:
         dkeys = torch.zeros(extra["keys_bf16"].shape, dtype=torch.float32, device=dout.device)
@@ -1138,7 +1147,7 @@ def stack_backward_steps(ctx, dout, complete_layers: Optional[bool] = None, noti
             if "keys_bf16" in kw:
                 kw = dict(kw, dkeys=dkeys)
             dst, src = target(g2, gown2)
-            post, nxt = f.backward(s1, s2, g1, dst, b, t, slot=slots[(i, "f")], d_src=src, **kw, **chain.args(i, "f", s2),
+            post, nxt = f.backward(s1, s2, g1, dst, b, t, slot=slots[(i, "f")], d_src=src, join=joined(i), **kw, **chain.args(i, "f", s2),
                                    **chain.grad_args(i, "f", g1))
             g2, gown2 = dst, True
             chain.done(post, s1)
@@ -1153,7 +1162,7 @@ def stack_backward_steps(ctx, dout, complete_layers: Optional[bool] = None, noti
             chain.done(post, s2)
             chain.grad_done(nxt, g1)
             dst, src = target(g2, gown2)
-            post, nxt = f.backward(s1, s2, g1, dst, b, t, slot=slots[(i, "f")], d_src=src, **kw, **chain.args(i, "f", s2),
+            post, nxt = f.backward(s1, s2, g1, dst, b, t, slot=slots[(i, "f")], d_src=src, join=joined(i), **kw, **chain.args(i, "f", s2),
                                    **chain.grad_args(i, "f", g1))
             g2, gown2 = dst, True
             chain.done(post, s1)
@@ -1171,7 +1180,7 @@ def stack_backward_steps(ctx, dout, complete_layers: Optional[bool] = None, noti
         elif pending_wgrads() >= WGRAD_MAX_PENDING:
             flush_wgrad()      # nobody waits for a block's gradients (one GPU): they go out in a few large groups at the
             #                    end of the backward; this only bounds the operands held
-    dx = (g1 + g2).view(b, t, d)
+    dx = (g2 if join_last else g1 + g2).view(b, t, d)
     return dx, (None if dkeys is None else dkeys.view(b, -1, d))
 
 

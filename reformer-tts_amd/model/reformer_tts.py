@@ -1,6 +1,7 @@
 """Top-level module (``/root/reference/reformer_tts/model/reformer_tts.py``)."""
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -9,6 +10,9 @@ import torch.nn.functional as F
 
 from .modules import DecoderPreNet, EncoderPreNet, PostConvNet, ScaledPositionalEncoding
 from .reformer import ReformerDec, ReformerEnc
+
+
+FUSED_INPUTS = os.environ.get("RTTS_FUSED_INPUTS", "1") != "0"      # A/B: the ATen sequence of _encode_inputs in the training step
 
 
 class Encoder(nn.Module):
@@ -97,12 +101,41 @@ class ReformerTTS(nn.Module):
         spectrogram_mask = pad_to_multiple(spectrogram_mask.unsqueeze(-1).to(dev), self.pad_base).squeeze(-1).to(torch.bool)
         return pad_phonemes, phoneme_mask, spectrogram_mask, pad_to_multiple(spectrogram, self.pad_base)
 
-    def decoder_hidden(self, phonemes, spectrogram, spectrogram_mask=None, keys_hook=None, enc_stack_hook=None, enc_stream=None):
+    def _encode_inputs_fused(self, phonemes, spectrogram, loss_mask):
+        """``_encode_inputs`` for the training step, where the frame mask is ``loss_mask.mean(-1)`` (``wrappers.py:60``): one launch
+        (``rtts_batch_masks``) writes the padded phonemes, both phoneme masks and the padded frame mask.  -> the tuple of
+        ``_encode_inputs`` with the inverted phoneme mask attached to the phoneme mask as ``_rtts_not``."""
+        from .. import _lib
+        self._require_gpu()
+        dev = spectrogram.device
+        b, lp = phonemes.shape
+        lm, n_mels = loss_mask.shape[1], loss_mask.shape[2]
+        lpp, lmp = _pad_len(lp, self.pad_base), _pad_len(lm, self.pad_base)
+        pad_ph = torch.empty(b, lpp, dtype=torch.long, device=dev)
+        ph_mask = torch.empty(b, lpp, dtype=torch.bool, device=dev)
+        ph_not = torch.empty(b, lpp, dtype=torch.bool, device=dev)
+        sp_mask = torch.empty(b, lmp, dtype=torch.bool, device=dev)
+        _lib.call("rtts_batch_masks", phonemes.data_ptr(), phonemes.stride(0), b, lp, lpp, loss_mask.data_ptr(), loss_mask.stride(0),
+                  loss_mask.stride(1), lm, lmp, n_mels, pad_ph.data_ptr(), ph_mask.data_ptr(), ph_not.data_ptr(), sp_mask.data_ptr(),
+                  torch.cuda.current_stream(dev).cuda_stream)
+        ph_mask._rtts_not = ph_not
+        return pad_ph, ph_mask, sp_mask, pad_to_multiple(spectrogram, self.pad_base)
+
+    def decoder_hidden(self, phonemes, spectrogram, spectrogram_mask=None, keys_hook=None, enc_stack_hook=None, enc_stream=None,
+                       loss_mask=None):
         """Decoder output (B, T_padded, d) in front of the mel/stop heads: the training step feeds it to the
         fused heads + postnet + loss executor (``edges.PostnetLoss``).  ``keys_hook`` (encoder output -> tensor the
         decoder reads) lets the data-parallel trainer cut the autograd graph between encoder and decoder so that the
         two halves of the backward are separate launches with a gradient all-reduce in between."""
-        pad_phonemes, phoneme_mask, spectrogram_mask, pad_spec = self._encode_inputs(phonemes, spectrogram, spectrogram_mask)
+        fused_inputs = (FUSED_INPUTS and loss_mask is not None and spectrogram_mask is None and phonemes.is_cuda and phonemes.dtype == torch.long
+                        and phonemes.dim() == 2 and phonemes.stride(1) == 1 and loss_mask.dtype == torch.float32 and loss_mask.dim() == 3
+                        and loss_mask.stride(2) == 1 and loss_mask.shape[1] == spectrogram.shape[1])
+        if fused_inputs:
+            pad_phonemes, phoneme_mask, spectrogram_mask, pad_spec = self._encode_inputs_fused(phonemes, spectrogram, loss_mask)
+        else:
+            if spectrogram_mask is None and loss_mask is not None:
+                spectrogram_mask = loss_mask.mean(dim=-1)
+            pad_phonemes, phoneme_mask, spectrogram_mask, pad_spec = self._encode_inputs(phonemes, spectrogram, spectrogram_mask)
         if enc_stream is not None:
             # the encoder (3,072 rows at the baseline shape: launch- and latency-bound kernels on three quarters of the chip) runs
             # on a stream of its own BESIDE the decoder prenet and the first decoder block, which do not read its output; the
@@ -124,7 +157,9 @@ class ReformerTTS(nn.Module):
             keys = self.enc(pad_phonemes, input_mask=phoneme_mask, stack_hook=enc_stack_hook)
         if keys_hook is not None:
             keys = keys_hook(keys)
-        kpm = ~phoneme_mask
+        kpm = getattr(phoneme_mask, "_rtts_not", None)
+        if kpm is None:
+            kpm = ~phoneme_mask
         kpm._rtts_not = phoneme_mask          # the stack executor wants the validity mask back: spares it the second inversion
         return self.dec.hidden(pad_spec, keys=keys, key_padding_mask=kpm, input_mask=spectrogram_mask)[0]
 

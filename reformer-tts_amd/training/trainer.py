@@ -324,7 +324,7 @@ class Trainer:
             if getattr(self, "_postnet_loss", None) is None:
                 self._postnet_loss = PostnetLoss(self.model, self.loss)
             overlap = split == "overlap"
-            y = self.model.decoder_hidden(batch["phonemes"], spec_in, spectrogram_mask=batch["loss_mask"].mean(dim=-1),
+            y = self.model.decoder_hidden(batch["phonemes"], spec_in, loss_mask=batch["loss_mask"],
                                           keys_hook=self._cut_at_encoder if split else None,
                                           enc_stack_hook=self._cut_at_enc_stack if (split and not overlap) else None,
                                           enc_stream=self._enc_stream() if side_enc else None)
@@ -369,8 +369,11 @@ class Trainer:
         leftover entry would be added to the NEXT step's gradients after ``zero_grad``.  A backward that raises drops its
         entries."""
         keys = self._queue_keys()             # this trainer's queues only: another trainer / thread keeps what it has pending
+        one = getattr(self, "_one", None)
+        if one is None or one.device != loss.device or one.dtype != loss.dtype:
+            one = self._one = torch.ones((), dtype=loss.dtype, device=loss.device)     # the root gradient: a constant, not a fill per step
         try:
-            loss.backward()
+            loss.backward(one if loss.dim() == 0 else None)
             engine.flush_wgrad(keys=keys)
         except BaseException:
             engine.discard_pending(keys)

@@ -48,6 +48,20 @@ def capture(order):
         small.add_(0.0)                       # common root
         if order in ("S", "L"):
             (S if order == "S" else L)()
+        elif order == "I":                    # both branches, their launches INTERLEAVED in program (= node creation) order
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            for i in range(24):
+                with torch.cuda.stream(side):
+                    if MODE == "tiny":
+                        for _ in range(8):
+                            small.add_(1.0)
+                    elif i % 2 == 0:
+                        torch.sort(chain_in, out=(chain_out, chain_idx))
+                if i % 3 == 0:
+                    L(1)
+            main.wait_stream(side)
         else:
             ev = torch.cuda.Event()
             ev.record(main)
@@ -100,13 +114,15 @@ import os
 print("DEBUG_CLR_GRAPH_PACKET_CAPTURE =", os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE"), " GPU_MAX_HW_QUEUES =", os.environ.get("GPU_MAX_HW_QUEUES"))
 eager_two_streams(2)
 print(f"eager, S on a side stream beside L: {eager_two_streams():8.1f} us (host-bound for S: 200 launches)", flush=True)
-for order in ("S", "L", "SL", "LS"):
+for order in ("S", "L", "SL", "LS", "I"):
     S(3); L(1)
     torch.cuda.synchronize()
     g = capture(order)
     print(f"{order:3s}: {timeit(g):8.1f} us per replay", flush=True)
 
 
+if os.environ.get("PROBE_SHORT"):
+    raise SystemExit(0)
 # two single-branch graphs launched on two streams
 gS, gL = capture("S"), capture("L")
 pstream = torch.cuda.Stream()
