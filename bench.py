@@ -27,6 +27,7 @@ under the top-level key ``stash`` (its own value / ms_per_step / peak memory) --
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -209,13 +210,21 @@ def main():
         return bool(ok)
 
     def timed(step_fn, steps):
+        # A collection of the host's garbage inside the timed region can free a replaced hipGraph and its memory pool (a second
+        # capture on the same trainer leaves one behind): hipFree synchronises the device -- seen as a one-off 5-9 ms stall in a
+        # 10-step region (profiles/r04b_stash_variance.log).  Collect now, and keep the collector off while the clock runs.
+        gc.collect()
+        gc.disable()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            last = step_fn()[0]
-        torch.cuda.synchronize()
+        try:
+            for _ in range(steps):
+                last = step_fn()[0]
+            torch.cuda.synchronize()
+        finally:
+            gc.enable()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
