@@ -43,6 +43,47 @@ __device__ __forceinline__ int xa_ds_off(int key, int gran) {
     return key * 256 + ((gran ^ ((k1 << 4) | (k0 << 3) | (k1 << 2) | (k2 << 1) | k3)) << 3);
 }
 
+// Row staging of the epilogues (lsh_attn_bwd.hip's ab_stg_w / ab_stg_r, where the bank arithmetic is written out): the
+// accumulators hold a row (query / key) per lane and 4 dh values per register group, so a lane's natural store is 8 bytes into
+// 16 different 128-byte rows -- 16 store instructions per lane that each touch 32 rows.  Through a swizzled [32][128 B] image a
+// wave leaves full rows instead: 4 ds_read_b128 + 4 16-byte write-through stores (8 complete rows per instruction).
+// (Round 4 also tried the forward with TWO passes over the key tiles -- maximum first, then Q K^T again, exp, row sum, P V --
+//  so that a query's 256 logits need not sit in registers: 168 instead of 288 registers, two workgroups per CU instead of one,
+//  bit-identical, and SLOWER: 25.2 against 22.2 us.  The kernel is bound by its vector work, not by exposed latency.)
+// (and a vector-instruction diet of the same kernel -- padding-only key tiles skipped, all-valid tiles unmasked, scale and maximum in
+//  one fma: 22.1 against 22.0 us.  With one four-wave workgroup per CU the kernel's time is the serial chain "64 KB of K and V
+//  rows arrive (every CU at once: ~3 us) -> products and softmax (~2.5 us) -> rows leave"; neither fewer instructions nor more
+//  resident waves shorten it.  Both variants removed again; profiles/r04_xattn_ab.log.)
+#ifndef XA_STAGED
+#define XA_STAGED 1    // 0: the 8-byte stores of rounds 1-3, for A/B runs
+#endif
+__device__ __forceinline__ int xa_stg_w(int r, int piece, int hh) { return r * 128 + ((piece ^ (r & 7)) << 4) + ((hh ^ ((r >> 3) & 1)) << 3); }
+__device__ __forceinline__ int xa_stg_r(int i, int srow, int spiece) { return (i * 8 + srow) * 128 + ((spiece ^ srow) << 4); }
+// acc[dt][4 g + j] of lane (r, hh) = element (row r, dh = 32 dt + 8 g + 4 hh + j), times `mul`  ->  32 rows of 64 bf16 at
+// dst + row * ld (16-byte aligned rows), through the wave-private 4 KB image `stg`
+__device__ __forceinline__ void xa_store_rows(unsigned char* stg, const f32x16 (&acc)[2], float mul, bf16_t* dst, int64_t ld, int lane) {
+    const int r = lane & 31, hh = lane >> 5, srow = lane >> 3, spiece = lane & 7;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 pk;
+            pk.x = pack_bf16x2(acc[dt][4 * g] * mul, acc[dt][4 * g + 1] * mul);
+            pk.y = pack_bf16x2(acc[dt][4 * g + 2] * mul, acc[dt][4 * g + 3] * mul);
+            *reinterpret_cast<uint2*>(stg + xa_stg_w(r, dt * 4 + g, hh)) = pk;
+        }
+    __builtin_amdgcn_wave_barrier();
+    uint4 rowv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint4 v = *reinterpret_cast<const uint4*>(stg + xa_stg_r(i, srow, spiece));
+        rowv[i] = (i & 1) ? uint4{v.z, v.w, v.x, v.y} : v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rtts_store16_out(dst + (size_t)(i * 8 + srow) * ld + spiece * 8, rowv[i]);
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int TK, bool MULTI>
 __global__ __launch_bounds__(256) void xattn_fwd_kernel(const bf16_t* __restrict__ q, int64_t ld_q, const bf16_t* __restrict__ kv,
                                                         int64_t ld_kv, const uint8_t* __restrict__ kvalid, int H, int Tq, int TKtot_,
@@ -173,6 +214,10 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const bf16_t* __restrict
             }
     }
     const float inv_l = 1.f / l_run;
+#if XA_STAGED
+    __syncthreads();                 // every wave is done with the K image: it becomes the waves' row staging (4 KB each)
+    xa_store_rows(Ks + wave * 4096, oacc, inv_l, o + ((size_t)b * Tq + qb * XA_QB + wave * 32) * ld_o + (size_t)h * XA_DH, ld_o, lane);
+#else
     bf16_t* optr = o + ((size_t)b * Tq + qrow) * ld_o + (size_t)h * XA_DH;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -183,6 +228,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const bf16_t* __restrict
             pk.y = pack_bf16x2(oacc[dt][4 * g + 2] * inv_l, oacc[dt][4 * g + 3] * inv_l);
             *reinterpret_cast<uint2*>(optr + dt * 32 + 8 * g + 4 * hh) = pk;
         }
+#endif
     if (hh == 0) lse[(size_t)bh * Tq + qrow] = m_run + logf(l_run);
 }
 
@@ -359,6 +405,20 @@ __global__ __launch_bounds__(TK * 2 / XA_KT2) void xattn_bwd_kernel(const bf16_t
 
     // dK | dV partial slab of this query block: layout (nqb, B, TKtot, 2d)
     bf16_t* slab = dkv_part + (((size_t)qb * B + b) * TKtot + kc0) * (size_t)(2 * d) + (size_t)h * XA_DH;
+#if XA_STAGED
+    __syncthreads();                 // every dS^T tile is in Ds; nobody reads the Q / dout images any more: they become the row staging
+    {
+        static_assert(2 * XA_QB * 128 >= NW * 4096, "the Q and dout images must hold a 4 KB staging per wave");
+        unsigned char* stg = Qs + wave * 4096;
+#pragma unroll
+        for (int k2 = 0; k2 < KT2; ++k2) {
+            // rows of this wave's 32-key tile are consecutive keys: myrow[k2] = first key + r
+            bf16_t* dkp = slab + (size_t)(myrow[k2] - r) * (2 * d);
+            xa_store_rows(stg, gacc[k2], 1.f, dkp, 2 * d, lane);
+            xa_store_rows(stg, dvacc[k2], 1.f, dkp + d, 2 * d, lane);
+        }
+    }
+#else
 #pragma unroll
     for (int k2 = 0; k2 < KT2; ++k2) {
         bf16_t* dkp = slab + (size_t)myrow[k2] * (2 * d);
@@ -377,6 +437,7 @@ __global__ __launch_bounds__(TK * 2 / XA_KT2) void xattn_bwd_kernel(const bf16_t
             }
     }
     __syncthreads();
+#endif
 
     // dQ^T[dh][q] = K^T dS^T: the 8 (query tile, dh half) outputs are dealt over the waves
     constexpr int NOUT = (XA_QB / 32) * 2;
