@@ -1069,6 +1069,46 @@ def test_cross_attention_dropout_vs_autograd(gpu, tk):
         assert float((got - ref).norm() / ref.norm()) < 3e-2, name
 
 
+@pytest.mark.parametrize("tk,drop", [(256, 0.0), (128, 0.0), (256, 0.1)])
+def test_cross_attention_forward_forms_are_bit_identical(gpu, tk, drop):
+    """rtts_xattn_fwd picks, from the grid it would launch, between one 128-query block per workgroup and the form in which a
+    workgroup loads the K / V images once and works two consecutive query blocks (B * H * T_q / 128 / 2 >= 256 workgroups: the
+    bench shape).  A sample's output does not depend on the batch it is part of: the same rows through a batch of 12 (the second
+    form) and through three batches of 4 (the first) must agree bit for bit, outputs and log-sum-exps, also with the dropout whose
+    mask is keyed by (head, query, key)."""
+    from reformer_tts_amd import _lib
+    b, h, t, dh = 12, 8, 1024, 64
+    e = h * dh
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(tk + 7)
+    q = (torch.randn(b * t, e, generator=g) * 1.5).bfloat16().to(gpu)
+    kv = torch.randn(b * tk, 2 * e, generator=g).bfloat16().to(gpu)
+    valid = torch.ones(b, tk, dtype=torch.uint8, device=gpu)
+    valid[:, tk - 56:] = 0
+    valid[3, : tk // 2] = 0
+
+    def run(b0, nb):
+        o = torch.empty(nb * t, e, dtype=torch.bfloat16, device=gpu)
+        lse = torch.empty(nb * h, t, device=gpu)
+        _lib.call("rtts_xattn_fwd", q[b0 * t:].data_ptr(), e, kv[b0 * tk:].data_ptr(), 2 * e, valid[b0:].data_ptr(), nb, h, t, tk, dh, o.data_ptr(),
+                  e, lse.data_ptr(), drop, 1234, None, s)
+        return o, lse
+    o_all, lse_all = run(0, b)
+    torch.cuda.synchronize()
+    for b0 in range(0, b if drop == 0.0 else 4, 4):      # (the dropout mask is keyed by the sample's index IN the call: the first four)
+        o4, lse4 = run(b0, 4)
+        assert torch.equal(o4, o_all[b0 * t:(b0 + 4) * t]) and torch.equal(lse4, lse_all[b0 * h:(b0 + 4) * h])
+    # and against float32 torch on the same bf16 inputs (no dropout)
+    if drop == 0.0:
+        qr = q.float().view(b, t, h, dh).transpose(1, 2)
+        kr = kv.float().view(b, tk, 2, h, dh)[:, :, 0].transpose(1, 2)
+        vr = kv.float().view(b, tk, 2, h, dh)[:, :, 1].transpose(1, 2)
+        sc = (qr @ kr.transpose(-1, -2) / 8.0).masked_fill(valid.view(b, 1, 1, tk) == 0, float("-inf"))
+        oref = torch.softmax(sc, dim=-1) @ vr
+        assert float((o_all.float().view(b, t, h, dh).transpose(1, 2) - oref).abs().max()) < 2e-2
+        assert float((lse_all.view(b, h, t) - torch.logsumexp(sc, dim=-1)).abs().max()) < 2e-3
+
+
 @pytest.mark.parametrize("tk", [128, 256, 384, 512, 768])
 def test_cross_attention_key_chunks_vs_autograd(gpu, tk):
     """rtts_xattn_fwd / rtts_xattn_bwd for every supported key count: one on-chip pass (128, 256) or chunks with a running
