@@ -53,7 +53,8 @@ __device__ __forceinline__ int xa_ds_off(int key, int gran) {
 // (and a vector-instruction diet of the same kernel -- padding-only key tiles skipped, all-valid tiles unmasked, scale and maximum in
 //  one fma: 22.1 against 22.0 us.  With one four-wave workgroup per CU the kernel's time is the serial chain "64 KB of K and V
 //  rows arrive (every CU at once: ~3 us) -> products and softmax (~2.5 us) -> rows leave"; neither fewer instructions nor more
-//  resident waves shorten it.  Both variants removed again; profiles/r04_xattn_ab.log.)
+//  resident waves shorten it.  A third variant -- a workgroup loads the K / V images once and works TWO query blocks -- was 29.7
+//  against 21.9 us: the load is not what a block's 7.3 us are spent on either.  All three removed again; profiles/r04_xattn_ab.log.)
 #ifndef XA_STAGED
 #define XA_STAGED 1    // 0: the 8-byte stores of rounds 1-3, for A/B runs
 #endif
@@ -230,131 +231,6 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const bf16_t* __restrict
         }
 #endif
     if (hh == 0) lse[(size_t)bh * Tq + qrow] = m_run + logf(l_run);
-}
-
-// ------------------------------------------------------------------------------ forward, several query blocks per workgroup
-// All keys of a (batch, head) fit the chip (T_k = TK) and there are enough query blocks to fill it: a workgroup loads the K and V
-// images ONCE and works XA_QPW consecutive 128-query blocks against them.  With one four-wave workgroup per CU (288 registers) the
-// kernel above is a serial chain per workgroup -- 64 KB of rows arrive (every CU at once: ~3 us), products and softmax (~2.5 us),
-// rows leave -- so the load is paid once per XA_QPW blocks, the next block's Q fragments are requested before the current block's
-// P V product, and the rows of a block leave through a wave-private staging while the wave starts the next block.  Same
-// arithmetic, same order: outputs bit-identical to xattn_fwd_kernel<TK, false>.
-#ifndef XA_QPW
-#define XA_QPW 2
-#endif
-template <int TK, int QPW>
-__global__ __launch_bounds__(256) void xattn_fwd_multiq_kernel(const bf16_t* __restrict__ q, int64_t ld_q, const bf16_t* __restrict__ kv,
-                                                               int64_t ld_kv, const uint8_t* __restrict__ kvalid, int H, int Tq,
-                                                               bf16_t* __restrict__ o, int64_t ld_o, float* __restrict__ lse, uint32_t seed,
-                                                               const uint32_t* __restrict__ seed_dev, uint32_t thresh, float dscale) {
-    constexpr int NKT = TK / 32;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* Ks = smem;                       // [TK][128] swizzled (xa_off), like V
-    unsigned char* Vs = Ks + TK * 128;
-    int* kval = reinterpret_cast<int*>(Vs + TK * 128);
-    unsigned char* Stg = reinterpret_cast<unsigned char*>(kval + TK);     // [4 waves][32][128]
-
-    const int nqg = Tq / (XA_QB * QPW);
-    const uint32_t wi = xcd_remap(blockIdx.x, gridDim.x);
-    const int bh = wi / nqg, qg = wi % nqg;
-    const int b = bh / H, h = bh % H;
-    const int d = H * XA_DH;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, hh = lane >> 5;
-    const bf16_t* kbase = kv + (size_t)b * TK * ld_kv + (size_t)h * XA_DH;
-    const bf16_t* vbase = kbase + d;
-    constexpr int ITERS = TK * 8 / 256;
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        const int rowb = it * 32 + wave * 8;                     // wave-uniform: first row of this instruction
-        const int row = rowb + (lane >> 3);
-        const int lp = (lane & 7) ^ xa_sw(row);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + (size_t)row * ld_kv + lp * 8),
-                                         (RTTS_LDS void*)(Ks + rowb * 128), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + (size_t)row * ld_kv + lp * 8),
-                                         (RTTS_LDS void*)(Vs + rowb * 128), 16, 0, 0);
-    }
-    for (int j = tid; j < TK; j += 256) kval[j] = kvalid ? (int)kvalid[(size_t)b * TK + j] : 1;
-    if (thresh && seed_dev) seed += seed_dev[0];
-    const int q0 = qg * QPW * XA_QB + wave * 32;                 // this wave's first query of the group's first block
-    const bf16_t* qptr = q + ((size_t)b * Tq + q0 + r) * ld_q + (size_t)h * XA_DH;
-    bf16x8 qf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qptr + ks * 16 + 8 * hh);
-    const int trq = (lane & 15) >> 2, trp = lane & 3, trc = (lane >> 4) & 1;
-    __syncthreads();
-
-#pragma unroll 1
-    for (int qi = 0; qi < QPW; ++qi) {
-        const int qrow = q0 + qi * XA_QB + r;
-        f32x16 s[NKT];
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            f32x16 acc = {0};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + xa_off(kt * 32 + r, ks * 2 + hh));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc, 0, 0, 0);
-            }
-            s[kt] = acc;
-        }
-        if (qi + 1 < QPW) {          // the next block's Q rows: requested now, used after this block's row stores
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qptr + (size_t)(qi + 1) * XA_QB * ld_q + ks * 16 + 8 * hh);
-        }
-        float m = -FLT_MAX;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int4 kvv = *reinterpret_cast<const int4*>(kval + kt * 32 + 8 * g + 4 * hh);
-                const int vv[4] = {kvv.x, kvv.y, kvv.z, kvv.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float x = vv[j] ? s[kt][4 * g + j] * 0.125f : -FLT_MAX;
-                    s[kt][4 * g + j] = x;
-                    m = fmaxf(m, x);
-                }
-            }
-        m = rtts_xhalf_max(m);
-        float l = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float p = s[kt][i] == -FLT_MAX ? 0.f : __expf(s[kt][i] - m);
-                s[kt][i] = p;
-                l += p;
-            }
-        const float l_run = rtts_xhalf_sum(l);
-        if (thresh) {
-            const uint32_t base = ((uint32_t)bh * (uint32_t)Tq + (uint32_t)qrow) * (uint32_t)TK;
-#pragma unroll
-            for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    s[kt][i] *= rtts_drop_keep(seed, base + (uint32_t)(kt * 32 + 8 * (i >> 2) + 4 * hh + (i & 3)), thresh, dscale);
-        }
-        f32x16 oacc[2] = {{0}, {0}};
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const int o8 = 8 * s2;
-                const bf16x8 pf = cvt_bf16x8(s[kt][o8], s[kt][o8 + 1], s[kt][o8 + 2], s[kt][o8 + 3], s[kt][o8 + 4], s[kt][o8 + 5],
-                                             s[kt][o8 + 6], s[kt][o8 + 7]);
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const int blk = (kt * 32 + 16 * s2) * 128;
-                    const int t0 = xa_off(4 * hh + trq, dt * 4 + 2 * trc + (trp >> 1)) + 8 * (trp & 1);
-                    const int t1 = xa_off(4 * hh + trq, (dt ^ 1) * 4 + 2 * trc + (trp >> 1)) + 8 * (trp & 1);
-                    const bf16x8 vf = xa_tr_frag(Vs + blk + t0, Vs + blk + 8 * 128 + t1);
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
-                }
-            }
-        xa_store_rows(Stg + wave * 4096, oacc, 1.f / l_run, o + ((size_t)b * Tq + q0 + qi * XA_QB) * ld_o + (size_t)h * XA_DH, ld_o, lane);
-        if (hh == 0) lse[(size_t)bh * Tq + qrow] = m + logf(l_run);
-    }
 }
 
 // ------------------------------------------------------------------------------ backward
@@ -648,25 +524,6 @@ extern "C" int rtts_xattn_fwd(const void* q, int64_t ld_q, const void* kv, int64
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q, ld_q, (const bf16_t*)kv, ld_kv, \
                            kvalid, H, Tq, Tk, (bf16_t*)o, ld_o, lse, seed, seed_dev, rtts_drop_thresh(drop_p), 1.f / (1.f - drop_p)); \
     } while (0)
-#if XA_STAGED && XA_QPW > 1
-    // enough query blocks for every CU even when XA_QPW of them share a workgroup, and all keys on chip at once
-    if (Tk == chunk && (Tq / XA_QB) % XA_QPW == 0 && (long long)B * H * (Tq / XA_QB) / XA_QPW >= 256) {
-        const dim3 mgrid(B * H * (Tq / XA_QB) / XA_QPW);
-        const size_t mlds = lds + 4 * 4096;
-#define GOQ(TK_)                                                                                                          \
-    do {                                                                                                                  \
-        auto kern = xattn_fwd_multiq_kernel<TK_, XA_QPW>;                                                                 \
-        static RttsLdsState st_;                                                                                          \
-        RTTS_ENSURE_LDS("rtts_xattn_fwd", kern, mlds, st_);                                                               \
-        hipLaunchKernelGGL(kern, mgrid, dim3(256), mlds, (hipStream_t)stream, (const bf16_t*)q, ld_q, (const bf16_t*)kv, ld_kv, \
-                           kvalid, H, Tq, (bf16_t*)o, ld_o, lse, seed, seed_dev, rtts_drop_thresh(drop_p), 1.f / (1.f - drop_p)); \
-    } while (0)
-        if (chunk == 256) GOQ(256); else GOQ(128);
-#undef GOQ
-        RTTS_LAUNCH_CHECK("rtts_xattn_fwd");
-        return 0;
-    }
-#endif
     if (chunk == 256) GO(256); else GO(128);
 #undef GO
     RTTS_LAUNCH_CHECK("rtts_xattn_fwd");

@@ -1070,12 +1070,11 @@ def test_cross_attention_dropout_vs_autograd(gpu, tk):
 
 
 @pytest.mark.parametrize("tk,drop", [(256, 0.0), (128, 0.0), (256, 0.1)])
-def test_cross_attention_forward_forms_are_bit_identical(gpu, tk, drop):
-    """rtts_xattn_fwd picks, from the grid it would launch, between one 128-query block per workgroup and the form in which a
-    workgroup loads the K / V images once and works two consecutive query blocks (B * H * T_q / 128 / 2 >= 256 workgroups: the
-    bench shape).  A sample's output does not depend on the batch it is part of: the same rows through a batch of 12 (the second
-    form) and through three batches of 4 (the first) must agree bit for bit, outputs and log-sum-exps, also with the dropout whose
-    mask is keyed by (head, query, key)."""
+def test_cross_attention_is_independent_of_the_batch_it_runs_in(gpu, tk, drop):
+    """A sample's cross-attention output does not depend on the batch it is part of (the workgroup -> tile mapping does:
+    xcd_remap over a grid of 768 or of 256 workgroups; and any future kernel form picked from the grid size): the same rows through
+    a batch of 12 (the bench shape) and through three batches of 4 must agree bit for bit, outputs and log-sum-exps, also with the
+    dropout whose mask is keyed by (head, query, key); and with float32 torch on the same bf16 inputs."""
     from reformer_tts_amd import _lib
     b, h, t, dh = 12, 8, 1024, 64
     e = h * dh
