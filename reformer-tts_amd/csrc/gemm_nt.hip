@@ -766,6 +766,16 @@ static int gn_run(const void* a, int64_t lda, const void* w, int64_t ldw, int w_
                  "(rtts_gemm_nt_gate_words(M, N) > 0)");
     hipStream_t s = (hipStream_t)stream;
     int rc = 0;
+#ifdef GN_EXPERIMENT_ROWTILE
+    // timing experiment only (scripts/build_ab.sh ... -DGN_EXPERIMENT_ROWTILE): a tile that spans the WHOLE row of an N = 512 product
+    // (what a LayerNorm in the epilogue would need), one wave per 64 columns
+    if (g_gn_mode.load(std::memory_order_relaxed) == 1 && N == 512 && !w_is_kn && epilogue == 0 && M % 64 == 0) {
+        rc = gn_launch3<64, 512, 1, 8, false, 0, 2, 0>(G, M / 64, s);
+        if (rc) return rc;
+        RTTS_LAUNCH_CHECK("rtts_gemm_nt");
+        return 0;
+    }
+#endif
     switch (pick) {
         case 0: rc = gn_launch<256, 256, 4, 2>(G, w_is_kn, s); break;
         case 1: rc = gn_launch<192, 128, 4, 2>(G, w_is_kn, s); break;
