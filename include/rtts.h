@@ -454,6 +454,9 @@ int rtts_peak_copy(const void* src, void* dst, int64_t bytes, void* stream);
  * (+1 on every word) in 16 KB pieces with write-through stores and sleep `sleep` x ~0.5 us between pieces (pace of a link, not of
  * HBM).  scripts/comm_overlap_probe.py runs it beside the data-parallel chain of hipGraphs. */
 int rtts_comm_probe(const void* src, void* dst, int64_t bytes, int workgroups, int sleep, void* stream);
+/* TEST / MEASUREMENT ONLY: a one-lane kernel writes the device's 100 MHz wall clock into buf[slot] (uint64).  Capturable: markers inside
+ * a replayed hipGraph give the timeline of an UNPROFILED step (scripts/replay_stamps.py). */
+int rtts_debug_stamp(void* buf, int slot, void* stream);
 int rtts_peak_mfma(float* sink, int workgroups, int iters, void* stream);
 
 /* ---- SqueezeWave vocoder, inference -----------------------------------

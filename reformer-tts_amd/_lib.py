@@ -106,6 +106,7 @@ SIGNATURES = {
     "rtts_tts_loss": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32,
                       _vp, _i64, _i32, _i32, _i64, _i64, _vp, _i64, _i64, _vp],
     "rtts_pe_add": [_vp, _vp, _vp, _f32, _u32, _vp, _i32, _i64, _i32, _vp, _vp],
+    "rtts_debug_stamp": [_vp, _i32, _vp],
     "rtts_batch_masks": [_vp, _i64, _i32, _i32, _i32, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "rtts_pe_dalpha": [_vp, _vp, _f32, _u32, _vp, _i32, _i64, _i32, _vp, _vp, _vp],
     "rtts_relu_drop": [_vp, _f32, _u32, _vp, _i64, _vp],

@@ -81,6 +81,20 @@ extern "C" int rtts_comm_probe(const void* src, void* dst, int64_t bytes, int wo
     return 0;
 }
 
+// rtts_debug_stamp: one lane writes the 100 MHz wall clock into buf[slot] -- a marker that can be captured into a hipGraph, so that
+// the timeline of an UNPROFILED replay can be read back (scripts/replay_stamps.py: when does each branch of the step really start?).
+// Not on the training path.
+__global__ void stamp_kernel(unsigned long long* __restrict__ buf, int slot) {
+    if (threadIdx.x == 0) buf[slot] = wall_clock64();
+}
+extern "C" int rtts_debug_stamp(void* buf, int slot, void* stream) {
+    RTTS_ENTER(stream);
+    RTTS_REQUIRE(buf && slot >= 0, "rtts_debug_stamp: bad arguments");
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)buf, slot);
+    RTTS_LAUNCH_CHECK("rtts_debug_stamp");
+    return 0;
+}
+
 extern "C" int rtts_peak_copy(const void* src, void* dst, int64_t bytes, void* stream) {
     RTTS_ENTER(stream);
     RTTS_REQUIRE(src && dst && bytes > 0 && bytes % 16 == 0, "rtts_peak_copy: bytes must be a positive multiple of 16");

@@ -488,11 +488,59 @@ DEFER_WGRAD = True
 # have left it by the end of the step.
 WGRAD_FLUSH_PER_LAYER = os.environ.get("RTTS_WGRAD_FLUSH", "layer") == "layer"
 WGRAD_MAX_PENDING = 64
+# measurement only (scripts/replay_stamps.py): STAMPS = (uint64 device buffer, {name: slot}) makes stamp(name) launch a marker kernel
+# on the current stream; None (always, in product runs): stamp() does nothing
+STAMPS = None
+
+
+def stamp(name: str) -> None:
+    if STAMPS is None:
+        return
+    buf, names = STAMPS
+    slot = names.setdefault(name, len(names))
+    _lib.call("rtts_debug_stamp", buf.data_ptr(), slot, _s())
+
+
 JOIN_STREAMS = os.environ.get("RTTS_JOIN_STREAMS", "1") != "0"      # A/B: d(input) = g1 + g2 as a separate (ATen) pass after the stack's backward
 COPY_STREAMS = os.environ.get("RTTS_STREAM_COPIES", "0") == "1"     # A/B: copy x / dout into both streams instead of aliasing them
 # (A second HIP stream for the weight gradients, forked/joined by events = parallel branches of the captured hipGraph,
 #  was measured SLOWER on MI355X in round 1: 9.35 vs 8.94 ms/step; the cross-branch dependencies of the replayed graph
 #  cost more than the overlapped tails recover.  Removed.)
+
+
+# The overlapped one-process step ends with the ENCODER's backward alone on the chip: it cannot start before the decoder's lowest
+# cross-attention has run backwards (the keys' gradient), it is a chain of small-grid kernels (3,072 rows), and the decoder branch
+# beside it finishes 0.35-0.6 ms earlier (scripts/replay_stamps.py: markers inside the UNPROFILED replayed graph,
+# profiles/r04_replay_stamps_*.log).  The encoder stack's weight gradients are not part of that chain -- nothing reads them before
+# the optimizer -- so the trainer has them handed over: where the encoder stream's queue would be flushed, its weight-gradient
+# entries are set aside together with an event recorded on that stream, and the MAIN stream launches them after the decoder's own
+# work (Trainer.forward_backward_overlapped -> run_handed_over).  STEAL = None (always, outside that step).
+STEAL = None          # dict(src=(device index, stream handle), src_stream=torch.cuda.Stream, pending=[(event, [(grad, dy, x)...])])
+
+
+def run_handed_over(steal) -> int:
+    """Launch, on the CURRENT stream, the weight gradients that were set aside from ``steal['src']``'s queue (each group behind the
+    event that marks its operands' producers).  -> launches made."""
+    main = torch.cuda.current_stream()
+    n = 0
+    for ev, entries in steal["pending"]:
+        main.wait_event(ev)
+        for gv, dy, x in entries:
+            dy.record_stream(main)
+            x.record_stream(main)
+        pending = list(entries)
+        while pending:
+            group = pending[:_lib.GEMM_TN_MAX_GROUP]
+            del pending[:len(group)]
+            arr = (_lib.GemmTnProblem * len(group))()
+            for e, (gv, dy, x) in zip(arr, group):
+                e.a, e.lda, e.b, e.ldb, e.c, e.ldc = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), gv.data_ptr(), gv.stride(0)
+                e.M, e.N, e.K, e.accumulate = dy.shape[0], dy.shape[1], x.shape[1], 1
+            ws = _slab_ws(group[0][1].device)
+            _lib.call("rtts_gemm_tn_grouped", arr, len(group), ws.data_ptr(), ws.numel(), _s())
+            n += 1
+    del steal["pending"][:]
+    return n
 
 
 def _final_flush():
@@ -537,6 +585,12 @@ def flush_wgrad(colsums: bool = True, keys=None):
             elif q.colsums and (q.device, q.stream) == (torch.cuda.current_device(), _s()):
                 _queue_final_flush()
             pending = q.wgrads
+            steal = STEAL
+            if steal is not None and steal.get("armed") and pending and (q.device, q.stream) == steal["src"]:
+                ev = torch.cuda.Event()
+                ev.record(steal["src_stream"])            # everything this stream has been given so far: the operands' producers
+                steal["pending"].append((ev, list(pending)))
+                del pending[:]
             while pending:
                 group = pending[:_lib.GEMM_TN_MAX_GROUP]
                 del pending[:len(group)]
@@ -1048,8 +1102,10 @@ class FusedStackFn(torch.autograd.Function):
                     if keys_ready is not None and "keys_bf16" in kw:
                         # the encoder ran on a stream of its own beside the decoder's first blocks (Trainer, overlapped step):
                         # the first cross-attention is where the two meet
+                        stamp("decoder: first cross-attention reached (before the wait for the encoder)")
                         torch.cuda.current_stream().wait_event(keys_ready)
                         keys_ready = None
+                        stamp("decoder: first cross-attention starts (encoder output there)")
                     post = f.forward(s1, s2, b, t, slot=slots[(i, "f")], keep_streams=kept, fresh_acc=not own1, **kw,
                                      **chain.args(i, "f", s2))
                     s1, own1 = slots[(i, "f")].pop("acc_out", s1), True
@@ -1127,6 +1183,12 @@ def stack_backward_steps(ctx, dout, complete_layers: Optional[bool] = None, noti
     def target(g, owned):
         """-> (buffer the executor accumulates into, its source when that differs)"""
         return (g, None) if owned else (torch.empty_like(g), g)
+    steal = STEAL if (STEAL is not None and (torch.cuda.current_device(), _s()) == STEAL["src"]) else None
+    if steal is not None:
+        flush_at = min(flush_at, 4)      # this stack's weight gradients are handed to another stream: one hand-over (one event) per block,
+        #                                  so that the taker can start on the first blocks' while the chain is still in the last ones
+        steal["armed"] = True            # only the STACK's: what the prenet queues behind it stays on this stream (its event would be the
+        #                                  end of the chain, and the taker would wait for that)
     join_last = JOIN_STREAMS and steps[0][0] != "swap"
 
     def joined(i):
@@ -1180,6 +1242,8 @@ def stack_backward_steps(ctx, dout, complete_layers: Optional[bool] = None, noti
         elif pending_wgrads() >= WGRAD_MAX_PENDING:
             flush_wgrad()      # nobody waits for a block's gradients (one GPU): they go out in a few large groups at the
             #                    end of the backward; this only bounds the operands held
+    if steal is not None:
+        steal["armed"] = False
     dx = (g2 if join_last else g1 + g2).view(b, t, d)
     return dx, (None if dkeys is None else dkeys.view(b, -1, d))
 

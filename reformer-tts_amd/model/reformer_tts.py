@@ -140,14 +140,19 @@ class ReformerTTS(nn.Module):
             # the encoder (3,072 rows at the baseline shape: launch- and latency-bound kernels on three quarters of the chip) runs
             # on a stream of its own BESIDE the decoder prenet and the first decoder block, which do not read its output; the
             # decoder's first cross-attention waits for the event left on the keys (engine.FusedStackFn.forward)
+            from ..engine import stamp
             main = torch.cuda.current_stream()
+            stamp("fork (main stream)")
             enc_stream.wait_stream(main)
             for t_ in (pad_phonemes, phoneme_mask):
                 t_.record_stream(enc_stream)
             with torch.cuda.stream(enc_stream):
+                stamp("encoder branch: first kernel")
                 keys = self.enc(pad_phonemes, input_mask=phoneme_mask, stack_hook=enc_stack_hook)
+                stamp("encoder branch: forward done")
                 ready = torch.cuda.Event()
                 ready.record(enc_stream)
+            stamp("decoder branch: first kernel after the fork")
             keys.record_stream(main)
             twin = getattr(keys, "_rtts_bf16", None)
             if twin is not None:

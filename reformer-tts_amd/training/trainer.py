@@ -15,6 +15,7 @@ MI355X-first mechanics:
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -475,9 +476,24 @@ class Trainer:
     overlap_encoder = True      # Trainer.capture (one process): the encoder on a stream of its own, see train_step_overlapped
 
     def _enc_stream(self):
-        if getattr(self, "_enc_stream_obj", None) is None:
-            self._enc_stream_obj = torch.cuda.Stream(self.device)
-        return self._enc_stream_obj
+        """The encoder's side stream -- never the stream the caller is on.  ``torch.cuda.Stream()`` hands out the streams of a POOL
+        (32 per device and priority, round robin), so the n-th stream object of a process can BE the stream a hipGraph capture runs
+        on (torch.cuda.graph's capture stream comes from the same pool): the fork would then be a wait of a stream on itself and
+        the captured graph degenerate -- seen as a segmentation fault inside hipGraphLaunch once a test session had created enough
+        trainers (round 4).  Checked at every use: the current stream of a capture is not the one the warm-up ran on."""
+        cur = torch.cuda.current_stream(self.device).cuda_stream
+        s = getattr(self, "_enc_stream_obj", None)
+        if s is None or s.cuda_stream == cur:
+            # (default priority: a HIGH-priority stream for this branch -- it is the critical path of the backward's tail -- doubled
+            #  the step, 12.4 against 6.2 ms; profiles/r04_enc_stream_priority_ab.log)
+            for _ in range(64):
+                s = torch.cuda.Stream(self.device)
+                if s.cuda_stream != cur:
+                    break
+            else:
+                raise RuntimeError("no stream other than the current one could be obtained for the encoder branch")
+            self._enc_stream_obj = s
+        return s
 
     def train_step_overlapped(self, batch, update_hyper: bool = True):
         """``train_step`` with the ENCODER ON A STREAM OF ITS OWN (meant to be captured: in a hipGraph the two streams become
@@ -497,6 +513,8 @@ class Trainer:
         self.optimizer_step(update_hyper)
         return total.detach(), raw_l.detach(), post_l.detach(), stop_l.detach()
 
+    handover_encoder_wgrads = os.environ.get("RTTS_HANDOVER_WGRADS", "1") != "0"     # A/B: the encoder's weight gradients on its own stream
+
     def forward_backward_overlapped(self, batch, loss_scale=None):
         """Forward + loss + backward of one (micro-)batch in the two-stream schedule of ``train_step_overlapped``; gradients
         accumulate into the flat buffer.  ``loss_scale``: a device scalar multiplied into the loss before the backward (1 / number
@@ -505,13 +523,17 @@ class Trainer:
         dec_seq = self.model.dec.reformer.layers
         dec_seq.manual = {}
         try:
+            engine.stamp("step: first kernel of the forward")
             total, raw_l, post_l, stop_l = self.forward_loss(batch, split="overlap")
+            engine.stamp("forward + loss done")
             if "call" not in dec_seq.manual:
                 raise RuntimeError("the decoder stack did not take the explicit executor: the overlapped step needs it")
             self._run_backward(total if loss_scale is None else total * loss_scale)     # heads + postnet: stops at the decoder stack's output (a leaf)
             ctx, dec_x, _, dec_out = dec_seq.manual["call"]
             gen = engine.stack_backward_steps(ctx, dec_out.grad, notify_dkeys=True)
             dx = None
+            idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            steal = dict(src=(idx, side.cuda_stream), src_stream=side, pending=[]) if self.handover_encoder_wgrads else None
             while True:
                 try:
                     with torch.no_grad():
@@ -525,12 +547,27 @@ class Trainer:
                     ev.record(main)
                     side.wait_event(ev)
                     dkeys.record_stream(side)
-                    with torch.cuda.stream(side):
-                        self._enc_out.backward(dkeys)          # encoder stack + prenet, on the encoder's stream
-                        engine.flush_wgrad()
+                    engine.stamp("backward: d(keys) complete (main stream)")
+                    engine.STEAL = steal
+                    try:
+                        with torch.cuda.stream(side):
+                            engine.stamp("encoder branch: backward starts")
+                            self._enc_out.backward(dkeys)          # encoder stack + prenet, on the encoder's stream
+                            engine.flush_wgrad()
+                            engine.stamp("encoder branch: backward done")
+                    finally:
+                        engine.STEAL = None
             dec_x.backward(dx)                                 # decoder prenet + positional encoding
             engine.flush_wgrad()
+            engine.stamp("decoder branch: backward done")
+            if steal is not None and steal["pending"]:
+                # the encoder stack's weight gradients, handed over by its stream: the main stream has nothing left to do, the
+                # encoder's chain is still running (engine.STEAL).  (The prenet's convolution weight gradients handed over the same
+                # way measured null / slightly worse -- 6.22 vs 6.24 ms, stash 5.10 vs 5.05: profiles/r04_handover_ab.log -- removed.)
+                engine.run_handed_over(steal)
+                engine.stamp("main stream: the encoder's weight gradients done")
             main.wait_stream(side)
+            engine.stamp("backward joined")
             if engine.pending_all():
                 raise RuntimeError("deferred gradient launches were still queued at the end of the overlapped step")
         finally:

@@ -1587,6 +1587,36 @@ def test_odd_batch_shapes_on_the_executor(gpu, b, text, mel):
     assert torch.isfinite(tr.flat_p).all()
 
 
+def test_capture_when_the_side_stream_object_is_the_capture_stream(gpu):
+    """torch.cuda.Stream() objects come from a pool of 32 streams per device: after enough trainers, the object a trainer keeps for
+    its encoder branch can BE torch.cuda.graph's capture stream.  The fork of the overlapped step would be a stream waiting for
+    itself -- a degenerate graph that crashed inside hipGraphLaunch (round 4, found as an order-dependent segmentation fault of
+    this file).  The trainer must notice at use time and take another stream."""
+    from reformer_tts_amd.model.config import TTSTrainingConfig, model_config_from_dict
+    from reformer_tts_amd.model.lsh_attention import LSHSelfAttention
+    from reformer_tts_amd.training import Trainer, build_model, synthetic_batch
+    cfg = model_ref.small_cfg()
+    cfg["enc_reformer_kwargs"]["attn_kwargs"]["implementation"] = "hip"
+    cfg["dec_reformer_kwargs"]["self_attn_kwargs"]["implementation"] = "hip"
+    warm = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(warm):                                  # makes sure the class-level capture stream exists
+        torch.zeros(8, device=gpu).add_(1.0)
+    cap = torch.cuda.graph.default_capture_stream
+    assert cap is not None
+    torch.manual_seed(1)
+    model = build_model(model_config_from_dict(cfg), gpu)
+    for m in model.modules():
+        if isinstance(m, LSHSelfAttention):
+            m.forced_rotations = torch.randn(1, 64, 4, (128 if not m.causal else 256) // 64 // 2, generator=torch.Generator().manual_seed(5))
+    tr = Trainer(model, TTSTrainingConfig(batch_size=2, learning_rate=1e-3, warmup_steps=4, gradient_clip_val=1.0), gpu)
+    tr._enc_stream_obj = cap                                      # the collision, forced
+    batch = synthetic_batch(2, 100, 256, seed=1, device=gpu)
+    tr.capture(batch)
+    assert tr._enc_stream_obj.cuda_stream != cap.cuda_stream
+    losses = [float(tr.replay()[0]) for _ in range(3)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
 def test_graph_replay_reads_new_batch_contents(gpu):
     """A captured step is bound to its batch BUFFERS, not to their contents: after new data is copied into the same
     tensors (what BatchPrefetcher(into=...) does) the replay trains on the new batch -- same loss as an eager step on it."""
