@@ -291,6 +291,14 @@ int rtts_conv_w_perm_grouped(const rtts_conv_perm_job* jobs, int n, void* stream
 /* The adjoint for the gradients, likewise grouped: jobs[i].w = dwp (Co_pad, 5*CP) fp32, jobs[i].wp = dw (Co, Ci, 5) fp32,
  * dw[co][ci][k] += dwp[co][k][ci]. */
 int rtts_conv_dw_unperm_grouped(const rtts_conv_perm_job* jobs, int n, void* stream);
+/* The convolution in front of a BatchNorm (reference modules.py:19-54,103-169: Conv1d -> BatchNorm1d): y (M, C_out) fp32 = the forward
+ * of rtts_conv1d_k5 (no bias: BatchNorm cancels it) AND, from the same accumulators, the per-channel sums of y and y^2 over the rows that
+ * carry data, as rtts_gemm_nt_partial_rows(M, C_out) partial rows of [sum y | sum y^2] (2 C_out floats each) in `partial`.
+ * rtts_bn_stats_from_partials finishes them into mean / rstd / running statistics exactly as rtts_bn_stats does (which re-reads y). */
+int rtts_conv1d_k5_moments(const void* x, int64_t ldx, const void* wp, int64_t ldw, int M, int C_out, int C_in, void* y, int64_t ldy,
+                           int B, int L, int halo, float* partial, void* stream);
+int rtts_bn_stats_from_partials(const float* partial, int nrows, int B, int L, int C, float* mean, float* rstd, float* run_mean,
+                                float* run_var, const float* mean_shift, int64_t* num_batches, void* stream);
 int rtts_bn_stats(const float* y, int B, int L, int halo, int C, float* mean, float* rstd, float* run_mean, float* run_var,
                   const float* mean_shift, int64_t* num_batches, float* partial_ws, void* stream);
 int rtts_bn_act_fwd(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,

@@ -96,6 +96,8 @@ SIGNATURES = {
     "rtts_conv_dw_unperm": [_vp, _i32, _i32, _i32, _vp, _vp],
     "rtts_conv_w_perm_grouped": [C.POINTER(ConvPermJob), _i32, _vp],
     "rtts_conv_dw_unperm_grouped": [C.POINTER(ConvPermJob), _i32, _vp],
+    "rtts_conv1d_k5_moments": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp],
+    "rtts_bn_stats_from_partials": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "rtts_bn_stats": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "rtts_bn_act_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _u32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i64, _vp],
     "rtts_bn_act_bwd": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _u32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i64, _vp, _vp, _vp, _vp],

@@ -885,6 +885,17 @@ extern "C" int rtts_bn_stats(const float* y, int B, int L, int halo, int C, floa
     return 0;
 }
 
+// the second half of rtts_bn_stats on partial rows somebody else produced (rtts_conv1d_k5_moments: the convolution's own epilogue)
+extern "C" int rtts_bn_stats_from_partials(const float* partial, int nrows, int B, int L, int C, float* mean, float* rstd, float* run_mean,
+                                           float* run_var, const float* mean_shift, int64_t* num_batches, void* stream) {
+    RTTS_ENTER(stream);
+    RTTS_REQUIRE(partial && mean && rstd && nrows > 0 && B > 0 && L > 0 && C > 0 && C % 4 == 0, "rtts_bn_stats_from_partials: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((C + 63) / 64), dim3(64 * ED_FIN_WAVES), 0, (hipStream_t)stream, partial, nrows, B * L, C, mean,
+                       rstd, run_mean, run_var, mean_shift, (long long*)num_batches);
+    RTTS_LAUNCH_CHECK("rtts_bn_stats_from_partials");
+    return 0;
+}
+
 extern "C" int rtts_bn_act_fwd(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
                                float drop_p, uint32_t seed, const uint32_t* seed_dev, int B, int L, int halo, int C, void* z, int z_halo,
                                int z_lead, int64_t z_rows, void* stream) {

@@ -93,6 +93,10 @@ struct GnArgs {
     float* aux_out;
     int T, H, accum;
     int store_mode;      // bf16 outputs: 0 = 8-byte stores, 1 = 16-byte stores (lane-pair exchange), 2 = 16-byte write-through stores
+    // epilogue 7 (a convolution in front of a BatchNorm): fp32 store as epilogue 4 AND the per-channel moments of the output over the
+    // rows that carry data -- halo rows m = b * bn_P + bn_H + t, t < bn_L, m < bn_rows -- as partial rows in `colsum`:
+    // row (m0 / BM) * WM + wm holds [sum y | sum y^2] (2 N floats): what the BatchNorm statistics kernel re-read y for
+    int bn_P, bn_H, bn_L, bn_rows;
 };
 
 #define GN_MAX_GROUP 4
@@ -417,9 +421,21 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 192 && NST == 2) ? 4 : 1) void
     constexpr int epi = EPI;
     const int mrow = m0 + wm * (BM / WM) + r;
     const int ncol = n0 + wn * (BN / WN) + 4 * g;
-    f32x4 cs[TN];
+    f32x4 cs[TN], cs2[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) cs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TN; ++j) cs[j] = cs2[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    (void)cs2;
+    bool vrow[TM];                                 // epilogue 7: does row tile i of this lane carry data (not a halo / padding row)?
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        vrow[i] = false;
+        if constexpr (EPI == 7) {
+            const int m = mrow + 16 * i;
+            const int rr = m % P.bn_P - P.bn_H;
+            vrow[i] = m < P.bn_rows && (unsigned)rr < (unsigned)P.bn_L;
+        }
+    }
+    (void)vrow;
     float dl[TM];                                  // epilogue 5: this lane's share of delta of row tile i (its 4 x TN columns)
 #pragma unroll
     for (int i = 0; i < TM; ++i) dl[i] = 0.f;
@@ -468,10 +484,16 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 192 && NST == 2) ? 4 : 1) void
         // epilogue 4: unrounded fp32 result (rows of ldc floats): in front of a BatchNorm / the loss.  Epilogue 6 is the GROUP's
         // epilogue: each problem says at run time (a wave-uniform branch) whether it stores fp32 (its own epilogue 4) or bf16
         // (0, or 1 when it has a bias)
-        if (epi == 4 || (epi == 6 && P.epi == 4)) {
+        if (epi == 4 || epi == 7 || (epi == 6 && P.epi == 4)) {
             f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(P.c) + m * P.ldc + n);
             if (P.accum) v += *dst;        // C += result (the keys' gradient over the decoder layers)
             *dst = v;
+            if constexpr (epi == 7) {
+                if (vrow[i]) {
+                    cs[j] += v;
+                    cs2[j] += v * v;
+                }
+            }
             return false;
         }
         o.x = pack_bf16x2(v[0], v[1]);
@@ -495,7 +517,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 192 && NST == 2) ? 4 : 1) void
             bvl = *reinterpret_cast<const f32x4*>(P.bias + nl);
             bvh = *reinterpret_cast<const f32x4*>(P.bias + nh);
         }
-        if constexpr (epi == 4 || epi == 6) if (P.bias != nullptr) {
+        if constexpr (epi == 4 || epi == 6 || epi == 7) if (P.bias != nullptr) {
             bvl = *reinterpret_cast<const f32x4*>(P.bias + nl);
             bvh = *reinterpret_cast<const f32x4*>(P.bias + nh);
         }
@@ -564,6 +586,26 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 192 && NST == 2) ? 4 : 1) void
             }
             if (r == 0) *reinterpret_cast<f32x4*>(dst + ncol + 16 * j) = v;
         }
+    }
+    if constexpr (epi == 7) {
+        // the same reduction over the wave's rows, for both moments: row (m0 / BM) * WM + wm of the partial buffer = [sum y | sum y^2]
+        float* dst = P.colsum + ((size_t)(m0 / BM) * WM + wm) * (2 * (size_t)P.N);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x4 v = pl ? cs2[j] : cs[j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = v[e];
+                    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));     // lane ^ 1
+                    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));     // lane ^ 2
+                    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true));    // row_half_mirror
+                    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xF, 0xF, true));    // row_mirror
+                    v[e] = x;
+                }
+                if (r == 0) *reinterpret_cast<f32x4*>(dst + pl * P.N + ncol + 16 * j) = v;
+            }
     }
     if constexpr (MODE != 2) break;
     else {
@@ -649,7 +691,7 @@ static int gn_launch2(const GnGroup& G, hipStream_t s) {
     constexpr int NST = gn_nst<BM, BN>();
     const GnArgs& P = G.p[0];
     const int tiles = (P.M / BM) * (P.N / BN);
-    if constexpr (BM == 192 && BN == 128 && EPI != 4 && EPI != 5) {
+    if constexpr (BM == 192 && BN == 128 && EPI != 4 && EPI != 5 && EPI != 7) {
         // Several tiles per CU (N >= 1024 at M = 12288: 512 / 1024 tiles).  Round 3 launched them all, two workgroups per CU on a
         // 2-deep ring, so that one workgroup's prologue / epilogue fills with the other's MFMAs (N = 2048, K = 512: 37.4 vs 45.5 us
         // on the deep ring; profiles/r02_gemm_nt_probe.log).  Round 4: a grid of RESIDENT workgroups walks the tiles (MODE 2)
@@ -688,7 +730,8 @@ static int gn_launch(const GnGroup& G, int w_kn, hipStream_t s) {
         case 2: return gn_launch2<BM, BN, WM, WN, false, 2>(G, s);
         case 3: return gn_launch2<BM, BN, WM, WN, false, 3>(G, s);
         case 4: return gn_launch2<BM, BN, WM, WN, false, 4>(G, s);
-        default: rtts_set_error("rtts_gemm_nt: an [N][K] weight takes epilogue 0..4, got %d", P.epi); return -1;
+        case 7: return gn_launch2<BM, BN, WM, WN, false, 7>(G, s);
+        default: rtts_set_error("rtts_gemm_nt: an [N][K] weight takes epilogue 0..4 or 7, got %d", P.epi); return -1;
     }
 }
 
@@ -739,17 +782,18 @@ extern "C" int rtts_gemm_nt_partial_rows(int M, int N) {
 
 static int gn_run(const void* a, int64_t lda, const void* w, int64_t ldw, int w_is_kn, int M, int N, int K, void* c, int64_t ldc,
                   const float* bias, int epilogue, const void* gate, int64_t ldg, float* colsum_partial, int conv_cpt, int conv_sign,
-                  int64_t conv_wtap, void* stream, unsigned long long* gate_bits = nullptr) {
+                  int64_t conv_wtap, void* stream, unsigned long long* gate_bits = nullptr, const int* bn_geom = nullptr) {
     RTTS_REQUIRE(a && w && c, "rtts_gemm_nt: null pointer");
     RTTS_REQUIRE(M > 0 && N > 0 && K > 0 && K % GN_BK == 0, "rtts_gemm_nt: K must be a positive multiple of 64 (got M=%d N=%d K=%d)", M, N, K);
-    RTTS_REQUIRE(epilogue >= 0 && epilogue <= 4, "rtts_gemm_nt: epilogue 0..4 (5 and fp32 accumulation: rtts_gemm_nt_grouped)");
+    RTTS_REQUIRE((epilogue >= 0 && epilogue <= 4) || (epilogue == 7 && bn_geom && colsum_partial && !w_is_kn),
+                 "rtts_gemm_nt: epilogue 0..4 (5 and fp32 accumulation: rtts_gemm_nt_grouped; 7: rtts_conv1d_k5_moments)");
     RTTS_REQUIRE(!(epilogue == 1 || epilogue == 2) || bias, "rtts_gemm_nt: epilogue %d needs a bias", epilogue);
     RTTS_REQUIRE(epilogue != 3 || gate_bits || (gate && ldg >= N && ldg % 4 == 0),
                  "rtts_gemm_nt: epilogue 3 needs a gate (M, N) with ldg %% 4 == 0, or the forward's gate words");
     RTTS_REQUIRE(lda % 8 == 0 && (conv_cpt || lda >= K) && ldc >= N && ldc % 4 == 0, "rtts_gemm_nt: bad leading dimensions (lda=%lld ldc=%lld)",
                  (long long)lda, (long long)ldc);
     RTTS_REQUIRE(ldw % 8 == 0 && (conv_cpt || ldw >= (w_is_kn ? N : K)), "rtts_gemm_nt: bad ldw=%lld", (long long)ldw);
-    RTTS_REQUIRE((((uintptr_t)a | (uintptr_t)w) & 15) == 0 && (((uintptr_t)c | (uintptr_t)gate) & (epilogue == 4 ? 15 : 7)) == 0 &&
+    RTTS_REQUIRE((((uintptr_t)a | (uintptr_t)w) & 15) == 0 && (((uintptr_t)c | (uintptr_t)gate) & ((epilogue == 4 || epilogue == 7) ? 15 : 7)) == 0 &&
                  (((uintptr_t)bias | (uintptr_t)colsum_partial) & 15) == 0, "rtts_gemm_nt: misaligned buffer");
     const int pick = gn_pick(M, N);
     RTTS_REQUIRE(pick >= 0, "rtts_gemm_nt: M x N = %d x %d tiles by none of 256x256, 192x128, 256x128, 96x64, 128x64", M, N);
@@ -760,7 +804,8 @@ static int gn_run(const void* a, int64_t lda, const void* w, int64_t ldw, int w_
     P.colsum = colsum_partial; P.lda = lda; P.ldw = ldw; P.ldc = ldc; P.ldg = ldg; P.M = M; P.N = N; P.K = K; P.epi = epilogue;
     P.conv_cpt = conv_cpt; P.conv_sign = conv_sign; P.conv_wtap = conv_wtap;
     P.bits = gate_bits;
-    P.store_mode = epilogue == 4 ? 0 : gn_store_mode(c, ldc);
+    P.store_mode = (epilogue == 4 || epilogue == 7) ? 0 : gn_store_mode(c, ldc);
+    if (bn_geom) { P.bn_P = bn_geom[0]; P.bn_H = bn_geom[1]; P.bn_L = bn_geom[2]; P.bn_rows = bn_geom[3]; }
     RTTS_REQUIRE(!gate_bits || (pick != 0 && (epilogue == 2 || epilogue == 3) && ((uintptr_t)gate_bits & 7) == 0),
                  "rtts_gemm_nt_gated: gate words go with epilogue 2 (written) or 3 (read) and a tile shape that has them "
                  "(rtts_gemm_nt_gate_words(M, N) > 0)");
@@ -908,4 +953,17 @@ extern "C" int rtts_conv1d_k5(const void* x, int64_t ldx, const void* wp, int64_
     // transposed: y[m][co] = sum_{tap, ci} x[m - tap + 2][ci] * wp[ci][tap * C_out + co]             (wp (C_in, 5 C_out), [K][N])
     return gn_run(x, ldx, wp, ldw, transposed ? 1 : 0, M, C_out, 5 * C_in, y, ldy, bias, out_f32 ? 4 : 0, nullptr, 0, nullptr,
                   C_in / GN_BK, transposed ? -1 : 1, transposed ? (int64_t)C_out : 0, stream);
+}
+
+// The forward convolution in front of a BatchNorm: y (fp32, unrounded) as rtts_conv1d_k5(out_f32 = 1, no bias) AND, from the same
+// accumulators, the per-channel sums of y and y^2 over the rows that carry data (halo layout: B sequences of L rows, `halo` zero
+// rows on either side of each) as rtts_gemm_nt_partial_rows(M, C_out) partial rows of [sum y | sum y^2] (2 C_out floats each):
+// what rtts_bn_stats re-read all of y for.  rtts_bn_stats_from_partials finishes them.
+extern "C" int rtts_conv1d_k5_moments(const void* x, int64_t ldx, const void* wp, int64_t ldw, int M, int C_out, int C_in, void* y, int64_t ldy,
+                                      int B, int L, int halo, float* partial, void* stream) {
+    RTTS_ENTER(stream);
+    RTTS_REQUIRE(C_in > 0 && C_in % GN_BK == 0 && C_out > 0, "rtts_conv1d_k5_moments: channel counts must be multiples of 64 (got %d -> %d)", C_in, C_out);
+    RTTS_REQUIRE(partial && B > 0 && L > 0 && halo >= 0 && (long long)B * (L + 2 * halo) <= M, "rtts_conv1d_k5_moments: bad geometry");
+    const int geom[4] = {L + 2 * halo, halo, L, B * (L + 2 * halo)};
+    return gn_run(x, ldx, wp, ldw, 0, M, C_out, 5 * C_in, y, ldy, nullptr, 7, nullptr, 0, partial, C_in / GN_BK, 1, 0, stream, nullptr, geom);
 }

@@ -168,6 +168,19 @@ class ConvK5:
                   self.cop, None if bias is None else bias.data_ptr(), 1, _s())
         return y
 
+    def forward_moments(self, xh: torch.Tensor, g: Halo):
+        """``forward`` without a bias, plus the per-channel moments of y over the valid rows from the GEMM's own epilogue
+        (``rtts_conv1d_k5_moments``) -> (y, partial rows of [sum y | sum y^2], their count): what the BatchNorm behind this
+        convolution would otherwise re-read y for."""
+        y = torch.empty(g.mp, self.cop, dtype=torch.float32, device=xh.device)
+        nrows = _lib.load().rtts_gemm_nt_partial_rows(g.mp, self.cop)
+        if nrows <= 0:
+            raise _lib.RttsError(f"rtts_conv1d_k5_moments: no tile shape for {g.mp} x {self.cop}")
+        partial = torch.empty(nrows, 2 * self.cop, dtype=torch.float32, device=xh.device)
+        _lib.call("rtts_conv1d_k5_moments", g.body(xh).data_ptr(), self.cp, self.weight_perm().data_ptr(), 5 * self.cp, g.mp, self.cop, self.cp,
+                  y.data_ptr(), self.cop, g.b, g.l, g.H, partial.data_ptr(), _s())
+        return y, partial, nrows
+
     def backward(self, dyh: torch.Tensor, xh: torch.Tensor, g: Halo, need_dx: bool = True, dx_f32: bool = False):
         """dyh: halo buffer (alloc, cop) bf16, zero outside the valid set -> accumulates dW; returns dx (mp, cp) bf16 / fp32
         in halo rows (row 0 = halo row 0; rows outside the valid set hold no meaning)."""
@@ -206,6 +219,7 @@ class ConvK5:
 # all-reduced between the stage that produces them and the stage that uses them: 2*C + 1 floats per BatchNorm layer and
 # direction, six layers.  Eager steps only: a collective inside a hipGraph capture is not attempted.
 SYNC_BN = None
+CONV_MOMENTS = _os.environ.get("RTTS_CONV_MOMENTS", "1") != "0"      # A/B: the BatchNorm statistics from a second pass over y (rtts_bn_stats)
 
 
 class ConvBNAct:
@@ -217,7 +231,8 @@ class ConvBNAct:
 
     def forward(self, xh, g: Halo, plain_out: bool = False):
         """-> z (halo buffer (alloc, C) bf16, or (B*L, C) plain rows for the last layer of a stack), saved state."""
-        y = self.c.forward(xh, g)
+        fused = SYNC_BN is None and CONV_MOMENTS
+        y, partial, nrows = self.c.forward_moments(xh, g) if fused else (self.c.forward(xh, g), None, 0)
         c = y.shape[1]
         dev = y.device
         mean = torch.empty(c, dtype=torch.float32, device=dev)
@@ -225,7 +240,11 @@ class ConvBNAct:
         bn = self.bn
         # running_mean tracks the mean of (y + conv bias): the bias is left out of y (BatchNorm cancels it) and shifts
         # only the running mean; num_batches_tracked is bumped by the same launch
-        if SYNC_BN is None:
+        if fused:
+            # the sums of y and y^2 left the convolution's epilogue as partial rows: one small launch finishes them
+            _lib.call("rtts_bn_stats_from_partials", partial.data_ptr(), nrows, g.b, g.l, c, mean.data_ptr(), rstd.data_ptr(),
+                      bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self.c.conv.bias.data_ptr(), bn.num_batches_tracked.data_ptr(), _s())
+        elif SYNC_BN is None:
             _lib.call("rtts_bn_stats", y.data_ptr(), g.b, g.l, g.H, c, mean.data_ptr(), rstd.data_ptr(), bn.running_mean.data_ptr(),
                       bn.running_var.data_ptr(), self.c.conv.bias.data_ptr(), bn.num_batches_tracked.data_ptr(), _ws(dev, c).data_ptr(), _s())
         else:

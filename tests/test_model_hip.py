@@ -652,6 +652,53 @@ def test_conv1d_k5_implicit_gemm_vs_float64(gpu, b, l, ci, co):
         assert float(y[:, co:].abs().max()) == 0.0          # padded output channels: zero weight rows
 
 
+@pytest.mark.parametrize("b,l,ci,co", [(12, 256, 512, 512), (12, 1024, 512, 512), (12, 1024, 512, 80), (4, 4096, 512, 512), (3, 200, 128, 128)])
+def test_conv1d_k5_moments_epilogue(gpu, b, l, ci, co):
+    """rtts_conv1d_k5_moments: the convolution's fp32 output is bit-identical to rtts_conv1d_k5's, and the per-channel sums of y and
+    y^2 over the rows that carry data -- partial rows from the GEMM's epilogue, finished by rtts_bn_stats_from_partials -- give the
+    BatchNorm statistics rtts_bn_stats computes from a second pass over y (reference modules.py:29,127: BatchNorm1d in training
+    mode), also where the partial rows outnumber the 256 of the separate kernel (B = 4, L = 4096) and where halo / padding rows
+    and padded channels must stay out of the sums."""
+    from reformer_tts_amd import _lib, edges
+    torch.manual_seed(b + l + co)
+    conv = torch.nn.Conv1d(ci, co, 5, padding=2).to(gpu)
+    bn_a, bn_b = torch.nn.BatchNorm1d(co).to(gpu), torch.nn.BatchNorm1d(co).to(gpu)
+    ex = edges.ConvK5(conv)
+    g = edges.Halo(b, l)
+    xh = g.new(ex.cp, gpu)
+    xh.normal_()                                            # halo rows hold data here: the sums must still skip THEIR output rows
+    s = torch.cuda.current_stream().cuda_stream
+    y_ref = ex.forward(xh, g)
+    y, partial, nrows = ex.forward_moments(xh, g)
+    assert torch.equal(y, y_ref)
+    c = ex.cop
+    out = {}
+    for tag in ("separate", "epilogue"):
+        bn = bn_a if tag == "separate" else bn_b
+        rm, rv = torch.zeros(c, device=gpu), torch.ones(c, device=gpu)
+        rm[:co], rv[:co] = bn.running_mean, bn.running_var
+        nb = torch.zeros((), dtype=torch.long, device=gpu)
+        shift = torch.zeros(c, device=gpu)
+        shift[:co] = conv.bias.detach()
+        mean, rstd = torch.empty(c, device=gpu), torch.empty(c, device=gpu)
+        if tag == "separate":
+            ws = torch.empty((2 * 256 + 2) * c, device=gpu)
+            _lib.call("rtts_bn_stats", y_ref.data_ptr(), g.b, g.l, g.H, c, mean.data_ptr(), rstd.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                      shift.data_ptr(), nb.data_ptr(), ws.data_ptr(), s)
+        else:
+            _lib.call("rtts_bn_stats_from_partials", partial.data_ptr(), nrows, g.b, g.l, c, mean.data_ptr(), rstd.data_ptr(), rm.data_ptr(),
+                      rv.data_ptr(), shift.data_ptr(), nb.data_ptr(), s)
+        torch.cuda.synchronize()
+        out[tag] = (mean, rstd, rm, rv, int(nb))
+    for a_, b_ in zip(out["separate"][:4], out["epilogue"][:4]):
+        torch.testing.assert_close(b_, a_, rtol=2e-5, atol=2e-6)
+    assert out["epilogue"][4] == 1
+    # and against torch on the valid rows
+    yv = g.valid(y)[..., :co].double()
+    torch.testing.assert_close(out["epilogue"][0][:co].double(), yv.mean(dim=(0, 1)), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(out["epilogue"][1][:co].double(), (yv.var(dim=(0, 1), unbiased=False) + 1e-5).rsqrt(), rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("attn_dropout", [0.0, 0.2])
 def test_attention_stash_matches_pure_recompute(gpu, attn_dropout):
     """(attn_dropout > 0: the LSH layers' `dropout` knob -- probability dropout inside the attention kernels; the recomputing
