@@ -375,6 +375,10 @@ int rtts_embedding_fwd(const int64_t* ids, const float* E, int rows, int C, int 
                        const uint32_t* seed_dev, float* out, void* stream);
 int rtts_embedding_bwd(const int64_t* ids, const float* dx, int rows, int C, int n_embeddings, int padding_idx, float* dE,
                        float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
+/* the same with dx given as a (B, L, C) VIEW of a larger array (the convolution stack's gradient on its halo rows): batch stride and row
+ * stride in floats, rows = B * L */
+int rtts_embedding_bwd_strided(const int64_t* ids, const float* dx, int64_t batch_stride, int64_t row_stride, int L, int rows, int C,
+                               int n_embeddings, int padding_idx, float* dE, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
 
 /* ---- weight-gradient GEMM, split over the token dimension ------------------------------------
  * c[N][K] (fp32, stride ldc) (+)= sum_m a[m][N] * b[m][K]   (a, b bf16 with strides lda, ldb)

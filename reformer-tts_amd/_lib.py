@@ -113,6 +113,7 @@ SIGNATURES = {
     "rtts_pe_dalpha": [_vp, _vp, _f32, _u32, _vp, _i32, _i64, _i32, _vp, _vp, _vp],
     "rtts_relu_drop": [_vp, _f32, _u32, _vp, _i64, _vp],
     "rtts_embedding_bwd": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _f32, _u32, _vp, _vp],
+    "rtts_embedding_bwd_strided": [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _f32, _u32, _vp, _vp],
     "rtts_embedding_fwd": [_vp, _vp, _i32, _i32, _i32, _f32, _u32, _vp, _vp, _vp],
     "rtts_gemm_tn": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _i32, _vp, _i64, _vp],
     "rtts_gemm_tn_grouped": [C.POINTER(GemmTnProblem), _i32, _vp, _i64, _vp],

@@ -617,7 +617,10 @@ __global__ __launch_bounds__(ED_THREADS) void heads_grad_kernel(const float* __r
 // dE[id] += sum over rows with ids[row] == id of dx[row]: one block per (id, 64-channel group).  Wave w scans the
 // 64-row groups w, w+4, ...: the lanes compare 64 ids at once, the ballot lists the matching rows and they are added
 // in row order; the 4 wave sums are combined in wave order => deterministic, no atomics
-__global__ __launch_bounds__(ED_THREADS) void embedding_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dx, int rows,
+// dx row rr = (b, t), b = rr / L, t = rr % L, lives at dx + b * bstride + t * rstride (floats): the gradient of the convolution
+// stack arrives as a strided view of its halo rows (edges.Halo.valid) and is read in place instead of through a contiguous copy
+__global__ __launch_bounds__(ED_THREADS) void embedding_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dx, int64_t bstride,
+                                                                   int64_t rstride, int L, int rows,
                                                                    int C, int padding_idx, float* __restrict__ dE, uint32_t seed,
                                                                    const uint32_t* __restrict__ seed_dev, uint32_t thresh, float dscale) {
     __shared__ float red[4][64];
@@ -633,7 +636,8 @@ __global__ __launch_bounds__(ED_THREADS) void embedding_bwd_kernel(const int64_t
         while (m) {
             const int rr = base + __builtin_ctzll(m);
             m &= m - 1;
-            if (c < C) acc += dx[(size_t)rr * C + c] * (thresh ? rtts_drop_keep(seed, (uint32_t)rr * C + c, thresh, dscale) : 1.f);
+            const int bb = rr / L;
+            if (c < C) acc += dx[(size_t)bb * bstride + (size_t)(rr - bb * L) * rstride + c] * (thresh ? rtts_drop_keep(seed, (uint32_t)rr * C + c, thresh, dscale) : 1.f);
         }
     }
     red[wave][lane] = acc;
@@ -1039,8 +1043,21 @@ extern "C" int rtts_embedding_bwd(const int64_t* ids, const float* dx, int rows,
     RTTS_ENTER(stream);
     RTTS_REQUIRE(ids && dx && dE && rows > 0 && C > 0 && n_embeddings > 0 && drop_p >= 0.f && drop_p < 1.f, "rtts_embedding_bwd: bad arguments");
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3(n_embeddings, (C + 63) / 64), dim3(ED_THREADS), 0, (hipStream_t)stream,
-                       ids, dx, rows, C, padding_idx, dE, seed, seed_dev, ed_thresh(drop_p), 1.f / (1.f - drop_p));
+                       ids, dx, (int64_t)0, (int64_t)C, rows, rows, C, padding_idx, dE, seed, seed_dev, ed_thresh(drop_p), 1.f / (1.f - drop_p));
     RTTS_LAUNCH_CHECK("rtts_embedding_bwd");
+    return 0;
+}
+
+// the same with dx as a (B, L, C) view of a larger array: batch stride and row stride in floats (rows = B * L)
+extern "C" int rtts_embedding_bwd_strided(const int64_t* ids, const float* dx, int64_t batch_stride, int64_t row_stride, int L, int rows, int C,
+                                          int n_embeddings, int padding_idx, float* dE, float drop_p, uint32_t seed, const uint32_t* seed_dev,
+                                          void* stream) {
+    RTTS_ENTER(stream);
+    RTTS_REQUIRE(ids && dx && dE && rows > 0 && L > 0 && rows % L == 0 && C > 0 && row_stride >= C && batch_stride >= 0 && n_embeddings > 0 &&
+                     drop_p >= 0.f && drop_p < 1.f, "rtts_embedding_bwd_strided: bad arguments");
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(n_embeddings, (C + 63) / 64), dim3(ED_THREADS), 0, (hipStream_t)stream,
+                       ids, dx, batch_stride, row_stride, L, rows, C, padding_idx, dE, seed, seed_dev, ed_thresh(drop_p), 1.f / (1.f - drop_p));
+    RTTS_LAUNCH_CHECK("rtts_embedding_bwd_strided");
     return 0;
 }
 

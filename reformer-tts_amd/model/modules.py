@@ -92,6 +92,12 @@ class _EmbeddingFn(torch.autograd.Function):
         from ..engine import _grad
         ids2, weight, padding_idx, p, seed = ctx.state
         n, c = weight.shape
+        if dx.dim() == 3 and dx.dtype == torch.float32 and dx.stride(2) == 1 and not dx.is_contiguous():
+            # the convolution stack's gradient is a strided view of its halo rows: read in place, no contiguous copy
+            _lib.call("rtts_embedding_bwd_strided", ids2.data_ptr(), dx.data_ptr(), dx.stride(0), dx.stride(1), dx.shape[1],
+                      dx.shape[0] * dx.shape[1], c, n, -1 if padding_idx is None else padding_idx, _grad(weight).data_ptr(), p, seed,
+                      seed_base(dx.device).data_ptr(), torch.cuda.current_stream().cuda_stream)
+            return None, None, None, None
         dx2 = dx.reshape(-1, c)
         dx2 = dx2 if dx2.dtype == torch.float32 and dx2.is_contiguous() else dx2.float().contiguous()
         _lib.call("rtts_embedding_bwd", ids2.data_ptr(), dx2.data_ptr(), dx2.shape[0], c, n, -1 if padding_idx is None else padding_idx,

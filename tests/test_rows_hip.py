@@ -77,3 +77,27 @@ def test_batch_masks_match_the_reference_sequence(gpu, b, lp, lm):
     longer = torch.cat([loss_mask, loss_mask[:, :1]], dim=1)
     got2 = ReformerTTS._encode_inputs_fused(_Stub, phon, spec, longer[:, :-1])
     assert torch.equal(got2[2], want[2])
+
+
+def test_embedding_backward_reads_a_strided_gradient_in_place(gpu):
+    """rtts_embedding_bwd_strided: dx as a (B, L, C) view of halo rows (what the convolution stack's backward hands to the embedding:
+    edges.Halo.valid) gives bit for bit the gradient of the contiguous copy through rtts_embedding_bwd, with and without the
+    dropout mask (keyed by the LOGICAL row); reference modules.py:17,22,56 (nn.Embedding(padding_idx=0) + Dropout)."""
+    from reformer_tts_amd import _lib
+    from reformer_tts_amd._seeds import seed_base
+    torch.manual_seed(3)
+    b, l, c, n = 5, 200, 128, 77
+    halo = torch.randn(b, l + 4, c + 64, device=gpu)                 # a larger array: row stride c + 64, batch stride (l + 4) rows
+    dx = halo[:, 2:2 + l, :c]
+    assert not dx.is_contiguous() and dx.stride(2) == 1
+    ids = torch.randint(0, n, (b * l,), device=gpu)
+    s = torch.cuda.current_stream().cuda_stream
+    for p, seed in ((0.0, 0), (0.1, 4242)):
+        d_ref, d_str = torch.zeros(n, c, device=gpu), torch.zeros(n, c, device=gpu)
+        flat = dx.reshape(-1, c).contiguous()
+        _lib.call("rtts_embedding_bwd", ids.data_ptr(), flat.data_ptr(), b * l, c, n, 0, d_ref.data_ptr(), p, seed, seed_base(gpu).data_ptr(), s)
+        _lib.call("rtts_embedding_bwd_strided", ids.data_ptr(), dx.data_ptr(), dx.stride(0), dx.stride(1), l, b * l, c, n, 0, d_str.data_ptr(), p, seed,
+                  seed_base(gpu).data_ptr(), s)
+        torch.cuda.synchronize()
+        assert torch.equal(d_ref, d_str)
+        assert float(d_ref[0].abs().max()) == 0.0 and float(d_ref[1:].abs().max()) > 0.0
