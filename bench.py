@@ -259,7 +259,8 @@ def main():
         use_graph = capture()
     if use_graph:
         step_fn = trainer.replay
-        note("step captured into " + ("one hipGraph" if one_graph else f"{len(trainer._segments) + 1} hipGraphs around {len(trainer._segments)} gradient all-reduces"))
+        n_graphs = len(trainer._segments) + len(getattr(trainer, "_tail_main", ())) + len(getattr(trainer, "_tail_side", ()))
+        note("step captured into " + ("one hipGraph" if one_graph else f"{n_graphs + 1} hipGraphs around {len(trainer.segment_plan())} gradient all-reduces"))
     else:
         trainer._bulk_allreduce = False               # eager: per-block all-reduce overlapped with the backward
         step_fn = lambda: trainer.train_step(batch)   # noqa: E731
@@ -334,7 +335,7 @@ def main():
                        "dist": {"world_size": world, "backend": (dist.get_backend() if world > 1 else None),
                                 "backend_ranks": (dist.get_world_size() if world > 1 else 1),
                                 "allreduce_bytes_per_step": (4 * n_par if world > 1 else 0),
-                                "collectives_per_step": (len(trainer._segments) if (world > 1 and use_graph) else (0 if world == 1 else "per block")),
+                                "collectives_per_step": (len(trainer.segment_plan()) if (world > 1 and use_graph) else (0 if world == 1 else "per block")),
                                 "schedule": (trainer.segment_plan() if (world > 1 and use_graph) else None),
                                 "rank_seeds": "rotations and dropout seeded with seed + rank",
                                 # the communication policy (one-GPU probe: profiles/r04_comm_overlap_probe.log)

@@ -875,6 +875,7 @@ class Trainer:
         self._graph = torch.cuda.CUDAGraph()
         self._graph_opt = None
         self._segments = []
+        self._tail_main, self._tail_side = [], []
         self._segment_names = None
         self.set_step_hyper(self.global_step)
         if self._sync_bn is not None:
@@ -902,22 +903,35 @@ class Trainer:
             segs.append((self._graph, (dec_stack_end, self.n_params)))
             if "call" not in dec_seq.manual:
                 raise RuntimeError("the decoder stack did not take the explicit executor: the segmented capture needs it")
-            segs += self._capture_decoder_layers(dec_seq.manual["call"], enc_end)
+            two_lanes = self.two_lane_tail and enc_seq.manual is not None and "call" in enc_seq.manual
+            dec_segs, tail_main = self._capture_decoder_layers(dec_seq.manual["call"], enc_end, split=two_lanes)
+            segs += dec_segs
         finally:
             dec_seq.manual = None
             enc_call = enc_seq.manual.get("call") if enc_seq.manual is not None else None
             enc_seq.manual = None
+        tail_side = []
         if enc_call is not None:
-            block_segs, dx_enc = self._capture_encoder_blocks(enc_call, stack_begin)
-            segs += block_segs
+            # Two lanes behind the keys' gradient (two_lane_tail): the encoder's graphs are captured on a stream and in a memory pool of
+            # their own -- scratch buffers and deferred-gradient queues are keyed by the stream a launch is made on, graph-private memory
+            # by the pool -- because they REPLAY beside the rest of decoder layer 0 (`replay`).  One lane: everything in one pool, in order.
+            lane = None
+            if two_lanes:
+                cap_s = torch.cuda.graph.default_capture_stream
+                lane = dict(stream=self._distinct_stream(avoid=[torch.cuda.current_stream(self.device)] + ([cap_s] if cap_s is not None else [])), pool=None)
+            block_segs, dx_enc = self._capture_encoder_blocks(enc_call, stack_begin, lane)
             g = torch.cuda.CUDAGraph()
-            with self._capturing(g, pool=self._graph.pool()):
+            with self._capturing(g, **self._lane_kw(lane)):
                 self._pre_out.backward(dx_enc)
                 engine.flush_wgrad()
                 assert engine.pending_all() == 0
                 if self.overlap_encoder:
                     torch.cuda.current_stream().wait_stream(self._enc_stream())
-            segs.append((g, (0, stack_begin)))
+            block_segs.append((g, (0, stack_begin)))
+            if two_lanes:
+                tail_side = block_segs
+            else:
+                segs += block_segs
         else:
             g = torch.cuda.CUDAGraph()
             with self._capturing(g, pool=self._graph.pool()):
@@ -936,8 +950,36 @@ class Trainer:
                     torch.cuda.current_stream().wait_stream(self._enc_stream())
             segs.append((g, (0, stack_begin)))
         self._enc_out = self._enc_in = self._pre_out = self._pre_in = None
-        self._finish_chain(segs)
+        if tail_side:
+            n_dec = len(segs) - 2                                            # graphs of whole decoder layers in front of the cut
+            n_enc = len(tail_side) - 1
+            self._segment_names = (["forward + loss + heads/postnet backward"] +
+                                   [f"decoder layer {k} backward" for k in range(n_dec, 0, -1)] +
+                                   ["decoder layer 0 backward up to the keys' gradient"] +
+                                   [f"encoder block {k} backward (lane 2)" for k in range(n_enc - 1, -1, -1)] + ["encoder prenet backward (lane 2)"] +
+                                   ["rest of decoder layer 0 + decoder prenet backward (lane 1, beside lane 2)"])
+        self._finish_chain(segs, tail_main, tail_side)
         return self._graph_out
+
+    two_lane_tail = os.environ.get("RTTS_TWO_LANE_TAIL", "1") != "0"      # A/B: the encoder's graphs behind decoder layer 0's, one lane
+
+    def _distinct_stream(self, avoid):
+        """A pool stream whose handle is none of ``avoid``'s (torch.cuda.Stream() objects share 32 streams per device)."""
+        taken = {a.cuda_stream for a in avoid}
+        for _ in range(64):
+            s_ = torch.cuda.Stream(self.device)
+            if s_.cuda_stream not in taken:
+                return s_
+        raise RuntimeError("no distinct stream could be obtained")
+
+    def _lane_kw(self, lane):
+        """Arguments of ``_capturing`` for a graph of the encoder lane (its own stream, its own pool) or of the one-lane chain."""
+        if lane is None:
+            return dict(pool=self._graph.pool())
+        kw = dict(stream=lane["stream"])
+        if lane["pool"] is not None:
+            kw["pool"] = lane["pool"]
+        return kw
 
     def _flat_layout(self):
         """(end of the encoder's parameters, begin of the encoder stack's, end of the decoder stack's) in the flat buffer; checks
@@ -957,37 +999,47 @@ class Trainer:
             raise RuntimeError("flat buffer: heads and postnet are expected behind the decoder stack")
         return enc_end, stack_begin, dec_stack_end
 
-    def _capture_decoder_layers(self, dec_call, enc_end):
+    def _capture_decoder_layers(self, dec_call, enc_end, split: bool = False):
         """One graph per decoder layer, top to bottom, from d(loss)/d(stack output) = ``dec_out.grad`` (a buffer the first graph
         -- or the eager postnet island -- fills); the bottom layer's graph also holds the decoder prenet's backward and leaves
-        d(loss)/d(keys) on ``self._enc_in.grad``.  -> [(graph, gradient range)]"""
+        d(loss)/d(keys) on ``self._enc_in.grad``.  ``split``: the bottom layer is cut where d(loss)/d(keys) is complete (behind its
+        cross-attention's backward): the graph up to there carries no gradient range (None), what follows -- the layer's LSH
+        sublayer, the decoder prenet -- is returned apart: it replays BESIDE the encoder's graphs.
+        -> ([(graph, gradient range | None)], [(graph, range)] of the part behind the cut (empty without ``split``))"""
         ctx, dec_x, _, dec_out = dec_call
-        gen = engine.stack_backward_steps(ctx, dec_out.grad, complete_layers=True)
-        segs, finished = [], False
+        gen = engine.stack_backward_steps(ctx, dec_out.grad, complete_layers=True, notify_dkeys=split)
+        segs, tail, finished, behind_cut = [], [], False, False
         while not finished:
             g = torch.cuda.CUDAGraph()
+            rng_out, cut = None, False
             with self._capturing(g, pool=self._graph.pool()):
                 with torch.no_grad():
                     _, done = next(gen)      # one decoder layer's backward + its weight gradients and column sums
-                rng = [self.block_bucket[("dec", j)] for j in done if ("dec", j) in self.block_bucket]
-                lo, hi = min(r[0] for r in rng), max(r[1] for r in rng)
-                if 0 in done:                # the bottom layer: the generator ends; the decoder prenet's backward joins this graph
-                    try:
-                        with torch.no_grad():
-                            next(gen)
-                        raise RuntimeError("stack_backward_steps yielded after block 0")
-                    except StopIteration as fin:
-                        dx, dkeys = fin.value
-                    dec_x.backward(dx)
-                    self._enc_in.grad = dkeys
-                    engine.flush_wgrad()
-                    assert engine.pending_all() == 0
-                    lo = enc_end             # decoder prenet + positional encoding sit between the encoder and the stack
-                    finished = True
-            segs.append((g, (lo, hi)))
-        return segs
+                if isinstance(done, tuple) and len(done) == 2 and done[0] == "dkeys":
+                    self._enc_in.grad = done[1]          # complete: the encoder's backward may start here
+                    cut = True
+                else:
+                    rng = [self.block_bucket[("dec", j)] for j in done if ("dec", j) in self.block_bucket]
+                    lo, hi = min(r[0] for r in rng), max(r[1] for r in rng)
+                    if 0 in done:                # the bottom layer: the generator ends; the decoder prenet's backward joins this graph
+                        try:
+                            with torch.no_grad():
+                                next(gen)
+                            raise RuntimeError("stack_backward_steps yielded after block 0")
+                        except StopIteration as fin:
+                            dx, dkeys = fin.value
+                        dec_x.backward(dx)
+                        self._enc_in.grad = dkeys
+                        engine.flush_wgrad()
+                        assert engine.pending_all() == 0
+                        lo = enc_end             # decoder prenet + positional encoding sit between the encoder and the stack
+                        finished = True
+                    rng_out = (lo, hi)
+            (tail if behind_cut else segs).append((g, rng_out))
+            behind_cut = behind_cut or cut
+        return segs, tail
 
-    def _capture_encoder_blocks(self, enc_call, stack_begin):
+    def _capture_encoder_blocks(self, enc_call, stack_begin, lane=None):
         """The encoder stack driven by hand like the decoder's: one graph per encoder block (LSH + feed-forward: 4 weight
         gradients, 11.6 MB of gradients at the baseline widths), each block's range exchanged while the next one replays.
         -> ([(graph, gradient range)], d(loss)/d(stack input))"""
@@ -998,7 +1050,7 @@ class Trainer:
         segs, finished, dx_enc = [], False, None
         while not finished:
             g = torch.cuda.CUDAGraph()
-            with self._capturing(g, pool=self._graph.pool()):
+            with self._capturing(g, **self._lane_kw(lane)):
                 with torch.no_grad():
                     try:
                         _, done = next(gen)
@@ -1018,14 +1070,20 @@ class Trainer:
                     lo = stack_begin
                     finished = True
             segs.append((g, (lo, hi)))
+            if lane is not None and lane["pool"] is None:
+                lane["pool"] = g.pool()          # the lane's later graphs share this one's memory pool
         return segs, dx_enc
 
-    def _finish_chain(self, segs):
-        """Checks that the exchanged ranges tile the flat gradient buffer, stores the chain, captures clip + AdamW behind it."""
-        cover = sorted(r for _, r in segs if r is not None)
+    def _finish_chain(self, segs, tail_main=(), tail_side=()):
+        """Checks that the exchanged ranges tile the flat gradient buffer, stores the chain (``tail_main`` / ``tail_side``: the two
+        lanes behind the keys' gradient, replayed side by side), captures clip + AdamW behind it."""
+        cover = sorted(r for _, r in list(segs) + list(tail_main) + list(tail_side) if r is not None)
         if cover[0][0] != 0 or cover[-1][1] != self.n_params or any(a[1] != b[0] for a, b in zip(cover, cover[1:])):
             raise RuntimeError(f"segmented capture: the gradient ranges do not tile the flat buffer: {cover}")
         self._segments = segs
+        self._tail_main, self._tail_side = list(tail_main), list(tail_side)
+        if self._tail_side and getattr(self, "_lane_replay_stream", None) is None:
+            self._lane_replay_stream = self._distinct_stream(avoid=[torch.cuda.current_stream(self.device)])
         self._graph_opt = torch.cuda.CUDAGraph()
         with self._capturing(self._graph_opt, pool=self._graph.pool()):
             self.optimizer_step(update_hyper=False)
@@ -1125,7 +1183,7 @@ class Trainer:
             self._graph.replay()                   # real values in the hand-over buffers for the eager piece below (and its exchanges)
             postnet()
             segs.append((self._Eager(postnet), (dec_stack_end, self.n_params)))
-            segs += self._capture_decoder_layers(dec_seq.manual["call"], enc_end)
+            segs += self._capture_decoder_layers(dec_seq.manual["call"], enc_end)[0]
             n_dec = len(segs) - 3
             block_segs, st["dx_enc"] = self._capture_encoder_blocks(enc_seq.manual["call"], stack_begin)
             segs += block_segs
@@ -1161,10 +1219,18 @@ class Trainer:
                     enc_names + ["encoder prenet backward"]
             names[n_dec] += " + decoder prenet backward"
         out = []
-        for k, ((_, rng), nm) in enumerate(zip(self._segments, names)):
+        side, main = list(getattr(self, "_tail_side", None) or ()), list(getattr(self, "_tail_main", None) or ())
+        chain = list(self._segments) + side + main
+        first_side, first_main = len(self._segments), len(self._segments) + len(side)
+        for k, ((_, rng), nm) in enumerate(zip(chain, names)):
             if rng is None:
                 continue
-            nxt = names[k + 1] if k + 1 < len(names) else "nothing (exposed)"
+            if side and k >= first_main:
+                nxt = "the encoder lane's remaining graphs"
+            elif side and k >= first_side:
+                nxt = ("the other lane + " + names[k + 1]) if k + 1 < first_main else "the other lane's remainder, else nothing (exposed)"
+            else:
+                nxt = names[k + 1] if k + 1 < len(names) else "nothing (exposed)"
             out.append(dict(after=nm, allreduce_bytes=4 * (rng[1] - rng[0]), overlaps=nxt))
         return out
 
@@ -1181,10 +1247,25 @@ class Trainer:
         # data parallel: every segment's gradient range is final when its graph ends -- its all-reduce is issued at once and
         # runs while the next segment replays; only the last (the encoder prenet's 17 MB) has nothing to hide behind
         works = []
-        for g, rng in self._segments:
-            g.replay()                   # a hipGraph, or an eager piece that holds SyncBatchNorm's exchanges (_capture_around_sync_bn)
-            if self.world > 1 and rng is not None:
-                works.append(dist.all_reduce(self.flat_g[rng[0]:rng[1]], group=self.pg, async_op=True))
+
+        def run(lane):
+            for g, rng in lane:
+                g.replay()               # a hipGraph, or an eager piece that holds SyncBatchNorm's exchanges (_capture_around_sync_bn)
+                if self.world > 1 and rng is not None:
+                    works.append(dist.all_reduce(self.flat_g[rng[0]:rng[1]], group=self.pg, async_op=True))
+        run(self._segments)
+        if getattr(self, "_tail_side", None):
+            # behind the keys' gradient: the encoder's graphs on a stream of their own BESIDE the rest of decoder layer 0 and the
+            # decoder prenet (the one-graph step overlaps the same two pieces: Trainer.forward_backward_overlapped); each lane's
+            # all-reduces are issued from its own stream context, so that each waits for its own lane only
+            cur, side = torch.cuda.current_stream(self.device), self._lane_replay_stream
+            if side.cuda_stream == cur.cuda_stream:
+                side = self._lane_replay_stream = self._distinct_stream(avoid=[cur])
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                run(self._tail_side)
+            run(self._tail_main)
+            cur.wait_stream(side)
         for w in works:
             w.wait()
         self._graph_opt.replay()

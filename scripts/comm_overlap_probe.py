@@ -61,6 +61,7 @@ def main():
     tcfg.batch_size = 12
     tcfg.recompute = os.environ.get("PROBE_RECOMPUTE", "full")
     tr = Trainer(model, tcfg, dev)
+    tr.two_lane_tail = False        # this probe walks ONE lane of (graph, range) pairs: the chain before the two-lane tail
     batch = synthetic_batch(12, 200, 1024, seed=42, device=dev)
     tr.capture(batch, segmented=True)
     plan = tr.segment_plan()

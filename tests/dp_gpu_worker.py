@@ -1,8 +1,9 @@
 """Worker of tests/test_dp_gpu.py: one rank of a 2-process gloo job sharing cuda:0.  Runs three training steps of the small
 model in the two data-parallel modes of the trainer and checks (a) replicas stay identical, (b) the modes agree:
     eager      per-block all-reduce issued from the block-done hooks, overlapped with the backward
-    graphs     a chain of hipGraphs (fwd + heads/postnet bwd | one per decoder layer | one per encoder block | encoder prenet bwd | clip + AdamW)
-               with the all-reduce of each graph's gradient range issued while the next one replays
+    graphs     a chain of hipGraphs (fwd + heads/postnet bwd | one per decoder layer, the lowest cut at the keys' gradient | then two lanes side
+               by side: rest of that layer + decoder prenet || one per encoder block + encoder prenet | clip + AdamW) with the all-reduce of
+               each graph's gradient range issued while the next one replays
 (parameters after three steps, loss of the third step).  Then the same pair with ``sync_batchnorm``: the chain keeps the three pieces
 that hold BatchNorm's exchanges eager between its graphs (Trainer._capture_around_sync_bn); BatchNorm's running statistics
 after three steps must agree too (the eager pieces execute once more while the chain is built: that must leave no trace)."""
@@ -49,11 +50,13 @@ def run(mode, rank, dev, sync_bn=False):
             losses = [None, None, float(tr.replay()[0])]
             torch.cuda.synchronize()
             return tr, losses
-        # forward+loss+heads | one graph per decoder layer (depth 1 here) | one per encoder block (2) | encoder prenet, then the optimizer
-        assert len(tr._segments) == 5 and tr._graph_opt is not None, len(tr._segments)
+        # forward+loss+heads | decoder layer 0 up to the keys' gradient | then two lanes side by side: the rest of the layer + the decoder
+        # prenet || one graph per encoder block (2) + encoder prenet; then the optimizer
+        assert len(tr._segments) == 2 and len(tr._tail_main) == 1 and len(tr._tail_side) == 3 and tr._graph_opt is not None
+        assert tr._segments[1][1] is None                      # the cut graph exchanges nothing: the layer's range is final behind it
         plan = tr.segment_plan()
-        assert sum(p["allreduce_bytes"] for p in plan) == 4 * tr.n_params and plan[-1]["overlaps"].startswith("nothing")
-        assert [p["after"] for p in plan][2:4] == ["encoder block 1 backward", "encoder block 0 backward"], plan
+        assert len(plan) == 5 and sum(p["allreduce_bytes"] for p in plan) == 4 * tr.n_params, plan
+        assert [p["after"] for p in plan][1:3] == ["encoder block 1 backward (lane 2)", "encoder block 0 backward (lane 2)"], plan
         losses = [None, None, float(tr.replay()[0])]
     torch.cuda.synchronize()
     return tr, losses
