@@ -316,7 +316,7 @@ def main():
         frames = world * args.batch * args.mel_len * args.steps
         n_par = trainer.n_params
         launch = ("hipGraph replay (one graph; the encoder is a parallel branch beside the decoder: Trainer.train_step_overlapped)" if one_graph else
-                  "hipGraph replay (fwd + heads/postnet bwd | one graph per decoder layer bwd | enc stack bwd | enc prenet bwd | optimizer; the "
+                  "hipGraph replay (fwd + heads/postnet bwd | one graph per decoder layer bwd, the lowest cut at the keys' gradient | behind the cut two lanes side by side: rest of that layer + decoder prenet || one graph per encoder block + encoder prenet | optimizer; the "
                   "all-reduce of a graph's gradient range runs while the next graph replays: config.dist.schedule)") \
             if use_graph else "eager"
         workload = (f"config/baseline.yml full Reformer-TTS training step (enc 3 / dec 3 layers, d=512, LSH 8 rounds, buckets 64/128), "
