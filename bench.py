@@ -209,11 +209,17 @@ def main():
             ok = int(flag.item())
         return bool(ok)
 
+    def settle():
+        """Host garbage out of the way before the warm-up steps of a timed region (see `timed`)."""
+        torch.cuda.synchronize()
+        gc.collect()
+
     def timed(step_fn, steps):
         # A collection of the host's garbage inside the timed region can free a replaced hipGraph and its memory pool (a second
         # capture on the same trainer leaves one behind): hipFree synchronises the device -- seen as a one-off 5-9 ms stall in a
         # 10-step region (profiles/r04b_stash_variance.log).  Collect now, and keep the collector off while the clock runs.
-        gc.collect()
+        # (The collection itself runs BEFORE the warm-up steps -- `settle` -- so that the device does not sit idle through it right
+        #  in front of the clock: a 10-step region started from an idle chip read 6.39 ms/step where 100 steps read 6.31.)
         gc.disable()
         if world > 1:
             dist.barrier()
@@ -264,10 +270,10 @@ def main():
     else:
         trainer._bulk_allreduce = False               # eager: per-block all-reduce overlapped with the backward
         step_fn = lambda: trainer.train_step(batch)   # noqa: E731
-    for i in range(args.warmup):
+    settle()
+    for i in range(args.warmup):          # back to back, like the timed steps: the region starts from a busy chip, not from an idle one
         step_fn()
-        torch.cuda.synchronize()
-        note(f"warm-up step {i} done")
+    note(f"{args.warmup} warm-up step(s) launched")
     elapsed, loss = timed(step_fn, args.steps)
     note(f"timed region done: {1e3 * elapsed / args.steps:.2f} ms/step")
 
@@ -294,6 +300,7 @@ def main():
         set_mode(other_mode)
         ok = capture() if use_graph else True
         fn = trainer.replay if (use_graph and ok) else (lambda: trainer.train_step(batch))
+        settle()
         for _ in range(2):
             fn()
         k = max(3, min(args.steps, 10))
