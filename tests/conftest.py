@@ -17,3 +17,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_collection_modifyitems(config, items):
+    """RTTS_TEST_ORDER=reverse | shuffle:<seed>: run the collected tests in another order.  The suite must not depend on its order:
+    round 4 found a segmentation fault that only one ORDER of test_model_hip.py showed (stream objects of torch come from a pool of
+    32: after enough trainers a side stream WAS the capture stream) -- an order check is the cheapest detector of such state."""
+    order = os.environ.get("RTTS_TEST_ORDER", "")
+    if order == "reverse":
+        items.reverse()
+    elif order.startswith("shuffle:"):
+        import random
+        random.Random(int(order.split(":", 1)[1])).shuffle(items)
